@@ -1,0 +1,434 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under ``tests/golden`` FROM THE REFERENCE ITSELF.
+
+TEST INFRASTRUCTURE ONLY; runs only in the build container (needs
+``/root/reference``; the GPU box never has it).  It
+
+1. imports the reference's own hot-path modules from ``/root/reference/src`` with
+   the stand-ins of ``oracle/_ref_standins.py`` for the third-party packages this
+   image lacks (pytorch_lightning, torch_geometric, torch_cluster, ...),
+2. runs them on seeded inputs (and on the reference's own test graph
+   ``tests/test_data/graphs/test_graph.pt`` and its pinned known-answer values from
+   ``tests/test_losses.py:112-123``),
+3. asserts that the CPU restatement ``oracle/ref_cpu.py`` reproduces every output,
+4. writes inputs + reference outputs as small ``.npz`` fixtures.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 TORCHDYNAMO_DISABLE=1 python oracle/make_golden.py
+
+Nothing is ever written under /root/reference (bytecode writing is disabled
+before the first import; no reference builder that writes next to its inputs is
+called).
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+
+import pathlib  # noqa: E402
+import pickle  # noqa: E402
+import types  # noqa: E402
+import zipfile  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HERE = pathlib.Path(__file__).resolve().parent
+REPO = HERE.parent
+REF = pathlib.Path("/root/reference")
+OUT = REPO / "tests" / "golden"
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(REF / "src"))
+
+import _ref_standins  # noqa: E402
+
+_ref_standins.install()
+
+import ref_cpu as O  # noqa: E402
+
+from gnn_tracking.metrics.losses.ec import EdgeWeightBCELoss  # noqa: E402
+from gnn_tracking.metrics.losses.oc import (  # noqa: E402
+    CondensationLossRG,
+    CondensationLossTiger,
+)
+from gnn_tracking.models.edge_classifier import ECForGraphTCN  # noqa: E402
+from gnn_tracking.models.graph_construction import (  # noqa: E402
+    MLGraphConstruction,
+    knn_with_max_radius,
+)
+from gnn_tracking.models.interaction_network import InteractionNetwork  # noqa: E402
+from gnn_tracking.models.resin import ResIN  # noqa: E402
+
+Data = _ref_standins.Data
+torch.set_num_threads(4)
+
+
+# ----------------------------------------------------------------------------- io
+def load_reference_graph(path) -> Data:
+    """Read a PyG-pickled ``Data`` without PyG: tensors sit in
+    ``obj._store._mapping`` (torch_geometric.data.storage.GlobalStorage)."""
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __setstate__(self, st):
+            self.__dict__.update(st if isinstance(st, dict) else {"_state": st})
+
+    fake = {}
+    for m, names in {
+        "torch_geometric.data.data": ["Data", "DataEdgeAttr", "DataTensorAttr"],
+        "torch_geometric.data.storage": ["GlobalStorage", "BaseStorage", "NodeStorage",
+                                         "EdgeStorage"],
+    }.items():
+        mod = types.ModuleType(m)
+        for n in names:
+            setattr(mod, n, type(n, (_Any,), {}))
+        fake[m] = mod
+    saved = {m: sys.modules.get(m) for m in fake}
+    sys.modules.update(fake)
+    try:
+        obj = torch.load(str(path), weights_only=False)
+    finally:
+        for m, v in saved.items():
+            if v is None:
+                sys.modules.pop(m, None)
+            else:
+                sys.modules[m] = v
+    mapping = obj.__dict__["_store"].__dict__["_mapping"]
+    return Data(**dict(mapping))
+
+
+def npz(name: str, **arrs) -> None:
+    OUT.mkdir(parents=True, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    np.savez_compressed(OUT / name, **conv)
+    sz = (OUT / name).stat().st_size
+    print(f"  wrote tests/golden/{name}  ({sz/1024:.1f} KiB, {len(conv)} arrays)")
+
+
+def close(a, b, tol, what):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    scale = max(1.0, b.abs().max().item() if b.numel() else 1.0)
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    assert err <= tol * scale, f"{what}: max|diff| {err:.3e} > {tol:.1e}*{scale:.2e}"
+    return err
+
+
+def sd(model) -> dict:
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+# ------------------------------------------------------------- synthetic inputs
+def synth_graph(seed, N, E, Fn, Fe, dtype=torch.float32):
+    """Seeded graph with isolated nodes, duplicate edges and self loops."""
+    g = np.random.default_rng(seed)
+    x = torch.from_numpy(g.normal(size=(N, Fn))).to(dtype)
+    n_iso = max(1, N // 25)
+    live = g.permutation(N)[: N - n_iso]
+    src = live[g.integers(0, len(live), size=E)]
+    tgt = live[g.integers(0, len(live), size=E)]
+    src[: E // 50] = src[E // 50: 2 * (E // 50)]          # duplicate edges
+    tgt[: E // 50] = tgt[E // 50: 2 * (E // 50)]
+    tgt[-(E // 100):] = src[-(E // 100):]                 # self loops
+    ei = torch.from_numpy(np.stack([src, tgt])).long()
+    ea = torch.from_numpy(g.normal(size=(E, Fe))).to(dtype)
+    y = torch.from_numpy(g.random(E) < 0.31)
+    pt = torch.from_numpy(g.lognormal(0.0, 0.7, size=N)).to(dtype)
+    return x, ei, ea, y, pt
+
+
+# ----------------------------------------------------------------------- goldens
+def g1_ec_testgraph():
+    """ECForGraphTCN(14,14,L_ec=1) (tests/test_configs/ec.yml) on test_graph.pt,
+    torch.manual_seed(0): forward, BCE, grads, one Adam step (lr=wd=1e-4)."""
+    print("G1 ECForGraphTCN on test_graph.pt")
+    g = load_reference_graph(REF / "tests/test_data/graphs/test_graph.pt")
+    torch.manual_seed(0)
+    model = ECForGraphTCN(node_indim=14, edge_indim=14, L_ec=1)
+    p0 = sd(model)
+    out = model(g)
+    loss = EdgeWeightBCELoss()(w=out["W"], y=g.y.float(), pt=g.pt, edge_index=g.edge_index)
+    loss.backward()
+    grads = {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt.step()
+    p1 = sd(model)
+    # sanity markers recorded in SURVEY.md section 8c
+    assert abs(out["W"][0].item() - 0.45724145) < 1e-6, out["W"][:3]
+    assert abs(loss.item() - 0.5523450970649719) < 1e-6, loss.item()
+
+    oo, ol, og, op = O.ec_training_step(
+        g.x, g.edge_index, g.edge_attr, g.y, p0, model_kwargs=dict(L_ec=1))
+    e = [close(oo["W"], out["W"], 1e-6, "W"),
+         close(oo["node_embedding"], out["node_embedding"], 1e-6, "node_emb"),
+         close(oo["edge_embedding"], out["edge_embedding"], 1e-6, "edge_emb"),
+         close(ol, loss, 1e-6, "loss")]
+    for k in grads:
+        e.append(close(og[k], grads[k], 1e-5, "grad " + k))
+        e.append(close(op[k], p1[k], 1e-6, "adam " + k))
+    print(f"  oracle == reference (max diff {max(e):.2e})")
+    arrs = dict(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, y=g.y, pt=g.pt,
+                particle_id=g.particle_id, eta=g.eta, reconstructable=g.reconstructable,
+                layer=g.layer, sector=g.sector,
+                W=out["W"], node_embedding=out["node_embedding"],
+                edge_embedding=out["edge_embedding"], loss=loss)
+    for k in p0:
+        arrs["p0/" + k] = p0[k]
+        arrs["p1/" + k] = p1[k]
+        arrs["grad/" + k] = grads[k]
+    npz("g1_ec_testgraph.npz", **arrs)
+    return g
+
+
+EC_VARIANTS = {
+    "skip1_L3_h40": dict(L_ec=3, hidden_dim=40),
+    "skip1_L2_h2": dict(L_ec=2, hidden_dim=2),
+    "skip2_L2": dict(L_ec=2, hidden_dim=8, residual_type="skip2"),
+    "skiptop_L3": dict(L_ec=3, hidden_dim=8, residual_type="skip_top"),
+    "no_inter": dict(L_ec=2, hidden_dim=8, use_intermediate_edge_embeddings=False),
+    "no_inter_no_node": dict(L_ec=2, hidden_dim=8, use_intermediate_edge_embeddings=False,
+                             use_node_embedding=False),
+    "no_node": dict(L_ec=2, hidden_dim=8, use_node_embedding=False),
+    "alpha0": dict(L_ec=2, hidden_dim=None, alpha=0.0),
+}
+
+
+def g2_ec_variants():
+    """ECForGraphTCN variants (mirrors tests/test_tcn_training.py:57-82) on a seeded
+    synthetic graph N=300, E=2000, Fn=14, Fe=4: outputs + grads of BCE."""
+    print("G2 ECForGraphTCN variants")
+    x, ei, ea, y, pt = synth_graph(2, 300, 2000, 14, 4)
+    arrs = dict(x=x, edge_index=ei, edge_attr=ea, y=y, pt=pt)
+    worst = 0.0
+    for name, kw in EC_VARIANTS.items():
+        torch.manual_seed(7)
+        model = ECForGraphTCN(node_indim=14, edge_indim=4, **kw)
+        p0 = sd(model)
+        out = model(Data(x=x, edge_index=ei, edge_attr=ea))
+        loss = EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"], y=y.float(), pt=pt, edge_index=ei)
+        loss.backward()
+        okw = {k: v for k, v in kw.items() if k != "hidden_dim"}
+        oo, ol, og, _ = O.ec_training_step(x, ei, ea, y, p0, model_kwargs=okw, pt=pt,
+                                           pt_thld=0.9)
+        worst = max(worst, close(oo["W"], out["W"], 1e-6, name + " W"),
+                    close(oo["node_embedding"], out["node_embedding"], 1e-6, name),
+                    close(oo["edge_embedding"], out["edge_embedding"], 1e-6, name),
+                    close(ol, loss, 1e-6, name + " loss"))
+        arrs[f"{name}/W"] = out["W"]
+        arrs[f"{name}/node_embedding"] = out["node_embedding"]
+        arrs[f"{name}/edge_embedding"] = out["edge_embedding"]
+        arrs[f"{name}/loss"] = loss
+        for k, v in model.named_parameters():
+            gk = v.grad if v.grad is not None else torch.zeros_like(v)
+            worst = max(worst, close(og[k], gk, 1e-5, f"{name} grad {k}"))
+            arrs[f"{name}/p0/{k}"] = p0[k]
+            arrs[f"{name}/grad/{k}"] = gk
+    print(f"  oracle == reference (max diff {worst:.2e})")
+    npz("g2_ec_variants.npz", **arrs)
+
+
+def g3_in_layer():
+    """One InteractionNetwork(5,4 -> 5,4; H=40/40) and one with odd sizes, on a seeded
+    N=1000, E=10000 graph: outputs and grads wrt x, edge_attr and all parameters of
+    L = sum(x~ * rx) + sum(e~ * re)."""
+    print("G3 InteractionNetwork layer")
+    arrs = {}
+    worst = 0.0
+    for name, (dn, de, dno, deo, hn, he, N, E) in {
+        "std": (5, 4, 5, 4, 40, 40, 1000, 10000),
+        "odd": (7, 3, 6, 5, 24, 17, 257, 1531),
+    }.items():
+        x, ei, ea, _, _ = synth_graph(3, N, E, dn, de)
+        g = np.random.default_rng(33)
+        rx = torch.from_numpy(g.normal(size=(N, dno))).float()
+        re = torch.from_numpy(g.normal(size=(E, deo))).float()
+        torch.manual_seed(11)
+        m = InteractionNetwork(node_indim=dn, edge_indim=de, node_outdim=dno,
+                               edge_outdim=deo, node_hidden_dim=hn, edge_hidden_dim=he)
+        p0 = {"in." + k: v for k, v in sd(m).items()}
+        xr, er = x.clone().requires_grad_(True), ea.clone().requires_grad_(True)
+        xt, et = m(xr, ei, er)
+        ((xt * rx).sum() + (et * re).sum()).backward()
+        ps = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+        xo, eo = x.clone().requires_grad_(True), ea.clone().requires_grad_(True)
+        oxt, oet = O.interaction_network(xo, ei, eo, ps, "in")
+        ((oxt * rx).sum() + (oet * re).sum()).backward()
+        worst = max(worst, close(oxt, xt, 1e-6, "x~"), close(oet, et, 1e-6, "e~"),
+                    close(xo.grad, xr.grad, 1e-5, "gx"), close(eo.grad, er.grad, 1e-5, "ge"))
+        arrs.update({f"{name}/x": x, f"{name}/edge_index": ei, f"{name}/edge_attr": ea,
+                     f"{name}/rx": rx, f"{name}/re": re, f"{name}/x_tilde": xt,
+                     f"{name}/e_tilde": et, f"{name}/grad_x": xr.grad,
+                     f"{name}/grad_edge_attr": er.grad,
+                     f"{name}/dims": np.array([dn, de, dno, deo, hn, he])})
+        for k, v in m.named_parameters():
+            worst = max(worst, close(ps["in." + k].grad, v.grad, 1e-5, "g " + k))
+            arrs[f"{name}/p0/in.{k}"] = p0["in." + k]
+            arrs[f"{name}/grad/in.{k}"] = v.grad
+    print(f"  oracle == reference (max diff {worst:.2e})")
+    npz("g3_in_layer.npz", **arrs)
+
+
+def g3b_resin():
+    """ResIN skip1/skip2/skip_top standalone (collect_hidden_edge_embeds=True)."""
+    print("G3b ResIN")
+    x, ei, ea, _, _ = synth_graph(4, 200, 1500, 5, 4)
+    arrs = dict(x=x, edge_index=ei, edge_attr=ea)
+    worst = 0.0
+    for name, kw in {
+        "skip1": dict(n_layers=3, residual_type="skip1", alpha=0.5),
+        "skip2": dict(n_layers=2, residual_type="skip2", alpha=0.3),
+        "skip_top": dict(n_layers=3, residual_type="skip_top", alpha=0.7),
+    }.items():
+        torch.manual_seed(5)
+        m = ResIN(node_dim=5, edge_dim=4, object_hidden_dim=12, relational_hidden_dim=20,
+                  residual_kwargs={"collect_hidden_edge_embeds": True}, **kw)
+        p0 = {"r." + k: v for k, v in sd(m).items()}
+        xo, eo, es = m(x, ei, ea)
+        ox, oe, oes = O.resin(x, ei, ea, p0, "r", collect_hidden_edge_embeds=True, **kw)
+        worst = max(worst, close(ox, xo, 1e-6, name), close(oe, eo, 1e-6, name),
+                    close(torch.cat(oes, 1), torch.cat(es, 1), 1e-6, name))
+        arrs[f"{name}/x_out"] = xo
+        arrs[f"{name}/e_out"] = eo
+        arrs[f"{name}/edge_attrs_cat"] = torch.cat(es, 1)
+        for k, v in p0.items():
+            arrs[f"{name}/p0/{k}"] = v
+    print(f"  oracle == reference (max diff {worst:.2e})")
+    npz("g3b_resin.npz", **arrs)
+
+
+def g4_knn(test_graph):
+    """knn_with_max_radius on test_graph.x[:, :3] and on seeded uniform clouds."""
+    print("G4 kNN graph construction")
+    arrs = {}
+    clouds = {"tg3": test_graph.x[:, :3].contiguous()}
+    g = np.random.default_rng(44)
+    clouds["u2"] = torch.from_numpy(g.random((2000, 2))).float()
+    clouds["u8"] = torch.from_numpy(g.random((2000, 8))).float()
+    for cn, x in clouds.items():
+        arrs[f"{cn}/x"] = x
+        for k in (1, 2, 3, 9):
+            for r in (None, 1.0, 0.3):
+                ref = knn_with_max_radius(x, k=k, max_radius=r)
+                mine = O.knn_with_max_radius(x, k, r)
+                assert ref.shape == mine.shape and torch.equal(ref, mine), (cn, k, r)
+                arrs[f"{cn}/k{k}_r{r}"] = ref
+    assert tuple(arrs["tg3/k3_rNone"].shape) == (2, 270)       # SURVEY.md 8c marker
+    assert arrs["tg3/k3_rNone"][0, :3].tolist() == [5, 4, 6]
+    print("  oracle == reference (bit-exact edge_index)")
+    npz("g4_knn.npz", **arrs)
+
+
+def _loss_testdata(n_nodes, n_particles, seed, n_x=3):
+    """The seeded mock data of the reference's tests/test_losses.py:46-76 (same RNG
+    call sequence; ``true_edge_index`` is not needed here)."""
+    g = np.random.default_rng(seed)
+    pid = torch.from_numpy(g.choice(np.arange(n_particles), size=n_nodes))
+    uniq = torch.unique(pid)
+    pt = torch.from_numpy(2 * g.random(len(uniq)))[pid]
+    eta = torch.from_numpy(8 * (g.random(len(uniq)) - 0.5))[pid]
+    reco = torch.from_numpy(g.choice([0.0, 1.0], size=len(uniq)))[pid]
+    beta = torch.from_numpy(g.random(n_nodes))
+    x = torch.from_numpy(g.random((n_nodes, n_x)))
+    return dict(beta=beta, x=x, particle_id=pid, pt=pt, eta=eta, reconstructable=reco)
+
+
+PINNED = {  # /root/reference/tests/test_losses.py:112-123
+    "td1": {"attractive": 0.48778231210119105, "repulsive": 35939197600.633316,
+            "coward": 0.051056325062234675, "noise": 0.5346992111891886},
+    "td2": {"attractive": 1.5953161268602611, "repulsive": 3.478838882898964,
+            "coward": 0.03316374922649601, "noise": 0.564675177839844},
+}
+
+
+def g5_oc():
+    """Condensation losses: the reference's pinned float64 cases td1/td2, fp32
+    re-runs, grads wrt x and beta, and a larger seeded fp32 case."""
+    print("G5 object-condensation losses")
+    arrs = {}
+    cases = {"td1": _loss_testdata(50, 3, 0), "td2": _loss_testdata(100, 10, 0),
+             "td3": _loss_testdata(1500, 120, 5, n_x=4)}
+    for cn, td in cases.items():
+        for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            t = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in td.items()}
+            if cn == "td3":
+                t["x"] = t["x"] * 3.0      # spread out so the radius cut matters
+            for strat, cls in (("tiger", CondensationLossTiger), ("rg", CondensationLossRG)):
+                b = t["beta"].clone().requires_grad_(True)
+                x = t["x"].clone().requires_grad_(True)
+                ret = cls(lw_repulsive=2.0, lw_noise=0.5, lw_coward=0.25)(
+                    beta=b, x=x, particle_id=t["particle_id"],
+                    reconstructable=t["reconstructable"], pt=t["pt"], eta=t["eta"])
+                ld = ret.loss_dct
+                if cn in PINNED and dt is torch.float64:
+                    for k, v in PINNED[cn].items():
+                        assert abs(ld[k].item() - v) <= 1e-6 * abs(v), (cn, strat, k)
+                ret.loss.backward()
+                mask = O.good_node_mask(t["pt"], t["particle_id"], t["reconstructable"],
+                                        t["eta"])
+                bo = t["beta"].clone().requires_grad_(True)
+                xo = t["x"].clone().requires_grad_(True)
+                fn = O.condensation_loss_tiger if strat == "tiger" else O.condensation_loss_rg
+                od = fn(beta=bo, x=xo, particle_id=t["particle_id"], mask=mask)
+                tol = 1e-9 if dt is torch.float64 else 2e-5
+                for k in ("attractive", "repulsive", "coward", "noise"):
+                    close(od[k], ld[k], tol, f"{cn} {strat} {dt_name} {k}")
+                    arrs[f"{cn}/{dt_name}/{strat}/{k}"] = ld[k]
+                tot = (od["attractive"] + 2.0 * od["repulsive"] + 0.5 * od["noise"]
+                       + 0.25 * od["coward"])
+                tot.backward()
+                gt = 1e-8 if dt is torch.float64 else 2e-4
+                close(xo.grad, x.grad, gt, f"{cn} {strat} {dt_name} gx")
+                close(bo.grad, b.grad, gt, f"{cn} {strat} {dt_name} gbeta")
+                arrs[f"{cn}/{dt_name}/{strat}/grad_x"] = x.grad
+                arrs[f"{cn}/{dt_name}/{strat}/grad_beta"] = b.grad
+                arrs[f"{cn}/{dt_name}/{strat}/total"] = ret.loss
+            if dt is torch.float64:
+                for k, v in t.items():
+                    arrs[f"{cn}/{k}"] = v
+    for cn, d in PINNED.items():
+        arrs[f"{cn}/pinned"] = np.array([d["attractive"], d["repulsive"], d["coward"],
+                                         d["noise"]])
+    print("  oracle == reference; reference == its own pinned values")
+    npz("g5_oc.npz", **arrs)
+
+
+def g6_mlgc(test_graph):
+    """MLGraphConstruction(ml=None, embedding_slice=(0,3)) labels + edge features."""
+    print("G6 MLGraphConstruction edge labels / features")
+    arrs = {}
+    for k, r in ((4, 1.0), (16, 0.5)):
+        m = MLGraphConstruction(ml=None, embedding_slice=(0, 3), max_radius=r,
+                                max_num_neighbors=k)
+        d = Data(**{a: getattr(test_graph, a) for a in test_graph.keys()})
+        out = m(d)
+        ei = O.knn_with_max_radius(test_graph.x[:, :3], k, r)
+        yy, ff = O.ml_graph_construction_edges(test_graph.x, test_graph.particle_id, ei)
+        assert torch.equal(ei, out.edge_index) and torch.equal(yy, out.y)
+        close(ff, out.edge_attr, 0.0, "edge features")
+        arrs[f"k{k}_r{r}/edge_index"] = out.edge_index
+        arrs[f"k{k}_r{r}/y"] = out.y
+        arrs[f"k{k}_r{r}/edge_attr"] = out.edge_attr
+    print("  oracle == reference (bit-exact)")
+    npz("g6_mlgc.npz", **arrs)
+
+
+if __name__ == "__main__":
+    assert REF.is_dir(), "needs /root/reference (build container only)"
+    tg = g1_ec_testgraph()
+    g2_ec_variants()
+    g3_in_layer()
+    g3b_resin()
+    g4_knn(tg)
+    g5_oc()
+    g6_mlgc(tg)
+    print("all goldens written; oracle pinned against the reference.")

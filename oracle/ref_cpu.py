@@ -1,0 +1,363 @@
+"""CPU restatement of the reference hot path (ORACLE - test infrastructure only).
+
+This file restates, in plain functional PyTorch-CPU fp32/fp64 arithmetic, the
+algorithms of gnn_tracking's Interaction-Network edge-classification path, its
+kNN graph construction and its object-condensation losses.  It is the CHECKER:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  The product package ``gnn_tracking_amd`` never does, and has
+no CPU fallback.
+
+Pinning: ``oracle/make_golden.py`` runs the reference's own Python modules
+(imported from /root/reference with stand-ins for the third-party packages this
+image lacks) on seeded inputs, checks every function below against them, and
+commits inputs + reference outputs as ``tests/golden/*.npz``.  The pinned
+known-answer values of the reference's ``tests/test_losses.py:112-149`` are part
+of those fixtures.  ``tests/test_oracle_golden.py`` re-checks this file against
+the fixtures on every run (no reference needed).
+
+Parameters are passed as a flat ``dict[str, Tensor]`` whose keys are exactly the
+reference ``state_dict`` keys (e.g.
+``ec_resin.network.layers.0.relational_model.layers.0.weight``).
+
+Every function cites the reference file:line it follows (paths relative to
+``/root/reference/src/gnn_tracking``).
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+from torch import Tensor
+
+__all__ = [
+    "mlp",
+    "interaction_network",
+    "resin",
+    "ec_for_graph_tcn",
+    "falsify_low_pt_edges",
+    "edge_weight_bce_loss",
+    "knn_graph",
+    "radius_graph",
+    "knn_with_max_radius",
+    "ml_graph_construction_edges",
+    "good_node_mask",
+    "condensation_loss_rg",
+    "condensation_loss_tiger",
+]
+
+
+# --------------------------------------------------------------------------- MLP
+def mlp(x: Tensor, p: dict, prefix: str, L: int, *, bias: bool = True,
+        last_activation: bool = False) -> Tensor:
+    """models/mlp.py:18-62.  Linear -> (ReLU -> Linear) x (L-1); weights [out,in].
+
+    ``ModuleList`` index of the l-th Linear is ``2*l`` (ReLUs sit in between).
+    """
+    for l in range(L):
+        w = p[f"{prefix}.layers.{2 * l}.weight"]
+        x = x @ w.t()
+        if bias:
+            x = x + p[f"{prefix}.layers.{2 * l}.bias"]
+        if l < L - 1 or last_activation:
+            x = torch.clamp_min(x, 0.0)
+    return x
+
+
+# ------------------------------------------------------- Interaction network
+def interaction_network(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict,
+                        prefix: str) -> tuple[Tensor, Tensor]:
+    """models/interaction_network.py:54-103 (+ PyG propagate, add / source_to_target).
+
+    j = edge_index[0] (source), i = edge_index[1] (target).
+    e~ = relational([x_i, x_j, e]); aggr[n] = sum_{e: i(e)=n} e~[e];
+    x~ = object([x, aggr]).
+    """
+    src, tgt = edge_index[0], edge_index[1]
+    m = torch.cat([x[tgt], x[src], edge_attr], dim=1)
+    e_tilde = mlp(m, p, f"{prefix}.relational_model", 3)
+    aggr = torch.zeros(x.shape[0], e_tilde.shape[1], dtype=x.dtype)
+    aggr = aggr.index_add(0, tgt, e_tilde)
+    x_tilde = mlp(torch.cat([x, aggr], dim=1), p, f"{prefix}.object_model", 3)
+    return x_tilde, e_tilde
+
+
+def _sqconvex(delta: Tensor, residue: Tensor | None, alpha: float) -> Tensor:
+    """models/resin.py:17-42."""
+    if residue is None or math.isclose(alpha, 0.0):
+        return delta
+    return math.sqrt(alpha) * residue + math.sqrt(1 - alpha) * delta
+
+
+def resin(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, prefix: str, *,
+          n_layers: int, alpha: float = 0.5, residual_type: str = "skip1",
+          collect_hidden_edge_embeds: bool = False, connect_to: int = 1):
+    """models/resin.py:99-114 (skip1), :153-175 (skip2, no BN), :197-216 (skip_top).
+
+    Returns ``(x, edge_attr, edge_attrs or None)``.
+    """
+    relu = lambda t: torch.clamp_min(t, 0.0)  # noqa: E731
+    ident = lambda t: t  # noqa: E731
+    lp = lambda i: f"{prefix}.network.layers.{i}"  # noqa: E731
+    edge_attrs = [edge_attr] if collect_hidden_edge_embeds else None
+    if residual_type == "skip1":
+        for i in range(n_layers):
+            act = relu if i > 0 else ident
+            dx, edge_attr = interaction_network(act(x), edge_index, act(edge_attr), p, lp(i))
+            x = _sqconvex(dx, x, alpha)
+            if edge_attrs is not None:
+                edge_attrs.append(edge_attr)
+    elif residual_type == "skip2":
+        if n_layers % 2:
+            raise ValueError("Only even number of layers allowed at the moment")
+        # NB: the reference iterates ``pairwise(range(n))`` = (0,1),(1,2),...,(n-2,n-1)
+        # (resin.py:157), i.e. overlapping pairs: n-1 blocks of two IN applications.
+        for i0 in range(n_layers - 1):
+            i1 = i0 + 1
+            act0 = relu if i0 > 0 else ident
+            hx, he = interaction_network(act0(x), edge_index, act0(edge_attr), p, lp(i0))
+            dx, edge_attr = interaction_network(relu(hx), edge_index, relu(he), p, lp(i1))
+            x = _sqconvex(dx, x, alpha)
+            if edge_attrs is not None:
+                edge_attrs.append(edge_attr)
+    elif residual_type == "skip_top":
+        x_res = None
+        for i in range(n_layers):
+            if i == connect_to:
+                x_res = x
+            act = relu if i > 0 else ident
+            dx, edge_attr = interaction_network(act(x), edge_index, act(edge_attr), p, lp(i))
+            x = _sqconvex(dx, x_res, alpha) if x_res is not None else dx
+            if edge_attrs is not None:
+                edge_attrs.append(edge_attr)
+    else:
+        raise KeyError(residual_type)
+    return x, edge_attr, edge_attrs
+
+
+# ------------------------------------------------------------ Edge classifier
+def ec_for_graph_tcn(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *,
+                     L_ec: int = 3, alpha: float = 0.5, residual_type: str = "skip1",
+                     use_intermediate_edge_embeddings: bool = True,
+                     use_node_embedding: bool = True, connect_to: int = 1) -> dict:
+    """models/edge_classifier.py:89-121."""
+    relu = lambda t: torch.clamp_min(t, 0.0)  # noqa: E731
+    h = relu(mlp(x, p, "ec_node_encoder", 2, bias=False))
+    e = relu(mlp(edge_attr, p, "ec_edge_encoder", 2, bias=False))
+    h, e, es = resin(h, edge_index, e, p, "ec_resin", n_layers=L_ec, alpha=alpha,
+                     residual_type=residual_type,
+                     collect_hidden_edge_embeds=use_intermediate_edge_embeddings,
+                     connect_to=connect_to)
+    w_in = torch.cat(es, dim=1) if use_intermediate_edge_embeddings else e
+    if use_node_embedding:
+        w_in = torch.cat([h[edge_index[0]], h[edge_index[1]], w_in], dim=1)
+    eps = 0.001
+    w = eps + (1 - 2 * eps) * torch.sigmoid(mlp(w_in, p, "W", 3))
+    return {"W": w.squeeze(), "node_embedding": h, "edge_embedding": e}
+
+
+def falsify_low_pt_edges(y: Tensor, edge_index: Tensor | None, pt: Tensor | None,
+                         pt_thld: float = 0.0) -> Tensor:
+    """metrics/losses/ec.py:71-92."""
+    if math.isclose(pt_thld, 0.0):
+        return y
+    return y.bool() & (pt[edge_index[0]] > pt_thld)
+
+
+def edge_weight_bce_loss(w: Tensor, y: Tensor, edge_index: Tensor | None = None,
+                         pt: Tensor | None = None, pt_thld: float = 0.0) -> Tensor:
+    """metrics/losses/ec.py:103-121: mean BCE, log clamped at -100 (torch semantics)."""
+    y = falsify_low_pt_edges(y, edge_index, pt, pt_thld).to(w.dtype)
+    lw = torch.clamp_min(torch.log(w), -100.0)
+    l1w = torch.clamp_min(torch.log(1 - w), -100.0)
+    return -(y * lw + (1 - y) * l1w).mean()
+
+
+# ----------------------------------------------------------- kNN / radius graph
+def _sq_dists_seq(xq: Tensor, xc: Tensor) -> Tensor:
+    """[Q,C] squared distances, dimension-sequential fused accumulation
+    d <- fma(t, t, d), t = xq_d - xc_d  (the arithmetic the HIP kernel uses; the C
+    oracle ``oracle/knn_ref.c`` is the bit-exact statement of it - this torch
+    version uses float64 FMA emulation: product exact in f64, one f32 rounding)."""
+    d = torch.zeros(xq.shape[0], xc.shape[0], dtype=torch.float32)
+    for k in range(xq.shape[1]):
+        t = (xq[:, k].view(-1, 1) - xc[:, k].view(1, -1)).to(torch.float32)
+        # t*t is exact in float64 (24-bit x 24-bit); adding the f32 d and rounding
+        # once to f32 reproduces fmaf except for double-rounding corner cases.
+        d = (t.double() * t.double() + d.double()).to(torch.float32)
+    return d
+
+
+def knn_graph(x: Tensor, k: int, chunk: int = 1024) -> Tensor:
+    """torch_cluster.knn_graph(x, k) semantics as used at
+    models/graph_construction.py:233 (no batch, loop=False, source_to_target):
+    for every query q the k nearest other points, ascending distance, ties ->
+    lower index; row0 = neighbour (source j), row1 = query (target i)."""
+    N = x.shape[0]
+    kk = min(k, N - 1)
+    rows, cols = [], []
+    xf = x.to(torch.float32)
+    for s in range(0, N, chunk):
+        q = xf[s:s + chunk]
+        d = _sq_dists_seq(q, xf)
+        idx = torch.arange(s, min(s + chunk, N))
+        d[torch.arange(q.shape[0]), idx] = float("inf")
+        ds, order = torch.sort(d, dim=1, stable=True)
+        rows.append(order[:, :kk].reshape(-1))
+        cols.append(idx.view(-1, 1).expand(-1, kk).reshape(-1))
+    return torch.stack([torch.cat(rows), torch.cat(cols)])
+
+
+def radius_graph(x: Tensor, r: float, max_num_neighbors: int = 32, chunk: int = 1024,
+                 batch: Tensor | None = None) -> Tensor:
+    """torch_cluster.radius_graph(x, r, max_num_neighbors, loop=False) as used at
+    metrics/losses/oc.py:115-117: neighbours with d < r (we test d^2 < r^2 on the
+    sequential-fma squared distance), self excluded, at most ``max_num_neighbors``
+    per query (the nearest ones; the reference tests never reach the cap)."""
+    N = x.shape[0]
+    xf = x.to(torch.float32)
+    r2 = torch.tensor(float(r), dtype=torch.float32) ** 2
+    rows, cols = [], []
+    for s in range(0, N, chunk):
+        q = xf[s:s + chunk]
+        d = _sq_dists_seq(q, xf)
+        idx = torch.arange(s, min(s + chunk, N))
+        d[torch.arange(q.shape[0]), idx] = float("inf")
+        if batch is not None:
+            d = d.masked_fill(batch[idx].view(-1, 1) != batch.view(1, -1), float("inf"))
+        ds, order = torch.sort(d, dim=1, stable=True)
+        kk = min(max_num_neighbors, N - 1)
+        ok = ds[:, :kk] < r2
+        rows.append(order[:, :kk][ok])
+        cols.append(idx.view(-1, 1).expand(-1, kk)[ok])
+    return torch.stack([torch.cat(rows), torch.cat(cols)])
+
+
+def edge_lengths(x: Tensor, edge_index: Tensor) -> Tensor:
+    """||x[e0]-x[e1]||_2 in fp32, dimension-sequential (sqrt of the fma chain)."""
+    t = x[edge_index[0]].float() - x[edge_index[1]].float()
+    d = torch.zeros(t.shape[0], dtype=torch.float32)
+    for k in range(t.shape[1]):
+        d = (t[:, k].double() * t[:, k].double() + d.double()).to(torch.float32)
+    return torch.sqrt(d)
+
+
+def knn_with_max_radius(x: Tensor, k: int, max_radius: float | None = None) -> Tensor:
+    """models/graph_construction.py:222-237: kNN, then keep ``||x_j - x_i|| < r``
+    (strict, L2 norm - not squared - evaluated after the kNN)."""
+    ei = knn_graph(x, k)
+    if max_radius is not None:
+        ei = ei[:, edge_lengths(x, ei) < max_radius]
+    return ei
+
+
+def ml_graph_construction_edges(x: Tensor, particle_id: Tensor, edge_index: Tensor):
+    """models/graph_construction.py:365-367 and :386-393: edge labels (int64
+    compare, noise pid<=0 never true) and edge features ``[x_j - x_i, x_j + x_i]``
+    with j = edge_index[0], i = edge_index[1]."""
+    e0, e1 = edge_index[0], edge_index[1]
+    y = (particle_id[e0] == particle_id[e1]) & (particle_id[e0] > 0)
+    feat = torch.cat([x[e0] - x[e1], x[e0] + x[e1]], dim=1)
+    return y.long(), feat
+
+
+# ---------------------------------------------------------- condensation losses
+def good_node_mask(pt, particle_id, reconstructable, eta, pt_thld=0.9, max_eta=4.0):
+    """utils/graph_masks.py:19-28."""
+    return (pt > pt_thld) & (particle_id > 0) & (reconstructable > 0) & (eta.abs() < max_eta)
+
+
+def _condensation_points(beta: Tensor, particle_id: Tensor, mask: Tensor):
+    """metrics/losses/oc.py:16-43: per particle of interest (masked hits only) the
+    hit with the largest beta.  Returns ``alphas_k`` (global hit indices, ordered by
+    ascending particle id) and the boolean per-hit CP flag."""
+    idx = torch.nonzero(mask).view(-1)
+    pid_m, beta_m = particle_id[idx], beta[idx]
+    uniq, inv = torch.unique(pid_m, sorted=True, return_inverse=True)
+    K = uniq.shape[0]
+    assert K > 0, "No particles found, cannot evaluate loss"
+    # arg-max of beta per particle; descending-beta order -> first occurrence
+    order = torch.argsort(beta_m, descending=True, stable=True)
+    first = torch.full((K,), -1, dtype=torch.long)
+    inv_o = inv[order]
+    # iterate from the back so that the earliest (largest beta) entry wins
+    first[inv_o.flip(0)] = order.flip(0)
+    alphas = idx[first]
+    is_cp = torch.zeros_like(particle_id, dtype=torch.bool)
+    is_cp[alphas] = True
+    return alphas, is_cp
+
+
+def condensation_loss_rg(*, beta, x, particle_id, mask, q_min=0.01,
+                         radius_threshold=1.0, max_num_neighbors=256,
+                         radius_edges: Tensor | None = None) -> dict:
+    """metrics/losses/oc.py:87-161 (the four loss terms, un-weighted)."""
+    alphas, is_cp = _condensation_points(beta, particle_id, mask)
+    q = torch.arctanh(beta) ** 2 + q_min
+    if radius_edges is None:
+        radius_edges = radius_graph(x, radius_threshold, max_num_neighbors)
+    e0, e1 = radius_edges[0], radius_edges[1]
+    # repulsive: edges whose first endpoint is a CP and that join different particles
+    keep = is_cp[e0] & (particle_id[e0] != particle_id[e1])
+    r0, r1 = e0[keep], e1[keep]
+    d2 = ((x[r0] - x[r1]) ** 2).sum(-1)
+    vr = ((radius_threshold - torch.sqrt(1e-9 + d2)) * q[r0] * q[r1]).sum()
+    # attractive: every masked non-CP hit to the CP of its particle
+    non_cp = torch.nonzero(~is_cp & mask).view(-1)
+    cp_of = alphas[torch.searchsorted(particle_id[alphas], particle_id[non_cp])]
+    va = (((x[non_cp] - x[cp_of]) ** 2).sum(-1) * q[non_cp] * q[cp_of]).sum()
+    n_hits = mask.shape[0]
+    n_oi = mask.sum()
+    K = alphas.shape[0]
+    eps = 1e-9
+    return {
+        "attractive": va / (eps + n_oi - K),
+        "repulsive": vr / (eps + (K - 1) * n_hits),
+        "coward": (1 - beta[alphas]).mean(),
+        "noise": beta[particle_id == 0].mean(),
+    }
+
+
+def condensation_loss_tiger(*, beta, x, particle_id, mask, q_min=0.01) -> dict:
+    """metrics/losses/oc.py:251-347 with ``max_n_rep=0`` (no sub-sampling) and
+    ``noise_threshold=0``: dense N x K formulation."""
+    eps = 1e-9
+    uniq = torch.unique(particle_id[mask])
+    assert uniq.numel() > 0, "No particles of interest found, cannot evaluate loss"
+    att = particle_id.view(-1, 1) == uniq.view(1, -1)          # [N,K]
+    q = torch.arctanh(beta) ** 2 + q_min
+    alphas = torch.argmax(q.view(-1, 1) * att, dim=0)           # [K]
+    qw = q.view(-1, 1) * q[alphas].view(1, -1)
+    dist = torch.cdist(x, x[alphas])
+    n_hits = mask.shape[0]
+    K = alphas.shape[0]
+    norm_rep = eps + (K - 1) * n_hits
+    norm_att = eps + mask.sum() - K
+    v_att = (qw[att] * dist[att] ** 2).sum() / norm_att
+    rep = (~att) & (dist < 1)
+    v_rep = (qw[rep] * (1 - dist[rep])).sum() / norm_rep
+    return {
+        "attractive": v_att,
+        "repulsive": v_rep,
+        "coward": (1 - beta[alphas]).mean(),
+        "noise": beta[~(particle_id > 0)].mean(),
+        "n_rep": rep.sum(),
+    }
+
+
+# ------------------------------------------------------------- training step (H)
+def ec_training_step(x, edge_index, edge_attr, y, params: dict, *, model_kwargs: dict,
+                     lr=1e-4, weight_decay=1e-4, pt=None, pt_thld=0.0):
+    """training/ec.py:33-53 + training/base.py:106-116: forward, BCE, backward, one
+    Adam step.  Returns (out, loss, grads, params_after)."""
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    out = ec_for_graph_tcn(x, edge_index, edge_attr, ps, **model_kwargs)
+    loss = edge_weight_bce_loss(out["W"], y.float(), edge_index, pt, pt_thld)
+    names = list(ps.keys())
+    grads = torch.autograd.grad(loss, [ps[n] for n in names], allow_unused=True)
+    for n, g in zip(names, grads):
+        ps[n].grad = g if g is not None else torch.zeros_like(ps[n])
+    opt = torch.optim.Adam([ps[n] for n in names], lr=lr, weight_decay=weight_decay)
+    opt.step()
+    return out, loss, {n: ps[n].grad for n in names}, {n: ps[n].detach() for n in names}

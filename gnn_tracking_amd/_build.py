@@ -1,0 +1,86 @@
+"""Build libgnntrk.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc.
+
+In-tree build: objects under ``gnn_tracking_amd/csrc/_obj``, library at
+``gnn_tracking_amd/libgnntrk.so`` (git-ignored; travels to the GPU box with the
+snapshot).  hipcc cross-compiles without a GPU.
+"""
+
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import pathlib
+import shutil
+import subprocess
+import sys
+
+PKG = pathlib.Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+INCLUDE = PKG.parent / "include"
+OBJ = CSRC / "_obj"
+LIB = PKG / "libgnntrk.so"
+ARCH = "gfx950"
+
+FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+    "-Wall", "-Wno-unused-function", "-Wno-pass-failed", f"-I{INCLUDE}", f"-I{CSRC}",
+]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and pathlib.Path(c).exists():
+            return c
+    raise RuntimeError("hipcc not found: cannot build libgnntrk.so (ROCm toolchain required)")
+
+
+def _stamp(src: pathlib.Path) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    h.update(src.read_bytes())
+    for hdr in sorted(list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))):
+        h.update(hdr.read_bytes())
+    return h.hexdigest()
+
+
+def _compile(src: pathlib.Path, verbose: bool) -> pathlib.Path:
+    obj = OBJ / (src.stem + ".o")
+    stamp = OBJ / (src.stem + ".stamp")
+    want = _stamp(src)
+    if obj.exists() and stamp.exists() and stamp.read_text() == want:
+        return obj
+    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError(f"hipcc failed on {src.name}")
+    if verbose and r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    stamp.write_text(want)
+    return obj
+
+
+def build_lib(verbose: bool = False, jobs: int | None = None) -> pathlib.Path:
+    OBJ.mkdir(parents=True, exist_ok=True)
+    srcs = sorted(CSRC.glob("*.hip"))
+    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
+    newest = max(o.stat().st_mtime for o in objs)
+    if not LIB.exists() or LIB.stat().st_mtime < newest:
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB),
+               *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link of libgnntrk.so failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(verbose=True))

@@ -1,0 +1,159 @@
+"""ctypes binding of the C ABI in ``include/gnntrk.h`` (libgnntrk.so, HIP/gfx950).
+
+This module is the only place that touches the shared library.  There is NO
+fallback: if the library cannot be loaded (not built, no ROCm runtime) every op of
+the package raises ``RuntimeError`` - the product path never computes on the CPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+import threading
+
+MAX_SEGS = 10
+MAX_IN, MAX_HIDDEN, MAX_OUT = 48, 64, 16
+EPI_NONE, EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID = 0, 1, 2, 3
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libgnntrk.so"
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("dim", C.c_int32),
+                ("stride", C.c_int32), ("relu", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("in_dim", C.c_int32), ("hidden", C.c_int32),
+                ("out_dim", C.c_int32), ("W", C.c_void_p * 3), ("b", C.c_void_p * 3)]
+
+
+class MlpFwdArgs(C.Structure):
+    _fields_ = [("mlp", Mlp), ("n_seg", C.c_int32), ("epilogue", C.c_int32),
+                ("seg", Seg * MAX_SEGS), ("n_rows", C.c_int64), ("ca", C.c_float),
+                ("cb", C.c_float), ("res", C.c_void_p), ("res_stride", C.c_int32),
+                ("out_stride", C.c_int32), ("out", C.c_void_p), ("out_idx", C.c_void_p)]
+
+
+class GTerm(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("stride", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class GSeg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("stride", C.c_int32),
+                ("accumulate", C.c_int32)]
+
+
+class MlpBwdArgs(C.Structure):
+    _fields_ = [("mlp", Mlp), ("n_seg", C.c_int32), ("epilogue", C.c_int32),
+                ("seg", Seg * MAX_SEGS), ("n_rows", C.c_int64), ("ca", C.c_float),
+                ("cb", C.c_float), ("n_gout", C.c_int32), ("accumulate_params", C.c_int32),
+                ("gout", GTerm * 2), ("gseg", GSeg * MAX_SEGS), ("gW", C.c_void_p * 3),
+                ("gb", C.c_void_p * 3)]
+
+
+class GraphIndex(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("perm", C.c_void_p),
+                ("tgt", C.c_void_p), ("src", C.c_void_p), ("rowptr_t", C.c_void_p),
+                ("rowptr_s", C.c_void_p), ("spos", C.c_void_p)]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "gnntrk_version": (C.c_int, []),
+    "gnntrk_last_error": (C.c_char_p, []),
+    "gnntrk_device_cu_count": (C.c_int, []),
+    "gnntrk_graph_index_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gnntrk_graph_index_build": (C.c_int, [_P, C.POINTER(GraphIndex), _P, C.c_size_t, _P]),
+    "gnntrk_mlp_forward": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
+    "gnntrk_mlp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
+    "gnntrk_mlp_backward": (C.c_int, [C.POINTER(MlpBwdArgs), _P, C.c_size_t, _P]),
+    "gnntrk_segment_sum": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P,
+                                     C.c_int32, C.c_int32, _P]),
+    "gnntrk_permute_rows": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32,
+                                      C.c_int32, _P]),
+    "gnntrk_axpby": (C.c_int, [C.c_float, _P, C.c_float, _P, _P, _P, C.c_int64, _P]),
+    "gnntrk_bce_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnntrk_bce_forward": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P, _P, C.c_size_t,
+                                     _P]),
+    "gnntrk_bce_backward": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    """Attach restype/argtypes for every symbol of include/gnntrk.h."""
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib: C.CDLL | None = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load libgnntrk.so (building it in-tree first if absent).  Raises loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = pathlib.Path(os.environ.get("GNNTRK_LIB", LIB_PATH))
+        if not path.exists():
+            from . import _build
+
+            _build.build_lib()
+        try:
+            lib = C.CDLL(str(path))
+        except OSError as e:
+            raise RuntimeError(
+                f"gnn_tracking_amd: cannot load the HIP extension {path}: {e}. "
+                "The package has no CPU fallback; build it with "
+                "`python -m gnn_tracking_amd._build` on a ROCm machine.") from e
+        _lib = bind(lib)
+        return _lib
+
+
+def require_device(*tensors) -> None:
+    """Every tensor handed to the library must live in GPU memory (no CPU path)."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "gnn_tracking_amd: expected a HIP/CUDA tensor, got device "
+                f"{t.device}. This package has no CPU implementation; move the data "
+                "to the GPU (the CPU reference lives in oracle/ and is test-only).")
+
+
+def check(rc: int, lib: C.CDLL | None = None) -> None:
+    """Map a C return code to the reference's Python error conventions."""
+    if rc == 0:
+        return
+    lib = lib or load()
+    msg = (lib.gnntrk_last_error() or b"").decode(errors="replace")
+    if rc == 3:
+        # utils/oom.py:12-18 matches on "out of memory"
+        raise RuntimeError(f"HIP out of memory: {msg}")
+    if rc == 4:
+        raise NotImplementedError(f"gnntrk: {msg}")
+    if rc == 1:
+        raise ValueError(f"gnntrk: {msg}")
+    raise RuntimeError(f"gnntrk: {msg} (code {rc})")
+
+
+def make_mlp(weights, biases, in_dim: int, hidden: int, out_dim: int) -> Mlp:
+    """weights/biases: sequences of raw addresses (0/None = absent)."""
+    m = Mlp()
+    m.n_layers, m.in_dim, m.hidden, m.out_dim = len(weights), in_dim, hidden, out_dim
+    for i, w in enumerate(weights):
+        m.W[i] = w
+        m.b[i] = (biases[i] or None) if biases is not None else None
+    return m

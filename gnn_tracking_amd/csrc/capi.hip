@@ -1,0 +1,121 @@
+// extern "C" surface of libgnntrk.so (include/gnntrk.h): argument plumbing, error
+// strings, device queries.  No kernels here.
+#include <stdio.h>
+#include <string.h>
+
+#include "host_util.h"
+
+// ABI layout guards: gnn_tracking_amd/_capi.py mirrors these structs with ctypes
+static_assert(sizeof(gnntrk_seg) == 32, "gnntrk_seg layout");
+static_assert(sizeof(gnntrk_mlp) == 64, "gnntrk_mlp layout");
+static_assert(sizeof(gnntrk_mlp_fwd_args) == 440, "gnntrk_mlp_fwd_args layout");
+static_assert(sizeof(gnntrk_mlp_bwd_args) == 752, "gnntrk_mlp_bwd_args layout");
+static_assert(sizeof(gnntrk_graph_index) == 64, "gnntrk_graph_index layout");
+
+namespace gnntrk {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+    return code;
+}
+
+int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return GNNTRK_OK;
+    const char *s = hipGetErrorString(e);
+    const bool oom = s && (strstr(s, "out of memory") || strstr(s, "OutOfMemory"));
+    // utils/oom.py:12-18 of the reference looks for "out of memory" in the message
+    snprintf(g_err, sizeof(g_err), "%s: HIP error: %s%s", what, s ? s : "?",
+             oom ? " (HIP out of memory)" : "");
+    return oom ? GNNTRK_ENOMEM : GNNTRK_EHIP;
+}
+
+int check_launch(const char *what) { return check_hip(hipGetLastError(), what); }
+
+int cu_count() {
+    static thread_local int cached = 0;
+    if (cached > 0) return cached;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+        n = 256;
+    cached = n;
+    return n;
+}
+
+// segment.hip
+int segment_sum_launch(const float *, int, int, const int32_t *, const int32_t *, int64_t, float *,
+                       int, int, hipStream_t);
+int permute_rows_launch(const float *, int, int, const int32_t *, int64_t, float *, int, int,
+                        hipStream_t);
+int axpby_launch(float, const float *, float, const float *, const float *, float *, int64_t,
+                 hipStream_t);
+size_t bce_ws_bytes(int64_t);
+int bce_forward_launch(const float *, const float *, const int64_t *, const float *, float, int64_t,
+                       float *, void *, size_t, hipStream_t);
+int bce_backward_launch(const float *, const float *, const int64_t *, const float *, float,
+                        int64_t, const float *, float *, hipStream_t);
+// graph_index.hip
+size_t graph_index_ws_bytes(int64_t, int64_t);
+int graph_index_build(const int64_t *, const gnntrk_graph_index *, void *, size_t, hipStream_t);
+
+}  // namespace gnntrk
+
+using namespace gnntrk;
+
+extern "C" {
+
+int gnntrk_version(void) { return GNNTRK_VERSION; }
+const char *gnntrk_last_error(void) { return g_err; }
+int gnntrk_device_cu_count(void) { return cu_count(); }
+
+size_t gnntrk_graph_index_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+    return graph_index_ws_bytes(n_nodes, n_edges);
+}
+int gnntrk_graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *out,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    return graph_index_build(edge_index, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream) {
+    return mlp_forward_launch(args, (hipStream_t)stream);
+}
+size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp) {
+    return mlp_backward_ws_bytes(mlp);
+}
+int gnntrk_mlp_backward(const gnntrk_mlp_bwd_args *args, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+    return mlp_backward_launch(args, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int gnntrk_segment_sum(const float *rows, int32_t dim, int32_t row_stride, const int32_t *rowptr,
+                       const int32_t *pos, int64_t n_segments, float *out, int32_t out_stride,
+                       int32_t accumulate, void *stream) {
+    return segment_sum_launch(rows, dim, row_stride, rowptr, pos, n_segments, out, out_stride,
+                              accumulate, (hipStream_t)stream);
+}
+int gnntrk_permute_rows(const float *in, int32_t dim, int32_t in_stride, const int32_t *idx,
+                        int64_t n_rows, float *out, int32_t out_stride, int32_t scatter,
+                        void *stream) {
+    return permute_rows_launch(in, dim, in_stride, idx, n_rows, out, out_stride, scatter,
+                               (hipStream_t)stream);
+}
+int gnntrk_axpby(float a, const float *x, float b, const float *y, const float *relu_mask,
+                 float *out, int64_t n, void *stream) {
+    return axpby_launch(a, x, b, y, relu_mask, out, n, (hipStream_t)stream);
+}
+
+size_t gnntrk_bce_workspace_bytes(int64_t n) { return bce_ws_bytes(n); }
+int gnntrk_bce_forward(const float *w, const float *y, const int64_t *src_node, const float *pt,
+                       float pt_thld, int64_t n, float *loss_out, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+    return bce_forward_launch(w, y, src_node, pt, pt_thld, n, loss_out, workspace, workspace_bytes,
+                              (hipStream_t)stream);
+}
+int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node, const float *pt,
+                        float pt_thld, int64_t n, const float *gscale, float *gw, void *stream) {
+    return bce_backward_launch(w, y, src_node, pt, pt_thld, n, gscale, gw, (hipStream_t)stream);
+}
+
+}  // extern "C"

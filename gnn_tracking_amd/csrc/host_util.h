@@ -1,0 +1,35 @@
+// Host-side helpers shared by the C-ABI translation units: thread-local last-error
+// string, launch checking, device queries.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gnntrk.h"
+
+namespace gnntrk {
+
+// records msg as the thread's last error and returns code
+int fail(int code, const char *msg);
+// hipGetLastError() -> GNNTRK_OK / GNNTRK_EHIP / GNNTRK_ENOMEM (+ message)
+int check_launch(const char *what);
+int check_hip(hipError_t e, const char *what);
+int cu_count();
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// stable LSD radix sort of (key,value) pairs on the device (sort_pairs.hip: rocPRIM)
+size_t sort_pairs_temp_bytes(int64_t n);
+int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
+                   uint32_t *vals_out, int64_t n, int end_bit, void *temp, size_t temp_bytes,
+                   hipStream_t stream);
+
+// mlp.hip
+int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);
+size_t mlp_backward_ws_bytes(const gnntrk_mlp *m);
+int mlp_backward_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes,
+                        hipStream_t stream);
+
+}  // namespace gnntrk

@@ -1,0 +1,201 @@
+// HBM-bound helper kernels: deterministic CSR segment sums (aggregation and all
+// gradient scatters), row permutations, axpby, and the BCE loss reductions.
+#include "host_util.h"
+
+namespace gnntrk {
+
+constexpr int kTpb = 256;
+
+static int stream_grid(int64_t n) {
+    int64_t g = ceil_div(n, kTpb);
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+// thread <-> (segment n, feature f); consecutive threads read consecutive floats of
+// the same CSR row, consecutive segments read adjacent row ranges: coalesced when
+// pos == NULL, L2-resident gathers otherwise.  Summation in CSR order.
+__global__ __launch_bounds__(kTpb) void segment_sum_kernel(
+    const float *__restrict__ rows, int dim, int row_stride, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ pos, int64_t n_seg, float *__restrict__ out, int out_stride,
+    int accumulate) {
+    const int64_t total = n_seg * dim;
+    for (int64_t t = (int64_t)blockIdx.x * kTpb + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * kTpb) {
+        const int64_t n = t / dim;
+        const int f = (int)(t - n * dim);
+        const int32_t k0 = rowptr[n], k1 = rowptr[n + 1];
+        float s = 0.f;
+        if (pos) {
+            for (int32_t k = k0; k < k1; ++k) s += rows[(int64_t)pos[k] * row_stride + f];
+        } else {
+            for (int32_t k = k0; k < k1; ++k) s += rows[(int64_t)k * row_stride + f];
+        }
+        float *o = out + n * out_stride + f;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+__global__ __launch_bounds__(kTpb) void permute_rows_kernel(const float *__restrict__ in, int dim,
+                                                            int in_stride,
+                                                            const int32_t *__restrict__ idx,
+                                                            int64_t n_rows, float *__restrict__ out,
+                                                            int out_stride, int scatter) {
+    const int64_t total = n_rows * dim;
+    for (int64_t t = (int64_t)blockIdx.x * kTpb + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * kTpb) {
+        const int64_t m = t / dim;
+        const int f = (int)(t - m * dim);
+        const int64_t j = idx[m];
+        if (scatter)
+            out[j * out_stride + f] = in[m * in_stride + f];
+        else
+            out[m * out_stride + f] = in[j * in_stride + f];
+    }
+}
+
+__global__ __launch_bounds__(kTpb) void axpby_kernel(float a, const float *__restrict__ x, float b,
+                                                     const float *__restrict__ y,
+                                                     const float *__restrict__ mask,
+                                                     float *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kTpb) {
+        float v = a * x[i];
+        if (y) v += b * y[i];
+        if (mask && !(mask[i] > 0.f)) v = 0.f;
+        out[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------ BCE
+__device__ __forceinline__ float bce_target(const float *y, const int64_t *src_node,
+                                            const float *pt, float thld, int64_t e) {
+    float t = y[e];
+    if (thld > 0.f) t = (t != 0.f && pt[src_node[e]] > thld) ? 1.f : 0.f;
+    return t;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < kTpb / 64; ++i) s += sh[i];
+    return s;  // valid on thread 0
+}
+
+__global__ __launch_bounds__(kTpb) void bce_partial_kernel(const float *__restrict__ w,
+                                                           const float *__restrict__ y,
+                                                           const int64_t *__restrict__ src_node,
+                                                           const float *__restrict__ pt, float thld,
+                                                           int64_t n, double *__restrict__ part) {
+    __shared__ double sh[kTpb / 64];
+    double acc = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * kTpb + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * kTpb) {
+        const float t = bce_target(y, src_node, pt, thld, e);
+        const float wi = w[e];
+        const float lw = fmaxf(logf(wi), -100.f);
+        const float l1w = fmaxf(log1pf(-wi), -100.f);
+        acc += (double)(-(t * lw + (1.f - t) * l1w));
+    }
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kTpb) void bce_final_kernel(const double *__restrict__ part, int n_part,
+                                                         int64_t n, float *__restrict__ loss) {
+    __shared__ double sh[kTpb / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += kTpb) acc += part[i];
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) loss[0] = (float)(s / (double)n);
+}
+
+__global__ __launch_bounds__(kTpb) void bce_bwd_kernel(const float *__restrict__ w,
+                                                       const float *__restrict__ y,
+                                                       const int64_t *__restrict__ src_node,
+                                                       const float *__restrict__ pt, float thld,
+                                                       int64_t n, const float *__restrict__ gscale,
+                                                       float *__restrict__ gw) {
+    const float gs = gscale[0] / (float)n;
+    for (int64_t e = (int64_t)blockIdx.x * kTpb + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * kTpb) {
+        const float t = bce_target(y, src_node, pt, thld, e);
+        const float wi = w[e];
+        gw[e] = gs * (wi - t) / fmaxf((1.f - wi) * wi, 1e-12f);
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+int segment_sum_launch(const float *rows, int dim, int row_stride, const int32_t *rowptr,
+                       const int32_t *pos, int64_t n_seg, float *out, int out_stride,
+                       int accumulate, hipStream_t stream) {
+    if (!rows || !rowptr || !out || dim < 1 || row_stride < dim || out_stride < dim || n_seg < 0)
+        return fail(GNNTRK_EINVAL, "segment_sum: bad argument");
+    if (n_seg == 0) return GNNTRK_OK;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(stream_grid(n_seg * dim)), dim3(kTpb), 0, stream,
+                       rows, dim, row_stride, rowptr, pos, n_seg, out, out_stride, accumulate);
+    return check_launch("segment_sum");
+}
+
+int permute_rows_launch(const float *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
+                        float *out, int out_stride, int scatter, hipStream_t stream) {
+    if (!in || !idx || !out || dim < 1 || in_stride < dim || out_stride < dim || n_rows < 0)
+        return fail(GNNTRK_EINVAL, "permute_rows: bad argument");
+    if (n_rows == 0) return GNNTRK_OK;
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(stream_grid(n_rows * dim)), dim3(kTpb), 0, stream,
+                       in, dim, in_stride, idx, n_rows, out, out_stride, scatter);
+    return check_launch("permute_rows");
+}
+
+int axpby_launch(float a, const float *x, float b, const float *y, const float *mask, float *out,
+                 int64_t n, hipStream_t stream) {
+    if (!x || !out || n < 0) return fail(GNNTRK_EINVAL, "axpby: bad argument");
+    if (n == 0) return GNNTRK_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(n)), dim3(kTpb), 0, stream, a, x, b, y, mask,
+                       out, n);
+    return check_launch("axpby");
+}
+
+static int bce_grid(int64_t n) {
+    int g = stream_grid(n);
+    return g > 1024 ? 1024 : g;
+}
+
+size_t bce_ws_bytes(int64_t n) {
+    (void)n;
+    return 1024 * sizeof(double);
+}
+
+int bce_forward_launch(const float *w, const float *y, const int64_t *src_node, const float *pt,
+                       float thld, int64_t n, float *loss, void *ws, size_t ws_bytes,
+                       hipStream_t stream) {
+    if (!w || !y || !loss || n < 1) return fail(GNNTRK_EINVAL, "bce_forward: bad argument");
+    if (thld > 0.f && (!src_node || !pt))
+        return fail(GNNTRK_EINVAL, "bce_forward: pt threshold needs edge_index and pt");
+    if (!ws || ws_bytes < bce_ws_bytes(n)) return fail(GNNTRK_EINVAL, "bce_forward: workspace too small");
+    const int g = bce_grid(n);
+    double *part = reinterpret_cast<double *>(ws);
+    hipLaunchKernelGGL(bce_partial_kernel, dim3(g), dim3(kTpb), 0, stream, w, y, src_node, pt, thld,
+                       n, part);
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(kTpb), 0, stream,
+                       reinterpret_cast<const double *>(part), g, n, loss);
+    return check_launch("bce_forward");
+}
+
+int bce_backward_launch(const float *w, const float *y, const int64_t *src_node, const float *pt,
+                        float thld, int64_t n, const float *gscale, float *gw, hipStream_t stream) {
+    if (!w || !y || !gscale || !gw || n < 1) return fail(GNNTRK_EINVAL, "bce_backward: bad argument");
+    if (thld > 0.f && (!src_node || !pt))
+        return fail(GNNTRK_EINVAL, "bce_backward: pt threshold needs edge_index and pt");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(stream_grid(n)), dim3(kTpb), 0, stream, w, y, src_node,
+                       pt, thld, n, gscale, gw);
+    return check_launch("bce_backward");
+}
+
+}  // namespace gnntrk

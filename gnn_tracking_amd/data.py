@@ -1,0 +1,113 @@
+"""Minimal graph container + collate with the part of the PyG ``Data`` /
+``DataLoader`` behaviour the reference's hot path relies on.
+
+The modules of this package accept ANY object exposing ``.x / .edge_index /
+.edge_attr / ...`` (a real ``torch_geometric.data.Data`` works unchanged); this class
+exists so the package, its tests and the bench run without PyG installed.
+"""
+
+from __future__ import annotations
+
+import copy
+from typing import Iterable
+
+import torch
+from torch import Tensor
+
+
+class Data:
+    """Attribute bag.  Node-level attributes have ``num_nodes`` rows, edge-level ones
+    (``edge_attr``, ``y``, names starting with ``edge_``) have ``num_edges`` rows."""
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def keys(self) -> list[str]:
+        return [k for k in self.__dict__ if not k.startswith("_")]
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def __setitem__(self, k, v):
+        setattr(self, k, v)
+
+    def __contains__(self, k) -> bool:
+        return k in self.__dict__
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.x.shape[0])
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.edge_index.shape[1])
+
+    @property
+    def num_node_features(self) -> int:
+        return int(self.x.shape[1])
+
+    @property
+    def num_edge_features(self) -> int:
+        return int(self.edge_attr.shape[1])
+
+    def _map(self, fn):
+        out = copy.copy(self)
+        for k in self.keys():
+            v = getattr(self, k)
+            if torch.is_tensor(v):
+                setattr(out, k, fn(v))
+        return out
+
+    def to(self, device, **kw):
+        return self._map(lambda t: t.to(device, **kw))
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def detach(self):
+        return self._map(lambda t: t.detach())
+
+    def is_edge_attr(self, key: str) -> bool:
+        if key == "edge_index" or "index" in key:
+            return False
+        v = getattr(self, key)
+        return (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == self.num_edges
+                and (key.startswith("edge_") or key in ("y", "ec_edge_embedding")))
+
+    def is_node_attr(self, key: str) -> bool:
+        v = getattr(self, key)
+        return (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == self.num_nodes
+                and "index" not in key and not self.is_edge_attr(key))
+
+
+def collate(graphs: Iterable[Data]) -> Data:
+    """Concatenate graphs into one disjoint graph the way PyG's ``Batch`` does:
+    node-/edge-level tensors are concatenated along dim 0, every attribute whose name
+    contains ``index`` is concatenated along dim -1 after adding the cumulative node
+    count, and ``batch`` (graph id per node) / ``ptr`` (node offsets) are added."""
+    graphs = list(graphs)
+    if not graphs:
+        raise ValueError("collate: empty list")
+    out = Data()
+    offs = [0]
+    for g in graphs:
+        offs.append(offs[-1] + g.num_nodes)
+    for k in graphs[0].keys():
+        vals = [getattr(g, k) for g in graphs]
+        if not torch.is_tensor(vals[0]):
+            setattr(out, k, vals)
+        elif "index" in k:
+            setattr(out, k, torch.cat([v + o for v, o in zip(vals, offs)], dim=-1))
+        elif vals[0].dim() == 0:
+            setattr(out, k, torch.stack(vals))
+        else:
+            setattr(out, k, torch.cat(vals, dim=0))
+    dev = graphs[0].x.device
+    out.batch = torch.cat([torch.full((g.num_nodes,), i, dtype=torch.long, device=dev)
+                           for i, g in enumerate(graphs)])
+    out.ptr = torch.tensor(offs, dtype=torch.long, device=dev)
+    return out

@@ -1,0 +1,102 @@
+"""Edge classifier ``ECForGraphTCN`` on the fused HIP kernels.
+
+Reference: models/edge_classifier.py:15-121.  Same constructor keywords, ``hparams``,
+``state_dict`` keys (``ec_node_encoder``, ``ec_edge_encoder``, ``ec_resin``, ``W``),
+``latent_dim`` and output dict ``{"W", "node_embedding", "edge_embedding"}``, so the
+YAML ``class_path`` swap is the whole integration.
+
+The whole stack runs with edges in target-sorted order: the edge encoder gathers
+``edge_attr`` through the CSR permutation while reading it, every intermediate edge
+embedding stays in CSR order, and the classification head scatters ``W`` back to the
+caller's edge order while writing it.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from . import _capi, ops
+from .hparams import HyperparametersMixin, assert_feat_dim
+from .mlp import MLP
+from .resin import ResIN
+
+
+class ECForGraphTCN(nn.Module, HyperparametersMixin):
+    def __init__(self, *, node_indim: int, edge_indim: int, interaction_node_dim: int = 5,
+                 interaction_edge_dim: int = 4, hidden_dim: int | float | None = None,
+                 L_ec: int = 3, alpha: float = 0.5, residual_type="skip1",
+                 use_intermediate_edge_embeddings: bool = True, use_node_embedding: bool = True,
+                 residual_kwargs: dict | None = None):
+        """Edge classification step of the graph track condensation network.
+
+        Args:
+            node_indim: node feature dim
+            edge_indim: edge feature dim
+            interaction_node_dim: node dimension inside the interaction networks
+            interaction_edge_dim: edge dimension inside the interaction networks
+            hidden_dim: width of all hidden layers; ``None`` = per MLP max(in, out)
+            L_ec: message passing depth
+            alpha: strength of the residual connection
+            residual_type: 'skip1', 'skip2' or 'skip_top'
+            use_intermediate_edge_embeddings: feed the edge embeddings of all levels
+                (not only the last) to the final MLP
+            use_node_embedding: feed the endpoint node embeddings to the final MLP
+            residual_kwargs: keyword arguments passed on to ``ResIN``
+        """
+        super().__init__()
+        self.save_hyperparameters()
+        residual_kwargs = dict(residual_kwargs or {})
+        residual_kwargs["collect_hidden_edge_embeds"] = use_intermediate_edge_embeddings
+        self.relu = nn.ReLU()
+        self.ec_node_encoder = MLP(node_indim, interaction_node_dim, hidden_dim=hidden_dim, L=2,
+                                   bias=False)
+        self.ec_edge_encoder = MLP(edge_indim, interaction_edge_dim, hidden_dim=hidden_dim, L=2,
+                                   bias=False)
+        self.ec_resin = ResIN(node_dim=interaction_node_dim, edge_dim=interaction_edge_dim,
+                              object_hidden_dim=hidden_dim, relational_hidden_dim=hidden_dim,
+                              alpha=alpha, n_layers=L_ec, residual_type=residual_type,
+                              residual_kwargs=residual_kwargs)
+        w_input_dim = interaction_edge_dim
+        if use_intermediate_edge_embeddings:
+            w_input_dim = self.ec_resin.concat_edge_embeddings_length
+        if use_node_embedding:
+            w_input_dim += interaction_node_dim * 2
+        self.W = MLP(input_size=w_input_dim, output_size=1, hidden_dim=hidden_dim, L=3)
+        #: node, edge dim of the space before the final MLP
+        self.latent_dim = (interaction_node_dim, interaction_edge_dim)
+
+    def forward(self, data) -> dict[str, Tensor]:
+        """``data`` exposes ``x``, ``edge_index``, ``edge_attr`` (PyG ``Data`` or any
+        attribute bag).  Returns
+
+        * ``W``: edge weights in (0.001, 0.999), order of ``edge_index``
+        * ``node_embedding``: last node embedding
+        * ``edge_embedding``: last edge embedding, order of ``edge_index``
+        """
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        assert_feat_dim(x, self.hparams.node_indim)
+        assert_feat_dim(edge_attr, self.hparams.edge_indim)
+        gi = ops.graph_index(edge_index, x.shape[0])
+        E = gi.n_edges
+
+        h = self.ec_node_encoder.fused([ops.Seg(x)], epilogue=_capi.EPI_RELU)
+        e = self.ec_edge_encoder.fused([ops.Seg(edge_attr, gi.perm, False, "perm")],
+                                       n_rows=E, epilogue=_capi.EPI_RELU)
+        h, e, es = self.ec_resin.forward_csr(gi, h, e)
+
+        segs = []
+        if self.hparams.use_node_embedding:
+            segs += [ops.Seg(h, gi.src, False, ("src", gi)), ops.Seg(h, gi.tgt, False, ("tgt", gi))]
+        if self.hparams.use_intermediate_edge_embeddings:
+            segs += [ops.Seg(t) for t in es]
+        else:
+            segs.append(ops.Seg(e))
+        eps = 0.001
+        w = self.W.fused(segs, n_rows=E, epilogue=_capi.EPI_SIGMOID, ca=eps, cb=1 - 2 * eps,
+                         out_idx=gi.perm)
+        return {
+            "W": w.squeeze(),
+            "node_embedding": h,
+            "edge_embedding": ops.permute_rows(e, gi.perm, scatter=True),
+        }

@@ -1,0 +1,464 @@
+"""Tensor-level operators of the hot path: thin, autograd-aware wrappers over the C ABI.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); all arithmetic
+happens in the hand-written HIP kernels of ``libgnntrk.so``.
+
+Operators
+---------
+``GraphIndex`` / ``graph_index(edge_index, n_nodes)``
+    target-sorted (CSR) + source-sorted view of a COO ``edge_index``; replaces the
+    gather/scatter bookkeeping of PyG ``MessagePassing.propagate``
+    (reference ``models/interaction_network.py:67``).
+``fused_mlp(segs, weights, biases, ...)``
+    gather + concat + (2|3)-layer MLP + epilogue in one kernel, custom backward with
+    recompute (``models/mlp.py:59-62`` and its call sites).
+``segment_sum(rows, gi, by)``
+    per-node sum of edge rows (PyG ``aggr="add"``), deterministic.
+``permute_rows(x, idx, scatter)``
+    COO order <-> CSR order of edge tensors.
+``bce_loss(w, y, ...)``
+    ``metrics/losses/ec.py:95-121``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import weakref
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _capi
+
+__all__ = [
+    "GraphIndex", "graph_index", "Seg", "fused_mlp", "segment_sum", "permute_rows",
+    "axpby", "bce_loss",
+]
+
+
+def _stream(t: Tensor):
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None  # only reachable in the emulator tests (tests/emul)
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _as_rows(t: Tensor) -> Tensor:
+    """[M] -> [M,1]; make the feature axis dense (row stride may be anything)."""
+    if t.dim() == 1:
+        t = t.unsqueeze(1)
+    if t.dim() != 2:
+        raise ValueError(f"expected a 1-D or 2-D tensor, got shape {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"gnn_tracking_amd kernels are fp32; got {t.dtype}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _row_stride(t: Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def _ws(nbytes: int, like: Tensor) -> Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+# ------------------------------------------------------------------ graph index
+@dataclasses.dataclass
+class GraphIndex:
+    """Device-resident index of one COO edge list (see include/gnntrk.h)."""
+
+    n_nodes: int
+    n_edges: int
+    perm: Tensor      # [E] int32: CSR position -> original edge id
+    tgt: Tensor       # [E] int32 targets in CSR order (sorted)
+    src: Tensor       # [E] int32 sources in CSR order
+    rowptr_t: Tensor  # [N+1] int32
+    rowptr_s: Tensor  # [N+1] int32
+    spos: Tensor      # [E] int32: source-sorted order -> CSR position
+
+
+_GI_CACHE: dict[int, tuple] = {}
+
+
+def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True) -> GraphIndex:
+    """Build (or fetch) the index of ``edge_index`` ([2,E] int64, unsorted COO).
+
+    Cached per tensor OBJECT (weakref + version counter), so the L layers of a
+    ResIN stack and the forward/backward of one step share one build.
+    """
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
+    if edge_index.dtype != torch.int64:
+        raise TypeError("edge_index must be int64 (PyG convention)")
+    _capi.require_device(edge_index)
+    key = id(edge_index)
+    if cache:
+        hit = _GI_CACHE.get(key)
+        if hit is not None:
+            ref, ver, nn, gi = hit
+            if ref() is edge_index and ver == edge_index._version and nn == n_nodes:
+                return gi
+    lib = _capi.load()
+    ei = edge_index.contiguous()
+    E = int(ei.shape[1])
+    dev = ei.device
+    mk = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
+    gi = GraphIndex(n_nodes, E, mk(E), mk(E), mk(E), mk(n_nodes + 1), mk(n_nodes + 1), mk(E))
+    d = _capi.GraphIndex(n_nodes, E, _p(gi.perm), _p(gi.tgt), _p(gi.src), _p(gi.rowptr_t),
+                         _p(gi.rowptr_s), _p(gi.spos))
+    ws = _ws(lib.gnntrk_graph_index_workspace_bytes(n_nodes, E), ei)
+    _capi.check(lib.gnntrk_graph_index_build(_p(ei), C.byref(d), _p(ws), ws.numel(),
+                                             _stream(ei)), lib)
+    if cache:
+        if len(_GI_CACHE) > 16:
+            for k in [k for k, v in _GI_CACHE.items() if v[0]() is None]:
+                _GI_CACHE.pop(k, None)
+            while len(_GI_CACHE) > 16:
+                _GI_CACHE.pop(next(iter(_GI_CACHE)))
+        _GI_CACHE[key] = (weakref.ref(edge_index), edge_index._version, n_nodes, gi)
+    return gi
+
+
+# ---------------------------------------------------------------- plain helpers
+def _segment_sum_raw(rows: Tensor, rowptr: Tensor, pos: Optional[Tensor], n_seg: int,
+                     out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    lib = _capi.load()
+    rows = _as_rows(rows)
+    dim = rows.shape[1]
+    if out is None:
+        out = torch.empty(n_seg, dim, dtype=torch.float32, device=rows.device)
+        accumulate = False
+    _capi.check(lib.gnntrk_segment_sum(_p(rows), dim, _row_stride(rows), _p(rowptr), _p(pos),
+                                       n_seg, _p(out), _row_stride(out), int(accumulate),
+                                       _stream(rows)), lib)
+    return out
+
+
+def _permute_raw(x: Tensor, idx: Tensor, scatter: bool) -> Tensor:
+    lib = _capi.load()
+    x2 = _as_rows(x)
+    m = int(idx.shape[0])  # gather: rows of the result; scatter: idx is a permutation of them
+    if scatter and m != x2.shape[0]:
+        raise ValueError("permute_rows(scatter): idx must be a permutation of the rows")
+    out = torch.empty(m, x2.shape[1], dtype=torch.float32, device=x2.device)
+    _capi.check(lib.gnntrk_permute_rows(_p(x2), x2.shape[1], _row_stride(x2), _p(idx), m,
+                                        _p(out), _row_stride(out), int(scatter),
+                                        _stream(x2)), lib)
+    return out.view(-1) if x.dim() == 1 else out
+
+
+def _axpby_raw(a: float, x: Tensor, b: float = 0.0, y: Optional[Tensor] = None,
+               relu_mask: Optional[Tensor] = None) -> Tensor:
+    lib = _capi.load()
+    x = x.contiguous()
+    y = None if y is None else y.contiguous()
+    relu_mask = None if relu_mask is None else relu_mask.contiguous()
+    out = torch.empty_like(x)
+    _capi.check(lib.gnntrk_axpby(a, _p(x), b, _p(y), _p(relu_mask), _p(out), x.numel(),
+                                 _stream(x)), lib)
+    return out
+
+
+class _SegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, gi: GraphIndex, by: str):
+        _capi.require_device(rows)
+        ctx.gi, ctx.by = gi, by
+        if by == "tgt":
+            return _segment_sum_raw(rows, gi.rowptr_t, None, gi.n_nodes)
+        if by == "src":
+            return _segment_sum_raw(rows, gi.rowptr_s, gi.spos, gi.n_nodes)
+        raise ValueError(by)
+
+    @staticmethod
+    def backward(ctx, g):
+        # d/d rows[k] = g[node_of(k)]: a row gather by the CSR endpoint
+        gi = ctx.gi
+        idx = gi.tgt if ctx.by == "tgt" else gi.src
+        return _permute_raw(g.contiguous(), idx, scatter=False), None, None
+
+
+def segment_sum(rows: Tensor, gi: GraphIndex, by: str = "tgt") -> Tensor:
+    """``out[n] = sum of rows[k] over CSR positions k whose target (source) is n``.
+    ``rows`` must be in CSR order.  PyG ``aggr="add"`` (interaction_network.py:36)."""
+    return _SegmentSum.apply(rows, gi, by)
+
+
+class _PermuteRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, scatter: bool):
+        _capi.require_device(x)
+        ctx.idx, ctx.scatter = idx, scatter
+        return _permute_raw(x, idx, scatter)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _permute_raw(g.contiguous(), ctx.idx, not ctx.scatter), None, None
+
+
+def permute_rows(x: Tensor, idx: Tensor, scatter: bool = False) -> Tensor:
+    """gather: ``out[m] = x[idx[m]]``; scatter: ``out[idx[m]] = x[m]`` (idx a permutation)."""
+    return _PermuteRows.apply(x, idx, scatter)
+
+
+class _Axpby(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, a: float, b: float):
+        _capi.require_device(x, y)
+        ctx.a, ctx.b = a, b
+        return _axpby_raw(a, x, b, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return _axpby_raw(ctx.a, g), _axpby_raw(ctx.b, g), None, None
+
+
+def axpby(a: float, x: Tensor, b: float, y: Tensor) -> Tensor:
+    return _Axpby.apply(x, y, a, b)
+
+
+# -------------------------------------------------------------------- fused MLP
+@dataclasses.dataclass
+class Seg:
+    """One concat segment of a fused-MLP input.
+
+    ``t``      source rows ``[R, dim]`` (or ``[R]``)
+    ``idx``    int32 ``[M]`` row gather (None: row m of the op reads row m of ``t``)
+    ``relu``   ReLU applied on load (resin.py:103-104)
+    ``reduce`` how the backward folds per-row gradients onto ``t``:
+               None (identity rows), "perm" (idx is a permutation), or
+               ("tgt"|"src", GraphIndex) for node rows gathered by CSR endpoint.
+    """
+
+    t: Tensor
+    idx: Optional[Tensor] = None
+    relu: bool = False
+    reduce: object = None
+
+
+@dataclasses.dataclass
+class _MlpSpec:
+    n_seg: int
+    n_layers: int
+    has_bias: bool
+    idx: list
+    relu: list
+    reduce: list
+    epilogue: int
+    ca: float
+    cb: float
+    out_idx: Optional[Tensor]
+    out_rows: int
+    n_rows: int
+
+
+def _fill_mlp(weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]]):
+    n_layers = len(weights)
+    hidden = weights[0].shape[0]
+    in_dim = weights[0].shape[1]
+    out_dim = weights[-1].shape[0]
+    if n_layers not in (2, 3):
+        raise NotImplementedError(
+            f"fused MLP kernels cover L=2 and L=3 (the reference's uses); got L={n_layers}")
+    for i, w in enumerate(weights):
+        exp = (hidden if i < n_layers - 1 else out_dim, in_dim if i == 0 else hidden)
+        if tuple(w.shape) != exp:
+            raise ValueError(f"layer {i} weight has shape {tuple(w.shape)}, expected {exp}")
+    if in_dim > _capi.MAX_IN or hidden > _capi.MAX_HIDDEN or out_dim > _capi.MAX_OUT:
+        raise NotImplementedError(
+            f"fused MLP kernel limits: in<={_capi.MAX_IN}, hidden<={_capi.MAX_HIDDEN}, "
+            f"out<={_capi.MAX_OUT}; got in={in_dim}, hidden={hidden}, out={out_dim}")
+    return _capi.make_mlp([_p(w) for w in weights], [_p(b) for b in biases], in_dim, hidden,
+                          out_dim)
+
+
+class _FusedMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec: _MlpSpec, *tensors):
+        ns, nl = spec.n_seg, spec.n_layers
+        segs = [_as_rows(t) for t in tensors[:ns]]
+        weights = [w.contiguous() for w in tensors[ns:ns + nl]]
+        biases = [None if b is None else b.contiguous() for b in tensors[ns + nl:ns + 2 * nl]]
+        res = tensors[ns + 2 * nl]
+        _capi.require_device(*segs, *weights)
+        lib = _capi.load()
+        a = _capi.MlpFwdArgs()
+        a.mlp = _fill_mlp(weights, biases)
+        if sum(s.shape[1] for s in segs) != a.mlp.in_dim:
+            raise AssertionError(
+                f"Expected feature dimension {a.mlp.in_dim}, got {sum(s.shape[1] for s in segs)}")
+        a.n_seg, a.epilogue, a.n_rows = ns, spec.epilogue, spec.n_rows
+        for j, s in enumerate(segs):
+            a.seg[j] = _capi.Seg(_p(s), _p(spec.idx[j]), s.shape[1], _row_stride(s),
+                                 int(spec.relu[j]), 0)
+        a.ca, a.cb = spec.ca, spec.cb
+        if spec.epilogue == _capi.EPI_RESIDUAL:
+            res = _as_rows(res)
+            a.res, a.res_stride = _p(res), _row_stride(res)
+        out = torch.empty(spec.out_rows, a.mlp.out_dim, dtype=torch.float32,
+                          device=segs[0].device)
+        a.out, a.out_stride, a.out_idx = _p(out), _row_stride(out), _p(spec.out_idx)
+        _capi.check(lib.gnntrk_mlp_forward(C.byref(a), _stream(out)), lib)
+        ctx.spec = spec
+        ctx.save_for_backward(*segs, *weights, *[b for b in biases if b is not None])
+        ctx.bias_mask = [b is not None for b in biases]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        spec: _MlpSpec = ctx.spec
+        ns, nl = spec.n_seg, spec.n_layers
+        saved = ctx.saved_tensors
+        segs, weights = list(saved[:ns]), list(saved[ns:ns + nl])
+        bl = list(saved[ns + nl:])
+        biases = [bl.pop(0) if m else None for m in ctx.bias_mask]
+        lib = _capi.load()
+        g_out = _as_rows(g_out.contiguous())
+        dev = g_out.device
+        a = _capi.MlpBwdArgs()
+        a.mlp = _fill_mlp(weights, biases)
+        a.n_seg, a.epilogue, a.n_rows = ns, spec.epilogue, spec.n_rows
+        a.ca, a.cb = spec.ca, spec.cb
+        for j, s in enumerate(segs):
+            a.seg[j] = _capi.Seg(_p(s), _p(spec.idx[j]), s.shape[1], _row_stride(s),
+                                 int(spec.relu[j]), 0)
+        a.n_gout = 1
+        a.gout[0] = _capi.GTerm(_p(g_out), _p(spec.out_idx), _row_stride(g_out), 0)
+
+        need = ctx.needs_input_grad  # [spec, segs..., W..., b..., res]
+        M = spec.n_rows
+        seg_grads: list[Optional[Tensor]] = [None] * ns
+        row_tmp: list[Optional[Tensor]] = [None] * ns
+        for j, s in enumerate(segs):
+            if not need[1 + j]:
+                continue
+            red = spec.reduce[j]
+            if spec.idx[j] is None:
+                gj = torch.empty(s.shape[0], s.shape[1], dtype=torch.float32, device=dev)
+                if s.shape[0] != M:
+                    gj.zero_()
+                seg_grads[j] = gj
+                a.gseg[j] = _capi.GSeg(_p(gj), None, _row_stride(gj), 0)
+            elif red == "perm":
+                gj = torch.empty(s.shape[0], s.shape[1], dtype=torch.float32, device=dev)
+                if s.shape[0] != M:
+                    gj.zero_()
+                seg_grads[j] = gj
+                a.gseg[j] = _capi.GSeg(_p(gj), _p(spec.idx[j]), _row_stride(gj), 0)
+            else:
+                if red is None:
+                    raise RuntimeError("gathered segment requires a `reduce` rule for backward")
+                tmp = torch.empty(M, s.shape[1], dtype=torch.float32, device=dev)
+                row_tmp[j] = tmp
+                a.gseg[j] = _capi.GSeg(_p(tmp), None, _row_stride(tmp), 0)
+
+        want_dw = any(need[1 + ns:1 + ns + 2 * nl])
+        gW = [None] * nl
+        gb = [None] * nl
+        ws = None
+        if want_dw:
+            gW = [torch.empty_like(w) for w in weights]
+            gb = [None if b is None else torch.empty_like(b) for b in biases]
+            for i in range(nl):
+                a.gW[i] = _p(gW[i])
+                a.gb[i] = _p(gb[i])
+            ws = _ws(lib.gnntrk_mlp_backward_workspace_bytes(C.byref(a.mlp)), g_out)
+        a.accumulate_params = 0
+        _capi.check(lib.gnntrk_mlp_backward(C.byref(a), _p(ws), 0 if ws is None else ws.numel(),
+                                            _stream(g_out)), lib)
+
+        # fold gathered row gradients onto their source rows (deterministic CSR sums)
+        for j, s in enumerate(segs):
+            if row_tmp[j] is None:
+                continue
+            by, gi = spec.reduce[j]
+            rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
+            seg_grads[j] = _segment_sum_raw(row_tmp[j], rowptr, pos, s.shape[0])
+
+        g_res = None
+        if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
+            g_dense = g_out if spec.out_idx is None else _permute_raw(g_out, spec.out_idx, False)
+            g_res = _axpby_raw(spec.ca, g_dense.contiguous())
+        outs = [None, *seg_grads]
+        outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
+        outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
+        outs.append(g_res)
+        return tuple(outs)
+
+
+def fused_mlp(segs: Sequence[Seg], weights: Sequence[Tensor],
+              biases: Sequence[Optional[Tensor]], *, n_rows: Optional[int] = None,
+              epilogue: int = _capi.EPI_NONE, ca: float = 0.0, cb: float = 1.0,
+              res: Optional[Tensor] = None, out_idx: Optional[Tensor] = None,
+              out_rows: Optional[int] = None) -> Tensor:
+    """``epilogue( MLP( concat_j act_j(gather_j(seg_j)) ) )`` -> ``[out_rows, out_dim]``."""
+    if not 1 <= len(segs) <= _capi.MAX_SEGS:
+        raise ValueError(f"1..{_capi.MAX_SEGS} segments supported, got {len(segs)}")
+    if n_rows is None:
+        s0 = segs[0]
+        n_rows = int(s0.idx.shape[0]) if s0.idx is not None else int(s0.t.shape[0])
+    for s in segs:
+        if s.t.dim() == 1:
+            raise ValueError("fused_mlp segments must be 2-D [rows, dim]")
+    spec = _MlpSpec(len(segs), len(weights), any(b is not None for b in biases),
+                    [s.idx for s in segs], [s.relu for s in segs], [s.reduce for s in segs],
+                    epilogue, float(ca), float(cb), out_idx,
+                    int(out_rows if out_rows is not None else n_rows), int(n_rows))
+    return _FusedMLP.apply(spec, *[s.t for s in segs], *weights, *biases, res)
+
+
+# -------------------------------------------------------------------------- BCE
+class _BCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, y, src_nodes, pt, pt_thld: float):
+        _capi.require_device(w, y)
+        lib = _capi.load()
+        w = w.contiguous().view(-1)
+        y = y.contiguous().view(-1)
+        n = w.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=w.device)
+        ws = _ws(lib.gnntrk_bce_workspace_bytes(n), w)
+        _capi.check(lib.gnntrk_bce_forward(_p(w), _p(y), _p(src_nodes), _p(pt), pt_thld, n,
+                                           _p(loss), _p(ws), ws.numel(), _stream(w)), lib)
+        ctx.save_for_backward(w, y)
+        ctx.aux = (src_nodes, pt, pt_thld)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _capi.load()
+        w, y = ctx.saved_tensors
+        src_nodes, pt, thld = ctx.aux
+        g = g.contiguous().view(1).to(torch.float32)
+        gw = torch.empty_like(w)
+        _capi.check(lib.gnntrk_bce_backward(_p(w), _p(y), _p(src_nodes), _p(pt), thld, w.numel(),
+                                            _p(g), _p(gw), _stream(w)), lib)
+        return gw, None, None, None, None
+
+
+def bce_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None,
+             pt: Optional[Tensor] = None, pt_thld: float = 0.0) -> Tensor:
+    """mean BCE(w, y') with y' = falsify_low_pt_edges(y) (metrics/losses/ec.py:71-121)."""
+    if w.numel() == 0:
+        raise ValueError("bce_loss: empty input")
+    if w.dtype != torch.float32:
+        raise TypeError("bce_loss: w must be fp32")
+    y = y.to(torch.float32)
+    src_nodes = None
+    if pt_thld > 0.0:
+        assert edge_index is not None and pt is not None
+        src_nodes = edge_index[0].contiguous()
+        pt = pt.to(torch.float32).contiguous()
+    else:
+        pt = None
+    return _BCE.apply(w, y, src_nodes, pt, float(pt_thld))

@@ -1,0 +1,237 @@
+/*
+ * gnntrk.h - C ABI of libgnntrk.so: the MI355X (gfx950) native hot path of
+ * gnn_tracking's Interaction-Network edge classification, kNN graph construction
+ * and object-condensation loss reductions.
+ *
+ * This is the drop-in boundary.  The reference is pure Python; the "FFI" its hot
+ * path reaches is ATen / PyG / torch_cluster.  Every entry
+ * point below replaces one group of those calls and cites the reference call site
+ * (paths relative to /root/reference/src/gnn_tracking).  The Python side
+ * (gnn_tracking_amd/_capi.py) binds these with ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless noted;
+ *    the library never allocates or frees caller memory: scratch is a caller
+ *    workspace whose size comes from the matching *_workspace_bytes() query.
+ *  - every call is asynchronous on the given HIP stream (`stream` is a
+ *    hipStream_t passed as void*; NULL = default stream) and stateless/re-entrant.
+ *  - return value: 0 ok, 1 bad argument, 2 HIP runtime error, 3 out of memory
+ *    (message contains "out of memory" so utils/oom.py:12-18 keeps working),
+ *    4 unsupported size.  gnntrk_last_error() returns the thread-local message.
+ *  - floating point data is fp32 row-major; indices produced by the library are
+ *    int32 (graphs up to 2^31-1 nodes/edges), indices consumed from the reference
+ *    surface (`edge_index`, `particle_id`) are int64 exactly as PyG stores them.
+ */
+#ifndef GNNTRK_H
+#define GNNTRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNTRK_VERSION 100 /* 0.1.0 */
+#define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
+#define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
+#define GNNTRK_MAX_HIDDEN 64
+#define GNNTRK_MAX_OUT 16
+
+enum {
+    GNNTRK_OK = 0,
+    GNNTRK_EINVAL = 1,
+    GNNTRK_EHIP = 2,
+    GNNTRK_ENOMEM = 3,
+    GNNTRK_EUNSUPPORTED = 4
+};
+
+int gnntrk_version(void);
+const char *gnntrk_last_error(void);
+/* number of compute units of the current device (grid sizing; 256 on MI355X) */
+int gnntrk_device_cu_count(void);
+
+/* ------------------------------------------------------------------ graph index
+ * Replaces the bookkeeping PyG's MessagePassing.propagate does per call
+ * (models/interaction_network.py:67: x_j = x[edge_index[0]], x_i = x[edge_index[1]],
+ * scatter-add onto edge_index[1]) by a one-off index of the COO edge list:
+ *
+ *   perm[k]      original edge id of the k-th edge in target-sorted ("CSR") order;
+ *                the sort is STABLE, so edges of one target keep their COO order
+ *   tgt[k],src[k] endpoints of that edge (int32)
+ *   rowptr_t[n]  first CSR position whose target is n          (N+1 entries)
+ *   rowptr_s[n]  same for the source-sorted order              (N+1 entries)
+ *   spos[m]      CSR position of the m-th edge in source-sorted order (stable)
+ *
+ * With it, aggregation and all gradient scatters become deterministic segment
+ * sums (no atomics).  edge_index is int64 [2,E] row-major, unsorted.
+ */
+typedef struct gnntrk_graph_index {
+    int64_t n_nodes;
+    int64_t n_edges;
+    int32_t *perm;     /* [E]   */
+    int32_t *tgt;      /* [E]   */
+    int32_t *src;      /* [E]   */
+    int32_t *rowptr_t; /* [N+1] */
+    int32_t *rowptr_s; /* [N+1] */
+    int32_t *spos;     /* [E]   */
+} gnntrk_graph_index;
+
+size_t gnntrk_graph_index_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int gnntrk_graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *out,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------- fused gather-MLP
+ * One kernel family replaces, for every MLP site of the path
+ * (models/mlp.py:59-62 = addmm + clamp_min chain):
+ *   - the gathers feeding it (index_select via PyG _lift, interaction_network.py:67;
+ *     h_ec[edge_index[k]], edge_classifier.py:112-113),
+ *   - the torch.cat that builds its input (interaction_network.py:86, :102;
+ *     edge_classifier.py:110,114),
+ *   - the ReLU applied to its inputs by the residual stack (resin.py:103-104),
+ *   - its epilogue (residual combination resin.py:17-26; ReLU of the encoders
+ *     edge_classifier.py:102-103; clamped sigmoid edge_classifier.py:115-116).
+ *
+ * Input row m of the MLP is the concatenation over segments j of
+ *     act_j( seg[j].ptr[ (seg[j].idx ? seg[j].idx[m] : m) * seg[j].stride + 0..dim ) )
+ * Weights are nn.Linear layout [out,in] row-major fp32; bias pointers may be NULL
+ * (bias=False encoders, edge_classifier.py:62-67).  n_layers = 2 or 3
+ * (Linear-ReLU-Linear[-ReLU-Linear]); hidden <= 64, in <= 48, out <= 16.
+ */
+typedef struct gnntrk_seg {
+    const float *ptr;   /* [rows, stride]                                        */
+    const int32_t *idx; /* [M] row gather index, or NULL for identity            */
+    int32_t dim;        /* number of features taken from each row                */
+    int32_t stride;     /* row stride in floats                                  */
+    int32_t relu;       /* apply ReLU to the loaded values                       */
+    int32_t _pad;
+} gnntrk_seg;
+
+typedef struct gnntrk_mlp {
+    int32_t n_layers; /* 2 or 3 */
+    int32_t in_dim;   /* must equal the sum of segment dims */
+    int32_t hidden;
+    int32_t out_dim;
+    const float *W[3];
+    const float *b[3]; /* NULL = no bias */
+} gnntrk_mlp;
+
+enum {
+    GNNTRK_EPI_NONE = 0,     /* y                                                 */
+    GNNTRK_EPI_RELU = 1,     /* relu(y)                                           */
+    GNNTRK_EPI_RESIDUAL = 2, /* ca * res[m] + cb * y        (resin.py:26)         */
+    GNNTRK_EPI_SIGMOID = 3   /* ca + cb * sigmoid(y)        (edge_classifier:116) */
+};
+
+typedef struct gnntrk_mlp_fwd_args {
+    gnntrk_mlp mlp;
+    int32_t n_seg;
+    int32_t epilogue;
+    gnntrk_seg seg[GNNTRK_MAX_SEGS];
+    int64_t n_rows; /* M */
+    float ca, cb;
+    const float *res; /* [M, res_stride] residue rows (EPI_RESIDUAL)              */
+    int32_t res_stride;
+    int32_t out_stride;
+    float *out;             /* [*, out_stride]; row m is written at out_idx[m] or m */
+    const int32_t *out_idx; /* optional row scatter (a permutation)               */
+} gnntrk_mlp_fwd_args;
+
+int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream);
+
+/* Backward of the same fused op with full recompute (nothing but the op inputs is
+ * saved): replaces autograd's index_add_ / mm / threshold_backward chain
+ * (training/base.py:114-116).
+ *
+ * Upstream gradient of output row m, feature f:
+ *     g[m][f] = sum_t gout[t].ptr[(gout[t].idx ? gout[t].idx[m] : m)*gout[t].stride + f]
+ * (two terms let the relational model add "direct" and "through aggr" gradients
+ * without materialising their sum).  The epilogue is differentiated inside.
+ *
+ * Per-row input gradients are written row-aligned: for segment j, if
+ * gseg[j].ptr != NULL, row m of the segment's gradient slice goes to
+ *     gseg[j].ptr[(gseg[j].idx ? gseg[j].idx[m] : m) * gseg[j].stride + 0..dim)
+ * (= or += per gseg[j].accumulate; ReLU masks of the segment are applied).
+ * Gathered segments are reduced onto their source rows afterwards with
+ * gnntrk_segment_sum (deterministic).  gres (EPI_RESIDUAL) is NOT produced here:
+ * it is ca * g, an elementwise op of the caller.
+ *
+ * Weight/bias gradients are accumulated per wave in registers, written as partials
+ * into the workspace and reduced in a fixed order into gW[i]/gb[i]
+ * (+= when accumulate_params, else =): bit-reproducible run to run.
+ */
+typedef struct gnntrk_gterm {
+    const float *ptr;
+    const int32_t *idx;
+    int32_t stride;
+    int32_t _pad;
+} gnntrk_gterm;
+
+typedef struct gnntrk_gseg {
+    float *ptr;
+    const int32_t *idx;
+    int32_t stride;
+    int32_t accumulate;
+} gnntrk_gseg;
+
+typedef struct gnntrk_mlp_bwd_args {
+    gnntrk_mlp mlp;
+    int32_t n_seg;
+    int32_t epilogue;
+    gnntrk_seg seg[GNNTRK_MAX_SEGS];
+    int64_t n_rows;
+    float ca, cb;
+    int32_t n_gout; /* 1 or 2 */
+    int32_t accumulate_params;
+    gnntrk_gterm gout[2];
+    gnntrk_gseg gseg[GNNTRK_MAX_SEGS];
+    float *gW[3]; /* may be NULL: skip parameter gradients of that layer */
+    float *gb[3];
+} gnntrk_mlp_bwd_args;
+
+size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp);
+int gnntrk_mlp_backward(const gnntrk_mlp_bwd_args *args, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* --------------------------------------------------------------- segment sums
+ * out[n][0..dim) (=|+=) sum_{k in [rowptr[n], rowptr[n+1])} rows[(pos ? pos[k] : k)][0..dim)
+ * Replaces ATen scatter_add_ (PyG SumAggregation, interaction_network.py:36,67) in
+ * the forward, and index_add_ in the backward of the gathers.  Summation order is
+ * the CSR order (= COO order per target): deterministic.
+ */
+int gnntrk_segment_sum(const float *rows, int32_t dim, int32_t row_stride,
+                       const int32_t *rowptr, const int32_t *pos, int64_t n_segments,
+                       float *out, int32_t out_stride, int32_t accumulate, void *stream);
+
+/* out[m][0..dim) = in[idx[m]][0..dim)  (gather, scatter=0)  or
+ * out[idx[m]][0..dim) = in[m][0..dim)  (scatter=1; idx must be a permutation).      */
+int gnntrk_permute_rows(const float *in, int32_t dim, int32_t in_stride, const int32_t *idx,
+                        int64_t n_rows, float *out, int32_t out_stride, int32_t scatter,
+                        void *stream);
+
+/* out = a*x + b*y elementwise (n floats); y may be NULL (then out = a*x).
+ * relu_mask (optional, n floats): out is zeroed where relu_mask <= 0.               */
+int gnntrk_axpby(float a, const float *x, float b, const float *y, const float *relu_mask,
+                 float *out, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------ BCE loss
+ * metrics/losses/ec.py:71-121: mean binary cross entropy of edge weights w in
+ * (0,1) against y (float 0/1) with torch's log clamp at -100; optional
+ * falsify_low_pt_edges: y' = y && pt[src_node[e]] > pt_thld (pt_thld <= 0: off).
+ * loss_out: 1 float (device).  workspace >= gnntrk_bce_workspace_bytes().
+ * backward: gw[e] = gscale[0] * d/dw mean-BCE  (gscale: 1 device float, the
+ * upstream gradient of the scalar loss).
+ */
+size_t gnntrk_bce_workspace_bytes(int64_t n);
+int gnntrk_bce_forward(const float *w, const float *y, const int64_t *src_node,
+                       const float *pt, float pt_thld, int64_t n, float *loss_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
+                        const float *pt, float pt_thld, int64_t n, const float *gscale,
+                        float *gw, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNTRK_H */

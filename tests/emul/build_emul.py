@@ -1,0 +1,55 @@
+"""Compile the product kernel sources with g++ against the wave64 emulator shim.
+
+TEST INFRASTRUCTURE ONLY (see tests/emul/shim/hip/hip_runtime.h).  Output:
+tests/emul/_build/libgnntrk_emul[_asan].so with the same C ABI as libgnntrk.so,
+operating on host pointers.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import pathlib
+import subprocess
+import sys
+
+HERE = pathlib.Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+CSRC = REPO / "gnn_tracking_amd" / "csrc"
+OUT = HERE / "_build"
+SKIP = {"sort_pairs.hip"}  # rocPRIM unit; emul_runtime.cpp provides the host sort
+
+
+def build(asan: bool = False, verbose: bool = False) -> pathlib.Path:
+    OUT.mkdir(exist_ok=True)
+    name = "libgnntrk_emul_asan.so" if asan else "libgnntrk_emul.so"
+    lib = OUT / name
+    srcs = [s for s in sorted(CSRC.glob("*.hip")) if s.name not in SKIP]
+    deps = srcs + sorted(CSRC.glob("*.h")) + sorted((REPO / "include").glob("*.h")) + [
+        HERE / "shim/hip/hip_runtime.h", HERE / "emul_runtime.cpp"]
+    h = hashlib.sha256()
+    for d in deps:
+        h.update(d.read_bytes())
+    stamp = OUT / (name + ".stamp")
+    if lib.exists() and stamp.exists() and stamp.read_text() == h.hexdigest():
+        return lib
+    flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+             "-Wno-attributes", "-Wno-unknown-pragmas", "-Wno-ignored-attributes",
+             f"-I{HERE / 'shim'}", f"-I{REPO / 'include'}", f"-I{CSRC}"]
+    if asan:
+        flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    cmd = ["g++", *flags]
+    for s in srcs:
+        cmd += ["-x", "c++", str(s)]
+    cmd += ["-x", "c++", str(HERE / "emul_runtime.cpp"), "-o", str(lib)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("emulator build failed")
+    stamp.write_text(h.hexdigest())
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(asan="--asan" in sys.argv, verbose=True))

@@ -1,0 +1,213 @@
+"""Parity cases shared by the emulator tests (CPU, kernel sources on the wave64
+emulator) and the GPU tests (real MI355X through libgnntrk.so).  Each case builds the
+package's modules on ``device``, runs them, and compares with the committed golden
+vectors (generated from the reference itself by oracle/make_golden.py) and/or the CPU
+oracle.  Tolerances: outputs 1e-5 absolute-relative (north_star), gradients 1e-4."""
+
+from __future__ import annotations
+
+import pathlib
+
+import numpy as np
+import torch
+
+import gnn_tracking_amd as G
+from gnn_tracking_amd import ops
+import ref_cpu as O
+
+GOLD = pathlib.Path(__file__).resolve().parent / "golden"
+TOL_OUT = 1e-5
+TOL_GRAD = 1e-4
+
+
+def load(name):
+    return np.load(GOLD / name)
+
+
+def tt(a, device=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t if device is None else t.to(device)
+
+
+def assert_close(a, b, tol, what):
+    a = a.detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    if a.numel() == 0:
+        return
+    assert torch.isfinite(a).all(), f"{what}: non-finite values"
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, f"{what}: max|diff| {err:.3e} > {tol:.0e} * {scale:.3g}"
+
+
+def load_params(module, z, prefix):
+    sd = {k[len(prefix):]: tt(z[k]) for k in z.files if k.startswith(prefix)}
+    missing = module.load_state_dict(sd, strict=True)
+    return sd
+
+
+# --------------------------------------------------------------------- cases
+def case_graph_index(device):
+    g = np.random.default_rng(0)
+    for N, E in ((1, 0), (5, 1), (50, 300), (1000, 20000)):
+        ei = tt(g.integers(0, N, size=(2, E)), device).long()
+        gi = ops.graph_index(ei, N, cache=False)
+        eic = ei.cpu()
+        order = torch.argsort(eic[1], stable=True)
+        assert torch.equal(gi.perm.cpu().long(), order), "perm is the stable target sort"
+        assert torch.equal(gi.tgt.cpu().long(), eic[1][order])
+        assert torch.equal(gi.src.cpu().long(), eic[0][order])
+        cnt = torch.bincount(eic[1], minlength=N)
+        rp = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)])
+        assert torch.equal(gi.rowptr_t.cpu().long(), rp)
+        so = torch.argsort(gi.src.cpu().long(), stable=True)
+        assert torch.equal(gi.spos.cpu().long(), so), "spos is the stable source sort"
+        cnt = torch.bincount(eic[0], minlength=N)
+        rp = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)])
+        assert torch.equal(gi.rowptr_s.cpu().long(), rp)
+
+
+def case_mlp(device, shapes=((14, 40, 4, 3), (9, 40, 5, 3), (14, 14, 5, 2), (26, 40, 1, 3),
+                             (4, 2, 4, 2), (30, 33, 7, 3), (48, 64, 16, 3)), rows=77):
+    torch.manual_seed(0)
+    for (i, h, o, L) in shapes:
+        for bias in (True, False):
+            m = G.MLP(i, o, h, L=L, bias=bias)
+            x = torch.randn(rows, i)
+            r = torch.randn(rows, o)
+            p = {"m." + k: v.detach().clone().requires_grad_(True)
+                 for k, v in m.state_dict().items()}
+            xo = x.clone().requires_grad_(True)
+            yo = O.mlp(xo, p, "m", L, bias=bias)
+            (yo * r).sum().backward()
+            m = m.to(device)
+            xd = x.to(device).requires_grad_(True)
+            y = m(xd)
+            (y * r.to(device)).sum().backward()
+            tag = f"MLP {i}->{h}->{o} L={L} bias={bias}"
+            assert_close(y, yo, TOL_OUT, tag + " y")
+            assert_close(xd.grad, xo.grad, TOL_GRAD, tag + " gx")
+            for k, v in m.named_parameters():
+                assert_close(v.grad, p["m." + k].grad, TOL_GRAD, f"{tag} g {k}")
+
+
+def case_in_layer(device, which=("std", "odd")):
+    z = load("g3_in_layer.npz")
+    for name in which:
+        dn, de, dno, deo, hn, he = [int(v) for v in z[f"{name}/dims"]]
+        m = G.InteractionNetwork(node_indim=dn, edge_indim=de, node_outdim=dno, edge_outdim=deo,
+                                 node_hidden_dim=hn, edge_hidden_dim=he)
+        load_params(m, z, f"{name}/p0/in.")
+        m = m.to(device)
+        x = tt(z[f"{name}/x"], device).requires_grad_(True)
+        ea = tt(z[f"{name}/edge_attr"], device).requires_grad_(True)
+        ei = tt(z[f"{name}/edge_index"], device)
+        xt, et = m(x, ei, ea)
+        assert_close(xt, z[f"{name}/x_tilde"], TOL_OUT, name + " x~")
+        assert_close(et, z[f"{name}/e_tilde"], TOL_OUT, name + " e~")
+        ((xt * tt(z[f"{name}/rx"], device)).sum() + (et * tt(z[f"{name}/re"], device)).sum()).backward()
+        assert_close(x.grad, z[f"{name}/grad_x"], TOL_GRAD, name + " grad x")
+        assert_close(ea.grad, z[f"{name}/grad_edge_attr"], TOL_GRAD, name + " grad edge_attr")
+        for k, v in m.named_parameters():
+            assert_close(v.grad, z[f"{name}/grad/in.{k}"], TOL_GRAD, f"{name} grad {k}")
+
+
+def case_resin(device):
+    z = load("g3b_resin.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    for name, kw in {
+        "skip1": dict(n_layers=3, residual_type="skip1", alpha=0.5),
+        "skip2": dict(n_layers=2, residual_type="skip2", alpha=0.3),
+        "skip_top": dict(n_layers=3, residual_type="skip_top", alpha=0.7),
+    }.items():
+        m = G.ResIN(node_dim=5, edge_dim=4, object_hidden_dim=12, relational_hidden_dim=20,
+                    residual_kwargs={"collect_hidden_edge_embeds": True}, **kw)
+        load_params(m, z, f"{name}/p0/r.")
+        m = m.to(device)
+        xo, eo, es = m(x, ei, ea)
+        assert_close(xo, z[f"{name}/x_out"], TOL_OUT, name + " x")
+        assert_close(eo, z[f"{name}/e_out"], TOL_OUT, name + " e")
+        assert_close(torch.cat(es, 1), z[f"{name}/edge_attrs_cat"], TOL_OUT, name + " edge_attrs")
+
+
+def case_ec_testgraph(device):
+    """Row H of SURVEY.md section 8a: ECForGraphTCN(14,14,L_ec=1) on the reference's
+    test graph: init == reference init under manual_seed(0), forward, BCE, grads, and
+    the parameters after one Adam(lr=1e-4, weight_decay=1e-4) step."""
+    z = load("g1_ec_testgraph.npz")
+    torch.manual_seed(0)
+    model = G.ECForGraphTCN(node_indim=14, edge_indim=14, L_ec=1)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, tt(z["p0/" + k])), f"initial parameter {k} differs from reference"
+    model = model.to(device)
+    data = G.Data(x=tt(z["x"], device), edge_index=tt(z["edge_index"], device),
+                  edge_attr=tt(z["edge_attr"], device), y=tt(z["y"], device), pt=tt(z["pt"], device))
+    out = model(data)
+    assert_close(out["W"], z["W"], TOL_OUT, "W")
+    assert_close(out["node_embedding"], z["node_embedding"], TOL_OUT, "node_embedding")
+    assert_close(out["edge_embedding"], z["edge_embedding"], TOL_OUT, "edge_embedding")
+    loss = G.EdgeWeightBCELoss()(w=out["W"], y=data.y.float(), pt=data.pt,
+                                 edge_index=data.edge_index)
+    assert_close(loss, z["loss"], TOL_OUT, "BCE loss")
+    loss.backward()
+    for k, v in model.named_parameters():
+        assert_close(v.grad, z["grad/" + k], TOL_GRAD, "grad " + k)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt.step()
+    for k, v in model.state_dict().items():
+        assert_close(v, z["p1/" + k], 1e-6, "after Adam " + k)
+
+
+EC_VARIANTS = {
+    "skip1_L3_h40": dict(L_ec=3, hidden_dim=40),
+    "skip1_L2_h2": dict(L_ec=2, hidden_dim=2),
+    "skip2_L2": dict(L_ec=2, hidden_dim=8, residual_type="skip2"),
+    "skiptop_L3": dict(L_ec=3, hidden_dim=8, residual_type="skip_top"),
+    "no_inter": dict(L_ec=2, hidden_dim=8, use_intermediate_edge_embeddings=False),
+    "no_inter_no_node": dict(L_ec=2, hidden_dim=8, use_intermediate_edge_embeddings=False,
+                             use_node_embedding=False),
+    "no_node": dict(L_ec=2, hidden_dim=8, use_node_embedding=False),
+    "alpha0": dict(L_ec=2, hidden_dim=None, alpha=0.0),
+}
+
+
+def case_ec_variants(device, names=None):
+    z = load("g2_ec_variants.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y, pt = tt(z["y"], device), tt(z["pt"], device)
+    for name, kw in EC_VARIANTS.items():
+        if names is not None and name not in names:
+            continue
+        model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **kw)
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        out = model(G.Data(x=x, edge_index=ei, edge_attr=ea))
+        assert_close(out["W"], z[f"{name}/W"], TOL_OUT, name + " W")
+        assert_close(out["node_embedding"], z[f"{name}/node_embedding"], TOL_OUT, name + " node")
+        assert_close(out["edge_embedding"], z[f"{name}/edge_embedding"], TOL_OUT, name + " edge")
+        loss = G.EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"], y=y.float(), pt=pt, edge_index=ei)
+        assert_close(loss, z[f"{name}/loss"], TOL_OUT, name + " loss")
+        loss.backward()
+        for k, v in model.named_parameters():
+            gk = v.grad if v.grad is not None else torch.zeros_like(v)
+            assert_close(gk, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
+
+
+def case_edge_cases(device):
+    """Empty / ragged inputs: zero edges, one edge, isolated nodes only, a tile-size
+    multiple and +-1 row around it."""
+    torch.manual_seed(3)
+    model = G.ECForGraphTCN(node_indim=6, edge_indim=3, L_ec=2, hidden_dim=8)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(device)
+    g = np.random.default_rng(9)
+    for N, E in ((7, 1), (7, 2), (40, 15), (40, 16), (40, 17), (3, 64), (100, 63)):
+        x = tt(g.normal(size=(N, 6)).astype(np.float32))
+        ea = tt(g.normal(size=(E, 3)).astype(np.float32))
+        ei = tt(g.integers(0, N, size=(2, E))).long()
+        ref = O.ec_for_graph_tcn(x, ei, ea, p, L_ec=2)
+        out = model(G.Data(x=x.to(device), edge_index=ei.to(device), edge_attr=ea.to(device)))
+        assert_close(out["W"].reshape(-1), ref["W"].reshape(-1), TOL_OUT, f"N={N} E={E} W")
+        assert_close(out["node_embedding"], ref["node_embedding"], TOL_OUT, f"N={N} E={E} node")
+        assert_close(out["edge_embedding"], ref["edge_embedding"], TOL_OUT, f"N={N} E={E} edge")

@@ -1,0 +1,41 @@
+"""The package's Python layer + the REAL kernel sources, executed on the CPU wave64
+emulator (tests/emul), against goldens/oracle.  This is what catches layout, indexing
+and autograd-glue bugs in the build container, which has no GPU.  Sizes are reduced to
+keep the CPU suite at a few minutes; the full cases run under -m gpu."""
+
+import pytest
+
+import parity_cases as P
+from emul_util import emulated
+
+pytestmark = pytest.mark.emul
+
+
+def test_graph_index():
+    with emulated():
+        P.case_graph_index("cpu")
+
+
+def test_fused_mlp_forward_backward():
+    with emulated():
+        P.case_mlp("cpu", shapes=((14, 40, 4, 3), (14, 14, 5, 2), (30, 33, 7, 3)), rows=37)
+
+
+def test_interaction_network_layer():
+    with emulated():
+        P.case_in_layer("cpu", which=("odd",))
+
+
+def test_ec_testgraph_training_step():
+    with emulated():
+        P.case_ec_testgraph("cpu")
+
+
+def test_ec_variants_subset():
+    with emulated():
+        P.case_ec_variants("cpu", names=("skip2_L2", "no_inter_no_node"))
+
+
+def test_edge_cases():
+    with emulated():
+        P.case_edge_cases("cpu")

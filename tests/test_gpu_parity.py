@@ -1,0 +1,56 @@
+"""Parity tests proper: the HIP path (libgnntrk.so through the C ABI) on a real MI355X
+against the golden vectors generated from the reference, and against the CPU oracle."""
+
+import pytest
+import torch
+
+import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from gnn_tracking_amd import _capi
+
+    lib = _capi.load()  # fails loudly if the extension is missing
+    assert lib.gnntrk_version() == 100
+    return "cuda"
+
+
+def test_graph_index(dev):
+    P.case_graph_index(dev)
+
+
+def test_fused_mlp_forward_backward(dev):
+    P.case_mlp(dev)
+    P.case_mlp(dev, shapes=((14, 40, 4, 3), (26, 40, 1, 3)), rows=40001)
+
+
+def test_interaction_network_layer(dev):
+    P.case_in_layer(dev)
+
+
+def test_resin_variants(dev):
+    P.case_resin(dev)
+
+
+def test_ec_testgraph_training_step(dev):
+    P.case_ec_testgraph(dev)
+
+
+def test_ec_variants(dev):
+    P.case_ec_variants(dev)
+
+
+def test_edge_cases(dev):
+    P.case_edge_cases(dev)
+
+
+def test_cpu_tensor_is_rejected(dev):
+    import gnn_tracking_amd as G
+
+    m = G.MLP(4, 2, 8)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        m(torch.zeros(3, 4))

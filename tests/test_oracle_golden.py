@@ -1,0 +1,100 @@
+"""The CPU oracle (oracle/ref_cpu.py) against the committed golden vectors, which were
+produced by the reference's own modules (oracle/make_golden.py) and include the pinned
+known-answer values of the reference's tests/test_losses.py:112-123.  No GPU, no
+reference checkout needed."""
+
+import numpy as np
+import torch
+
+import parity_cases as P
+import ref_cpu as O
+from parity_cases import assert_close, load, tt
+
+
+def _params(z, prefix):
+    return {k[len(prefix):]: tt(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def test_ec_testgraph_training_step():
+    z = load("g1_ec_testgraph.npz")
+    p0 = _params(z, "p0/")
+    out, loss, grads, p1 = O.ec_training_step(tt(z["x"]), tt(z["edge_index"]), tt(z["edge_attr"]),
+                                              tt(z["y"]), p0, model_kwargs=dict(L_ec=1))
+    assert_close(out["W"], z["W"], 1e-6, "W")
+    assert_close(out["node_embedding"], z["node_embedding"], 1e-6, "node")
+    assert_close(out["edge_embedding"], z["edge_embedding"], 1e-6, "edge")
+    assert_close(loss, z["loss"], 1e-6, "loss")
+    assert abs(float(z["loss"]) - 0.5523450970649719) < 1e-6  # SURVEY.md 8c marker
+    for k in p0:
+        assert_close(grads[k], z["grad/" + k], 1e-5, "grad " + k)
+        assert_close(p1[k], z["p1/" + k], 1e-6, "adam " + k)
+
+
+def test_ec_variants():
+    z = load("g2_ec_variants.npz")
+    x, ei, ea, y, pt = (tt(z[k]) for k in ("x", "edge_index", "edge_attr", "y", "pt"))
+    for name, kw in P.EC_VARIANTS.items():
+        okw = {k: v for k, v in kw.items() if k != "hidden_dim"}
+        p0 = _params(z, f"{name}/p0/")
+        out, loss, grads, _ = O.ec_training_step(x, ei, ea, y, p0, model_kwargs=okw, pt=pt,
+                                                 pt_thld=0.9)
+        assert_close(out["W"], z[f"{name}/W"], 1e-6, name + " W")
+        assert_close(loss, z[f"{name}/loss"], 1e-6, name + " loss")
+        for k in p0:
+            assert_close(grads[k], z[f"{name}/grad/{k}"], 1e-5, f"{name} grad {k}")
+
+
+def test_interaction_network_and_resin():
+    z = load("g3_in_layer.npz")
+    for name in ("std", "odd"):
+        p = _params(z, f"{name}/p0/")
+        xt, et = O.interaction_network(tt(z[f"{name}/x"]), tt(z[f"{name}/edge_index"]),
+                                       tt(z[f"{name}/edge_attr"]), p, "in")
+        assert_close(xt, z[f"{name}/x_tilde"], 1e-6, name + " x~")
+        assert_close(et, z[f"{name}/e_tilde"], 1e-6, name + " e~")
+    z = load("g3b_resin.npz")
+    for name, kw in {"skip1": dict(n_layers=3, residual_type="skip1", alpha=0.5),
+                     "skip2": dict(n_layers=2, residual_type="skip2", alpha=0.3),
+                     "skip_top": dict(n_layers=3, residual_type="skip_top", alpha=0.7)}.items():
+        p = _params(z, f"{name}/p0/")
+        x, e, es = O.resin(tt(z["x"]), tt(z["edge_index"]), tt(z["edge_attr"]), p, "r",
+                           collect_hidden_edge_embeds=True, **kw)
+        assert_close(x, z[f"{name}/x_out"], 1e-6, name)
+        assert_close(torch.cat(es, 1), z[f"{name}/edge_attrs_cat"], 1e-6, name)
+
+
+def test_knn_bit_exact():
+    z = load("g4_knn.npz")
+    for cn in ("tg3", "u2", "u8"):
+        x = tt(z[f"{cn}/x"])
+        for k in (1, 2, 3, 9):
+            for r in (None, 1.0, 0.3):
+                ref = tt(z[f"{cn}/k{k}_r{r}"])
+                assert torch.equal(O.knn_with_max_radius(x, k, r), ref), (cn, k, r)
+
+
+def test_condensation_losses_pinned():
+    z = load("g5_oc.npz")
+    for cn in ("td1", "td2", "td3"):
+        t = {k: tt(z[f"{cn}/{k}"]) for k in ("beta", "x", "particle_id", "pt", "eta",
+                                              "reconstructable")}
+        mask = O.good_node_mask(t["pt"], t["particle_id"], t["reconstructable"], t["eta"])
+        for strat, fn in (("tiger", O.condensation_loss_tiger), ("rg", O.condensation_loss_rg)):
+            od = fn(beta=t["beta"], x=t["x"], particle_id=t["particle_id"], mask=mask)
+            for i, k in enumerate(("attractive", "repulsive", "coward", "noise")):
+                assert_close(od[k], z[f"{cn}/f64/{strat}/{k}"], 1e-9, f"{cn} {strat} {k}")
+                if cn in ("td1", "td2"):  # the reference's own pinned numbers
+                    pinned = float(z[f"{cn}/pinned"][i])
+                    assert abs(float(od[k]) - pinned) <= 1e-6 * abs(pinned), (cn, strat, k)
+
+
+def test_ml_graph_construction_edges():
+    z = load("g6_mlgc.npz")
+    g1 = load("g1_ec_testgraph.npz")
+    x, pid = tt(g1["x"]), tt(g1["particle_id"])
+    for k, r in ((4, 1.0), (16, 0.5)):
+        ei = O.knn_with_max_radius(x[:, :3], k, r)
+        y, f = O.ml_graph_construction_edges(x, pid, ei)
+        assert torch.equal(ei, tt(z[f"k{k}_r{r}/edge_index"]))
+        assert torch.equal(y, tt(z[f"k{k}_r{r}/y"]))
+        assert torch.equal(f, tt(z[f"k{k}_r{r}/edge_attr"]))

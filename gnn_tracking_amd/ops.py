@@ -71,6 +71,74 @@ def _ws(nbytes: int, like: Tensor) -> Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
 
+# ------------------------------------------------------------ kernel timing hook
+class KernelTimer:
+    """Optional per-launch timing of the fused-MLP kernels with HIP events on the
+    stream the kernels are launched on (bench.py's roofline leg).  Each record carries
+    the kernel instantiation key and the launch's ALGORITHMIC flops and bytes."""
+
+    def __init__(self):
+        self.records = []  # (key, ev0, ev1, flops, bytes, rows)
+
+    def summary(self) -> dict:
+        out: dict = {}
+        for key, e0, e1, fl, by, rows in self.records:
+            d = out.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, rows=0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+            d["rows"] += rows
+        return out
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(t: Optional[KernelTimer]) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+def kernel_key(direction: str, in_dim: int, hidden: int) -> str:
+    """Name of the kernel instantiation the C launcher dispatches to (mlp.hip)."""
+    kt, ht = (in_dim + 15) // 16, (hidden + 15) // 16
+    if kt <= 1 and ht <= 1:
+        inst = (1, 1)
+    elif kt <= 1 and ht <= 3:
+        inst = (1, 3)
+    elif kt <= 2 and ht <= 2:
+        inst = (2, 2)
+    elif kt <= 2 and ht <= 3:
+        inst = (2, 3)
+    else:
+        inst = (3, 4)
+    return f"mlp_{direction}_kernel<{inst[0]},{inst[1]}>"
+
+
+def _mlp_flops_per_row(m) -> int:
+    mid = m.hidden * m.hidden if m.n_layers == 3 else 0
+    return 2 * (m.in_dim * m.hidden + mid + m.hidden * m.out_dim)
+
+
+class _timed:
+    def __init__(self, t: Tensor, key: str, flops: float, nbytes: float, rows: int):
+        self.on = _TIMER is not None and t.is_cuda
+        self.args = (key, flops, nbytes, rows)
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            key, fl, by, rows = self.args
+            _TIMER.records.append((key, self.e0, self.e1, fl, by, rows))
+
+
 # ------------------------------------------------------------------ graph index
 @dataclasses.dataclass
 class GraphIndex:
@@ -87,6 +155,10 @@ class GraphIndex:
 
 
 _GI_CACHE: dict[int, tuple] = {}
+
+
+def clear_graph_index_cache() -> None:
+    _GI_CACHE.clear()
 
 
 def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True) -> GraphIndex:
@@ -308,7 +380,14 @@ class _FusedMLP(torch.autograd.Function):
         out = torch.empty(spec.out_rows, a.mlp.out_dim, dtype=torch.float32,
                           device=segs[0].device)
         a.out, a.out_stride, a.out_idx = _p(out), _row_stride(out), _p(spec.out_idx)
-        _capi.check(lib.gnntrk_mlp_forward(C.byref(a), _stream(out)), lib)
+        M = spec.n_rows
+        nbytes = M * (sum(4 * s.shape[1] + (4 if spec.idx[j] is not None else 0)
+                          for j, s in enumerate(segs)) + 4 * a.mlp.out_dim
+                      + (4 if spec.out_idx is not None else 0)
+                      + (4 * a.mlp.out_dim if spec.epilogue == _capi.EPI_RESIDUAL else 0))
+        with _timed(out, kernel_key("fwd", a.mlp.in_dim, a.mlp.hidden),
+                    _mlp_flops_per_row(a.mlp) * M, nbytes, M):
+            _capi.check(lib.gnntrk_mlp_forward(C.byref(a), _stream(out)), lib)
         ctx.spec = spec
         ctx.save_for_backward(*segs, *weights, *[b for b in biases if b is not None])
         ctx.bias_mask = [b is not None for b in biases]
@@ -374,8 +453,15 @@ class _FusedMLP(torch.autograd.Function):
                 a.gb[i] = _p(gb[i])
             ws = _ws(lib.gnntrk_mlp_backward_workspace_bytes(C.byref(a.mlp)), g_out)
         a.accumulate_params = 0
-        _capi.check(lib.gnntrk_mlp_backward(C.byref(a), _p(ws), 0 if ws is None else ws.numel(),
-                                            _stream(g_out)), lib)
+        nbytes = M * (sum(4 * s.shape[1] + (4 if spec.idx[j] is not None else 0)
+                          + (4 * s.shape[1] if need[1 + j] else 0)
+                          for j, s in enumerate(segs)) + 4 * a.mlp.out_dim
+                      + (4 if spec.out_idx is not None else 0))
+        with _timed(g_out, kernel_key("bwd", a.mlp.in_dim, a.mlp.hidden),
+                    3 * _mlp_flops_per_row(a.mlp) * M, nbytes, M):
+            _capi.check(lib.gnntrk_mlp_backward(C.byref(a), _p(ws),
+                                                0 if ws is None else ws.numel(),
+                                                _stream(g_out)), lib)
 
         # fold gathered row gradients onto their source rows (deterministic CSR sums)
         for j, s in enumerate(segs):

@@ -1,0 +1,66 @@
+"""Seeded synthetic TrackML-shaped hit graphs (SURVEY.md section 8d generator spec).
+
+There is no network for datasets, so bench/tests use graphs whose SHAPE statistics
+follow the graphs the reference's GraphBuilder produces from TrackML events: 14 node
+features with the measured value ranges, 4 edge features (dr, dphi, dz, dR), mean degree
+E/N, edges between hits that are close in phi, both edge directions, shuffled COO
+order, >=3 % isolated nodes, true-edge fraction 0.31, int64 particle ids up to 2^60 with
+4 % noise (id 0).  Node ids are NOT phi-sorted (worst case for gather locality).
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .data import Data
+
+
+def make_event(seed: int, n_nodes: int, n_edges: int, device="cpu", *, node_dim: int = 14,
+               isolated_frac: float = 0.03, max_offset: int = 64) -> Data:
+    assert node_dim >= 6 and n_edges % 2 == 0
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    U = lambda *s: torch.rand(*s, generator=g, device=dev)  # noqa: E731
+    N, E = n_nodes, n_edges
+    x = torch.empty(N, node_dim, device=dev)
+    x[:, 0] = 0.03 + 0.15 * U(N)                       # r
+    x[:, 1] = 2 * U(N) - 1                             # phi / pi
+    x[:, 2] = 3 * U(N) - 1.5                           # z
+    x[:, 3] = (2 * torch.randn(N, generator=g, device=dev)).clamp(-4.6, 4.6)  # eta
+    x[:, 4:6] = 66 * U(N, 2) - 33                      # u, v
+    x[:, 6:] = 1.5 * U(N, node_dim - 6)
+
+    # live (non-isolated) nodes, ordered by phi
+    n_iso = int(math.ceil(isolated_frac * N))
+    shuffled = torch.randperm(N, generator=g, device=dev)
+    live = shuffled[n_iso:]
+    live = live[torch.argsort(x[live, 1])]
+    L = live.numel()
+    half = E // 2
+    i = torch.randint(0, L, (half,), generator=g, device=dev)
+    off = torch.randint(1, max_offset + 1, (half,), generator=g, device=dev)
+    sign = torch.randint(0, 2, (half,), generator=g, device=dev) * 2 - 1
+    j = (i + sign * off) % L
+    a, b = live[i], live[j]
+    src = torch.cat([a, b])
+    tgt = torch.cat([b, a])
+    shuf = torch.randperm(E, generator=g, device=dev)
+    edge_index = torch.stack([src[shuf], tgt[shuf]]).contiguous()
+
+    s, t = edge_index[0], edge_index[1]
+    dr = x[s, 0] - x[t, 0]
+    dphi = x[s, 1] - x[t, 1]
+    dphi = dphi - 2 * torch.round(dphi / 2)            # wrap (phi is in units of pi)
+    dz = x[s, 2] - x[t, 2]
+    dR = torch.sqrt((x[s, 3] - x[t, 3]) ** 2 + dphi ** 2)
+    edge_attr = torch.stack([dr, dphi, dz, dR], dim=1).contiguous()
+
+    y = U(E) < 0.31
+    pid = torch.randint(2 ** 52, 2 ** 60, (N,), generator=g, device=dev, dtype=torch.int64)
+    pid[U(N) < 0.04] = 0
+    pt = torch.exp(0.7 * torch.randn(N, generator=g, device=dev))
+    return Data(x=x, edge_index=edge_index, edge_attr=edge_attr, y=y, pt=pt, particle_id=pid,
+                eta=x[:, 3].clone(), reconstructable=torch.ones(N, device=dev))

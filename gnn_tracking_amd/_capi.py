@@ -34,7 +34,8 @@ class MlpFwdArgs(C.Structure):
     _fields_ = [("mlp", Mlp), ("n_seg", C.c_int32), ("epilogue", C.c_int32),
                 ("seg", Seg * MAX_SEGS), ("n_rows", C.c_int64), ("ca", C.c_float),
                 ("cb", C.c_float), ("res", C.c_void_p), ("res_stride", C.c_int32),
-                ("out_stride", C.c_int32), ("out", C.c_void_p), ("out_idx", C.c_void_p)]
+                ("out_stride", C.c_int32), ("out", C.c_void_p), ("out_idx", C.c_void_p),
+                ("debug_flags", C.c_int32), ("_pad", C.c_int32)]
 
 
 class GTerm(C.Structure):
@@ -52,7 +53,7 @@ class MlpBwdArgs(C.Structure):
                 ("seg", Seg * MAX_SEGS), ("n_rows", C.c_int64), ("ca", C.c_float),
                 ("cb", C.c_float), ("n_gout", C.c_int32), ("accumulate_params", C.c_int32),
                 ("gout", GTerm * 2), ("gseg", GSeg * MAX_SEGS), ("gW", C.c_void_p * 3),
-                ("gb", C.c_void_p * 3)]
+                ("gb", C.c_void_p * 3), ("debug_flags", C.c_int32), ("_pad", C.c_int32)]
 
 
 class GraphIndex(C.Structure):

@@ -8,8 +8,8 @@
 // ABI layout guards: gnn_tracking_amd/_capi.py mirrors these structs with ctypes
 static_assert(sizeof(gnntrk_seg) == 32, "gnntrk_seg layout");
 static_assert(sizeof(gnntrk_mlp) == 64, "gnntrk_mlp layout");
-static_assert(sizeof(gnntrk_mlp_fwd_args) == 440, "gnntrk_mlp_fwd_args layout");
-static_assert(sizeof(gnntrk_mlp_bwd_args) == 752, "gnntrk_mlp_bwd_args layout");
+static_assert(sizeof(gnntrk_mlp_fwd_args) == 448, "gnntrk_mlp_fwd_args layout");
+static_assert(sizeof(gnntrk_mlp_bwd_args) == 760, "gnntrk_mlp_bwd_args layout");
 static_assert(sizeof(gnntrk_graph_index) == 64, "gnntrk_graph_index layout");
 
 namespace gnntrk {

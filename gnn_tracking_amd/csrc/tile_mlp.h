@@ -12,10 +12,13 @@
 // (cdna_hip_programming.md section 3), so results differ from the torch reference
 // only by summation order.
 //
-// A feature dimension D is split into q = D/16 full tiles (feature 16t+4g+r) and one
-// remainder tile that is packed "R registers deep": feature 16q + R*g + r, r < R,
-// R = ceil((D%16)/4).  That keeps the number of k-steps at ceil(D/4) (10 for the
-// default hidden width 40) instead of 4*ceil(D/16) (12).
+// A feature dimension D is split into q tiles in the plain mapping (feature
+// 16t+4g+r) and, when 1 <= D%16 <= 12, one remainder tile packed "R registers deep":
+// feature 16q + R*g + r, r < R, R = ceil((D%16)/4).  That keeps the number of k-steps
+// at ceil(D/4) (10 for the default hidden width 40) instead of 4*ceil(D/16) (12).
+// The k-step count alone fixes (q, R) = (ks/4, ks%4), which is what lets the hot
+// shapes be compiled with every loop bound static (StaticDims) - straight-line MFMA
+// code the scheduler can pipeline - next to a generic run-time version (DynDims).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,55 +30,88 @@ namespace gnntrk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBlock = 256;      // threads per workgroup (4 waves, one per SIMD)
-constexpr int kWaves = 4;        // waves per workgroup
-constexpr int kTileRows = 16;    // rows (edges / nodes) per MFMA tile
-constexpr int kTbLd = 20;        // leading dim (floats) of the transpose buffer
-constexpr int kTbRows = 64;      // max features staged at once
+// Pointers the kernels dereference in the tile loop are tagged as GLOBAL address space:
+// generic ("flat") loads count on vmcnt AND lgkmcnt, so every LDS wait would also drain
+// the software-prefetched gathers of the next tile.
+#define GNNTRK_GLOBAL __attribute__((address_space(1)))
+typedef const float GNNTRK_GLOBAL *gcf_ptr;
+typedef float GNNTRK_GLOBAL *gf_ptr;
+typedef const int32_t GNNTRK_GLOBAL *gci_ptr;
+
+constexpr int kBlock = 256;    // threads per workgroup (4 waves, one per SIMD)
+constexpr int kWaves = 4;      // waves per workgroup
+constexpr int kTileRows = 16;  // rows (edges / nodes) per MFMA tile
+constexpr int kTbLd = 20;      // leading dim (floats) of a transpose buffer
+constexpr int kTbRows = 64;    // max features staged at once (+1 garbage row for padding)
+constexpr int kTbBufs = 3;     // rotating transpose buffers per wave
+constexpr int kTbSize = (kTbRows + 1) * kTbLd;
 
 struct DimMap {
     int D;   // features
-    int q;   // full 16-feature tiles
-    int R;   // registers used in the remainder tile (0 if none)
-    int nt;  // tiles
+    int q;   // tiles in the plain mapping
+    int R;   // registers of the packed remainder tile (0: none)
+    int nt;  // tiles = q + (R ? 1 : 0)
     int ks;  // k-steps = 4q + R
 };
 
 __host__ __device__ inline DimMap make_dimmap(int D) {
     DimMap m;
     m.D = D;
-    m.q = D / 16;
     const int rem = D % 16;
-    m.R = (rem + 3) / 4;
-    m.nt = m.q + (rem ? 1 : 0);
+    if (rem == 0 || rem > 12) {
+        m.q = (D + 15) / 16;
+        m.R = 0;
+    } else {
+        m.q = D / 16;
+        m.R = (rem + 3) / 4;
+    }
+    m.nt = m.q + (m.R ? 1 : 0);
     m.ks = 4 * m.q + m.R;
     return m;
 }
 
 // feature held by lane-group g, register r of tile t; -1 = padding
 __host__ __device__ inline int feat_of(const DimMap &m, int t, int g, int r) {
-    if (t < m.q) return 16 * t + 4 * g + r;
+    if (t < m.q) {
+        const int f = 16 * t + 4 * g + r;
+        return f < m.D ? f : -1;
+    }
     if (t == m.q && r < m.R) {
-        const int f = m.R * g + r;
-        return (f < m.D - 16 * m.q) ? 16 * m.q + f : -1;
+        const int f = 16 * m.q + m.R * g + r;
+        return f < m.D ? f : -1;
     }
     return -1;
 }
-// is (tile t, register r) a k-step of the map?  (wave-uniform)
-__host__ __device__ inline bool kvalid(const DimMap &m, int t, int r) {
-    return t < m.q || (t == m.q && r < m.R);
-}
-__host__ __device__ inline int kindex(const DimMap &m, int t, int r) {
-    return t < m.q ? 4 * t + r : 4 * m.q + r;
-}
-__host__ __device__ inline void kstep_tr(const DimMap &m, int ks, int &t, int &r) {
-    if (ks < 4 * m.q) {
-        t = ks >> 2;
-        r = ks & 3;
-    } else {
-        t = m.q;
-        r = ks - 4 * m.q;
-    }
+
+// ---- loop-bound policies -------------------------------------------------------
+// k-step (t, r) of a dimension with `ks` k-steps has index 4t + r and exists iff
+// 4t + r < ks (both mappings).  Tiles: ceil(ks / 4).
+struct DynDims {
+    DimMap in, hid, out;
+    bool three_;
+    __device__ __forceinline__ int in_ks() const { return in.ks; }
+    __device__ __forceinline__ int hid_ks() const { return hid.ks; }
+    __device__ __forceinline__ int out_ks() const { return out.ks; }
+    __device__ __forceinline__ bool three() const { return three_; }
+    __device__ __forceinline__ void set_three(bool v) { three_ = v; }
+};
+template <int KSI, int KSH, int KSO, bool THREE>
+struct StaticDims {
+    DimMap in, hid, out;
+    __device__ __forceinline__ constexpr int in_ks() const { return KSI; }
+    __device__ __forceinline__ constexpr int hid_ks() const { return KSH; }
+    __device__ __forceinline__ constexpr int out_ks() const { return KSO; }
+    __device__ __forceinline__ constexpr bool three() const { return THREE; }
+    __device__ __forceinline__ void set_three(bool) {}
+};
+template <class Dims>
+__device__ __forceinline__ Dims make_dims(const gnntrk_mlp &m) {
+    Dims d;
+    d.in = make_dimmap(m.in_dim);
+    d.hid = make_dimmap(m.hidden);
+    d.out = make_dimmap(m.out_dim);
+    d.set_three(m.n_layers == 3);
+    return d;
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -95,18 +131,16 @@ __device__ __forceinline__ void lds_wave_sync() {
 // W[out][in] (ld = in_dim):  forward layer: Mat = W  (rows = out, k = in);
 // transposed (backward dX): Mat = W^T (rows = in, k = out).
 // dst[(to * kmap.ks + ks) * 64 + lane];  lane (g,c) holds
-//     Mat[feat_of(rowmap,to,c>>2,c&3)][feat_of(kmap,tk,g,rk)],  (tk,rk) = k-step ks.
+//     Mat[feat_of(rowmap,to,c>>2,c&3)][feat_of(kmap,ks>>2,g,ks&3)].
 __device__ inline void fill_frags(float *dst, const float *W, int ld, const DimMap rowmap,
                                   const DimMap kmap, bool transposed, int tid, int nthreads) {
     const int n = rowmap.nt * kmap.ks * 64;
     for (int i = tid; i < n; i += nthreads) {
         const int fr = i >> 6, l = i & 63;
         const int to = fr / kmap.ks, ks = fr - to * kmap.ks;
-        int tk, rk;
-        kstep_tr(kmap, ks, tk, rk);
         const int g = l >> 4, c = l & 15;
         const int rf = feat_of(rowmap, to, c >> 2, c & 3);
-        const int kf = feat_of(kmap, tk, g, rk);
+        const int kf = feat_of(kmap, ks >> 2, g, ks & 3);
         float v = 0.f;
         if (rf >= 0 && kf >= 0) v = transposed ? W[(int64_t)kf * ld + rf] : W[(int64_t)rf * ld + kf];
         dst[i] = v;
@@ -127,11 +161,6 @@ __device__ inline void fill_bias(f32x4 *dst, const float *b, const DimMap map, i
     }
 }
 
-struct Maps {
-    DimMap in, hid, out;
-    bool three;  // 3 linear layers (else 2)
-};
-
 // XCD-aware persistent tile schedule: block b runs on XCD b % 8 (observed dispatch
 // order, MI355X_MICROARCH.md "Workgroup dispatch"); give every XCD one contiguous
 // range of tiles so the node rows gathered by neighbouring tiles stay in ITS L2.
@@ -139,24 +168,17 @@ struct Maps {
 struct TileSched {
     int64_t cur, end, step;
 };
-__device__ inline TileSched make_sched(int64_t n_tiles) {
+__device__ inline TileSched make_sched(int64_t n_tiles, int waves = kWaves) {
     const int G = gridDim.x;
     const int nx = (G % 8 == 0) ? 8 : 1;
     const int x = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
     const int64_t t0 = n_tiles * x / nx, t1 = n_tiles * (x + 1) / nx;
     TileSched s;
-    s.cur = t0 + lb * kWaves + (threadIdx.x >> 6);
+    s.cur = t0 + lb * waves + (threadIdx.x >> 6);
     s.end = t1;
-    s.step = (int64_t)bpx * kWaves;
+    s.step = (int64_t)bpx * waves;
     return s;
 }
-
-// one concatenated-input feature slot of a lane: where to read it from
-struct InSlot {
-    const float *base;   // segment ptr + feature offset; nullptr = padding
-    const int32_t *idx;  // row gather index or nullptr
-    int32_t stride;
-};
 
 // Segment descriptors staged in LDS (kernel arguments cannot be indexed dynamically
 // without a scratch copy).  Filled by stage_segs() before the first __syncthreads().
@@ -190,6 +212,48 @@ __device__ __forceinline__ void stage_segs(SegTable &tab, const gnntrk_seg (&seg
         }
 }
 
+// one concatenated-input feature slot of a lane: where to read it from
+struct InSlot {
+    gcf_ptr base;  // segment ptr + feature offset; nullptr = padding
+    gci_ptr idx;   // row gather index or nullptr
+    int32_t stride;
+};
+
+// Weight (A-operand) fragments of one layer: either read from LDS at every use
+// (generic kernels) or copied once into registers (static kernels: with one wave per
+// SIMD and a 512-entry register file they are loop-invariant operands, and the MFMA
+// chain runs without a single LDS wait).
+template <int N>
+struct RegFrags {
+    float v[N];
+    __device__ __forceinline__ void load(const float *lds, int n, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = (i < n) ? lds[i * 64 + lane] : 0.f;
+    }
+    __device__ __forceinline__ float get(int i, int) const { return v[i]; }
+};
+template <int N>
+struct LdsFrags {
+    const float *p;
+    __device__ __forceinline__ void load(const float *lds, int, int) { p = lds; }
+    __device__ __forceinline__ float get(int i, int lane) const { return p[i * 64 + lane]; }
+};
+template <int N>
+struct RegBias {
+    f32x4 v[N];
+    __device__ __forceinline__ void load(const f32x4 *lds, int n, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = (i < n) ? lds[i * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ f32x4 get(int i, int) const { return v[i]; }
+};
+template <int N>
+struct LdsBias {
+    const f32x4 *p;
+    __device__ __forceinline__ void load(const f32x4 *lds, int, int) { p = lds; }
+    __device__ __forceinline__ f32x4 get(int i, int lane) const { return p[i * 64 + lane]; }
+};
+
 template <int KT>
 __device__ __forceinline__ void setup_in_slots(const SegTable &tab, int n_seg, const DimMap &in,
                                                int g, InSlot (&slot)[KT * 4], unsigned &relu_bits) {
@@ -207,8 +271,8 @@ __device__ __forceinline__ void setup_in_slots(const SegTable &tab, int n_seg, c
             for (int j = 0; j < n_seg; ++j) {
                 const int d = tab.dim[j];
                 if (f >= off && f < off + d) {
-                    s.base = tab.ptr[j] + (f - off);
-                    s.idx = tab.idx[j];
+                    s.base = (gcf_ptr)tab.ptr[j] + (f - off);
+                    s.idx = (gci_ptr)tab.idx[j];
                     s.stride = tab.stride[j];
                     if (tab.relu[j]) relu_bits |= 1u << (t * 4 + r);
                 }
@@ -218,23 +282,35 @@ __device__ __forceinline__ void setup_in_slots(const SegTable &tab, int n_seg, c
         }
 }
 
+// Two-stage input pipeline: row indices of tile n+2 and values of tile n+1 are in
+// flight while tile n is computed (one wave per SIMD cannot hide the two dependent
+// gathers idx -> value any other way).
 template <int KT>
-__device__ __forceinline__ void load_inputs(const InSlot (&slot)[KT * 4], unsigned relu_bits,
-                                            const DimMap &in, int64_t row, bool valid,
-                                            f32x4 (&bin)[KT]) {
+__device__ __forceinline__ void load_row_ids(const InSlot (&slot)[KT * 4], int nt_in, int64_t row,
+                                             bool valid, int32_t (&rid)[KT * 4]) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const InSlot &s = slot[t * 4 + r];
+            int32_t v = (int32_t)row;
+            if (t < nt_in && valid && s.base != nullptr && s.idx != nullptr) v = s.idx[row];
+            rid[t * 4 + r] = v;
+        }
+}
+
+template <int KT>
+__device__ __forceinline__ void load_values(const InSlot (&slot)[KT * 4], int nt_in, bool valid,
+                                            const int32_t (&rid)[KT * 4], f32x4 (&bin)[KT]) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t < in.nt) {
+        if (t < nt_in) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const InSlot &s = slot[t * 4 + r];
                 float x = 0.f;
-                if (valid && s.base != nullptr) {
-                    const int64_t rr = s.idx ? (int64_t)s.idx[row] : row;
-                    x = s.base[rr * s.stride];
-                    if ((relu_bits >> (t * 4 + r)) & 1u) x = fmaxf(x, 0.f);
-                }
+                if (valid && s.base != nullptr) x = s.base[(int64_t)rid[t * 4 + r] * s.stride];
                 v[r] = x;
             }
         }
@@ -242,20 +318,25 @@ __device__ __forceinline__ void load_inputs(const InSlot (&slot)[KT * 4], unsign
     }
 }
 
+template <int KT>
+__device__ __forceinline__ void apply_input_relu(unsigned relu_bits, f32x4 (&bin)[KT]) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((relu_bits >> (t * 4 + r)) & 1u) bin[t][r] = fmaxf(bin[t][r], 0.f);
+}
+
 // Forward of the (2- or 3-layer) MLP on one 16-row tile.  a1/a2 are post-ReLU hidden
-// activations, y the linear output (all in accumulator layout).  For two layers a2 is
-// not computed and the output layer reads a1.
-template <int KT, int HT>
-__device__ __forceinline__ void mlp_tile_forward(const Maps &mp, const float *w1, const float *w2,
-                                                 const float *w3, const f32x4 *b1, const f32x4 *b2,
-                                                 const f32x4 *b3, int lane, const f32x4 (&bin)[KT],
-                                                 f32x4 (&a1)[HT], f32x4 (&a2)[HT], f32x4 &y,
-                                                 bool want_y) {
-    // layer 1: in -> hid
+// activations (a2 = a1 for two layers), y the linear output, all in accumulator layout.
+template <int KT, int HT, class Dims, class W1, class B1>
+__device__ __forceinline__ void mlp_layer1(const Dims &dm, const W1 &w1, const B1 &b1, int lane,
+                                           const f32x4 (&bin)[KT], f32x4 (&a1)[HT]) {
+    const int nth = (dm.hid_ks() + 3) >> 2;
 #pragma unroll
     for (int to = 0; to < HT; ++to) {
-        if (to < mp.hid.nt)
-            a1[to] = b1[to * 64 + lane];
+        if (to < nth)
+            a1[to] = b1.get(to, lane);
         else
             a1[to] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -263,24 +344,27 @@ __device__ __forceinline__ void mlp_tile_forward(const Maps &mp, const float *w1
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (kvalid(mp.in, t, r)) {
-                const int ks = kindex(mp.in, t, r);
+            if (4 * t + r < dm.in_ks()) {
 #pragma unroll
                 for (int to = 0; to < HT; ++to)
-                    if (to < mp.hid.nt)
-                        a1[to] = mfma4(w1[(to * mp.in.ks + ks) * 64 + lane], bin[t][r], a1[to]);
+                    if (to < nth)
+                        a1[to] = mfma4(w1.get(to * dm.in_ks() + 4 * t + r, lane), bin[t][r], a1[to]);
             }
 #pragma unroll
     for (int to = 0; to < HT; ++to)
 #pragma unroll
         for (int r = 0; r < 4; ++r) a1[to][r] = fmaxf(a1[to][r], 0.f);
+}
 
-    // layer 2: hid -> hid
-    if (mp.three) {
+template <int HT, class Dims, class W2, class B2>
+__device__ __forceinline__ void mlp_layer2(const Dims &dm, const W2 &w2, const B2 &b2, int lane,
+                                           const f32x4 (&a1)[HT], f32x4 (&a2)[HT]) {
+    const int nth = (dm.hid_ks() + 3) >> 2;
+    if (dm.three()) {
 #pragma unroll
         for (int to = 0; to < HT; ++to) {
-            if (to < mp.hid.nt)
-                a2[to] = b2[to * 64 + lane];
+            if (to < nth)
+                a2[to] = b2.get(to, lane);
             else
                 a2[to] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -288,36 +372,33 @@ __device__ __forceinline__ void mlp_tile_forward(const Maps &mp, const float *w1
         for (int t = 0; t < HT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (kvalid(mp.hid, t, r)) {
-                    const int ks = kindex(mp.hid, t, r);
+                if (4 * t + r < dm.hid_ks()) {
 #pragma unroll
                     for (int to = 0; to < HT; ++to)
-                        if (to < mp.hid.nt)
-                            a2[to] = mfma4(w2[(to * mp.hid.ks + ks) * 64 + lane], a1[t][r], a2[to]);
+                        if (to < nth)
+                            a2[to] = mfma4(w2.get(to * dm.hid_ks() + 4 * t + r, lane), a1[t][r],
+                                           a2[to]);
                 }
 #pragma unroll
         for (int to = 0; to < HT; ++to)
 #pragma unroll
             for (int r = 0; r < 4; ++r) a2[to][r] = fmaxf(a2[to][r], 0.f);
-    }
-
-    // output layer: hid -> out (one tile)
-    y = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!mp.three) {
+    } else {
 #pragma unroll
         for (int to = 0; to < HT; ++to) a2[to] = a1[to];
     }
-    if (want_y) {
-        y = b3[lane];
+}
+
+template <int HT, class Dims, class W3>
+__device__ __forceinline__ f32x4 mlp_layer3(const Dims &dm, const W3 &w3, f32x4 b3, int lane,
+                                            const f32x4 (&a2)[HT]) {
+    f32x4 y = b3;
 #pragma unroll
-        for (int t = 0; t < HT; ++t)
+    for (int t = 0; t < HT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (kvalid(mp.hid, t, r)) {
-                    const int ks = kindex(mp.hid, t, r);
-                    y = mfma4(w3[ks * 64 + lane], a2[t][r], y);
-                }
-    }
+        for (int r = 0; r < 4; ++r)
+            if (4 * t + r < dm.hid_ks()) y = mfma4(w3.get(4 * t + r, lane), a2[t][r], y);
+    return y;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

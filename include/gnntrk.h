@@ -136,6 +136,8 @@ typedef struct gnntrk_mlp_fwd_args {
     int32_t out_stride;
     float *out;             /* [*, out_stride]; row m is written at out_idx[m] or m */
     const int32_t *out_idx; /* optional row scatter (a permutation)               */
+    int32_t debug_flags;    /* 0 in production; 1 skip stores, 2 skip input loads  */
+    int32_t _pad;
 } gnntrk_mlp_fwd_args;
 
 int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream);
@@ -188,6 +190,10 @@ typedef struct gnntrk_mlp_bwd_args {
     gnntrk_gseg gseg[GNNTRK_MAX_SEGS];
     float *gW[3]; /* may be NULL: skip parameter gradients of that layer */
     float *gb[3];
+    int32_t debug_flags; /* 0 in production. Ablation switches for tools/ablate_mlp.py:
+                            1 skip input-gradient stores, 2 skip input loads (zeros),
+                            8 skip the LDS transposes (weight grads become garbage)      */
+    int32_t _pad;
 } gnntrk_mlp_bwd_args;
 
 size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp);

@@ -44,10 +44,10 @@ def test_struct_layout_matches_header():
 
     assert ctypes.sizeof(_capi.Seg) == 32
     assert ctypes.sizeof(_capi.Mlp) == 64
-    assert ctypes.sizeof(_capi.MlpFwdArgs) == 440
+    assert ctypes.sizeof(_capi.MlpFwdArgs) == 448
     assert _capi.MlpFwdArgs.n_rows.offset == 392
     assert ctypes.sizeof(_capi.GraphIndex) == 64
-    assert ctypes.sizeof(_capi.MlpBwdArgs) == 752
+    assert ctypes.sizeof(_capi.MlpBwdArgs) == 760
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -60,6 +60,14 @@ int bce_backward_launch(const float *, const float *, const int64_t *, const flo
 size_t graph_index_ws_bytes(int64_t, int64_t);
 int graph_index_build(const int64_t *, const gnntrk_graph_index *, void *, size_t, hipStream_t);
 
+// knn.hip
+int knn_search_launch(const float *, int64_t, int, int, int, float, int32_t *, int32_t *,
+                      hipStream_t);
+int knn_emit_launch(const int32_t *, const int32_t *, int64_t, int, int64_t *, int64_t *, int64_t,
+                    hipStream_t);
+int edge_features_launch(const float *, int, int, const int64_t *, int64_t, float *, hipStream_t);
+int edge_labels_launch(const int64_t *, const int64_t *, int64_t, int64_t *, hipStream_t);
+
 }  // namespace gnntrk
 
 using namespace gnntrk;
@@ -116,6 +124,23 @@ int gnntrk_bce_forward(const float *w, const float *y, const int64_t *src_node, 
 int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node, const float *pt,
                         float pt_thld, int64_t n, const float *gscale, float *gw, void *stream) {
     return bce_backward_launch(w, y, src_node, pt, pt_thld, n, gscale, gw, (hipStream_t)stream);
+}
+
+int gnntrk_knn_search(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k,
+                      float max_radius, int32_t *nbr, int32_t *cnt, void *stream) {
+    return knn_search_launch(x, n, dim, x_stride, k, max_radius, nbr, cnt, (hipStream_t)stream);
+}
+int gnntrk_knn_emit(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k, int64_t *offsets,
+                    int64_t *edge_index, int64_t n_edges, void *stream) {
+    return knn_emit_launch(nbr, cnt, n, k, offsets, edge_index, n_edges, (hipStream_t)stream);
+}
+int gnntrk_edge_labels(const int64_t *particle_id, const int64_t *edge_index, int64_t n_edges,
+                       int64_t *y, void *stream) {
+    return edge_labels_launch(particle_id, edge_index, n_edges, y, (hipStream_t)stream);
+}
+int gnntrk_edge_features(const float *x, int32_t dim, int32_t x_stride, const int64_t *edge_index,
+                         int64_t n_edges, float *out, void *stream) {
+    return edge_features_launch(x, dim, x_stride, edge_index, n_edges, out, (hipStream_t)stream);
 }
 
 }  // extern "C"

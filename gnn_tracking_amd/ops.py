@@ -34,7 +34,7 @@ from . import _capi
 
 __all__ = [
     "GraphIndex", "graph_index", "Seg", "fused_mlp", "segment_sum", "permute_rows",
-    "axpby", "bce_loss",
+    "axpby", "bce_loss", "knn_graph", "edge_labels", "edge_features",
 ]
 
 
@@ -501,6 +501,62 @@ def fused_mlp(segs: Sequence[Seg], weights: Sequence[Tensor],
                     epilogue, float(ca), float(cb), out_idx,
                     int(out_rows if out_rows is not None else n_rows), int(n_rows))
     return _FusedMLP.apply(spec, *[s.t for s in segs], *weights, *biases, res)
+
+
+# ------------------------------------------------------------------- kNN graphs
+def knn_graph(x: Tensor, k: int, max_radius: Optional[float] = None) -> Tensor:
+    """``knn_with_max_radius`` (models/graph_construction.py:222-237): int64 ``[2, M]``
+    edge index, row 0 = neighbour (source), row 1 = query (target), grouped by query,
+    ascending distance, self excluded; with ``max_radius`` only ``||x_j - x_i|| < r``."""
+    _capi.require_device(x)
+    lib = _capi.load()
+    if x.dim() != 2:
+        raise ValueError("knn_graph: x must be [N, D]")
+    x = _as_rows(x.detach())
+    n, dim = int(x.shape[0]), int(x.shape[1])
+    dev = x.device
+    if n <= 1:
+        return torch.empty(2, 0, dtype=torch.int64, device=dev)
+    kk = min(int(k), n - 1)
+    nbr = torch.empty(n * kk, dtype=torch.int32, device=dev)
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    st = _stream(x)
+    r = float(max_radius) if max_radius is not None else -1.0
+    _capi.check(lib.gnntrk_knn_search(_p(x), n, dim, _row_stride(x), kk, r, _p(nbr), _p(cnt), st),
+                lib)
+    off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    _capi.check(lib.gnntrk_knn_emit(_p(nbr), _p(cnt), n, kk, _p(off), None, 0, st), lib)
+    m = int(off[n].item())  # the one host sync: the output size is data dependent
+    ei = torch.empty(2, m, dtype=torch.int64, device=dev)
+    _capi.check(lib.gnntrk_knn_emit(_p(nbr), _p(cnt), n, kk, _p(off), _p(ei), m, st), lib)
+    return ei
+
+
+def edge_labels(particle_id: Tensor, edge_index: Tensor) -> Tensor:
+    """``(pid[e0] == pid[e1]) & (pid[e0] > 0)`` as int64 (graph_construction.py:365-367)."""
+    _capi.require_device(particle_id, edge_index)
+    lib = _capi.load()
+    pid = particle_id.to(torch.int64).contiguous()
+    ei = edge_index.contiguous()
+    m = int(ei.shape[1])
+    y = torch.empty(m, dtype=torch.int64, device=ei.device)
+    _capi.check(lib.gnntrk_edge_labels(_p(pid), _p(ei), m, _p(y), _stream(ei)), lib)
+    return y
+
+
+def edge_features(x: Tensor, edge_index: Tensor) -> Tensor:
+    """``cat[x[e0] - x[e1], x[e0] + x[e1]]`` -> ``[M, 2F]`` (graph_construction.py:386-393)."""
+    _capi.require_device(x, edge_index)
+    lib = _capi.load()
+    if x.requires_grad:
+        raise NotImplementedError("edge_features: inputs that require grad are not supported")
+    x = _as_rows(x)
+    ei = edge_index.contiguous()
+    m, f = int(ei.shape[1]), int(x.shape[1])
+    out = torch.empty(m, 2 * f, dtype=torch.float32, device=x.device)
+    _capi.check(lib.gnntrk_edge_features(_p(x), f, _row_stride(x), _p(ei), m, _p(out),
+                                         _stream(x)), lib)
+    return out
 
 
 # -------------------------------------------------------------------------- BCE

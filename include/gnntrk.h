@@ -237,6 +237,34 @@ int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
                         const float *pt, float pt_thld, int64_t n, const float *gscale,
                         float *gw, void *stream);
 
+/* ------------------------------------------------------------- kNN graph build
+ * models/graph_construction.py:222-237 knn_with_max_radius(x, k, max_radius) =
+ * torch_cluster.knn_graph(x, k) (no batch, loop=False, flow source_to_target) followed by
+ * the strict L2 filter ||x_j - x_i|| < max_radius.  Arithmetic contract (bit-exact against
+ * oracle/knn_ref.c): d2 = fmaf chain over dimensions in order; the k smallest (d2, index)
+ * pairs per query, ties -> lower index, self excluded by index; filter sqrtf(d2) < r.
+ *
+ *  gnntrk_knn_search  : nbr[q*k + i], i < cnt[q]: neighbours of q, ascending distance
+ *                       (max_radius <= 0: no radius).  dim <= 32, k <= 448.
+ *  gnntrk_knn_emit    : edge_index == NULL: offsets[0..n] = exclusive scan of cnt
+ *                       (offsets[n] = number of edges M; read it back to size the output);
+ *                       else writes int64 edge_index[2, M]: row 0 = neighbour (source j),
+ *                       row 1 = query (target i), grouped by query ascending.
+ */
+int gnntrk_knn_search(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k,
+                      float max_radius, int32_t *nbr, int32_t *cnt, void *stream);
+int gnntrk_knn_emit(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k, int64_t *offsets,
+                    int64_t *edge_index, int64_t n_edges, void *stream);
+
+/* MLGraphConstruction.forward, models/graph_construction.py:365-367 and :386-393:
+ *   y[e]        = (pid[e0] == pid[e1]) && pid[e0] > 0        (int64 compare, int64 0/1 out)
+ *   feat[e]     = [x[e0] - x[e1], x[e0] + x[e1]]             ([M, 2*dim])
+ * with e0 = edge_index[0][e], e1 = edge_index[1][e] (int64 [2, M]).                      */
+int gnntrk_edge_labels(const int64_t *particle_id, const int64_t *edge_index, int64_t n_edges,
+                       int64_t *y, void *stream);
+int gnntrk_edge_features(const float *x, int32_t dim, int32_t x_stride, const int64_t *edge_index,
+                         int64_t n_edges, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -361,3 +361,33 @@ def ec_training_step(x, edge_index, edge_attr, y, params: dict, *, model_kwargs:
     opt = torch.optim.Adam([ps[n] for n in names], lr=lr, weight_decay=weight_decay)
     opt.step()
     return out, loss, {n: ps[n].grad for n in names}, {n: ps[n].detach() for n in names}
+
+
+# ------------------------------------------------------------- compiled kNN oracle
+def knn_graph_c(x: Tensor, k: int, max_radius: float | None = None) -> Tensor:
+    """Bit-exact kNN(+radius) edge list from the C oracle (oracle/knn_ref.c): the
+    arithmetic spec of the HIP kernel (explicit fmaf chain, (d2, index) order)."""
+    import ctypes
+    import importlib.util
+    import pathlib
+
+    here = pathlib.Path(__file__).resolve().parent
+    spec = importlib.util.spec_from_file_location("build_oracle", here / "build_oracle.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = ctypes.CDLL(str(mod.build()))
+    lib.knn_ref_search.restype = ctypes.c_int64
+    lib.knn_ref_search.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p]
+    xf = x.detach().to(torch.float32).contiguous().cpu()
+    n, dim = xf.shape
+    kk = max(1, min(k, n - 1)) if n > 1 else 1
+    nbr = torch.zeros(n * kk, dtype=torch.int32)
+    cnt = torch.zeros(n, dtype=torch.int32)
+    lib.knn_ref_search(xf.data_ptr(), n, dim, kk, float(max_radius or -1.0), nbr.data_ptr(), None,
+                       cnt.data_ptr())
+    nbr = nbr.view(n, kk)
+    keep = torch.arange(kk).view(1, -1) < cnt.view(-1, 1)
+    q = torch.arange(n).view(-1, 1).expand(n, kk)
+    return torch.stack([nbr[keep].long(), q[keep]])

@@ -233,11 +233,14 @@ inline T __shfl_down(T v, unsigned d, int = 64) {
     return hipemul_shfl(v, (l + (int)d < 64) ? l + (int)d : l);
 }
 inline unsigned long long __ballot(int pred) {
+    hipemul::Wave &w = hipemul::wave();
+    const int l = hipemul::lane();
+    w.xch[l] = pred ? 1 : 0;
+    w.bar.wait("ballot");
     unsigned long long m = 0;
-    for (int i = 0; i < 64; ++i) {
-        int p = hipemul_shfl(pred, i);
-        if (p) m |= 1ull << i;
-    }
+    for (int i = 0; i < 64; ++i)
+        if (w.xch[i]) m |= 1ull << i;
+    w.bar.wait("ballot");
     return m;
 }
 
@@ -270,3 +273,13 @@ inline float __fsub_rn(float a, float b) { return a - b; }
 inline float __fsqrt_rn(float a) { return sqrtf(a); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline unsigned __float_as_uint(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+inline float __uint_as_float(unsigned u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}

@@ -211,3 +211,51 @@ def case_edge_cases(device):
         assert_close(out["W"].reshape(-1), ref["W"].reshape(-1), TOL_OUT, f"N={N} E={E} W")
         assert_close(out["node_embedding"], ref["node_embedding"], TOL_OUT, f"N={N} E={E} node")
         assert_close(out["edge_embedding"], ref["edge_embedding"], TOL_OUT, f"N={N} E={E} edge")
+
+
+# ----------------------------------------------------------------- kNN / graphs
+def case_knn_goldens(device, clouds=("tg3", "u2", "u8")):
+    """knn_with_max_radius against the edge lists the reference produced (G4), bit-exact."""
+    from gnn_tracking_amd.graph_construction import knn_with_max_radius
+
+    z = load("g4_knn.npz")
+    for cn in clouds:
+        x = tt(z[f"{cn}/x"], device)
+        for k in (1, 2, 3, 9):
+            for r in (None, 1.0, 0.3):
+                ei = knn_with_max_radius(x, k=k, max_radius=r)
+                ref = tt(z[f"{cn}/k{k}_r{r}"])
+                assert ei.dtype == torch.int64
+                assert torch.equal(ei.cpu(), ref), f"kNN {cn} k={k} r={r} differs from reference"
+
+
+def case_knn_oracle(device, shapes=((300, 3, 4, None), (300, 8, 16, 0.9), (257, 2, 70, None),
+                                    (130, 8, 3, 0.5), (65, 3, 100, 0.4), (1, 3, 4, None),
+                                    (2, 3, 4, None))):
+    """bit-exact against the C oracle incl. ties, k > n, buffer pruning and radius prefix."""
+    g = np.random.default_rng(3)
+    for (n, d, k, r) in shapes:
+        x = tt(g.random((n, d)).astype(np.float32))
+        ei = ops.knn_graph(x.to(device), k, r)
+        ref = O.knn_graph_c(x, k, r) if n > 1 else torch.empty(2, 0, dtype=torch.int64)
+        assert torch.equal(ei.cpu(), ref), f"kNN n={n} d={d} k={k} r={r}"
+    x = torch.zeros(100, 3)
+    x[50:] = 1.0  # massive ties: order must be by index
+    assert torch.equal(ops.knn_graph(x.to(device), 5, None).cpu(), O.knn_graph_c(x, 5, None))
+
+
+def case_ml_graph_construction(device):
+    """MLGraphConstruction(ml=None, embedding_slice=(0,3)) vs the reference's output (G6)."""
+    from gnn_tracking_amd.graph_construction import MLGraphConstruction
+
+    z, g1 = load("g6_mlgc.npz"), load("g1_ec_testgraph.npz")
+    for k, r in ((4, 1.0), (16, 0.5)):
+        d = G.Data(x=tt(g1["x"], device), edge_index=tt(g1["edge_index"], device),
+                   particle_id=tt(g1["particle_id"], device), pt=tt(g1["pt"], device),
+                   eta=tt(g1["eta"], device), reconstructable=tt(g1["reconstructable"], device),
+                   layer=tt(g1["layer"], device), sector=tt(g1["sector"], device))
+        m = MLGraphConstruction(ml=None, embedding_slice=(0, 3), max_radius=r, max_num_neighbors=k)
+        out = m(d)
+        assert torch.equal(out.edge_index.cpu(), tt(z[f"k{k}_r{r}/edge_index"]))
+        assert torch.equal(out.y.cpu(), tt(z[f"k{k}_r{r}/y"]))
+        assert torch.equal(out.edge_attr.cpu(), tt(z[f"k{k}_r{r}/edge_attr"])), "edge features"

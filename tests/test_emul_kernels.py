@@ -39,3 +39,11 @@ def test_ec_variants_subset():
 def test_edge_cases():
     with emulated():
         P.case_edge_cases("cpu")
+
+
+def test_knn_against_c_oracle_and_goldens():
+    with emulated():
+        P.case_knn_oracle("cpu", shapes=((130, 8, 3, 0.5), (257, 2, 70, None), (65, 3, 100, 0.4),
+                                         (1, 3, 4, None), (2, 3, 4, None)))
+        P.case_knn_goldens("cpu", clouds=("tg3",))
+        P.case_ml_graph_construction("cpu")

@@ -48,6 +48,16 @@ def test_edge_cases(dev):
     P.case_edge_cases(dev)
 
 
+def test_knn_goldens_and_oracle(dev):
+    P.case_knn_goldens(dev)
+    P.case_knn_oracle(dev)
+    P.case_knn_oracle(dev, shapes=((5000, 8, 64, 1.0), (4097, 3, 256, None), (3000, 24, 16, 2.0)))
+
+
+def test_ml_graph_construction(dev):
+    P.case_ml_graph_construction(dev)
+
+
 def test_cpu_tensor_is_rejected(dev):
     import gnn_tracking_amd as G
 

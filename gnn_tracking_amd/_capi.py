@@ -62,6 +62,14 @@ class GraphIndex(C.Structure):
                 ("rowptr_s", C.c_void_p), ("spos", C.c_void_p)]
 
 
+class OcArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("beta", C.c_void_p), ("particle_id", C.c_void_p),
+                ("mask", C.c_void_p), ("gid", C.c_void_p), ("alphas", C.c_void_p),
+                ("n_cp", C.c_void_p), ("n", C.c_int64), ("dim", C.c_int32), ("stride", C.c_int32),
+                ("q_min", C.c_float), ("radius", C.c_float), ("eps_sqrt", C.c_float),
+                ("mode", C.c_int32)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -87,6 +95,13 @@ _SIGNATURES = {
     "gnntrk_knn_emit": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
     "gnntrk_edge_labels": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "gnntrk_edge_features": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),
+    "gnntrk_good_node_mask": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, _P, _P]),
+    "gnntrk_oc_select_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnntrk_oc_select_cps": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P,
+                                       C.c_size_t, _P]),
+    "gnntrk_oc_forward_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnntrk_oc_forward": (C.c_int, [C.POINTER(OcArgs), _P, _P, C.c_size_t, _P]),
+    "gnntrk_oc_backward": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -68,6 +68,17 @@ int knn_emit_launch(const int32_t *, const int32_t *, int64_t, int, int64_t *, i
 int edge_features_launch(const float *, int, int, const int64_t *, int64_t, float *, hipStream_t);
 int edge_labels_launch(const int64_t *, const int64_t *, int64_t, int64_t *, hipStream_t);
 
+// oc.hip
+int good_node_mask_launch(const float *, const int64_t *, const float *, const float *, int64_t, float,
+                          float, uint8_t *, hipStream_t);
+size_t oc_select_ws_bytes(int64_t);
+int oc_select_launch(const float *, const int64_t *, const uint8_t *, int64_t, int, int32_t *,
+                     int32_t *, int32_t *, void *, size_t, hipStream_t);
+size_t oc_forward_ws_bytes(int64_t);
+int oc_forward_launch(const gnntrk_oc_args *, float *, void *, size_t, hipStream_t);
+int oc_backward_launch(const gnntrk_oc_args *, const float *, const float *, float *, float *, int64_t,
+                       hipStream_t);
+
 }  // namespace gnntrk
 
 using namespace gnntrk;
@@ -141,6 +152,29 @@ int gnntrk_edge_labels(const int64_t *particle_id, const int64_t *edge_index, in
 int gnntrk_edge_features(const float *x, int32_t dim, int32_t x_stride, const int64_t *edge_index,
                          int64_t n_edges, float *out, void *stream) {
     return edge_features_launch(x, dim, x_stride, edge_index, n_edges, out, (hipStream_t)stream);
+}
+
+int gnntrk_good_node_mask(const float *pt, const int64_t *particle_id, const float *reconstructable,
+                          const float *eta, int64_t n, float pt_thld, float max_eta, uint8_t *mask,
+                          void *stream) {
+    return good_node_mask_launch(pt, particle_id, reconstructable, eta, n, pt_thld, max_eta, mask,
+                                 (hipStream_t)stream);
+}
+size_t gnntrk_oc_select_workspace_bytes(int64_t n) { return oc_select_ws_bytes(n); }
+int gnntrk_oc_select_cps(const float *score, const int64_t *particle_id, const uint8_t *mask,
+                         int64_t n, int32_t mode, int32_t *alphas, int32_t *gid, int32_t *n_cp,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    return oc_select_launch(score, particle_id, mask, n, mode, alphas, gid, n_cp, workspace,
+                            workspace_bytes, (hipStream_t)stream);
+}
+size_t gnntrk_oc_forward_workspace_bytes(int64_t n) { return oc_forward_ws_bytes(n); }
+int gnntrk_oc_forward(const gnntrk_oc_args *args, float *out, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+    return oc_forward_launch(args, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int gnntrk_oc_backward(const gnntrk_oc_args *args, const float *g, const float *fwd, float *gx,
+                       float *gbeta, int64_t max_cps, void *stream) {
+    return oc_backward_launch(args, g, fwd, gx, gbeta, max_cps, (hipStream_t)stream);
 }
 
 }  // extern "C"

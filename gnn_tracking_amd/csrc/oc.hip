@@ -1,0 +1,552 @@
+// Object-condensation loss reductions (reference: metrics/losses/oc.py:16-347,
+// utils/graph_masks.py:19-28).
+//
+// Both reference variants - CondensationLossRG (radius graph) and CondensationLossTiger
+// (dense N x K) - reduce to sums over (hit j, condensation point k) pairs:
+//     attractive  sum_{j in particle k} q_j q_k |x_j - x_k|^2
+//     repulsive   sum_{pid_j != pid_k, |x_j - x_k| < r} q_j q_k (r - sqrt(eps + |x_j - x_k|^2))
+// plus two means over beta.  No N x K matrix and no radius graph is materialised: one
+// thread owns a hit and streams the K condensation points through LDS (K ~ 1e3, a few KB);
+// the gradient w.r.t. the condensation points is the transposed pass (thread = CP, hits
+// streamed).  All sums are fixed-order (per-thread -> per-block fp64 partials -> one block):
+// deterministic, no atomics.  Bound: fp32 VALU (N*K*D fma); HBM traffic is negligible.
+//
+// The radius-graph variant's `max_num_neighbors` cap is not emulated (torch_cluster keeps an
+// implementation-defined subset when a hit has more neighbours than the cap; the reference
+// tests never reach it) - see DESIGN.md.
+#include "host_util.h"
+
+namespace gnntrk {
+
+typedef unsigned long long u64;
+constexpr int kOcTpb = 256;
+constexpr int kOcChunk = 128;  // condensation points staged per LDS pass
+constexpr int kOcMaxDim = 32;
+
+static int oc_grid(int64_t n) {
+    int64_t g = ceil_div(n, kOcTpb);
+    return (int)(g < 1 ? 1 : g);
+}
+
+__device__ __forceinline__ double oc_block_sum(double v, double *sh) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < kOcTpb / 64; ++i) s += sh[i];
+    __syncthreads();
+    return s;  // valid on thread 0
+}
+
+// utils/graph_masks.py:19-28
+__global__ __launch_bounds__(kOcTpb) void good_node_mask_kernel(
+    const float *__restrict__ pt, const int64_t *__restrict__ pid, const float *__restrict__ reco,
+    const float *__restrict__ eta, int64_t n, float pt_thld, float max_eta,
+    uint8_t *__restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    if (i < n)
+        mask[i] = (pt[i] > pt_thld && pid[i] > 0 && reco[i] > 0.f && fabsf(eta[i]) < max_eta) ? 1 : 0;
+}
+
+// ---- condensation point selection (oc.py:16-43 / :279-292) ---------------------------
+__global__ __launch_bounds__(kOcTpb) void oc_keys_kernel(const int64_t *__restrict__ pid, int64_t n,
+                                                         u64 *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    if (i < n) {
+        keys[i] = (u64)pid[i];
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// one thread per sorted position that starts a particle: best hit of the particle.
+// mode 0 (RG):    candidates = masked hits, score = beta; qualifies iff a masked hit exists
+// mode 1 (Tiger): candidates = all hits of the particle, score = q; qualifies iff any masked
+// ties -> lowest hit index (the sort is stable, so hits of a particle are in index order)
+__global__ __launch_bounds__(kOcTpb) void oc_segment_best_kernel(
+    const u64 *__restrict__ keys, const uint32_t *__restrict__ order, const float *__restrict__ score,
+    const uint8_t *__restrict__ mask, int64_t n, int mode, int32_t *__restrict__ seg_flag,
+    int32_t *__restrict__ seg_best) {
+    const int64_t s = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    if (s >= n) return;
+    int32_t flag = 0, best = -1;
+    if (s == 0 || keys[s] != keys[s - 1]) {
+        const u64 key = keys[s];
+        if (key != 0ull) {  // noise (pid 0) never is an object of interest (mask needs pid > 0)
+            float bs = -1.f;
+            bool any = false;
+            for (int64_t t = s; t < n && keys[t] == key; ++t) {
+                const uint32_t h = order[t];
+                const bool m = mask[h] != 0;
+                any = any || m;
+                if ((mode == 1 || m) && score[h] > bs) {
+                    bs = score[h];
+                    best = (int32_t)h;
+                }
+            }
+            flag = (any && best >= 0) ? 1 : 0;
+        }
+    }
+    seg_flag[s] = flag;
+    seg_best[s] = best;
+}
+
+// after the exclusive scan of seg_flag: alphas[k] = CP hit of the k-th particle of interest
+// (ascending pid); gid[h] = k for every hit of that particle, else -1
+__global__ __launch_bounds__(kOcTpb) void oc_assign_kernel(
+    const u64 *__restrict__ keys, const uint32_t *__restrict__ order,
+    const int32_t *__restrict__ seg_flag, const int32_t *__restrict__ seg_best,
+    const int64_t *__restrict__ seg_off, int64_t n, int32_t *__restrict__ alphas,
+    int32_t *__restrict__ gid, int32_t *__restrict__ n_cp) {
+    const int64_t s = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    if (s >= n) return;
+    if (s == 0) n_cp[0] = (int32_t)seg_off[n];
+    if (s == 0 || keys[s] != keys[s - 1]) {
+        const u64 key = keys[s];
+        const int32_t k = seg_flag[s] ? (int32_t)seg_off[s] : -1;
+        if (k >= 0) alphas[k] = seg_best[s];
+        for (int64_t t = s; t < n && keys[t] == key; ++t) gid[order[t]] = k;
+    }
+}
+
+__global__ __launch_bounds__(1024) void oc_scan_kernel(const int32_t *__restrict__ cnt, int64_t n,
+                                                       int64_t *__restrict__ off) {
+    __shared__ long long s_part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = t * per, e = (b + per < n) ? b + per : n;
+    long long s = 0;
+    for (int64_t i = b; i < e; ++i) s += cnt[i];
+    s_part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const long long v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+        off[n] = run;
+    }
+    __syncthreads();
+    long long run = s_part[t];
+    for (int64_t i = b; i < e; ++i) {
+        off[i] = run;
+        run += cnt[i];
+    }
+}
+
+// ---- potentials -----------------------------------------------------------------------
+struct OcParams {
+    const float *x;
+    const float *beta;
+    const int64_t *pid;
+    const uint8_t *mask;
+    const int32_t *gid;
+    const int32_t *alphas;
+    const int32_t *n_cp;
+    int64_t n;
+    int32_t dim, stride;
+    float q_min, radius, eps_sqrt;
+    int32_t mode;  // 0 RG, 1 Tiger
+};
+
+__device__ __forceinline__ float oc_q(float beta, float q_min) {
+    const float a = atanhf(beta);
+    return a * a + q_min;
+}
+
+// forward: per-block partial sums part[block][4] = {attractive, repulsive, n_rep_pairs, unused}
+template <int DP>
+__global__ __launch_bounds__(kOcTpb) void oc_forward_kernel(const OcParams p,
+                                                            double *__restrict__ part) {
+    __shared__ float s_x[kOcChunk][DP];
+    __shared__ float s_q[kOcChunk];
+    __shared__ long long s_pid[kOcChunk];
+    __shared__ double s_red[kOcTpb / 64];
+    const int64_t j = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    const bool live = j < p.n;
+    const int K = p.n_cp[0];
+    float xj[DP];
+    float qj = 0.f;
+    long long pj = -1;
+    int gj = -1;
+    bool mj = false, is_cp = false;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) xj[d] = (live && d < p.dim) ? p.x[j * p.stride + d] : 0.f;
+    if (live) {
+        qj = oc_q(p.beta[j], p.q_min);
+        pj = p.pid[j];
+        gj = p.gid[j];
+        mj = p.mask[j] != 0;
+        is_cp = gj >= 0 && p.alphas[gj] == (int32_t)j;
+    }
+    const float r2 = p.radius * p.radius;
+    double va = 0.0, vr = 0.0, nrep = 0.0;
+    for (int k0 = 0; k0 < K; k0 += kOcChunk) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kOcChunk; i += kOcTpb) {
+            const int k = k0 + i;
+            if (k < K) {
+                const int32_t a = p.alphas[k];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) s_x[i][d] = d < p.dim ? p.x[(int64_t)a * p.stride + d] : 0.f;
+                s_q[i] = oc_q(p.beta[a], p.q_min);
+                s_pid[i] = p.pid[a];
+            }
+        }
+        __syncthreads();
+        if (!live) continue;
+        const int kn = (K - k0 < kOcChunk) ? (K - k0) : kOcChunk;
+        for (int i = 0; i < kn; ++i) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const float t = xj[d] - s_x[i][d];
+                d2 += t * t;
+            }
+            const float qq = qj * s_q[i];
+            if (s_pid[i] == pj) {
+                const bool att = (p.mode == 1) ? (gj == k0 + i) : (gj == k0 + i && mj && !is_cp);
+                if (att) va += (double)(qq * d2);
+            } else if (d2 < r2) {
+                vr += (double)(qq * (p.radius - sqrtf(p.eps_sqrt + d2)));
+                nrep += 1.0;
+            }
+        }
+    }
+    const double a = oc_block_sum(va, s_red), r = oc_block_sum(vr, s_red),
+                 c = oc_block_sum(nrep, s_red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 4 + 0] = a;
+        part[blockIdx.x * 4 + 1] = r;
+        part[blockIdx.x * 4 + 2] = c;
+        part[blockIdx.x * 4 + 3] = 0.0;
+    }
+}
+
+// out[0..3] = attractive, repulsive, coward, noise; out[4..7] = norm_att, norm_rep, K, n_rep
+__global__ __launch_bounds__(kOcTpb) void oc_finalize_kernel(const OcParams p,
+                                                             const double *__restrict__ part,
+                                                             int n_part, float *__restrict__ out) {
+    __shared__ double s_red[kOcTpb / 64];
+    const int K = p.n_cp[0];
+    double va = 0, vr = 0, nrep = 0, cow = 0, noise = 0, n_noise = 0, n_oi = 0;
+    for (int i = threadIdx.x; i < n_part; i += kOcTpb) {
+        va += part[i * 4 + 0];
+        vr += part[i * 4 + 1];
+        nrep += part[i * 4 + 2];
+    }
+    for (int k = threadIdx.x; k < K; k += kOcTpb) cow += (double)(1.f - p.beta[p.alphas[k]]);
+    for (int64_t j = threadIdx.x; j < p.n; j += kOcTpb) {
+        const bool is_noise = (p.mode == 1) ? !(p.pid[j] > 0) : (p.pid[j] == 0);
+        if (is_noise) {
+            noise += (double)p.beta[j];
+            n_noise += 1.0;
+        }
+        if (p.mask[j]) n_oi += 1.0;
+    }
+    va = oc_block_sum(va, s_red);
+    vr = oc_block_sum(vr, s_red);
+    nrep = oc_block_sum(nrep, s_red);
+    cow = oc_block_sum(cow, s_red);
+    noise = oc_block_sum(noise, s_red);
+    n_noise = oc_block_sum(n_noise, s_red);
+    n_oi = oc_block_sum(n_oi, s_red);
+    if (threadIdx.x == 0) {
+        const double eps = 1e-9;
+        const double norm_att = eps + n_oi - (double)K;
+        const double norm_rep = eps + ((double)K - 1.0) * (double)p.n;
+        out[0] = (float)(va / norm_att);
+        out[1] = (float)(vr / norm_rep);
+        out[2] = (float)(cow / (double)K);
+        out[3] = (float)(noise / n_noise);
+        out[4] = (float)norm_att;
+        out[5] = (float)norm_rep;
+        out[6] = (float)K;
+        out[7] = (float)nrep;
+        out[8] = (float)n_noise;
+    }
+}
+
+// backward, hit side: gx[j] and gq[j] from the pairs of hit j; g = upstream grads of the 4
+// (normalised) loss terms; norms from the forward's out[4..8]
+template <int DP>
+__global__ __launch_bounds__(kOcTpb) void oc_backward_hits_kernel(const OcParams p,
+                                                                  const float *__restrict__ g,
+                                                                  const float *__restrict__ fwd,
+                                                                  float *__restrict__ gx,
+                                                                  float *__restrict__ gbeta) {
+    __shared__ float s_x[kOcChunk][DP];
+    __shared__ float s_q[kOcChunk];
+    __shared__ long long s_pid[kOcChunk];
+    const int64_t j = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    const bool live = j < p.n;
+    const int K = p.n_cp[0];
+    const float ca = g[0] / fwd[4], cr = g[1] / fwd[5];
+    float xj[DP], gxj[DP];
+    float qj = 0.f, gqj = 0.f;
+    long long pj = -1;
+    int gj = -1;
+    bool mj = false, is_cp = false;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        xj[d] = (live && d < p.dim) ? p.x[j * p.stride + d] : 0.f;
+        gxj[d] = 0.f;
+    }
+    float bj = 0.5f;
+    if (live) {
+        bj = p.beta[j];
+        qj = oc_q(bj, p.q_min);
+        pj = p.pid[j];
+        gj = p.gid[j];
+        mj = p.mask[j] != 0;
+        is_cp = gj >= 0 && p.alphas[gj] == (int32_t)j;
+    }
+    const float r2 = p.radius * p.radius;
+    for (int k0 = 0; k0 < K; k0 += kOcChunk) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kOcChunk; i += kOcTpb) {
+            const int k = k0 + i;
+            if (k < K) {
+                const int32_t a = p.alphas[k];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) s_x[i][d] = d < p.dim ? p.x[(int64_t)a * p.stride + d] : 0.f;
+                s_q[i] = oc_q(p.beta[a], p.q_min);
+                s_pid[i] = p.pid[a];
+            }
+        }
+        __syncthreads();
+        if (!live) continue;
+        const int kn = (K - k0 < kOcChunk) ? (K - k0) : kOcChunk;
+        for (int i = 0; i < kn; ++i) {
+            float t[DP];
+            float d2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                t[d] = xj[d] - s_x[i][d];
+                d2 += t[d] * t[d];
+            }
+            float cx = 0.f, cq = 0.f;  // d/dx_j = cx * t ; d/dq_j = cq
+            if (s_pid[i] == pj) {
+                const bool att = (p.mode == 1) ? (gj == k0 + i) : (gj == k0 + i && mj && !is_cp);
+                if (att) {
+                    cx = ca * 2.f * qj * s_q[i];
+                    cq = ca * s_q[i] * d2;
+                }
+            } else if (d2 < r2) {
+                const float sd = sqrtf(p.eps_sqrt + d2);
+                cx = sd > 0.f ? -cr * qj * s_q[i] / sd : 0.f;
+                cq = cr * s_q[i] * (p.radius - sd);
+            }
+#pragma unroll
+            for (int d = 0; d < DP; ++d) gxj[d] += cx * t[d];
+            gqj += cq;
+        }
+    }
+    if (live) {
+        for (int d = 0; d < p.dim; ++d) gx[j * p.stride + d] = gxj[d];
+        // q = atanh(beta)^2 + q_min ; plus the noise mean (the coward term is added by the CP pass)
+        const float a = atanhf(bj);
+        float gb = gqj * 2.f * a / (1.f - bj * bj);
+        const bool is_noise = (p.mode == 1) ? !(pj > 0) : (pj == 0);
+        if (is_noise) gb += g[3] / fwd[8];
+        gbeta[j] = gb;
+    }
+}
+
+// backward, condensation-point side: thread = CP k, hits streamed; adds into gx[alpha_k],
+// gbeta[alpha_k] (alpha_k are distinct hits: no conflicts).  Runs after the hit pass.
+template <int DP>
+__global__ __launch_bounds__(kOcTpb) void oc_backward_cps_kernel(const OcParams p,
+                                                                 const float *__restrict__ g,
+                                                                 const float *__restrict__ fwd,
+                                                                 float *__restrict__ gx,
+                                                                 float *__restrict__ gbeta) {
+    __shared__ float s_x[kOcChunk][DP];
+    __shared__ float s_q[kOcChunk];
+    __shared__ long long s_pid[kOcChunk];
+    __shared__ int s_att[kOcChunk];  // gid if the hit takes part in the attractive sum, else -2
+    const int K = p.n_cp[0];
+    const int k = blockIdx.x * kOcTpb + threadIdx.x;
+    const bool live = k < K;
+    const float ca = g[0] / fwd[4], cr = g[1] / fwd[5];
+    float xk[DP], gxk[DP];
+    float qk = 0.f, gqk = 0.f, bk = 0.5f;
+    long long pk = -1;
+    int32_t ak = 0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        xk[d] = 0.f;
+        gxk[d] = 0.f;
+    }
+    if (live) {
+        ak = p.alphas[k];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xk[d] = d < p.dim ? p.x[(int64_t)ak * p.stride + d] : 0.f;
+        bk = p.beta[ak];
+        qk = oc_q(bk, p.q_min);
+        pk = p.pid[ak];
+    }
+    const float r2 = p.radius * p.radius;
+    for (int64_t j0 = 0; j0 < p.n; j0 += kOcChunk) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kOcChunk; i += kOcTpb) {
+            const int64_t j = j0 + i;
+            if (j < p.n) {
+#pragma unroll
+                for (int d = 0; d < DP; ++d) s_x[i][d] = d < p.dim ? p.x[j * p.stride + d] : 0.f;
+                s_q[i] = oc_q(p.beta[j], p.q_min);
+                s_pid[i] = p.pid[j];
+                const int gj = p.gid[j];
+                bool att = gj >= 0;
+                if (p.mode == 0) att = att && p.mask[j] != 0 && p.alphas[gj] != (int32_t)j;
+                s_att[i] = att ? gj : -2;
+            }
+        }
+        __syncthreads();
+        if (!live) continue;
+        const int jn = (int)((p.n - j0 < kOcChunk) ? (p.n - j0) : kOcChunk);
+        for (int i = 0; i < jn; ++i) {
+            float t[DP];
+            float d2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                t[d] = s_x[i][d] - xk[d];  // x_j - x_k
+                d2 += t[d] * t[d];
+            }
+            float cx = 0.f, cq = 0.f;  // d/dx_k = -cx * t ; d/dq_k = cq
+            if (s_pid[i] == pk) {
+                if (s_att[i] == k) {
+                    cx = ca * 2.f * s_q[i] * qk;
+                    cq = ca * s_q[i] * d2;
+                }
+            } else if (d2 < r2) {
+                const float sd = sqrtf(p.eps_sqrt + d2);
+                cx = sd > 0.f ? -cr * s_q[i] * qk / sd : 0.f;
+                cq = cr * s_q[i] * (p.radius - sd);
+            }
+#pragma unroll
+            for (int d = 0; d < DP; ++d) gxk[d] -= cx * t[d];
+            gqk += cq;
+        }
+    }
+    if (live) {
+        for (int d = 0; d < p.dim; ++d) gx[(int64_t)ak * p.stride + d] += gxk[d];
+        const float a = atanhf(bk);
+        gbeta[ak] += gqk * 2.f * a / (1.f - bk * bk) - g[2] / fwd[6];  // coward: mean(1 - beta)
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------
+size_t sort_pairs_u64_temp_bytes(int64_t n);
+int sort_pairs_u64(const u64 *keys_in, u64 *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                   int64_t n, void *temp, size_t temp_bytes, hipStream_t stream);
+
+int good_node_mask_launch(const float *pt, const int64_t *pid, const float *reco, const float *eta,
+                          int64_t n, float pt_thld, float max_eta, uint8_t *mask,
+                          hipStream_t stream) {
+    if (n < 0) return fail(GNNTRK_EINVAL, "good_node_mask: bad argument");
+    if (n == 0) return GNNTRK_OK;
+    if (!pt || !pid || !reco || !eta || !mask) return fail(GNNTRK_EINVAL, "good_node_mask: NULL pointer");
+    hipLaunchKernelGGL(good_node_mask_kernel, dim3(oc_grid(n)), dim3(kOcTpb), 0, stream, pt, pid, reco,
+                       eta, n, pt_thld, max_eta, mask);
+    return check_launch("good_node_mask");
+}
+
+size_t oc_select_ws_bytes(int64_t n) {
+    const size_t a8 = align_up((size_t)(n > 0 ? n : 1) * 8, 256);
+    const size_t a4 = align_up((size_t)(n > 0 ? n : 1) * 4, 256);
+    return 2 * a8 /*keys*/ + 2 * a4 /*vals*/ + 2 * a4 /*flag,best*/ + align_up((size_t)(n + 1) * 8, 256) +
+           align_up(sort_pairs_u64_temp_bytes(n), 256);
+}
+
+int oc_select_launch(const float *score, const int64_t *pid, const uint8_t *mask, int64_t n, int mode,
+                     int32_t *alphas, int32_t *gid, int32_t *n_cp, void *ws, size_t ws_bytes,
+                     hipStream_t stream) {
+    if (!score || !pid || !mask || !alphas || !gid || !n_cp || n < 1 || (mode != 0 && mode != 1))
+        return fail(GNNTRK_EINVAL, "oc_select_cps: bad argument");
+    if (n > 0x7fffffff) return fail(GNNTRK_EUNSUPPORTED, "oc_select_cps: n must fit int32");
+    if (!ws || ws_bytes < oc_select_ws_bytes(n)) return fail(GNNTRK_EINVAL, "oc_select_cps: workspace too small");
+    char *w = reinterpret_cast<char *>(ws);
+    const size_t a8 = align_up((size_t)n * 8, 256), a4 = align_up((size_t)n * 4, 256);
+    u64 *keys_a = (u64 *)w; w += a8;
+    u64 *keys_b = (u64 *)w; w += a8;
+    uint32_t *vals_a = (uint32_t *)w; w += a4;
+    uint32_t *vals_b = (uint32_t *)w; w += a4;
+    int32_t *flag = (int32_t *)w; w += a4;
+    int32_t *best = (int32_t *)w; w += a4;
+    int64_t *off = (int64_t *)w; w += align_up((size_t)(n + 1) * 8, 256);
+    void *temp = w;
+    const int grid = oc_grid(n);
+    hipLaunchKernelGGL(oc_keys_kernel, dim3(grid), dim3(kOcTpb), 0, stream, pid, n, keys_a, vals_a);
+    int rc = sort_pairs_u64(keys_a, keys_b, vals_a, vals_b, n, temp, sort_pairs_u64_temp_bytes(n), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(oc_segment_best_kernel, dim3(grid), dim3(kOcTpb), 0, stream,
+                       (const u64 *)keys_b, (const uint32_t *)vals_b, score, mask, n, mode, flag, best);
+    hipLaunchKernelGGL(oc_scan_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t *)flag, n, off);
+    hipLaunchKernelGGL(oc_assign_kernel, dim3(grid), dim3(kOcTpb), 0, stream, (const u64 *)keys_b,
+                       (const uint32_t *)vals_b, (const int32_t *)flag, (const int32_t *)best,
+                       (const int64_t *)off, n, alphas, gid, n_cp);
+    return check_launch("oc_select_cps");
+}
+
+static int oc_check(const gnntrk_oc_args *a) {
+    if (!a || !a->x || !a->beta || !a->particle_id || !a->mask || !a->gid || !a->alphas || !a->n_cp)
+        return fail(GNNTRK_EINVAL, "oc_potential: NULL pointer");
+    if (a->n < 1 || a->dim < 1 || a->dim > kOcMaxDim || a->stride < a->dim)
+        return fail(GNNTRK_EINVAL, "oc_potential: bad sizes (1 <= dim <= 32)");
+    if (a->mode != 0 && a->mode != 1) return fail(GNNTRK_EINVAL, "oc_potential: mode must be 0 or 1");
+    return GNNTRK_OK;
+}
+
+static OcParams oc_params(const gnntrk_oc_args *a) {
+    OcParams p;
+    p.x = a->x; p.beta = a->beta; p.pid = a->particle_id; p.mask = a->mask; p.gid = a->gid;
+    p.alphas = a->alphas; p.n_cp = a->n_cp; p.n = a->n; p.dim = a->dim; p.stride = a->stride;
+    p.q_min = a->q_min; p.radius = a->radius; p.eps_sqrt = a->eps_sqrt; p.mode = a->mode;
+    return p;
+}
+
+size_t oc_forward_ws_bytes(int64_t n) { return (size_t)oc_grid(n) * 4 * sizeof(double); }
+
+#define OC_DISPATCH(CALL)                \
+    if (a->dim <= 2) { CALL(2); }        \
+    else if (a->dim <= 4) { CALL(4); }   \
+    else if (a->dim <= 8) { CALL(8); }   \
+    else if (a->dim <= 16) { CALL(16); } \
+    else { CALL(32); }
+
+int oc_forward_launch(const gnntrk_oc_args *a, float *out, void *ws, size_t ws_bytes, hipStream_t stream) {
+    int rc = oc_check(a);
+    if (rc) return rc;
+    if (!out || !ws || ws_bytes < oc_forward_ws_bytes(a->n)) return fail(GNNTRK_EINVAL, "oc_forward: workspace too small");
+    const OcParams p = oc_params(a);
+    const int grid = oc_grid(a->n);
+    double *part = reinterpret_cast<double *>(ws);
+#define CALL_F(DP) hipLaunchKernelGGL(oc_forward_kernel<DP>, dim3(grid), dim3(kOcTpb), 0, stream, p, part)
+    OC_DISPATCH(CALL_F)
+#undef CALL_F
+    hipLaunchKernelGGL(oc_finalize_kernel, dim3(1), dim3(kOcTpb), 0, stream, p, (const double *)part, grid, out);
+    return check_launch("oc_forward");
+}
+
+int oc_backward_launch(const gnntrk_oc_args *a, const float *g, const float *fwd, float *gx, float *gbeta,
+                       int64_t max_cps, hipStream_t stream) {
+    int rc = oc_check(a);
+    if (rc) return rc;
+    if (!g || !fwd || !gx || !gbeta || max_cps < 1) return fail(GNNTRK_EINVAL, "oc_backward: bad argument");
+    const OcParams p = oc_params(a);
+    const int grid = oc_grid(a->n), kgrid = oc_grid(max_cps);
+#define CALL_BH(DP) hipLaunchKernelGGL(oc_backward_hits_kernel<DP>, dim3(grid), dim3(kOcTpb), 0, stream, p, g, fwd, gx, gbeta)
+    OC_DISPATCH(CALL_BH)
+#undef CALL_BH
+#define CALL_BC(DP) hipLaunchKernelGGL(oc_backward_cps_kernel<DP>, dim3(kgrid), dim3(kOcTpb), 0, stream, p, g, fwd, gx, gbeta)
+    OC_DISPATCH(CALL_BC)
+#undef CALL_BC
+    return check_launch("oc_backward");
+}
+
+}  // namespace gnntrk

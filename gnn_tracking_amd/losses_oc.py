@@ -1,0 +1,193 @@
+"""Object-condensation losses on fused HIP reductions.
+
+Reference: metrics/losses/__init__.py:13-41 (``MultiLossFctReturn``) and
+metrics/losses/oc.py:164-436 (``CondensationLossRG``, ``CondensationLossTiger``): same
+constructor keywords, ``hparams`` and return type.  Neither the N x K matrices of the Tiger
+variant nor the radius graph of the RG variant are materialised: both are sums over
+(hit, condensation point) pairs evaluated by ``gnntrk_oc_forward/backward`` (csrc/oc.hip).
+
+Not implemented (raise): ``sample_pids < 1`` and Tiger's ``max_n_rep > 0`` - both are random
+sub-sampling switches for memory that the fused kernels make unnecessary.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+from torch import Tensor as T
+
+from . import _capi, ops
+from .graph_masks import get_good_node_mask_tensors
+from .hparams import HyperparametersMixin
+
+
+@dataclass(kw_only=True)
+class MultiLossFctReturn:
+    """Return type of loss functions with several terms (losses/__init__.py:13-35)."""
+
+    #: individual loss terms
+    loss_dct: dict[str, T]
+    #: their weights
+    weight_dct: dict[str, T] | dict[str, float]
+    #: other things to log
+    extra_metrics: dict[str, Any] = field(default_factory=dict)
+
+    def __post_init__(self) -> None:
+        assert self.loss_dct.keys() == self.weight_dct.keys()
+
+    @property
+    def loss(self) -> T:
+        loss = sum(self.weighted_losses.values())
+        assert isinstance(loss, torch.Tensor)
+        return loss
+
+    @property
+    def weighted_losses(self) -> dict[str, T]:
+        return {k: v * self.weight_dct[k] for k, v in self.loss_dct.items()}
+
+
+class MultiLossFct(torch.nn.Module):
+    """Base class of loss functions returning ``MultiLossFctReturn``."""
+
+    def forward(self, *args: Any, **kwargs: Any) -> MultiLossFctReturn: ...
+
+
+class _CondensationPotentials(torch.autograd.Function):
+    """(attractive, repulsive, coward, noise) and their gradients w.r.t. (beta, x)."""
+
+    @staticmethod
+    def forward(ctx, beta, x, particle_id, mask, q_min: float, radius: float, eps_sqrt: float,
+                mode: int):
+        _capi.require_device(beta, x, particle_id, mask)
+        lib = _capi.load()
+        dev = x.device
+        beta_c = beta.detach().to(torch.float32).contiguous()
+        x_c = x.detach().to(torch.float32).contiguous()
+        pid = particle_id.to(torch.int64).contiguous()
+        mask8 = mask.to(torch.uint8).contiguous()
+        n, dim = int(x_c.shape[0]), int(x_c.shape[1])
+        st = ops._stream(x_c)
+        alphas = torch.empty(n, dtype=torch.int32, device=dev)
+        gid = torch.empty(n, dtype=torch.int32, device=dev)
+        n_cp = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = ops._ws(lib.gnntrk_oc_select_workspace_bytes(n), x_c)
+        _capi.check(lib.gnntrk_oc_select_cps(ops._p(beta_c), ops._p(pid), ops._p(mask8), n, mode,
+                                             ops._p(alphas), ops._p(gid), ops._p(n_cp), ops._p(ws),
+                                             ws.numel(), st), lib)
+        a = _capi.OcArgs(ops._p(x_c), ops._p(beta_c), ops._p(pid), ops._p(mask8), ops._p(gid),
+                         ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode)
+        out = torch.empty(9, dtype=torch.float32, device=dev)
+        ws2 = ops._ws(lib.gnntrk_oc_forward_workspace_bytes(n), x_c)
+        _capi.check(lib.gnntrk_oc_forward(C.byref(a), ops._p(out), ops._p(ws2), ws2.numel(), st), lib)
+        ctx.save_for_backward(beta_c, x_c, pid, mask8, gid, alphas, n_cp, out)
+        ctx.cfg = (q_min, radius, eps_sqrt, mode, beta.dtype, x.dtype)
+        return out[0], out[1], out[2], out[3], out[7].detach()
+
+    @staticmethod
+    def backward(ctx, g_att, g_rep, g_cow, g_noise, _g_nrep):
+        lib = _capi.load()
+        beta_c, x_c, pid, mask8, gid, alphas, n_cp, out = ctx.saved_tensors
+        q_min, radius, eps_sqrt, mode, bdt, xdt = ctx.cfg
+        n, dim = int(x_c.shape[0]), int(x_c.shape[1])
+        g = torch.stack([t.to(torch.float32).reshape(()) if t is not None
+                         else torch.zeros((), device=x_c.device)
+                         for t in (g_att, g_rep, g_cow, g_noise)]).contiguous()
+        a = _capi.OcArgs(ops._p(x_c), ops._p(beta_c), ops._p(pid), ops._p(mask8), ops._p(gid),
+                         ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode)
+        gx = torch.empty_like(x_c)
+        gbeta = torch.empty_like(beta_c)
+        _capi.check(lib.gnntrk_oc_backward(C.byref(a), ops._p(g), ops._p(out), ops._p(gx),
+                                           ops._p(gbeta), n, ops._stream(x_c)), lib)
+        return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None
+
+
+class _CondensationLoss(MultiLossFct, HyperparametersMixin):
+    _mode = 0
+    _eps_sqrt = 1e-9
+
+    def _forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
+                 ec_hit_mask: T | None, eta: T, mask_eta: bool) -> MultiLossFctReturn:
+        if ec_hit_mask is not None:
+            # model outputs already carry the post-EC node mask, data attributes do not
+            particle_id = particle_id[ec_hit_mask]
+            reconstructable = reconstructable[ec_hit_mask]
+            pt = pt[ec_hit_mask]
+            if mask_eta:
+                eta = eta[ec_hit_mask]
+        mask = get_good_node_mask_tensors(pt=pt, particle_id=particle_id,
+                                          reconstructable=reconstructable, eta=eta,
+                                          pt_thld=self.hparams.pt_thld,
+                                          max_eta=self.hparams.max_eta)
+        if self.hparams.sample_pids < 1:
+            raise NotImplementedError(
+                "sample_pids < 1 (random sub-sampling to save memory) is not implemented: the "
+                "fused kernels never materialise the N x K matrices it exists to shrink")
+        # If there are no hits left after masking, then we get a NaN loss.
+        assert bool(mask.any()), "No hits left after masking"
+        att, rep, cow, noise, n_rep = _CondensationPotentials.apply(
+            beta, x, particle_id, mask, float(self.hparams.q_min), 1.0, self._eps_sqrt, self._mode)
+        losses = {"attractive": att, "repulsive": rep, "coward": cow, "noise": noise}
+        weights = {"attractive": 1.0, "repulsive": self.hparams.lw_repulsive,
+                   "noise": self.hparams.lw_noise, "coward": self.hparams.lw_coward}
+        extra = {"n_rep": n_rep} if self._mode == 1 else {}
+        return MultiLossFctReturn(loss_dct=losses, weight_dct=weights, extra_metrics=extra)
+
+
+class CondensationLossRG(_CondensationLoss):
+    _mode = 0
+    _eps_sqrt = 1e-9
+
+    def __init__(self, *, lw_repulsive: float = 1.0, lw_noise: float = 0.0, lw_coward: float = 0.0,
+                 q_min: float = 0.01, pt_thld: float = 0.9, max_eta: float = 4.0,
+                 max_num_neighbors: int = 256, sample_pids: float = 1.0):
+        """Condensation loss, radius-graph formulation (oc.py:164-248).
+
+        Args:
+            lw_repulsive: weight of the repulsive potential
+            lw_noise: weight of the noise loss
+            lw_coward: weight of the coward loss
+            q_min: minimal charge (object condensation paper)
+            pt_thld: pt threshold of the particles of interest
+            max_eta: eta threshold of the particles of interest
+            max_num_neighbors: neighbour cap of the reference's radius graph.  Kept for
+                interface parity; the fused kernel sums over ALL hits within the unit radius
+                (the reference's result whenever the cap is not reached - with the cap reached
+                torch_cluster keeps an implementation-defined subset)
+            sample_pids: must be 1.0
+        """
+        super().__init__()
+        self.save_hyperparameters()
+
+    def forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
+                ec_hit_mask: T | None = None, eta: T, **kwargs) -> MultiLossFctReturn:
+        # NB: like the reference (oc.py:207-213) eta is NOT sliced by ec_hit_mask here
+        return self._forward(beta=beta, x=x, particle_id=particle_id,
+                             reconstructable=reconstructable, pt=pt, ec_hit_mask=ec_hit_mask,
+                             eta=eta, mask_eta=False)
+
+
+class CondensationLossTiger(_CondensationLoss):
+    _mode = 1
+    _eps_sqrt = 0.0
+
+    def __init__(self, *, lw_repulsive: float = 1.0, lw_noise: float = 0.0, lw_coward: float = 0.0,
+                 q_min: float = 0.01, pt_thld: float = 0.9, max_eta: float = 4.0, max_n_rep: int = 0,
+                 sample_pids: float = 1.0):
+        """Condensation loss, dense formulation (oc.py:350-436) without the N x K matrices.
+
+        Args: as ``CondensationLossRG``; ``max_n_rep`` (random sub-sampling of repulsive
+            pairs) must be 0.
+        """
+        super().__init__()
+        self.save_hyperparameters()
+        if max_n_rep:
+            raise NotImplementedError("max_n_rep > 0 (random sub-sampling) is not implemented")
+
+    def forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
+                ec_hit_mask: T | None = None, eta: T, **kwargs) -> MultiLossFctReturn:
+        return self._forward(beta=beta, x=x, particle_id=particle_id,
+                             reconstructable=reconstructable, pt=pt, ec_hit_mask=ec_hit_mask,
+                             eta=eta, mask_eta=True)

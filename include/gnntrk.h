@@ -265,6 +265,50 @@ int gnntrk_edge_labels(const int64_t *particle_id, const int64_t *edge_index, in
 int gnntrk_edge_features(const float *x, int32_t dim, int32_t x_stride, const int64_t *edge_index,
                          int64_t n_edges, float *out, void *stream);
 
+/* ------------------------------------------------------ condensation losses
+ * utils/graph_masks.py:19-28: mask = pt > thld && pid > 0 && reconstructable > 0 && |eta| < max_eta */
+int gnntrk_good_node_mask(const float *pt, const int64_t *particle_id, const float *reconstructable,
+                          const float *eta, int64_t n, float pt_thld, float max_eta, uint8_t *mask,
+                          void *stream);
+
+/* Condensation-point selection (metrics/losses/oc.py:16-43 and :279-292): for every particle
+ * id that has at least one masked hit, the hit with the largest score (beta); mode 0 (RG):
+ * among its masked hits, mode 1 (Tiger): among all its hits; ties -> lowest hit index.
+ * alphas[0..K): CP hit per particle of interest, ascending particle id; gid[h] = k of hit h's
+ * particle or -1; n_cp[0] = K (device).  Index work: one stable 64-bit radix sort + scans. */
+size_t gnntrk_oc_select_workspace_bytes(int64_t n);
+int gnntrk_oc_select_cps(const float *score, const int64_t *particle_id, const uint8_t *mask,
+                         int64_t n, int32_t mode, int32_t *alphas, int32_t *gid, int32_t *n_cp,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* Potential / background loss terms (metrics/losses/oc.py:46-161 RG with mode 0,
+ * :251-347 Tiger with mode 1; q = atanh(beta)^2 + q_min):
+ *   out[0] attractive = sum q_j q_k |x_j-x_k|^2 / (1e-9 + n_oi - K)
+ *   out[1] repulsive  = sum_{pid_j != pid_k, |x_j-x_k| < radius} q_j q_k (radius - sqrt(eps_sqrt + d2))
+ *                       / (1e-9 + (K-1) n)
+ *   out[2] coward     = mean(1 - beta[alphas]);  out[3] noise = mean(beta[noise hits])
+ *   out[4..8]         = norm_att, norm_rep, K, number of repulsive pairs, number of noise hits
+ * backward: gx[n,dim], gbeta[n] = sum_t g[t] * d out[t] / d(x, beta); fwd = forward's out.   */
+typedef struct gnntrk_oc_args {
+    const float *x;    /* [n, stride] latent coordinates */
+    const float *beta; /* [n] */
+    const int64_t *particle_id;
+    const uint8_t *mask;
+    const int32_t *gid;
+    const int32_t *alphas;
+    const int32_t *n_cp;
+    int64_t n;
+    int32_t dim, stride;
+    float q_min, radius, eps_sqrt;
+    int32_t mode;
+} gnntrk_oc_args;
+
+size_t gnntrk_oc_forward_workspace_bytes(int64_t n);
+int gnntrk_oc_forward(const gnntrk_oc_args *args, float *out /*[9]*/, void *workspace,
+                      size_t workspace_bytes, void *stream);
+int gnntrk_oc_backward(const gnntrk_oc_args *args, const float *g /*[4]*/, const float *fwd /*[9]*/,
+                       float *gx, float *gbeta, int64_t max_cps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

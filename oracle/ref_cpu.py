@@ -277,12 +277,14 @@ def _condensation_points(beta: Tensor, particle_id: Tensor, mask: Tensor):
     uniq, inv = torch.unique(pid_m, sorted=True, return_inverse=True)
     K = uniq.shape[0]
     assert K > 0, "No particles found, cannot evaluate loss"
-    # arg-max of beta per particle; descending-beta order -> first occurrence
+    # arg-max of beta per particle (ties -> lowest hit index), written without the
+    # duplicate-index scatter of the reference (oc.py:20-23 relies on last-write-wins,
+    # which torch only honours for small single-threaded tensors)
     order = torch.argsort(beta_m, descending=True, stable=True)
-    first = torch.full((K,), -1, dtype=torch.long)
-    inv_o = inv[order]
-    # iterate from the back so that the earliest (largest beta) entry wins
-    first[inv_o.flip(0)] = order.flip(0)
+    grouped = order[torch.argsort(inv[order], stable=True)]      # by particle, beta descending
+    counts = torch.bincount(inv, minlength=K)
+    starts = torch.cumsum(counts, 0) - counts
+    first = grouped[starts]
     alphas = idx[first]
     is_cp = torch.zeros_like(particle_id, dtype=torch.bool)
     is_cp[alphas] = True

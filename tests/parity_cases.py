@@ -259,3 +259,45 @@ def case_ml_graph_construction(device):
         assert torch.equal(out.edge_index.cpu(), tt(z[f"k{k}_r{r}/edge_index"]))
         assert torch.equal(out.y.cpu(), tt(z[f"k{k}_r{r}/y"]))
         assert torch.equal(out.edge_attr.cpu(), tt(z[f"k{k}_r{r}/edge_attr"])), "edge features"
+
+
+# ------------------------------------------------------------ condensation losses
+def case_condensation_losses(device, cases=("td1", "td2", "td3")):
+    """CondensationLossRG / Tiger vs the reference (G5): the reference's pinned float64
+    known-answer cases td1/td2 (tests/test_losses.py:112-123) are run here in fp32 and
+    compared with the reference's own fp32 re-run, loss terms and gradients."""
+    from gnn_tracking_amd.losses_oc import CondensationLossRG, CondensationLossTiger
+
+    z = load("g5_oc.npz")
+    for cn in cases:
+        t = {k: tt(z[f"{cn}/{k}"]) for k in ("beta", "x", "particle_id", "pt", "eta",
+                                              "reconstructable")}
+        if cn == "td3":
+            pass  # x was already scaled when the golden was generated
+        for strat, cls in (("tiger", CondensationLossTiger), ("rg", CondensationLossRG)):
+            b = t["beta"].float().to(device).requires_grad_(True)
+            x = t["x"].float().to(device).requires_grad_(True)
+            ret = cls(lw_repulsive=2.0, lw_noise=0.5, lw_coward=0.25)(
+                beta=b, x=x, particle_id=t["particle_id"].to(device),
+                reconstructable=t["reconstructable"].float().to(device),
+                pt=t["pt"].float().to(device), eta=t["eta"].float().to(device))
+            for k in ("attractive", "repulsive", "coward", "noise"):
+                assert_close(ret.loss_dct[k], z[f"{cn}/f32/{strat}/{k}"], 2e-5, f"{cn} {strat} {k}")
+            assert_close(ret.loss, z[f"{cn}/f32/{strat}/total"], 2e-5, f"{cn} {strat} total")
+            ret.loss.backward()
+            assert_close(x.grad, z[f"{cn}/f32/{strat}/grad_x"], 2e-4, f"{cn} {strat} grad x")
+            assert_close(b.grad, z[f"{cn}/f32/{strat}/grad_beta"], 2e-4, f"{cn} {strat} grad beta")
+
+
+def case_good_node_mask(device):
+    from gnn_tracking_amd.graph_masks import get_good_node_mask_tensors
+
+    z = load("g5_oc.npz")
+    t = {k: tt(z[f"td3/{k}"]) for k in ("particle_id", "pt", "eta", "reconstructable")}
+    ref = O.good_node_mask(t["pt"].float(), t["particle_id"], t["reconstructable"].float(),
+                           t["eta"].float())
+    got = get_good_node_mask_tensors(pt=t["pt"].float().to(device),
+                                     particle_id=t["particle_id"].to(device),
+                                     reconstructable=t["reconstructable"].float().to(device),
+                                     eta=t["eta"].float().to(device))
+    assert got.dtype == torch.bool and torch.equal(got.cpu(), ref)

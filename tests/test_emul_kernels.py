@@ -47,3 +47,9 @@ def test_knn_against_c_oracle_and_goldens():
                                          (1, 3, 4, None), (2, 3, 4, None)))
         P.case_knn_goldens("cpu", clouds=("tg3",))
         P.case_ml_graph_construction("cpu")
+
+
+def test_condensation_losses_and_mask():
+    with emulated():
+        P.case_good_node_mask("cpu")
+        P.case_condensation_losses("cpu")

@@ -58,6 +58,11 @@ def test_ml_graph_construction(dev):
     P.case_ml_graph_construction(dev)
 
 
+def test_condensation_losses(dev):
+    P.case_good_node_mask(dev)
+    P.case_condensation_losses(dev)
+
+
 def test_cpu_tensor_is_rejected(dev):
     import gnn_tracking_amd as G
 

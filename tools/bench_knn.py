@@ -19,18 +19,23 @@ def cloud(seed, n, d=8, n_clusters=6000, sigma=0.05, noise=0.1):
     x = np.concatenate([pts, ball(n_noise)]).astype(np.float32)
     return torch.from_numpy(x[g.permutation(n)])
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
-x = cloud(500, n)
-xd = x.cuda()
-for k in (16, 64):
-    ops.knn_graph(xd[:4096], k, 1.0)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    ei = ops.knn_graph(xd, k, 1.0)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"GPU kNN n={n} k={k} r=1: {dt*1e3:.1f} ms, {ei.shape[1]} edges, "
-          f"{n*n*8*2/dt/1e12:.2f} Tflop/s (N^2*D fma)")
-    ns = 20000
-    t0 = time.perf_counter(); ref = O.knn_graph_c(x[:ns], k, 1.0); dtc = time.perf_counter() - t0
-    got = ops.knn_graph(xd[:ns], k, 1.0).cpu()
-    print(f"  C oracle (OpenMP, {os.cpu_count()} cpus) on first {ns}: {dtc:.2f} s -> full-size estimate "
-          f"{dtc*(n/ns)**2:.0f} s; subset bit-exact: {torch.equal(got, ref)}")
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+    x = cloud(500, n)
+    xd = x.cuda()
+    for k in (16, 64):
+        ops.knn_graph(xd[:4096], k, 1.0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ei = ops.knn_graph(xd, k, 1.0)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"GPU kNN n={n} k={k} r=1: {dt*1e3:.1f} ms, {ei.shape[1]} edges, "
+              f"{n*n*8*2/dt/1e12:.2f} Tflop/s (N^2*D fma)")
+        ns = 20000
+        t0 = time.perf_counter(); ref = O.knn_graph_c(x[:ns], k, 1.0); dtc = time.perf_counter() - t0
+        got = ops.knn_graph(xd[:ns], k, 1.0).cpu()
+        print(f"  C oracle (OpenMP, {os.cpu_count()} cpus) on first {ns}: {dtc:.2f} s -> full-size estimate "
+              f"{dtc*(n/ns)**2:.0f} s; subset bit-exact: {torch.equal(got, ref)}")
+
+
+if __name__ == "__main__":
+    main()

@@ -30,12 +30,22 @@ struct OperandPolicy {  // DynDims
     template <int N>
     using Bias = LdsBias<N>;
 };
-template <int KSI, int KSH, int KSO, bool THREE>
-struct OperandPolicy<StaticDims<KSI, KSH, KSO, THREE>> {
+template <int KSI, int KSH, int KSO, bool THREE, int NIT>
+struct OperandPolicy<StaticDims<KSI, KSH, KSO, THREE, NIT>> {
     template <int N>
     using Frags = RegFrags<N>;
     template <int N>
     using Bias = RegBias<N>;
+};
+
+// exact k-step counts for LDS sizing: static shapes know them, generic ones take the tile max
+template <class Dims, int KT, int HT>
+struct KsOf {
+    static constexpr int in = 4 * KT, hid = 4 * HT, out = 4;
+};
+template <int KSI, int KSH, int KSO, bool THREE, int NIT, int KT, int HT>
+struct KsOf<StaticDims<KSI, KSH, KSO, THREE, NIT>, KT, HT> {
+    static constexpr int in = KSI, hid = KSH, out = KSO;
 };
 
 // ------------------------------------------------------------------- forward
@@ -47,15 +57,19 @@ struct FwdSmem {
     f32x4 b1[HT * 64];
     f32x4 b2[HT * 64];
     f32x4 b3[64];
+    float sin[kWaves][(16 * KT + 2) * kTbLd];  // input staging per wave ([feature][row])
     SegTable segs;
+    LoadList ll;
 };
 
 template <int KT, int HT, class Dims>
 __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_args a) {
     __shared__ __attribute__((aligned(16))) FwdSmem<KT, HT> sm;
     using OP = OperandPolicy<Dims>;
+    constexpr int NI = Dims::kItems > 0 ? Dims::kItems : 4 * KT + 4;
     const Dims dm = make_dims<Dims>(a.mlp);
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15, wv = tid >> 6;
+    const int part = g;
     const int last = a.mlp.n_layers - 1;
 
     fill_frags(sm.w1, a.mlp.W[0], a.mlp.in_dim, dm.hid, dm.in, false, tid, kBlock);
@@ -65,6 +79,9 @@ __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_ar
     if (dm.three()) fill_bias(sm.b2, a.mlp.b[1], dm.hid, tid, kBlock);
     fill_bias(sm.b3, a.mlp.b[last], dm.out, tid, kBlock);
     stage_segs(sm.segs, a.seg, nullptr, a.n_seg, tid);
+    for (int i = tid; i < kWaves * (16 * KT + 2) * kTbLd; i += kBlock) (&sm.sin[0][0])[i] = 0.f;
+    __syncthreads();
+    if (tid == 0) build_load_list(sm.ll, sm.segs, a.n_seg);
     __syncthreads();
 
     const int nti = (dm.in_ks() + 3) >> 2;
@@ -80,9 +97,10 @@ __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_ar
     b2.load(sm.b2, dm.three() ? nth : 0, lane);
     const f32x4 b3 = sm.b3[lane];
 
-    InSlot slot[KT * 4];
-    unsigned relu_bits;
-    setup_in_slots<KT>(sm.segs, a.n_seg, dm.in, g, slot, relu_bits);
+    Items<NI> it;
+    it.load(sm.ll);
+    int boff[KT * 4];
+    operand_offsets<KT>(dm.in, g, c, 16 * KT + 1, boff);
 
     int fo[4];
 #pragma unroll
@@ -95,34 +113,43 @@ __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_ar
     const TileSched sch = make_sched(n_tiles);
     int64_t tile = sch.cur;
     if (tile >= sch.end) return;
+    const int64_t last_row = a.n_rows - 1;
+    const bool ld_on = !(a.debug_flags & 2);
+    auto clamp_row = [&](int64_t t) {
+        const int64_t r = t * kTileRows + c;
+        return r < last_row ? r : last_row;
+    };
+    auto row_valid = [&](int64_t t) { return t < sch.end && t * kTileRows + c < a.n_rows; };
 
-    // software pipeline: values of tile n+1 and row ids of tile n+2 in flight
-    int32_t rid_n[KT * 4];
-    f32x4 bin_c[KT];
+    // software pipeline: values of tile n+1 (registers) and row ids of tile n+2 are in flight
+    // while tile n computes; the values are staged into LDS at the end of tile n
+    int32_t rid_n[NI];
+    float pv[NI];
+    float *sc = sm.sin[wv];
     {
-        const int64_t row = tile * kTileRows + c;
-        int32_t rid_c[KT * 4];
-        load_row_ids<KT>(slot, nti, row, row < a.n_rows, rid_c);
-        load_values<KT>(slot, nti, row < a.n_rows, rid_c, bin_c);
-        const int64_t row_n = (tile + sch.step) * kTileRows + c;
-        load_row_ids<KT>(slot, nti, row_n, tile + sch.step < sch.end && row_n < a.n_rows, rid_n);
+        int32_t rid_c[NI];
+        item_row_ids<NI>(it, clamp_row(tile), rid_c);
+        item_values<NI>(it, rid_c, part, row_valid(tile) && ld_on, pv);
+        stage_items<NI>(it, sc, part, c, pv);
+        item_row_ids<NI>(it, clamp_row(tile + sch.step < sch.end ? tile + sch.step : tile), rid_n);
     }
     for (; tile < sch.end; tile += sch.step) {
         const int64_t row = tile * kTileRows + c;
         const bool valid = row < a.n_rows;
-        const int64_t row_n = (tile + sch.step) * kTileRows + c;
-        const int64_t row_nn = (tile + 2 * sch.step) * kTileRows + c;
-        const bool valid_n = tile + sch.step < sch.end && row_n < a.n_rows;
-        const bool valid_nn = tile + 2 * sch.step < sch.end && row_nn < a.n_rows;
-        f32x4 bin_n[KT];
-        load_values<KT>(slot, nti, valid_n && !(a.debug_flags & 2), rid_n, bin_n);
-        load_row_ids<KT>(slot, nti, row_nn, valid_nn && !(a.debug_flags & 2), rid_n);
+        item_values<NI>(it, rid_n, part, row_valid(tile + sch.step) && ld_on, pv);
+        {
+            const int64_t t2 = tile + 2 * sch.step;
+            item_row_ids<NI>(it, clamp_row(t2 < sch.end ? t2 : tile), rid_n);
+        }
         int64_t orow = row;
         if (valid && out_idx) orow = out_idx[row];
 
-        apply_input_relu<KT>(relu_bits, bin_c);
+        lds_wave_sync();
+        f32x4 bin[KT];
+        read_operand<KT>(sc, boff, nti, bin);
+        lds_wave_sync();  // all lanes hold their operands: the buffer may be restaged
         f32x4 a1[HT], a2[HT];
-        mlp_layer1<KT, HT>(dm, w1, b1, lane, bin_c, a1);
+        mlp_layer1<KT, HT>(dm, w1, b1, lane, bin, a1);
         mlp_layer2<HT>(dm, w2, b2, lane, a1, a2);
         const f32x4 y = mlp_layer3<HT>(dm, w3, b3, lane, a2);
         if (valid && !((a.debug_flags & 1) && y[0] != 12345.678f)) {
@@ -141,31 +168,33 @@ __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_ar
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < KT; ++t) bin_c[t] = bin_n[t];
+        stage_items<NI>(it, sc, part, c, pv);
     }
 }
 
 // ------------------------------------------------------------------ backward
-template <int KT, int HT, int WPB>
+template <int KT, int HT, int WPB, class KS>
 struct BwdSmem {
-    float w1[HT * 4 * KT * 64];   // W1   rows=hid, k=in
-    float w2[HT * 4 * HT * 64];   // W2   rows=hid, k=hid
-    float w3[4 * HT * 64];        // Wout rows=out, k=hid
-    float w1t[KT * 4 * HT * 64];  // W1^T rows=in,  k=hid
-    float w2t[HT * 4 * HT * 64];  // W2^T rows=hid, k=hid
-    float w3t[HT * 4 * 64];       // Wout^T rows=hid, k=out
+    float w1[HT * KS::in * 64];    // W1   rows=hid, k=in
+    float w2[HT * KS::hid * 64];   // W2   rows=hid, k=hid
+    float w3[KS::hid * 64];        // Wout rows=out, k=hid
+    float w1t[KT * KS::hid * 64];  // W1^T rows=in,  k=hid
+    float w2t[HT * KS::hid * 64];  // W2^T rows=hid, k=hid
+    float w3t[HT * KS::out * 64];  // Wout^T rows=hid, k=out
     f32x4 b1[HT * 64];
     f32x4 b2[HT * 64];
     f32x4 b3[64];
-    float tb[WPB][kTbBufs][(16 * (HT > KT ? HT : KT) + 1) * kTbLd];  // wave-private transpose buffers
+    // wave-private buffers, all [feature][row] with leading dim kTbLd; each has two extra rows:
+    // a write-only garbage row (padding registers) and a never-written zero row
+    float sin[WPB][(16 * KT + 2) * kTbLd];  // staged inputs = m (B operand) and m^T (dW1)
+    float sgy[WPB][(4 * KS::out + 2) * kTbLd];  // staged upstream gradient
+    float tb0[WPB][(16 * KT + 2) * kTbLd];  // gy^T, then the outgoing input gradient
+    float tb[WPB][2][(16 * HT + 2) * kTbLd];  // a1 / dl and a2 / d1 transposes
     SegTable segs;
+    LoadList ll;
 };
 
-// Transposes between the accumulator layout (feature on (g,r), row on c) and the
-// "rows on k" layout the weight-gradient MFMAs need (feature on c, rows 4g..4g+3):
-// 4 ds_write_b32 + 1 ds_read_b128 per 16x16 tile through a wave-private buffer.  Writes
-// are branch-free: padding registers go to a garbage row (kTbRows).
+// accumulator layout -> LDS [feature][row]; padding registers go to the garbage row
 template <int NT>
 __device__ __forceinline__ void tr_offsets(const DimMap &map, int g, int c, int garbage_row,
                                            int (&off)[NT * 4]) {
@@ -186,6 +215,7 @@ __device__ __forceinline__ void tr_write(float *tb, const int (&off)[NT * 4], in
         for (int r = 0; r < 4; ++r)
             if (t < nt && 4 * t + r < ks) tb[off[t * 4 + r]] = x[t][r];
 }
+// "rows on k" operand: xT[t][s] = buffer[feature 16t + c][row 4g + s]
 template <int NT>
 __device__ __forceinline__ void tr_read(const float *tb, int nt, int g, int c, f32x4 (&xT)[NT]) {
 #pragma unroll
@@ -218,45 +248,21 @@ __host__ __device__ inline BwdPartLayout part_layout(const gnntrk_mlp &m) {
     return p;
 }
 
-// dW tile (rows 16to.., cols 16ti..) in accumulator layout -> partial block
-__device__ __forceinline__ void store_dw_tile(float *dst, int rows, int cols, int to, int ti, int g,
-                                              int c, const f32x4 &v) {
+// dW tile (rows 16to.., cols 16ti..) in accumulator layout -> partial block.  With the
+// constant-one row trick the column `cols` of the tile is the bias gradient.
+__device__ __forceinline__ void store_dw_tile(float *dst, float *dstb, int rows, int cols, int to,
+                                              int ti, int g, int c, const f32x4 &v) {
     const int i = 16 * ti + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 16 * to + 4 * g + r;
-        if (o < rows && i < cols) dst[o * cols + i] = v[r];
+        if (o < rows) {
+            if (i < cols)
+                dst[o * cols + i] = v[r];
+            else if (i == cols && dstb != nullptr)
+                dstb[o] = v[r];
+        }
     }
-}
-
-// raw upstream gradient of one tile row (sum of the gout terms), B layout (k = out feature)
-struct GoutRows {
-    int32_t r0, r1;
-};
-__device__ __forceinline__ GoutRows load_gout_rows(const gnntrk_mlp_bwd_args &a, int64_t row,
-                                                   bool valid) {
-    GoutRows q;
-    q.r0 = q.r1 = (int32_t)row;
-    if (valid) {
-        if (a.gout[0].idx) q.r0 = ((gci_ptr)a.gout[0].idx)[row];
-        if (a.n_gout > 1 && a.gout[1].idx) q.r1 = ((gci_ptr)a.gout[1].idx)[row];
-    }
-    return q;
-}
-__device__ __forceinline__ f32x4 load_gout(const gnntrk_mlp_bwd_args &a, const GoutRows &q,
-                                           bool valid, const int (&fo)[4]) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (fo[r] >= 0) {
-                float x = ((gcf_ptr)a.gout[0].ptr)[(int64_t)q.r0 * a.gout[0].stride + fo[r]];
-                if (a.n_gout > 1)
-                    x += ((gcf_ptr)a.gout[1].ptr)[(int64_t)q.r1 * a.gout[1].stride + fo[r]];
-                v[r] = x;
-            }
-    }
-    return v;
 }
 
 // WPB waves per workgroup: the static shapes run 8 (two per SIMD, 256 registers each,
@@ -264,13 +270,17 @@ __device__ __forceinline__ f32x4 load_gout(const gnntrk_mlp_bwd_args &a, const G
 // waits; the generic shapes keep 4 (their LDS footprint does not allow more).
 template <int KT, int HT, class Dims, int WPB>
 __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_args a,
-                                                           float *__restrict__ part) {
-    __shared__ __attribute__((aligned(16))) BwdSmem<KT, HT, WPB> sm;
+                                                           float *__restrict__ part_out) {
+    using KS = KsOf<Dims, KT, HT>;
+    __shared__ __attribute__((aligned(16))) BwdSmem<KT, HT, WPB, KS> sm;
     using OP = OperandPolicy<DynDims>;
+    constexpr int kGyRows = 4 * KS::out + 2;
     constexpr int kBwdBlock = WPB * 64;
-    constexpr int kBwdWaves = WPB;
+    constexpr int NI = Dims::kItems > 0 ? Dims::kItems : 4 * KT + 4;
+    constexpr int NGC = KsOf<Dims, KT, HT>::out;  // 4-feature chunks of the upstream gradient
     const Dims dm = make_dims<Dims>(a.mlp);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15, wv = tid >> 6;
+    const int part = g;
     const int last = a.mlp.n_layers - 1;
 
     fill_frags(sm.w1, a.mlp.W[0], a.mlp.in_dim, dm.hid, dm.in, false, tid, kBwdBlock);
@@ -284,18 +294,34 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
     fill_bias(sm.b1, a.mlp.b[0], dm.hid, tid, kBwdBlock);
     if (dm.three()) fill_bias(sm.b2, a.mlp.b[1], dm.hid, tid, kBwdBlock);
     fill_bias(sm.b3, a.mlp.b[last], dm.out, tid, kBwdBlock);
-    constexpr int kTbRowsK = 16 * (HT > KT ? HT : KT);
-    constexpr int kTbN = kBwdWaves * kTbBufs * (kTbRowsK + 1) * kTbLd;
-    for (int i = tid; i < kTbN; i += kBwdBlock) (&sm.tb[0][0][0])[i] = 0.f;
     stage_segs(sm.segs, a.seg, a.gseg, a.n_seg, tid);
+    // constant-one rows: feature row `D` of a buffer whose features stop short of a tile
+    // boundary makes column D of the matching weight-gradient tile the bias gradient
+    const bool ones_i = Dims::kStatic || (a.mlp.in_dim % 16) != 0,
+               ones_h = Dims::kStatic || (a.mlp.hidden % 16) != 0;
+    constexpr int kSinN = (16 * KT + 2) * kTbLd, kTbN = (16 * HT + 2) * kTbLd;
+    for (int i = tid; i < WPB * kSinN; i += kBwdBlock) {
+        const int f = (i % kSinN) / kTbLd, col = i % kTbLd;
+        (&sm.sin[0][0])[i] = (ones_i && f == a.mlp.in_dim && col < 16) ? 1.f : 0.f;
+        (&sm.tb0[0][0])[i] = 0.f;
+    }
+    for (int i = tid; i < WPB * kGyRows * kTbLd; i += kBwdBlock) (&sm.sgy[0][0])[i] = 0.f;
+    for (int i = tid; i < WPB * 2 * kTbN; i += kBwdBlock) {
+        const int f = (i % kTbN) / kTbLd, col = i % kTbLd;
+        (&sm.tb[0][0][0])[i] = (ones_h && f == a.mlp.hidden && col < 16) ? 1.f : 0.f;
+    }
     __syncthreads();
-    float *tb0 = sm.tb[wv][0], *tb1 = sm.tb[wv][1], *tb2 = sm.tb[wv][2];
+    if (tid == 0) build_load_list(sm.ll, sm.segs, a.n_seg);
+    __syncthreads();
+    float *tb0 = sm.tb0[wv], *tb1 = sm.tb[wv][0], *tb2 = sm.tb[wv][1];
+    float *sc = sm.sin[wv], *gc = sm.sgy[wv];
 
     const int nti = (dm.in_ks() + 3) >> 2;
     const int nth = (dm.hid_ks() + 3) >> 2;
     const bool need_y = a.epilogue == GNNTRK_EPI_RELU || a.epilogue == GNNTRK_EPI_SIGMOID;
     const bool want_dw = a.gW[0] != nullptr;
     const bool tr_on = !(a.debug_flags & 8);
+    const bool ld_on = !(a.debug_flags & 2);
 
     typename OP::template Frags<HT * KT * 4> w1;
     typename OP::template Frags<HT * HT * 4> w2;
@@ -314,43 +340,21 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
     b2.load(sm.b2, dm.three() ? nth : 0, lane);
     const f32x4 b3 = sm.b3[lane];
 
-    InSlot slot[KT * 4];
-    unsigned relu_bits;
-    setup_in_slots<KT>(sm.segs, a.n_seg, dm.in, g, slot, relu_bits);
+    Items<NI> it;
+    it.load(sm.ll);
+    GradItems<NI> gi;
+    gi.load(sm.ll, it.n);
+    int boff[KT * 4], ooff[4], off_i[KT * 4], off_h[HT * 4], off_o[4];
+    operand_offsets<KT>(dm.in, g, c, 16 * KT + 1, boff);
+    operand_offsets<1>(dm.out, g, c, kGyRows - 1, ooff);
+    tr_offsets<KT>(dm.in, g, c, 16 * KT, off_i);   // -> tb0
+    tr_offsets<HT>(dm.hid, g, c, 16 * HT, off_h);  // -> tb1 / tb2
+    tr_offsets<1>(dm.out, g, c, 16 * KT, off_o);   // -> tb0
 
-    // per-lane gradient slots (same feature <-> (tile,reg) map as the loader)
-    gf_ptr gbase[KT * 4];
-    gci_ptr gidx[KT * 4];
-    int32_t gstride[KT * 4];
-    unsigned gacc_bits = 0;
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            gbase[t * 4 + r] = nullptr;
-            gidx[t * 4 + r] = nullptr;
-            gstride[t * 4 + r] = 0;
-            const int f = feat_of(dm.in, t, g, r);
-            int off = 0;
-            for (int j = 0; j < a.n_seg; ++j) {
-                const int d = sm.segs.dim[j];
-                if (f >= off && f < off + d && sm.segs.gptr[j] != nullptr) {
-                    gbase[t * 4 + r] = (gf_ptr)sm.segs.gptr[j] + (f - off);
-                    gidx[t * 4 + r] = (gci_ptr)sm.segs.gidx[j];
-                    gstride[t * 4 + r] = sm.segs.gstride[j];
-                    if (sm.segs.gacc[j]) gacc_bits |= 1u << (t * 4 + r);
-                }
-                off += d;
-            }
-        }
-
-    int fo[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) fo[r] = feat_of(dm.out, 0, g, r);
-    int off_i[KT * 4], off_h[HT * 4], off_o[4];
-    tr_offsets<KT>(dm.in, g, c, kTbRowsK, off_i);
-    tr_offsets<HT>(dm.hid, g, c, kTbRowsK, off_h);
-    tr_offsets<1>(dm.out, g, c, kTbRowsK, off_o);
+    // upstream-gradient terms (uniform descriptors)
+    const gcf_ptr go_ptr0 = (gcf_ptr)a.gout[0].ptr, go_ptr1 = (gcf_ptr)a.gout[1].ptr;
+    const gci_ptr go_idx0 = (gci_ptr)a.gout[0].idx, go_idx1 = (gci_ptr)a.gout[1].idx;
+    const int n_och = (a.mlp.out_dim + 3) >> 2;  // 4-feature chunks of the output
 
     // weight-gradient accumulators (accumulator layout: rows = out feature, cols = in feature)
     f32x4 dW1[HT][KT], dW2[HT][HT], dW3[HT], db1[HT], db2[HT], db3;
@@ -368,70 +372,85 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
     db3 = zero4;
 
     const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
-    const TileSched sch = make_sched(n_tiles, kBwdWaves);
+    const TileSched sch = make_sched(n_tiles, WPB);
     int64_t tile = sch.cur;
+    const int64_t last_row = a.n_rows - 1;
+    auto clamp_row = [&](int64_t t) {
+        const int64_t r = t * kTileRows + c;
+        return r < last_row ? r : last_row;
+    };
+    auto row_valid = [&](int64_t t) { return t < sch.end && t * kTileRows + c < a.n_rows; };
+    // upstream gradient of (row, chunk ch, element part): sum of the gout terms
+    auto gout_rows = [&](int64_t r, int32_t &r0, int32_t &r1) {
+        r0 = r1 = (int32_t)r;
+        if (go_idx0) r0 = go_idx0[r];
+        if (a.n_gout > 1 && go_idx1) r1 = go_idx1[r];
+    };
+    auto gout_vals = [&](int32_t r0, int32_t r1, bool valid, float (&gv)[NGC]) {
+#pragma unroll
+        for (int ch = 0; ch < NGC; ++ch) {
+            float v = 0.f;
+            const int f = 4 * ch + part;
+            if (ch < n_och && valid && f < a.mlp.out_dim) {
+                v = go_ptr0[(int64_t)r0 * a.gout[0].stride + f];
+                if (a.n_gout > 1) v += go_ptr1[(int64_t)r1 * a.gout[1].stride + f];
+            }
+            gv[ch] = v;
+        }
+    };
+    auto stage_gout = [&](float *buf, const float (&gv)[NGC]) {
+#pragma unroll
+        for (int ch = 0; ch < NGC; ++ch)
+            if (ch < n_och) buf[(4 * ch + part) * kTbLd + c] = gv[ch];
+    };
 
     // software pipeline: values of tile n+1 and row ids of tile n+2 in flight
-    int32_t rid_n[KT * 4];
-    GoutRows gr_n;
-    gr_n.r0 = gr_n.r1 = 0;
-    f32x4 bin_c[KT], gy_c = zero4;
+    int32_t rid_n[NI], gr0_n = 0, gr1_n = 0;
+    float pv[NI], gv[NGC];
     if (tile < sch.end) {
-        const int64_t row = tile * kTileRows + c;
-        const bool valid = row < a.n_rows;
-        int32_t rid_c[KT * 4];
-        load_row_ids<KT>(slot, nti, row, valid, rid_c);
-        const GoutRows gr_c = load_gout_rows(a, row, valid);
-        load_values<KT>(slot, nti, valid, rid_c, bin_c);
-        gy_c = load_gout(a, gr_c, valid, fo);
-        const int64_t row_n = (tile + sch.step) * kTileRows + c;
-        const bool valid_n = tile + sch.step < sch.end && row_n < a.n_rows;
-        load_row_ids<KT>(slot, nti, row_n, valid_n, rid_n);
-        gr_n = load_gout_rows(a, row_n, valid_n);
+        int32_t rid_c[NI], r0, r1;
+        item_row_ids<NI>(it, clamp_row(tile), rid_c);
+        gout_rows(clamp_row(tile), r0, r1);
+        item_values<NI>(it, rid_c, part, row_valid(tile) && ld_on, pv);
+        gout_vals(r0, r1, row_valid(tile) && ld_on, gv);
+        stage_items<NI>(it, sc, part, c, pv);
+        stage_gout(gc, gv);
+        const int64_t t1 = tile + sch.step < sch.end ? tile + sch.step : tile;
+        item_row_ids<NI>(it, clamp_row(t1), rid_n);
+        gout_rows(clamp_row(t1), gr0_n, gr1_n);
     }
     for (; tile < sch.end; tile += sch.step) {
         const int64_t row = tile * kTileRows + c;
         const bool valid = row < a.n_rows;
-        const int64_t row_n = (tile + sch.step) * kTileRows + c;
-        const int64_t row_nn = (tile + 2 * sch.step) * kTileRows + c;
-        const bool valid_n = tile + sch.step < sch.end && row_n < a.n_rows;
-        const bool valid_nn = tile + 2 * sch.step < sch.end && row_nn < a.n_rows;
-        const bool ld_on = !(a.debug_flags & 2);
-        f32x4 bin_n[KT];
-        load_values<KT>(slot, nti, valid_n && ld_on, rid_n, bin_n);
-        const f32x4 gy_n = load_gout(a, gr_n, valid_n && ld_on, fo);
-        load_row_ids<KT>(slot, nti, row_nn, valid_nn && ld_on, rid_n);
-        gr_n = load_gout_rows(a, row_nn, valid_nn && ld_on);
-        // row ids of the gradient stores (needed only at the end of the tile)
-        int32_t grow[KT * 4];
-#pragma unroll
-        for (int i = 0; i < KT * 4; ++i) {
-            grow[i] = (int32_t)row;
-            if (valid && ld_on && gbase[i] != nullptr && gidx[i] != nullptr) grow[i] = gidx[i][row];
+        item_values<NI>(it, rid_n, part, row_valid(tile + sch.step) && ld_on, pv);
+        gout_vals(gr0_n, gr1_n, row_valid(tile + sch.step) && ld_on, gv);
+        {
+            const int64_t t2 = tile + 2 * sch.step < sch.end ? tile + 2 * sch.step : tile;
+            item_row_ids<NI>(it, clamp_row(t2), rid_n);
+            gout_rows(clamp_row(t2), gr0_n, gr1_n);
         }
+        lds_wave_sync();  // staged inputs of this tile are visible
+        f32x4 bin[KT], gyv[1];
+        read_operand<KT>(sc, boff, nti, bin);
+        read_operand<1>(gc, ooff, 1, gyv);
+        f32x4 gy = gyv[0];
 
-        apply_input_relu<KT>(relu_bits, bin_c);
-
-        // ---- S0: layer 1; stage m and a1 for the weight-gradient MFMAs -------------
+        // ---- S0: layer 1; a1 goes to LDS for the weight-gradient MFMAs ----------------
         f32x4 a1[HT], a2[HT];
-        mlp_layer1<KT, HT>(dm, w1, b1, lane, bin_c, a1);
-        if (want_dw && tr_on) {
-            tr_write<KT>(tb0, off_i, nti, dm.in_ks(), bin_c);
-            tr_write<HT>(tb1, off_h, nth, dm.hid_ks(), a1);
-        }
+        mlp_layer1<KT, HT>(dm, w1, b1, lane, bin, a1);
+        if (want_dw && tr_on) tr_write<HT>(tb1, off_h, nth, dm.hid_ks(), a1);
         // ---- S1: layer 2 (covers the LDS write latency) ---------------------------
         mlp_layer2<HT>(dm, w2, b2, lane, a1, a2);
         f32x4 mT[KT], a1T[HT];
 #pragma unroll
-        for (int t = 0; t < KT; ++t) mT[t] = bin_c[t];
+        for (int t = 0; t < KT; ++t) mT[t] = bin[t];
 #pragma unroll
         for (int t = 0; t < HT; ++t) a1T[t] = a1[t];
         if (want_dw && tr_on) {
             lds_wave_sync();
-            tr_read<KT>(tb0, nti, g, c, mT);
+            tr_read<KT>(sc, nti, g, c, mT);  // the staging buffer IS m^T
             tr_read<HT>(tb1, nth, g, c, a1T);
         }
-        f32x4 gy = gy_c;
         if (need_y) {
             const f32x4 y = mlp_layer3<HT>(dm, w3, b3, lane, a2);
 #pragma unroll
@@ -448,10 +467,9 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
             for (int r = 0; r < 4; ++r) gy[r] *= a.cb;
         }
         if (want_dw && tr_on) {
-            lds_wave_sync();  // reads of tb0 done before it is rewritten
             tr_write<HT>(tb2, off_h, nth, dm.hid_ks(), a2);
-            f32x4 gyv[1] = {gy};
-            tr_write<1>(tb0, off_o, 1, dm.out_ks(), gyv);
+            f32x4 gyw[1] = {gy};
+            tr_write<1>(tb0, off_o, 1, dm.out_ks(), gyw);
         }
         // ---- S2: delta at the last hidden layer: (Wout^T gy) * relu' ---------------
         f32x4 dl[HT];
@@ -469,14 +487,16 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
 #pragma unroll
             for (int r = 0; r < 4; ++r) dl[to][r] = a2[to][r] > 0.f ? dl[to][r] : 0.f;
         if (want_dw) {
+            if (!ones_h) {
 #pragma unroll
-            for (int to = 0; to < HT; ++to) {
-                if (dm.three())
-                    db2[to] += dl[to];
-                else
-                    db1[to] += dl[to];
+                for (int to = 0; to < HT; ++to) {
+                    if (dm.three())
+                        db2[to] += dl[to];
+                    else
+                        db1[to] += dl[to];
+                }
+                db3 += gy;
             }
-            db3 += gy;
             f32x4 a2T[HT], gyT[1];
 #pragma unroll
             for (int t = 0; t < HT; ++t) a2T[t] = a2[t];
@@ -514,8 +534,10 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) d1[to][r] = a1[to][r] > 0.f ? d1[to][r] : 0.f;
             if (want_dw) {
+                if (!ones_i) {
 #pragma unroll
-                for (int to = 0; to < HT; ++to) db1[to] += d1[to];
+                    for (int to = 0; to < HT; ++to) db1[to] += d1[to];
+                }
                 f32x4 dlT[HT];
 #pragma unroll
                 for (int t = 0; t < HT; ++t) dlT[t] = dl[t];
@@ -537,6 +559,14 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
         } else {
 #pragma unroll
             for (int to = 0; to < HT; ++to) d1[to] = dl[to];  // a2 == a1: mask already applied
+            if (want_dw && !ones_i) {
+                // two layers: db1 was accumulated from dl only when the hidden ones-row is
+                // absent; with it present but no input ones-row, take it here
+                if (ones_h) {
+#pragma unroll
+                    for (int to = 0; to < HT; ++to) db1[to] += d1[to];
+                }
+            }
         }
         // ---- S4: input gradient W1^T d1 (rows = concatenated input features) -------
         f32x4 gin[KT];
@@ -571,43 +601,50 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
                         for (int ti = 0; ti < KT; ++ti)
                             if (ti < nti) dW1[to][ti] = mfma4(d1T[to][s], mT[ti][s], dW1[to][ti]);
                     }
-            if (tr_on) lds_wave_sync();  // all reads retired before the next tile's writes
         }
-        if (valid && !((a.debug_flags & 1) && gin[0][0] != 12345.678f)) {
+        // ---- output: input-gradient slices leave through tb0, row-wise per item ------
+        lds_wave_sync();  // tb0 (gy^T) reads are done
+        tr_write<KT>(tb0, off_i, nti, dm.in_ks(), gin);
+        lds_wave_sync();
+        if (!((a.debug_flags & 1) && gin[0][0] != 12345.678f)) {
 #pragma unroll
-            for (int i = 0; i < KT * 4; ++i) {
-                if (gbase[i] != nullptr) {
-                    float v = gin[i >> 2][i & 3];
-                    if (((relu_bits >> i) & 1u) && !(bin_c[i >> 2][i & 3] > 0.f)) v = 0.f;
-                    gf_ptr p = gbase[i] + (int64_t)grow[i] * gstride[i];
-                    if (gacc_bits != 0u && ((gacc_bits >> i) & 1u)) v += *p;
-                    *p = v;
+            for (int i = 0; i < NI; ++i) {
+                if (i < it.n && gi.ptr[i] != nullptr) {
+                    if (valid && part < it.rem[i]) {
+                        const int o = (it.frow[i] + part) * kTbLd + c;
+                        float v = tb0[o];
+                        if (it.relu[i] && !(sc[o] > 0.f)) v = 0.f;
+                        gi.ptr[i][row * gi.stride[i] + part] = v;
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < KT; ++t) bin_c[t] = bin_n[t];
-        gy_c = gy_n;
+        // stage the next tile (every read of this tile's buffers is behind the syncs above)
+        stage_items<NI>(it, sc, part, c, pv);
+        stage_gout(gc, gv);
     }
 
     if (want_dw) {
         const BwdPartLayout pl = part_layout(a.mlp);
-        float *dst = part + (int64_t)(blockIdx.x * kBwdWaves + wv) * pl.total;
-        // weights
+        float *dst = part_out + (int64_t)(blockIdx.x * WPB + wv) * pl.total;
+        float *b_in = ones_i ? dst + pl.b[0] : nullptr;                  // db1 from dW1's ones column
+        float *b_mid = (ones_h && dm.three()) ? dst + pl.b[1] : nullptr;  // db2 from dW2's
+        float *b_out = ones_h ? dst + pl.b[last] : nullptr;               // db3 from dW3's
 #pragma unroll
         for (int to = 0; to < HT; ++to) {
 #pragma unroll
             for (int ti = 0; ti < KT; ++ti)
-                store_dw_tile(dst + pl.w[0], a.mlp.hidden, a.mlp.in_dim, to, ti, g, c, dW1[to][ti]);
+                store_dw_tile(dst + pl.w[0], b_in, a.mlp.hidden, a.mlp.in_dim, to, ti, g, c, dW1[to][ti]);
             if (dm.three()) {
 #pragma unroll
                 for (int ti = 0; ti < HT; ++ti)
-                    store_dw_tile(dst + pl.w[1], a.mlp.hidden, a.mlp.hidden, to, ti, g, c,
+                    store_dw_tile(dst + pl.w[1], b_mid, a.mlp.hidden, a.mlp.hidden, to, ti, g, c,
                                   dW2[to][ti]);
             }
-            store_dw_tile(dst + pl.w[last], a.mlp.out_dim, a.mlp.hidden, 0, to, g, c, dW3[to]);
+            store_dw_tile(dst + pl.w[last], b_out, a.mlp.out_dim, a.mlp.hidden, 0, to, g, c, dW3[to]);
         }
-        // biases: reduce the per-lane partial sums over the 16 row-lanes
+        // biases without a ones row: reduce the per-lane partial sums over the 16 row-lanes
+        const bool db1_valu = !ones_i, db2_valu = dm.three() && !ones_h, db3_valu = !ones_h;
 #pragma unroll
         for (int to = 0; to < HT; ++to)
 #pragma unroll
@@ -620,8 +657,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
                 }
                 const int f = feat_of(dm.hid, to, g, r);
                 if (c == 0 && f >= 0) {
-                    dst[pl.b[0] + f] = v1;
-                    if (dm.three()) dst[pl.b[1] + f] = v2;
+                    if (db1_valu) dst[pl.b[0] + f] = v1;
+                    if (db2_valu) dst[pl.b[1] + f] = v2;
                 }
             }
 #pragma unroll
@@ -629,7 +666,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
             float v = db3[r];
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
-            if (c == 0 && fo[r] >= 0) dst[pl.b[last] + fo[r]] = v;
+            const int fo = feat_of(dm.out, 0, g, r);
+            if (c == 0 && fo >= 0 && db3_valu) dst[pl.b[last] + fo] = v;
         }
     }
 }
@@ -679,6 +717,12 @@ static int check_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg) {
     return GNNTRK_OK;
 }
 
+static int count_items(int n_seg, const gnntrk_seg *seg) {
+    int n = 0;
+    for (int j = 0; j < n_seg; ++j) n += (seg[j].dim + 3) / 4;
+    return n;
+}
+
 static int grid_for(int64_t n_rows, int blocks_per_cu, int waves = kWaves) {
     const int64_t tiles = (n_rows + kTileRows - 1) / kTileRows;
     int64_t g = (tiles + waves - 1) / waves;
@@ -696,17 +740,18 @@ constexpr int kFwdBlocksPerCu = 4;
 // code) for the shapes of the reference's default configuration (hidden width 37..40,
 // models/edge_classifier.py + tests/test_configs): key = (k-steps in, k-steps hidden,
 // k-steps out, 3 layers).  Everything else takes the generic run-time-bound kernels.
+// last column: load-list capacity (4-feature chunks over all segments)
 #define GNNTRK_STATIC_SHAPES(X) \
-    X(4, 10, 2, false) /* node encoder   14 -> 40 -> 5      */ \
-    X(1, 10, 1, false) /* edge encoder    4 -> 40 -> 4      */ \
-    X(4, 10, 1, true)  /* relational     14 -> 40 -> 40 -> 4 */ \
-    X(3, 10, 2, true)  /* object          9 -> 40 -> 40 -> 5 */ \
-    X(7, 10, 1, true)  /* W head         26 -> 40 -> 40 -> 1 */
+    X(4, 10, 2, false, 4) /* node encoder   14 -> 40 -> 5       x[14]                   */ \
+    X(1, 10, 1, false, 1) /* edge encoder    4 -> 40 -> 4       edge_attr[4]            */ \
+    X(4, 10, 1, true, 5)  /* relational     14 -> 40 -> 40 -> 4  h[5], h[5], e[4]        */ \
+    X(3, 10, 2, true, 3)  /* object          9 -> 40 -> 40 -> 5  h[5], aggr[4]           */ \
+    X(7, 10, 1, true, 8)  /* W head         26 -> 40 -> 40 -> 1  h[5], h[5], 4 x e[4]    */
 
-static bool static_shape(int ksi, int ksh, int kso, bool three) {
+static bool static_shape(int ksi, int ksh, int kso, bool three, int n_items) {
     bool hit = false;
-#define GNNTRK_MATCH(KSI, KSH, KSO, THREE) \
-    hit = hit || (ksi == KSI && ksh == KSH && kso == KSO && three == THREE);
+#define GNNTRK_MATCH(KSI, KSH, KSO, THREE, NIT) \
+    hit = hit || (ksi == KSI && ksh == KSH && kso == KSO && three == THREE && n_items <= NIT);
     GNNTRK_STATIC_SHAPES(GNNTRK_MATCH)
 #undef GNNTRK_MATCH
     return hit;
@@ -735,14 +780,19 @@ int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
         return fail(GNNTRK_EINVAL, "mlp_forward: residual epilogue needs res");
     if (a->n_rows < 0) return fail(GNNTRK_EINVAL, "mlp_forward: negative n_rows");
     if (a->n_rows == 0) return GNNTRK_OK;
-    const int kt = (a->mlp.in_dim + 15) / 16, ht = (a->mlp.hidden + 15) / 16;
+    const int n_items = count_items(a->n_seg, a->seg);
+    if (n_items > kMaxItems) return fail(GNNTRK_EUNSUPPORTED, "mlp_forward: too many input segments/chunks (max 16 4-feature chunks)");
+    int kt = (a->mlp.in_dim + 15) / 16;
+    const int ht = (a->mlp.hidden + 15) / 16;
+    while (4 * kt + 4 < n_items) ++kt;  // the load list of an instantiation holds 4*KT+4 items
     const int grid = grid_for(a->n_rows, kFwdBlocksPerCu);
-    const int ksi = make_dimmap(a->mlp.in_dim).ks, ksh = make_dimmap(a->mlp.hidden).ks,
-              kso = make_dimmap(a->mlp.out_dim).ks;
+    const int ksh = make_dimmap(a->mlp.hidden).ks, kso = make_dimmap(a->mlp.out_dim).ks;
     const bool three = a->mlp.n_layers == 3;
-#define CALL_FWD_S(KSI, KSH, KSO, THREE)                                                       \
-    if (!done_ && ksi == KSI && ksh == KSH && kso == KSO && three == THREE) {                   \
-        auto kfn = mlp_fwd_kernel<(KSI + 3) / 4, (KSH + 3) / 4, StaticDims<KSI, KSH, KSO, THREE>>; \
+    // static instantiations need their own load-list capacity
+    const int ksi = (n_items <= 4 * ((a->mlp.in_dim + 15) / 16) + 4) ? make_dimmap(a->mlp.in_dim).ks : -1;
+#define CALL_FWD_S(KSI, KSH, KSO, THREE, NIT)                                                  \
+    if (!done_ && ksi == KSI && ksh == KSH && kso == KSO && three == THREE && n_items <= NIT) { \
+        auto kfn = mlp_fwd_kernel<(KSI + 3) / 4, (KSH + 3) / 4, StaticDims<KSI, KSH, KSO, THREE, NIT>>; \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);                       \
         done_ = true;                                                                           \
     }
@@ -772,6 +822,10 @@ int mlp_backward_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes,
         return fail(GNNTRK_EINVAL, "mlp_backward: bad upstream gradient terms");
     if (a->epilogue < 0 || a->epilogue > 3) return fail(GNNTRK_EINVAL, "mlp_backward: bad epilogue");
     if (a->n_rows < 0) return fail(GNNTRK_EINVAL, "mlp_backward: negative n_rows");
+    for (int j = 0; j < a->n_seg; ++j)
+        if (a->gseg[j].ptr && (a->gseg[j].idx || a->gseg[j].accumulate))
+            return fail(GNNTRK_EUNSUPPORTED,
+                        "mlp_backward: gseg.idx / gseg.accumulate are reserved (row-aligned '=' only)");
     const bool want_dw = a->gW[0] != nullptr;
     if (want_dw) {
         for (int i = 0; i < a->mlp.n_layers; ++i)
@@ -781,20 +835,26 @@ int mlp_backward_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes,
     }
     const BwdPartLayout pl = part_layout(a->mlp);
     int grid = 0, wpb = 4;
-    const int ksi0 = make_dimmap(a->mlp.in_dim).ks, ksh0 = make_dimmap(a->mlp.hidden).ks,
-              kso0 = make_dimmap(a->mlp.out_dim).ks;
+    const int n_items = count_items(a->n_seg, a->seg);
+    if (n_items > kMaxItems) return fail(GNNTRK_EUNSUPPORTED, "mlp_backward: too many input segments/chunks (max 16 4-feature chunks)");
+    const bool items_fit = n_items <= 4 * ((a->mlp.in_dim + 15) / 16) + 4;
+    // the static kernels also rely on the constant-one rows for the bias gradients
+    const bool ones_ok = (a->mlp.in_dim % 16) != 0 && (a->mlp.hidden % 16) != 0;
+    const int ksi0 = (items_fit && ones_ok) ? make_dimmap(a->mlp.in_dim).ks : -1,
+              ksh0 = make_dimmap(a->mlp.hidden).ks, kso0 = make_dimmap(a->mlp.out_dim).ks;
     if (a->n_rows > 0) {
-        const int kt = (a->mlp.in_dim + 15) / 16, ht = (a->mlp.hidden + 15) / 16;
-        const bool is_static = static_shape(ksi0, ksh0, kso0, a->mlp.n_layers == 3);
+        int kt = (a->mlp.in_dim + 15) / 16;
+        const int ht = (a->mlp.hidden + 15) / 16;
+        while (4 * kt + 4 < n_items) ++kt;
+        const bool is_static = static_shape(ksi0, ksh0, kso0, a->mlp.n_layers == 3, n_items);
         wpb = is_static ? 8 : 4;
         grid = grid_for(a->n_rows, is_static ? 1 : 2, wpb);
         float *part = reinterpret_cast<float *>(ws);
-        const int ksi = make_dimmap(a->mlp.in_dim).ks, ksh = make_dimmap(a->mlp.hidden).ks,
-                  kso = make_dimmap(a->mlp.out_dim).ks;
+        const int ksi = ksi0, ksh = ksh0, kso = kso0;
         const bool three = a->mlp.n_layers == 3;
-#define CALL_BWD_S(KSI, KSH, KSO, THREE)                                                       \
-    if (!done_ && ksi == KSI && ksh == KSH && kso == KSO && three == THREE) {                   \
-        auto kfn = mlp_bwd_kernel<(KSI + 3) / 4, (KSH + 3) / 4, StaticDims<KSI, KSH, KSO, THREE>, 8>; \
+#define CALL_BWD_S(KSI, KSH, KSO, THREE, NIT)                                                  \
+    if (!done_ && ksi == KSI && ksh == KSH && kso == KSO && three == THREE && n_items <= NIT) { \
+        auto kfn = mlp_bwd_kernel<(KSI + 3) / 4, (KSH + 3) / 4, StaticDims<KSI, KSH, KSO, THREE, NIT>, 8>; \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), 0, stream, *a, part);                    \
         done_ = true;                                                                           \
     }

@@ -87,6 +87,8 @@ __host__ __device__ inline int feat_of(const DimMap &m, int t, int g, int r) {
 // k-step (t, r) of a dimension with `ks` k-steps has index 4t + r and exists iff
 // 4t + r < ks (both mappings).  Tiles: ceil(ks / 4).
 struct DynDims {
+    static constexpr bool kStatic = false;
+    static constexpr int kItems = 0;
     DimMap in, hid, out;
     bool three_;
     __device__ __forceinline__ int in_ks() const { return in.ks; }
@@ -95,8 +97,10 @@ struct DynDims {
     __device__ __forceinline__ bool three() const { return three_; }
     __device__ __forceinline__ void set_three(bool v) { three_ = v; }
 };
-template <int KSI, int KSH, int KSO, bool THREE>
+template <int KSI, int KSH, int KSO, bool THREE, int NITEMS = 0>
 struct StaticDims {
+    static constexpr bool kStatic = true;  // host dispatch guarantees the ones-row conditions
+    static constexpr int kItems = NITEMS;  // load-list capacity (0: 4*KT+4)
     DimMap in, hid, out;
     __device__ __forceinline__ constexpr int in_ks() const { return KSI; }
     __device__ __forceinline__ constexpr int hid_ks() const { return KSH; }
@@ -212,13 +216,6 @@ __device__ __forceinline__ void stage_segs(SegTable &tab, const gnntrk_seg (&seg
         }
 }
 
-// one concatenated-input feature slot of a lane: where to read it from
-struct InSlot {
-    gcf_ptr base;  // segment ptr + feature offset; nullptr = padding
-    gci_ptr idx;   // row gather index or nullptr
-    int32_t stride;
-};
-
 // Weight (A-operand) fragments of one layer: either read from LDS at every use
 // (generic kernels) or copied once into registers (static kernels: with one wave per
 // SIMD and a 512-entry register file they are loop-invariant operands, and the MFMA
@@ -254,77 +251,148 @@ struct LdsBias {
     __device__ __forceinline__ f32x4 get(int i, int lane) const { return p[i * 64 + lane]; }
 };
 
-template <int KT>
-__device__ __forceinline__ void setup_in_slots(const SegTable &tab, int n_seg, const DimMap &in,
-                                               int g, InSlot (&slot)[KT * 4], unsigned &relu_bits) {
-    relu_bits = 0;
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            InSlot s;
-            s.base = nullptr;
-            s.idx = nullptr;
-            s.stride = 0;
-            const int f = feat_of(in, t, g, r);
-            int off = 0;
-            for (int j = 0; j < n_seg; ++j) {
-                const int d = tab.dim[j];
-                if (f >= off && f < off + d) {
-                    s.base = (gcf_ptr)tab.ptr[j] + (f - off);
-                    s.idx = (gci_ptr)tab.idx[j];
-                    s.stride = tab.stride[j];
-                    if (tab.relu[j]) relu_bits |= 1u << (t * 4 + r);
-                }
-                off += d;
-            }
-            slot[t * 4 + r] = s;
+// ---- row-staged input / output through LDS ------------------------------------------
+// The concatenated input of a tile is assembled in an LDS staging buffer laid out
+// [feature][row] (leading dim kTbLd): the wave walks a uniform "load list" - one item per
+// (segment, 4-feature chunk) - with lane = (row c = lane & 15, element part = lane >> 4), so
+// every global access is wave-uniform in control flow, addressed as uniform base + 32-bit
+// offset, and row-contiguous.  The MFMA B operand is then one ds_read_b32 per k-step from the
+// buffer, and the transposed copy the weight-gradient MFMAs need is a ds_read_b128 of the
+// SAME buffer.  Gradient slices leave the same way in reverse.
+constexpr int kMaxItems = 16;
+
+struct LoadList {  // lives in LDS, built once per workgroup
+    const float *ptr[kMaxItems];    // segment base + 4 * chunk
+    const int32_t *idx[kMaxItems];  // row gather index or nullptr
+    float *gptr[kMaxItems];         // gradient slice base + 4 * chunk, or nullptr
+    const int32_t *gidx[kMaxItems];
+    int32_t stride[kMaxItems], gstride[kMaxItems];
+    int32_t rem[kMaxItems];   // features in this chunk: min(4, dim - 4 * chunk)
+    int32_t frow[kMaxItems];  // first feature row of the chunk in the staging buffer
+    int32_t relu[kMaxItems], gacc[kMaxItems];
+    int32_t n;
+};
+
+__device__ inline void build_load_list(LoadList &L, const SegTable &tab, int n_seg) {
+    int n = 0, foff = 0;
+    for (int j = 0; j < n_seg; ++j) {
+        const int d = tab.dim[j];
+        for (int ch = 0; 4 * ch < d && n < kMaxItems; ++ch, ++n) {
+            L.ptr[n] = tab.ptr[j] + 4 * ch;
+            L.idx[n] = tab.idx[j];
+            L.gptr[n] = tab.gptr[j] ? tab.gptr[j] + 4 * ch : nullptr;
+            L.gidx[n] = tab.gidx[j];
+            L.stride[n] = tab.stride[j];
+            L.gstride[n] = tab.gstride[j];
+            L.rem[n] = (d - 4 * ch < 4) ? d - 4 * ch : 4;
+            L.frow[n] = foff + 4 * ch;
+            L.relu[n] = tab.relu[j];
+            L.gacc[n] = tab.gacc[j];
         }
+        foff += d;
+    }
+    L.n = n;
 }
 
-// Two-stage input pipeline: row indices of tile n+2 and values of tile n+1 are in
-// flight while tile n is computed (one wave per SIMD cannot hide the two dependent
-// gathers idx -> value any other way).
-template <int KT>
-__device__ __forceinline__ void load_row_ids(const InSlot (&slot)[KT * 4], int nt_in, int64_t row,
-                                             bool valid, int32_t (&rid)[KT * 4]) {
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const InSlot &s = slot[t * 4 + r];
-            int32_t v = (int32_t)row;
-            if (t < nt_in && valid && s.base != nullptr && s.idx != nullptr) v = s.idx[row];
-            rid[t * 4 + r] = v;
-        }
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T uni_ptr(const void *p) {  // wave-uniform pointer -> SGPR pair
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned long long u = ((unsigned long long)uni32((uint32_t)(v >> 32)) << 32) |
+                                 (unsigned long long)uni32((uint32_t)v);
+    return (T)u;
 }
 
-template <int KT>
-__device__ __forceinline__ void load_values(const InSlot (&slot)[KT * 4], int nt_in, bool valid,
-                                            const int32_t (&rid)[KT * 4], f32x4 (&bin)[KT]) {
+// uniform per-item descriptors held by every wave (SGPRs)
+template <int NI>
+struct GradItems {  // where the (row-aligned) input-gradient slice of every item goes
+    gf_ptr ptr[NI];
+    int32_t stride[NI];
+    __device__ __forceinline__ void load(const LoadList &L, int n) {
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t < nt_in) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const InSlot &s = slot[t * 4 + r];
-                float x = 0.f;
-                if (valid && s.base != nullptr) x = s.base[(int64_t)rid[t * 4 + r] * s.stride];
-                v[r] = x;
-            }
+        for (int i = 0; i < NI; ++i) {
+            const bool on = i < n;
+            ptr[i] = on ? uni_ptr<gf_ptr>(L.gptr[i]) : nullptr;
+            stride[i] = on ? (int32_t)uni32((uint32_t)L.gstride[i]) : 0;
         }
-        bin[t] = v;
+    }
+};
+
+template <int NI>
+struct Items {
+    gcf_ptr ptr[NI];
+    gci_ptr idx[NI];
+    int32_t stride[NI], rem[NI], frow[NI], relu[NI];
+    int32_t n;
+    __device__ __forceinline__ void load(const LoadList &L) {
+        n = (int32_t)uni32((uint32_t)L.n);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bool on = i < n;
+            ptr[i] = on ? uni_ptr<gcf_ptr>(L.ptr[i]) : nullptr;
+            idx[i] = on ? uni_ptr<gci_ptr>(L.idx[i]) : nullptr;
+            stride[i] = on ? (int32_t)uni32((uint32_t)L.stride[i]) : 0;
+            rem[i] = on ? (int32_t)uni32((uint32_t)L.rem[i]) : 0;
+            frow[i] = on ? (int32_t)uni32((uint32_t)L.frow[i]) : 0;
+            relu[i] = on ? (int32_t)uni32((uint32_t)L.relu[i]) : 0;
+        }
+    }
+};
+
+// row ids of one tile row for every item (row is pre-clamped to a valid row)
+template <int NI>
+__device__ __forceinline__ void item_row_ids(const Items<NI> &it, int64_t row, int32_t (&rid)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int32_t v = (int32_t)row;
+        if (i < it.n && it.idx[i] != nullptr) v = it.idx[i][row];
+        rid[i] = v;
     }
 }
-
-template <int KT>
-__device__ __forceinline__ void apply_input_relu(unsigned relu_bits, f32x4 (&bin)[KT]) {
+template <int NI>
+__device__ __forceinline__ void item_values(const Items<NI> &it, const int32_t (&rid)[NI], int part,
+                                            bool valid, float (&pv)[NI]) {
 #pragma unroll
-    for (int t = 0; t < KT; ++t)
+    for (int i = 0; i < NI; ++i) {
+        float v = 0.f;
+        if (i < it.n && valid && part < it.rem[i])
+            v = it.ptr[i][(int64_t)rid[i] * it.stride[i] + part];
+        pv[i] = v;
+    }
+}
+// staging buffer [feature][row]: value of (item i, element part) of row c
+template <int NI>
+__device__ __forceinline__ void stage_items(const Items<NI> &it, float *sbuf, int part, int c,
+                                            const float (&pv)[NI]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if ((relu_bits >> (t * 4 + r)) & 1u) bin[t][r] = fmaxf(bin[t][r], 0.f);
+    for (int i = 0; i < NI; ++i)
+        if (i < it.n && part < it.rem[i])
+            sbuf[(it.frow[i] + part) * kTbLd + c] = it.relu[i] ? fmaxf(pv[i], 0.f) : pv[i];
+}
+// LDS offsets of a lane's B-operand features (padding -> zero row `zrow`)
+template <int NT>
+__device__ __forceinline__ void operand_offsets(const DimMap &map, int g, int c, int zrow,
+                                                int (&off)[NT * 4]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = feat_of(map, t, g, r);
+            off[t * 4 + r] = (f >= 0 ? f : zrow) * kTbLd + c;
+        }
+}
+template <int NT>
+__device__ __forceinline__ void read_operand(const float *sbuf, const int (&off)[NT * 4], int nt,
+                                             f32x4 (&x)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sbuf[off[t * 4 + r]];
+        }
+        x[t] = v;
+    }
 }
 
 // Forward of the (2- or 3-layer) MLP on one 16-row tile.  a1/a2 are post-ReLU hidden

@@ -428,12 +428,6 @@ class _FusedMLP(torch.autograd.Function):
                     gj.zero_()
                 seg_grads[j] = gj
                 a.gseg[j] = _capi.GSeg(_p(gj), None, _row_stride(gj), 0)
-            elif red == "perm":
-                gj = torch.empty(s.shape[0], s.shape[1], dtype=torch.float32, device=dev)
-                if s.shape[0] != M:
-                    gj.zero_()
-                seg_grads[j] = gj
-                a.gseg[j] = _capi.GSeg(_p(gj), _p(spec.idx[j]), _row_stride(gj), 0)
             else:
                 if red is None:
                     raise RuntimeError("gathered segment requires a `reduce` rule for backward")
@@ -466,6 +460,11 @@ class _FusedMLP(torch.autograd.Function):
         # fold gathered row gradients onto their source rows (deterministic CSR sums)
         for j, s in enumerate(segs):
             if row_tmp[j] is None:
+                continue
+            if spec.reduce[j] == "perm":  # idx is a permutation of the source rows
+                if s.shape[0] != M:
+                    raise RuntimeError("'perm' segments must cover all source rows")
+                seg_grads[j] = _permute_raw(row_tmp[j], spec.idx[j], scatter=True)
                 continue
             by, gi = spec.reduce[j]
             rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)

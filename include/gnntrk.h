@@ -153,8 +153,8 @@ int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream);
  *
  * Per-row input gradients are written row-aligned: for segment j, if
  * gseg[j].ptr != NULL, row m of the segment's gradient slice goes to
- *     gseg[j].ptr[(gseg[j].idx ? gseg[j].idx[m] : m) * gseg[j].stride + 0..dim)
- * (= or += per gseg[j].accumulate; ReLU masks of the segment are applied).
+ *     gseg[j].ptr[m * gseg[j].stride + 0..dim)      (ReLU masks of the segment applied;
+ * gseg[j].idx and gseg[j].accumulate are reserved and must be NULL / 0).
  * Gathered segments are reduced onto their source rows afterwards with
  * gnntrk_segment_sum (deterministic).  gres (EPI_RESIDUAL) is NOT produced here:
  * it is ca * g, an elementwise op of the caller.

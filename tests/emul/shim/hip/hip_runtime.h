@@ -283,3 +283,4 @@ inline float __uint_as_float(unsigned u) {
     memcpy(&f, &u, 4);
     return f;
 }
+inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }  // callers pass uniform values

@@ -154,9 +154,19 @@ def require_device(*tensors) -> None:
                 "to the GPU (the CPU reference lives in oracle/ and is test-only).")
 
 
+_DEBUG_SYNC = bool(os.environ.get("GNNTRK_DEBUG_SYNC"))
+
+
 def check(rc: int, lib: C.CDLL | None = None) -> None:
     """Map a C return code to the reference's Python error conventions."""
     if rc == 0:
+        if _DEBUG_SYNC:  # debugging aid: surface asynchronous faults at the offending call
+            import sys
+            import torch
+
+            fr = sys._getframe(1)
+            print(f"[gnntrk] sync after {fr.f_code.co_name}:{fr.f_lineno}", flush=True)
+            torch.cuda.synchronize()
         return
     lib = lib or load()
     msg = (lib.gnntrk_last_error() or b"").decode(errors="replace")

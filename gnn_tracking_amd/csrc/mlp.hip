@@ -65,7 +65,8 @@ struct FwdSmem {
 template <int KT, int HT, class Dims>
 __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_args a) {
     __shared__ __attribute__((aligned(16))) FwdSmem<KT, HT> sm;
-    using OP = OperandPolicy<Dims>;
+    using OP = OperandPolicy<DynDims>;  // operands from LDS: thread-level parallelism (4-5 waves
+                                        // per SIMD) hides the gather latency of the short tiles
     constexpr int NI = Dims::kItems > 0 ? Dims::kItems : 4 * KT + 4;
     const Dims dm = make_dims<Dims>(a.mlp);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15, wv = tid >> 6;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_ar
     b2.load(sm.b2, dm.three() ? nth : 0, lane);
     const f32x4 b3 = sm.b3[lane];
 
-    Items<NI> it;
+    Items<NI, Dims::kStatic> it;
     it.load(sm.ll);
     int boff[KT * 4];
     operand_offsets<KT>(dm.in, g, c, 16 * KT + 1, boff);
@@ -340,10 +341,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
     b2.load(sm.b2, dm.three() ? nth : 0, lane);
     const f32x4 b3 = sm.b3[lane];
 
-    Items<NI> it;
+    Items<NI, Dims::kStatic> it;
     it.load(sm.ll);
-    GradItems<NI> gi;
-    gi.load(sm.ll, it.n);
     int boff[KT * 4], ooff[4], off_i[KT * 4], off_h[HT * 4], off_o[4];
     operand_offsets<KT>(dm.in, g, c, 16 * KT + 1, boff);
     operand_offsets<1>(dm.out, g, c, kGyRows - 1, ooff);
@@ -609,12 +608,17 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
         if (!((a.debug_flags & 1) && gin[0][0] != 12345.678f)) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                if (i < it.n && gi.ptr[i] != nullptr) {
-                    if (valid && part < it.rem[i]) {
-                        const int o = (it.frow[i] + part) * kTbLd + c;
-                        float v = tb0[o];
-                        if (it.relu[i] && !(sc[o] > 0.f)) v = 0.f;
-                        gi.ptr[i][row * gi.stride[i] + part] = v;
+                if (i < it.n) {
+                    const gf_ptr gp = it.gptr(i);
+                    if (gp != nullptr) {
+                        const int rm = it.rem(i), fr = it.frow(i), gst = it.gstride(i);
+                        const bool rl = it.relu(i);
+                        if (valid && part < rm) {
+                            const int o = (fr + part) * kTbLd + c;
+                            float v = tb0[o];
+                            if (rl && !(sc[o] > 0.f)) v = 0.f;
+                            gp[row * gst + part] = v;
+                        }
                     }
                 }
             }
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
         stage_gout(gc, gv);
     }
 
-    if (want_dw) {
+    if (want_dw && !(a.debug_flags & 16)) {
         const BwdPartLayout pl = part_layout(a.mlp);
         float *dst = part_out + (int64_t)(blockIdx.x * WPB + wv) * pl.total;
         float *b_in = ones_i ? dst + pl.b[0] : nullptr;                  // db1 from dW1's ones column
@@ -672,17 +676,25 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
     }
 }
 
-// fixed-order reduction of the per-wave partial blocks into the gradient tensors
+// fixed-order reduction of the per-wave partial blocks into the gradient tensors.
+// One workgroup per 64 parameters: wave w sums the partial blocks w, w+4, w+8, ... (lane =
+// parameter, coalesced 256 B rows), then the four wave sums are added in wave order.
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float *__restrict__ part,
                                                                  int n_part, int total,
                                                                  gnntrk_mlp mlp, float *gW0,
                                                                  float *gW1, float *gW2, float *gb0,
                                                                  float *gb1, float *gb2,
                                                                  int accumulate) {
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= total) return;
-    float s = 0.f;
-    for (int w = 0; w < n_part; ++w) s += part[(int64_t)w * total + p];
+    __shared__ float s_sum[kWaves][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (p < total)
+        for (int w = wv; w < n_part; w += kWaves) acc += part[(int64_t)w * total + p];
+    s_sum[wv][lane] = acc;
+    __syncthreads();
+    if (wv != 0 || p >= total) return;
+    const float s = ((s_sum[0][lane] + s_sum[1][lane]) + s_sum[2][lane]) + s_sum[3][lane];
     const BwdPartLayout pl = part_layout(mlp);
     float *gW[3] = {gW0, gW1, gW2};
     float *gb[3] = {gb0, gb1, gb2};
@@ -869,9 +881,9 @@ int mlp_backward_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes,
         rc = check_launch("mlp_backward");
         if (rc) return rc;
     }
-    if (want_dw) {
+    if (want_dw && !(a->debug_flags & 32)) {
         const int n_part = grid * wpb;
-        const int rgrid = (pl.total + kBlock - 1) / kBlock;
+        const int rgrid = (pl.total + 63) / 64;
         auto rfn = reduce_partials_kernel;
         hipLaunchKernelGGL(rfn, dim3(rgrid), dim3(kBlock), 0, stream,
                            reinterpret_cast<const float *>(ws), n_part, pl.total, a->mlp, a->gW[0],

@@ -37,6 +37,37 @@ __global__ __launch_bounds__(kTpb) void segment_sum_kernel(
     }
 }
 
+// dim == 4 (the default edge width): one thread per segment, 16-B row loads
+__global__ __launch_bounds__(kTpb) void segment_sum4_kernel(
+    const float *__restrict__ rows, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ pos, int64_t n_seg, float *__restrict__ out, int out_stride,
+    int accumulate) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(rows);
+    for (int64_t n = (int64_t)blockIdx.x * kTpb + threadIdx.x; n < n_seg;
+         n += (int64_t)gridDim.x * kTpb) {
+        const int32_t k0 = rowptr[n], k1 = rowptr[n + 1];
+        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+        for (int32_t k = k0; k < k1; ++k) {
+            const float4 v = r4[pos ? (int64_t)pos[k] : (int64_t)k];
+            sx += v.x;
+            sy += v.y;
+            sz += v.z;
+            sw += v.w;
+        }
+        float *o = out + n * out_stride;
+        if (accumulate) {
+            sx += o[0];
+            sy += o[1];
+            sz += o[2];
+            sw += o[3];
+        }
+        o[0] = sx;
+        o[1] = sy;
+        o[2] = sz;
+        o[3] = sw;
+    }
+}
+
 __global__ __launch_bounds__(kTpb) void permute_rows_kernel(const float *__restrict__ in, int dim,
                                                             int in_stride,
                                                             const int32_t *__restrict__ idx,
@@ -138,6 +169,11 @@ int segment_sum_launch(const float *rows, int dim, int row_stride, const int32_t
     if (!rows || !rowptr || !out || dim < 1 || row_stride < dim || out_stride < dim || n_seg < 0)
         return fail(GNNTRK_EINVAL, "segment_sum: bad argument");
     if (n_seg == 0) return GNNTRK_OK;
+    if (dim == 4 && row_stride == 4 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) {
+        hipLaunchKernelGGL(segment_sum4_kernel, dim3(stream_grid(n_seg)), dim3(kTpb), 0, stream, rows,
+                           rowptr, pos, n_seg, out, out_stride, accumulate);
+        return check_launch("segment_sum");
+    }
     hipLaunchKernelGGL(segment_sum_kernel, dim3(stream_grid(n_seg * dim)), dim3(kTpb), 0, stream,
                        rows, dim, row_stride, rowptr, pos, n_seg, out, out_stride, accumulate);
     return check_launch("segment_sum");

@@ -304,70 +304,98 @@ __device__ __forceinline__ T uni_ptr(const void *p) {  // wave-uniform pointer -
 }
 
 // uniform per-item descriptors held by every wave (SGPRs)
-template <int NI>
-struct GradItems {  // where the (row-aligned) input-gradient slice of every item goes
-    gf_ptr ptr[NI];
-    int32_t stride[NI];
-    __device__ __forceinline__ void load(const LoadList &L, int n) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const bool on = i < n;
-            ptr[i] = on ? uni_ptr<gf_ptr>(L.gptr[i]) : nullptr;
-            stride[i] = on ? (int32_t)uni32((uint32_t)L.gstride[i]) : 0;
-        }
-    }
-};
+// Uniform per-item descriptors.  Static shapes hoist them into SGPRs once (HOIST = true);
+// the generic kernels re-read them from the LDS load list at every use - they already run
+// out of scalar registers, and hundreds of SGPR spills are not worth a few LDS reads.
+template <int NI, bool HOIST>
+struct Items;
 
 template <int NI>
-struct Items {
-    gcf_ptr ptr[NI];
-    gci_ptr idx[NI];
-    int32_t stride[NI], rem[NI], frow[NI], relu[NI];
+struct Items<NI, true> {
+    gcf_ptr ptr_[NI];
+    gci_ptr idx_[NI];
+    gf_ptr gptr_[NI];
+    int32_t stride_[NI], meta_[NI], gstride_[NI];  // meta = rem | frow << 8 | relu << 24
     int32_t n;
     __device__ __forceinline__ void load(const LoadList &L) {
         n = (int32_t)uni32((uint32_t)L.n);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const bool on = i < n;
-            ptr[i] = on ? uni_ptr<gcf_ptr>(L.ptr[i]) : nullptr;
-            idx[i] = on ? uni_ptr<gci_ptr>(L.idx[i]) : nullptr;
-            stride[i] = on ? (int32_t)uni32((uint32_t)L.stride[i]) : 0;
-            rem[i] = on ? (int32_t)uni32((uint32_t)L.rem[i]) : 0;
-            frow[i] = on ? (int32_t)uni32((uint32_t)L.frow[i]) : 0;
-            relu[i] = on ? (int32_t)uni32((uint32_t)L.relu[i]) : 0;
+            ptr_[i] = on ? uni_ptr<gcf_ptr>(L.ptr[i]) : nullptr;
+            idx_[i] = on ? uni_ptr<gci_ptr>(L.idx[i]) : nullptr;
+            gptr_[i] = on ? uni_ptr<gf_ptr>(L.gptr[i]) : nullptr;
+            stride_[i] = on ? (int32_t)uni32((uint32_t)L.stride[i]) : 0;
+            gstride_[i] = on ? (int32_t)uni32((uint32_t)L.gstride[i]) : 0;
+            meta_[i] = on ? (int32_t)uni32((uint32_t)(L.rem[i] | (L.frow[i] << 8) | (L.relu[i] << 24))) : 0;
         }
     }
+    __device__ __forceinline__ gcf_ptr ptr(int i) const { return ptr_[i]; }
+    __device__ __forceinline__ gci_ptr idx(int i) const { return idx_[i]; }
+    __device__ __forceinline__ gf_ptr gptr(int i) const { return gptr_[i]; }
+    __device__ __forceinline__ int stride(int i) const { return stride_[i]; }
+    __device__ __forceinline__ int gstride(int i) const { return gstride_[i]; }
+    __device__ __forceinline__ int rem(int i) const { return meta_[i] & 0xff; }
+    __device__ __forceinline__ int frow(int i) const { return (meta_[i] >> 8) & 0xffff; }
+    __device__ __forceinline__ bool relu(int i) const { return (meta_[i] >> 24) != 0; }
+};
+
+template <int NI>
+struct Items<NI, false> {
+    const LoadList *L;
+    int32_t n;
+    __device__ __forceinline__ void load(const LoadList &l) {
+        L = &l;
+        n = (int32_t)uni32((uint32_t)l.n);
+    }
+    __device__ __forceinline__ gcf_ptr ptr(int i) const { return uni_ptr<gcf_ptr>(L->ptr[i]); }
+    __device__ __forceinline__ gci_ptr idx(int i) const { return uni_ptr<gci_ptr>(L->idx[i]); }
+    __device__ __forceinline__ gf_ptr gptr(int i) const { return uni_ptr<gf_ptr>(L->gptr[i]); }
+    __device__ __forceinline__ int stride(int i) const { return (int)uni32((uint32_t)L->stride[i]); }
+    __device__ __forceinline__ int gstride(int i) const { return (int)uni32((uint32_t)L->gstride[i]); }
+    __device__ __forceinline__ int rem(int i) const { return (int)uni32((uint32_t)L->rem[i]); }
+    __device__ __forceinline__ int frow(int i) const { return (int)uni32((uint32_t)L->frow[i]); }
+    __device__ __forceinline__ bool relu(int i) const { return uni32((uint32_t)L->relu[i]) != 0; }
 };
 
 // row ids of one tile row for every item (row is pre-clamped to a valid row)
-template <int NI>
-__device__ __forceinline__ void item_row_ids(const Items<NI> &it, int64_t row, int32_t (&rid)[NI]) {
+template <int NI, bool H>
+__device__ __forceinline__ void item_row_ids(const Items<NI, H> &it, int64_t row, int32_t (&rid)[NI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         int32_t v = (int32_t)row;
-        if (i < it.n && it.idx[i] != nullptr) v = it.idx[i][row];
+        if (i < it.n) {
+            const gci_ptr ix = it.idx(i);
+            if (ix != nullptr) v = ix[row];
+        }
         rid[i] = v;
     }
 }
-template <int NI>
-__device__ __forceinline__ void item_values(const Items<NI> &it, const int32_t (&rid)[NI], int part,
-                                            bool valid, float (&pv)[NI]) {
+template <int NI, bool H>
+__device__ __forceinline__ void item_values(const Items<NI, H> &it, const int32_t (&rid)[NI],
+                                            int part, bool valid, float (&pv)[NI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         float v = 0.f;
-        if (i < it.n && valid && part < it.rem[i])
-            v = it.ptr[i][(int64_t)rid[i] * it.stride[i] + part];
+        if (i < it.n) {
+            const gcf_ptr p = it.ptr(i);
+            const int st = it.stride(i), rm = it.rem(i);
+            if (valid && part < rm) v = p[(int64_t)rid[i] * st + part];
+        }
         pv[i] = v;
     }
 }
 // staging buffer [feature][row]: value of (item i, element part) of row c
-template <int NI>
-__device__ __forceinline__ void stage_items(const Items<NI> &it, float *sbuf, int part, int c,
+template <int NI, bool H>
+__device__ __forceinline__ void stage_items(const Items<NI, H> &it, float *sbuf, int part, int c,
                                             const float (&pv)[NI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-        if (i < it.n && part < it.rem[i])
-            sbuf[(it.frow[i] + part) * kTbLd + c] = it.relu[i] ? fmaxf(pv[i], 0.f) : pv[i];
+        if (i < it.n) {
+            const int rm = it.rem(i), fr = it.frow(i);
+            const bool rl = it.relu(i);
+            if (part < rm) sbuf[(fr + part) * kTbLd + c] = rl ? fmaxf(pv[i], 0.f) : pv[i];
+        }
 }
 // LDS offsets of a lane's B-operand features (padding -> zero row `zrow`)
 template <int NT>

@@ -447,10 +447,18 @@ class _FusedMLP(torch.autograd.Function):
                 a.gb[i] = _p(gb[i])
             ws = _ws(lib.gnntrk_mlp_backward_workspace_bytes(C.byref(a.mlp)), g_out)
         a.accumulate_params = 0
+        a.debug_flags = int(__import__("os").environ.get("GNNTRK_DEBUG_FLAGS", "0"))
         nbytes = M * (sum(4 * s.shape[1] + (4 if spec.idx[j] is not None else 0)
                           + (4 * s.shape[1] if need[1 + j] else 0)
                           for j, s in enumerate(segs)) + 4 * a.mlp.out_dim
                       + (4 if spec.out_idx is not None else 0))
+        if __import__("os").environ.get("GNNTRK_DEBUG_PTRS"):
+            def rng(t):
+                return "None" if t is None else f"[{t.data_ptr():#x},{t.data_ptr() + t.numel() * t.element_size():#x})"
+            print("bwd ptrs: g_out", rng(g_out), "ws", rng(ws), "segs", [rng(s) for s in segs],
+                  "W", [rng(w) for w in weights], "gW", [rng(w) for w in gW], "gb", [rng(b) for b in gb],
+                  "gseg", [rng(t) for t in seg_grads], "tmp", [rng(t) for t in row_tmp],
+                  "M", M, "dims", a.mlp.in_dim, a.mlp.hidden, a.mlp.out_dim, flush=True)
         with _timed(g_out, kernel_key("bwd", a.mlp.in_dim, a.mlp.hidden),
                     3 * _mlp_flops_per_row(a.mlp) * M, nbytes, M):
             _capi.check(lib.gnntrk_mlp_backward(C.byref(a), _p(ws),

@@ -301,3 +301,55 @@ def case_good_node_mask(device):
                                      reconstructable=t["reconstructable"].float().to(device),
                                      eta=t["eta"].float().to(device))
     assert got.dtype == torch.bool and torch.equal(got.cpu(), ref)
+
+
+def case_mlp_stress(device, rounds=3, seed=5, cases_per_round=12, row_choices=(1, 15, 16, 17, 77, 1000, 4099)):
+    """Random MLP shapes / row counts / segmentations, forward + backward, repeated: the
+    generic (run-time bound) kernels next to the static ones, tails, multi-segment inputs
+    with and without gathers, alternating with and without parameter / input gradients."""
+    g = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    for rnd in range(rounds):
+        for _ in range(cases_per_round):
+            L = int(g.integers(2, 4))
+            n_seg = int(g.integers(1, 5))
+            dims = [int(g.integers(1, 13)) for _ in range(n_seg)]
+            while sum(dims) > 48:
+                dims[int(np.argmax(dims))] -= 1
+            hid, out = int(g.integers(1, 65)), int(g.integers(1, 17))
+            rows = int(g.choice(list(row_choices)))
+            src_rows = int(g.integers(3, 200))
+            bias = bool(g.integers(0, 2))
+            m = G.MLP(sum(dims), out, hid, L=L, bias=bias)
+            p = {"m." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+            segs_cpu, idxs = [], []
+            for d in dims:
+                if g.random() < 0.5:
+                    segs_cpu.append(torch.randn(src_rows, d))
+                    idxs.append(torch.from_numpy(g.integers(0, src_rows, size=rows)).int())
+                else:
+                    segs_cpu.append(torch.randn(rows, d))
+                    idxs.append(None)
+            want_dx = bool(g.integers(0, 2))
+            ref_in = [s.clone().requires_grad_(want_dx) for s in segs_cpu]
+            cat = torch.cat([s if i is None else s[i.long()] for s, i in zip(ref_in, idxs)], dim=1)
+            yo = O.mlp(cat, p, "m", L, bias=bias)
+            r = torch.randn(rows, out)
+            (yo * r).sum().backward()
+            m = m.to(device)
+            dev_in = [s.clone().to(device).requires_grad_(want_dx) for s in segs_cpu]
+            # gathered segments fold their row gradients with torch's index_add here (the CSR
+            # folds are covered by the interaction-network cases): give them reduce=None by
+            # materialising the gather through autograd-aware indexing
+            segs = []
+            for s, i in zip(dev_in, idxs):
+                segs.append(ops.Seg(s) if i is None else ops.Seg(s[i.to(device).long()]))
+            y = m.fused(segs)
+            (y * r.to(device)).sum().backward()
+            tag = f"stress L={L} dims={dims} hid={hid} out={out} rows={rows} bias={bias}"
+            assert_close(y, yo, TOL_OUT, tag + " y")
+            for k, v in m.named_parameters():
+                assert_close(v.grad, p["m." + k].grad, TOL_GRAD, f"{tag} g {k}")
+            if want_dx:
+                for a, b in zip(dev_in, ref_in):
+                    assert_close(a.grad, b.grad, TOL_GRAD, tag + " gx")

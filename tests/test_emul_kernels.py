@@ -21,6 +21,11 @@ def test_fused_mlp_forward_backward():
         P.case_mlp("cpu", shapes=((14, 40, 4, 3), (14, 14, 5, 2), (30, 33, 7, 3)), rows=37)
 
 
+def test_fused_mlp_stress_small():
+    with emulated():
+        P.case_mlp_stress("cpu", rounds=1, seed=11, cases_per_round=6, row_choices=(1, 16, 17, 45))
+
+
 def test_interaction_network_layer():
     with emulated():
         P.case_in_layer("cpu", which=("odd",))

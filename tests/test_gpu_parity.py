@@ -28,6 +28,10 @@ def test_fused_mlp_forward_backward(dev):
     P.case_mlp(dev, shapes=((14, 40, 4, 3), (26, 40, 1, 3)), rows=40001)
 
 
+def test_fused_mlp_stress(dev):
+    P.case_mlp_stress(dev, rounds=4)
+
+
 def test_interaction_network_layer(dev):
     P.case_in_layer(dev)
 

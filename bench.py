@@ -39,6 +39,7 @@ from gnn_tracking_amd import ops, synthetic  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
 PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
+TRAFFIC_PROFILE = "r01_hbm_traffic_v5.json"
 
 WORKLOADS = {
     # name: (events per GPU, hits per event, edges per event, model kwargs)
@@ -101,6 +102,20 @@ def cpu_baseline(event, model, iters: int) -> dict:
                       f"torch {torch.__version__} CPU, {threads} threads (fastest of "
                       f"{sorted(probe)} probed on a 1/8-event slice; host has {ncpu} CPUs)",
             "s_per_iter": dt, "thread_probe_s": probe}
+
+
+def measured_traffic(kernel: str, rows_per_launch: float):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and
+    WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; see the JSON's _about),
+    scaled by rows when this run's launch size differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)["kernels"].get(kernel)
+    if rec is None:
+        return None
+    return rec["hbm_bytes_per_launch"] * rows_per_launch / rec["rows_per_launch"]
 
 
 def main():
@@ -176,7 +191,8 @@ def main():
             d = ks[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": measured_traffic(dom, d["rows"] / d["launches"]),
                     "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
                     "alg_flops_per_launch": d["flops"] / d["launches"],
                     "alg_bytes_per_launch": d["bytes"] / d["launches"],

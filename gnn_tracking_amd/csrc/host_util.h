@@ -29,6 +29,8 @@ int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *
 // mlp.hip
 int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);
 size_t mlp_backward_ws_bytes(const gnntrk_mlp *m);
+int mlp_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int backward, char *buf,
+                    size_t len);
 int mlp_backward_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes,
                         hipStream_t stream);
 

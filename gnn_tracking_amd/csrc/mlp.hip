@@ -782,6 +782,36 @@ static bool static_shape(int ksi, int ksh, int kso, bool three, int n_items) {
         }                                                                       \
     }
 
+// Name of the instantiation the launchers below pick (as rocprofv3 prints it), so that
+// host-side timers and profiles can be matched kernel by kernel.
+int mlp_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int backward,
+                    char *buf, size_t len) {
+    if (!m || !seg || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
+    const int n_items = count_items(n_seg, seg);
+    int kt = (m->in_dim + 15) / 16;
+    const int ht = (m->hidden + 15) / 16;
+    const bool items_fit = n_items <= 4 * kt + 4;
+    while (4 * kt + 4 < n_items) ++kt;
+    const bool ones_ok = (m->in_dim % 16) != 0 && (m->hidden % 16) != 0;
+    const int ksi = (items_fit && (!backward || ones_ok)) ? make_dimmap(m->in_dim).ks : -1;
+    const int ksh = make_dimmap(m->hidden).ks, kso = make_dimmap(m->out_dim).ks;
+    const bool three = m->n_layers == 3;
+    const char *dir = backward ? "bwd" : "fwd";
+#define NAME_S(KSI, KSH, KSO, THREE, NIT)                                                       \
+    if (!done_ && ksi == KSI && ksh == KSH && kso == KSO && three == THREE && n_items <= NIT) { \
+        snprintf(buf, len, "mlp_%s_kernel<%d, %d, StaticDims<%d, %d, %d, %s, %d>%s>", dir,      \
+                 (KSI + 3) / 4, (KSH + 3) / 4, KSI, KSH, KSO, THREE ? "true" : "false", NIT,    \
+                 backward ? ", 8" : " ");                                                       \
+        done_ = true;                                                                           \
+    }
+#define NAME_D(K, H) \
+    { snprintf(buf, len, "mlp_%s_kernel<%d, %d, DynDims%s>", dir, K, H, backward ? ", 4" : ""); }
+    GNNTRK_DISPATCH(NAME_S, NAME_D)
+#undef NAME_S
+#undef NAME_D
+    return GNNTRK_OK;
+}
+
 int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     if (!a) return fail(GNNTRK_EINVAL, "mlp_forward: NULL args");
     int rc = check_mlp(a->mlp, a->n_seg, a->seg);

@@ -100,20 +100,15 @@ def set_kernel_timer(t: Optional[KernelTimer]) -> None:
     _TIMER = t
 
 
-def kernel_key(direction: str, in_dim: int, hidden: int) -> str:
-    """Name of the kernel instantiation the C launcher dispatches to (mlp.hip)."""
-    kt, ht = (in_dim + 15) // 16, (hidden + 15) // 16
-    if kt <= 1 and ht <= 1:
-        inst = (1, 1)
-    elif kt <= 1 and ht <= 3:
-        inst = (1, 3)
-    elif kt <= 2 and ht <= 2:
-        inst = (2, 2)
-    elif kt <= 2 and ht <= 3:
-        inst = (2, 3)
-    else:
-        inst = (3, 4)
-    return f"mlp_{direction}_kernel<{inst[0]},{inst[1]}>"
+def kernel_key(lib, args, backward: bool) -> str:
+    """Name of the kernel instantiation the C launcher dispatches to (mlp.hip), exactly as
+    rocprofv3 prints it.  Only evaluated while a KernelTimer is installed."""
+    if _TIMER is None:
+        return ""
+    buf = C.create_string_buffer(160)
+    _capi.check(lib.gnntrk_mlp_kernel_name(C.byref(args.mlp), args.n_seg, args.seg,
+                                           1 if backward else 0, buf, len(buf)), lib)
+    return buf.value.decode()
 
 
 def _mlp_flops_per_row(m) -> int:
@@ -385,7 +380,7 @@ class _FusedMLP(torch.autograd.Function):
                           for j, s in enumerate(segs)) + 4 * a.mlp.out_dim
                       + (4 if spec.out_idx is not None else 0)
                       + (4 * a.mlp.out_dim if spec.epilogue == _capi.EPI_RESIDUAL else 0))
-        with _timed(out, kernel_key("fwd", a.mlp.in_dim, a.mlp.hidden),
+        with _timed(out, kernel_key(lib, a, False),
                     _mlp_flops_per_row(a.mlp) * M, nbytes, M):
             _capi.check(lib.gnntrk_mlp_forward(C.byref(a), _stream(out)), lib)
         ctx.spec = spec
@@ -459,7 +454,7 @@ class _FusedMLP(torch.autograd.Function):
                   "W", [rng(w) for w in weights], "gW", [rng(w) for w in gW], "gb", [rng(b) for b in gb],
                   "gseg", [rng(t) for t in seg_grads], "tmp", [rng(t) for t in row_tmp],
                   "M", M, "dims", a.mlp.in_dim, a.mlp.hidden, a.mlp.out_dim, flush=True)
-        with _timed(g_out, kernel_key("bwd", a.mlp.in_dim, a.mlp.hidden),
+        with _timed(g_out, kernel_key(lib, a, True),
                     3 * _mlp_flops_per_row(a.mlp) * M, nbytes, M):
             _capi.check(lib.gnntrk_mlp_backward(C.byref(a), _p(ws),
                                                 0 if ws is None else ws.numel(),

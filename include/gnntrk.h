@@ -197,6 +197,12 @@ typedef struct gnntrk_mlp_bwd_args {
 } gnntrk_mlp_bwd_args;
 
 size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp);
+
+/* Name (as rocprofv3 prints it) of the kernel instantiation gnntrk_mlp_forward /
+ * gnntrk_mlp_backward dispatch to for this MLP and input-segment list; written
+ * NUL-terminated into buf[len].  For matching host-side timings with profiles. */
+int gnntrk_mlp_kernel_name(const gnntrk_mlp *mlp, int32_t n_seg, const gnntrk_seg *seg,
+                           int32_t backward, char *buf, size_t len);
 int gnntrk_mlp_backward(const gnntrk_mlp_bwd_args *args, void *workspace,
                         size_t workspace_bytes, void *stream);
 

@@ -28,6 +28,11 @@ FLAGS = [
 ]
 
 
+# per-file additions: the bf16 kernels convert every MFMA result straight away (pack to
+# bf16), so results should land in VGPRs instead of AGPRs + v_accvgpr_read copies
+EXTRA_FLAGS = {"mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and pathlib.Path(c).exists():
@@ -37,7 +42,7 @@ def _hipcc() -> str:
 
 def _stamp(src: pathlib.Path) -> str:
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src.name, [])).encode())
     h.update(src.read_bytes())
     for hdr in sorted(list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))):
         h.update(hdr.read_bytes())
@@ -50,7 +55,7 @@ def _compile(src: pathlib.Path, verbose: bool) -> pathlib.Path:
     want = _stamp(src)
     if obj.exists() and stamp.exists() and stamp.read_text() == want:
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

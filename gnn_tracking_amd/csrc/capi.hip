@@ -100,8 +100,12 @@ int gnntrk_graph_index_build(const int64_t *edge_index, const gnntrk_graph_index
 int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream) {
     return mlp_forward_launch(args, (hipStream_t)stream);
 }
+int gnntrk_mlp_forward_bf16(const gnntrk_mlp_fwd_args *args, void *stream) {
+    return mlp_forward_bf16_launch(args, (hipStream_t)stream);
+}
 int gnntrk_mlp_kernel_name(const gnntrk_mlp *mlp, int32_t n_seg, const gnntrk_seg *seg,
                            int32_t backward, char *buf, size_t len) {
+    if (backward & 2) return mlp16_kernel_name(mlp, n_seg, seg, backward & 1, buf, len);
     return mlp_kernel_name(mlp, n_seg, seg, backward, buf, len);
 }
 size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp) {

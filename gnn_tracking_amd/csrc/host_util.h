@@ -34,4 +34,10 @@ int mlp_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int b
 int mlp_backward_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes,
                         hipStream_t stream);
 
+
+// mlp_bf16.hip
+int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int backward, char *buf,
+                      size_t len);
+int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);
+
 }  // namespace gnntrk

@@ -100,14 +100,15 @@ def set_kernel_timer(t: Optional[KernelTimer]) -> None:
     _TIMER = t
 
 
-def kernel_key(lib, args, backward: bool) -> str:
+def kernel_key(lib, args, backward: bool, bf16: bool = False) -> str:
     """Name of the kernel instantiation the C launcher dispatches to (mlp.hip), exactly as
     rocprofv3 prints it.  Only evaluated while a KernelTimer is installed."""
     if _TIMER is None:
         return ""
     buf = C.create_string_buffer(160)
     _capi.check(lib.gnntrk_mlp_kernel_name(C.byref(args.mlp), args.n_seg, args.seg,
-                                           1 if backward else 0, buf, len(buf)), lib)
+                                           (1 if backward else 0) + (2 if bf16 else 0), buf,
+                                           len(buf)), lib)
     return buf.value.decode()
 
 

@@ -1,0 +1,102 @@
+"""bf16-storage variants of the fused ops (BASELINE configs 3/4).
+
+Activations live in HBM as ``torch.bfloat16`` rows padded to a multiple of four
+elements (8-byte chunks: one load per lane and chunk in the kernels); parameters,
+parameter gradients and the edge weights ``W`` stay fp32; all accumulation is fp32
+(include/gnntrk.h: gnntrk_mlp_forward_bf16 / gnntrk_mlp_backward_bf16).
+
+A logical ``[R, dim]`` bf16 tensor is a view ``buf[:, :dim]`` of a ``[R, pad4(dim)]``
+buffer, so ``tensor.stride(0)`` carries the padded row stride through autograd.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _capi
+
+BF16 = torch.bfloat16
+
+
+def pad4(d: int) -> int:
+    return (int(d) + 3) // 4 * 4
+
+
+def empty_rows(n: int, dim: int, device, zero: bool = False) -> Tensor:
+    """[n, dim] bf16 view of a padded, 8-byte aligned buffer."""
+    mk = torch.zeros if zero else torch.empty
+    return mk(int(n), pad4(dim), dtype=BF16, device=device)[:, :dim]
+
+
+def rows16(t: Tensor) -> Tensor:
+    """Make ``t`` a kernel-ready bf16 row tensor (no copy when it already is)."""
+    if t.dim() == 1:
+        t = t.unsqueeze(1)
+    if t.dim() != 2:
+        raise ValueError(f"expected a 1-D or 2-D tensor, got shape {tuple(t.shape)}")
+    if t.dtype != BF16:
+        raise TypeError(f"bf16 path got {t.dtype}")
+    ok = ((t.shape[1] == 1 or t.stride(1) == 1) and t.stride(0) % 4 == 0
+          and t.stride(0) >= pad4(t.shape[1]) and t.data_ptr() % 8 == 0)
+    if t.shape[0] <= 1:
+        ok = ok and t.data_ptr() % 8 == 0 and t.stride(0) >= pad4(t.shape[1]) and t.stride(0) % 4 == 0
+    if ok:
+        return t
+    out = empty_rows(t.shape[0], t.shape[1], t.device, zero=True)
+    out.copy_(t)
+    return out
+
+
+def to_rows16(x: Tensor, idx: Optional[Tensor] = None) -> Tensor:
+    """fp32 rows -> padded bf16 rows (RNE), optionally gathered: ``out[m] = x[idx[m]]``.
+    One pass (gnntrk_rows_to_bf16): the dataset's fp32 ``x`` / ``edge_attr`` enter the bf16
+    stack through it, ``edge_attr`` already permuted into CSR order."""
+    from . import ops
+    lib = _capi.load()
+    x = ops._as_rows(x.detach())
+    m = int(idx.shape[0]) if idx is not None else int(x.shape[0])
+    out = empty_rows(m, x.shape[1], x.device)
+    _capi.check(lib.gnntrk_rows_to_bf16(ops._p(x), x.shape[1], ops._row_stride(x), ops._p(idx), m,
+                                        ops._p(out), out.stride(0), ops._stream(x)), lib)
+    return out
+
+
+def _seg16(t: Tensor, idx, relu: bool):
+    return _capi.Seg(t.data_ptr(), None if idx is None else idx.data_ptr(), t.shape[1], t.stride(0),
+                     int(relu), 0)
+
+
+def mlp_forward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], relu: Sequence[bool],
+                    weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]], *, n_rows: int,
+                    epilogue: int, ca: float, cb: float, res: Optional[Tensor],
+                    out_idx: Optional[Tensor], out_rows: int, mlp) -> Tensor:
+    """One launch of gnntrk_mlp_forward_bf16; ``segs``/``res`` kernel-ready (rows16)."""
+    from . import ops
+    lib = _capi.load()
+    a = _capi.MlpFwdArgs()
+    a.mlp = mlp
+    a.n_seg, a.epilogue, a.n_rows = len(segs), epilogue, n_rows
+    for j, s in enumerate(segs):
+        a.seg[j] = _seg16(s, idx[j], relu[j])
+    a.ca, a.cb = ca, cb
+    if epilogue == _capi.EPI_RESIDUAL:
+        a.res, a.res_stride = res.data_ptr(), res.stride(0)
+    dev = segs[0].device
+    if epilogue == _capi.EPI_SIGMOID:
+        out = torch.empty(out_rows, mlp.out_dim, dtype=torch.float32, device=dev)
+    else:
+        out = empty_rows(out_rows, mlp.out_dim, dev)
+    a.out, a.out_stride, a.out_idx = out.data_ptr(), out.stride(0), ops._p(out_idx)
+    M = n_rows
+    nbytes = M * (sum(2 * s.shape[1] + (4 if idx[j] is not None else 0) for j, s in enumerate(segs))
+                  + (4 if epilogue == _capi.EPI_SIGMOID else 2) * mlp.out_dim
+                  + (4 if out_idx is not None else 0)
+                  + (2 * mlp.out_dim if epilogue == _capi.EPI_RESIDUAL else 0))
+    with ops._timed(out, ops.kernel_key(lib, a, False, bf16=True), ops._mlp_flops_per_row(mlp) * M,
+                    nbytes, M):
+        _capi.check(lib.gnntrk_mlp_forward_bf16(C.byref(a), ops._stream(out)), lib)
+    return out

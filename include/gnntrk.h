@@ -142,6 +142,22 @@ typedef struct gnntrk_mlp_fwd_args {
 
 int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream);
 
+/* bf16-storage variant (BASELINE configs 3/4: "bf16 storage for x, e, e~, aggr and the
+ * MFMA inputs, fp32 accumulate"; the reference reaches it through Lightning's
+ * precision="bf16-mixed" autocast around the same modules).  Same argument block, read
+ * with these changes:
+ *   - seg[j].ptr, res and out address bf16 elements (uint16_t storage; the `float *`
+ *     field types are reinterpreted), strides are in ELEMENTS, must be multiples of 4 and
+ *     >= the feature count rounded up to 4, row starts 8-byte aligned.  Padding elements
+ *     of input rows are ignored (forced to 0), padding elements of output rows up to the
+ *     next multiple of 4 are written as 0;
+ *   - weights/biases are fp32 in memory and rounded to bf16 when loaded; every layer
+ *     accumulates in fp32; hidden activations and the output are rounded to bf16 (RNE);
+ *   - GNNTRK_EPI_SIGMOID writes an fp32 output [*, out_stride floats] (the edge weights
+ *     feed the fp32 loss); GNNTRK_EPI_RESIDUAL reads bf16 res rows;
+ *   - limits: <= 16 four-feature input chunks, hidden <= 63, out <= 16, n_rows < 2^31. */
+int gnntrk_mlp_forward_bf16(const gnntrk_mlp_fwd_args *args, void *stream);
+
 /* Backward of the same fused op with full recompute (nothing but the op inputs is
  * saved): replaces autograd's index_add_ / mm / threshold_backward chain
  * (training/base.py:114-116).
@@ -200,7 +216,8 @@ size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp);
 
 /* Name (as rocprofv3 prints it) of the kernel instantiation gnntrk_mlp_forward /
  * gnntrk_mlp_backward dispatch to for this MLP and input-segment list; written
- * NUL-terminated into buf[len].  For matching host-side timings with profiles. */
+ * NUL-terminated into buf[len].  backward: 0 forward, 1 backward, +2 for the bf16 entry
+ * points.  For matching host-side timings with profiles. */
 int gnntrk_mlp_kernel_name(const gnntrk_mlp *mlp, int32_t n_seg, const gnntrk_seg *seg,
                            int32_t backward, char *buf, size_t len);
 int gnntrk_mlp_backward(const gnntrk_mlp_bwd_args *args, void *workspace,

@@ -20,6 +20,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <functional>
@@ -133,6 +134,8 @@ struct Wave {
     Barrier bar;
     float A[16][4];
     float B[4][16];
+    float A32[16][32];
+    float B32[32][16];
     uint64_t xch[64];
 };
 
@@ -203,6 +206,99 @@ inline f32x4_emul __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_e
     w.bar.wait("mfma");
     return d;
 }
+
+// ---- bf16 primitives of gnn_tracking_amd/csrc/tile_bf16.h (host models) ---------------
+#define GNNTRK_BF16_PRIMITIVES 1
+namespace gnntrk {
+typedef uint32_t u32x4_emul __attribute__((vector_size(16)));
+typedef uint32_t u32x2_emul __attribute__((vector_size(8)));
+inline float hipemul_bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline uint16_t hipemul_f32_to_bf16(float f) {  // round to nearest even (v_cvt_pk_bf16_f32)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline uint32_t bf16x2_pack(float lo, float hi) {
+    return (uint32_t)hipemul_f32_to_bf16(lo) | ((uint32_t)hipemul_f32_to_bf16(hi) << 16);
+}
+inline uint32_t i16x2_max(uint32_t a, uint32_t b) {
+    const int16_t l = std::max((int16_t)(a & 0xffff), (int16_t)(b & 0xffff));
+    const int16_t h = std::max((int16_t)(a >> 16), (int16_t)(b >> 16));
+    return (uint32_t)(uint16_t)l | ((uint32_t)(uint16_t)h << 16);
+}
+inline uint32_t i16x2_min(uint32_t a, uint32_t b) {
+    const int16_t l = std::min((int16_t)(a & 0xffff), (int16_t)(b & 0xffff));
+    const int16_t h = std::min((int16_t)(a >> 16), (int16_t)(b >> 16));
+    return (uint32_t)(uint16_t)l | ((uint32_t)(uint16_t)h << 16);
+}
+inline uint32_t u16x2_mul(uint32_t a, uint32_t b) {
+    const uint16_t l = (uint16_t)((a & 0xffff) * (b & 0xffff));
+    const uint16_t h = (uint16_t)((a >> 16) * (b >> 16));
+    return (uint32_t)l | ((uint32_t)h << 16);
+}
+// v_mfma_f32_16x16x{32,16}_bf16: A[i=l&15][k=(K/4)(l>>4)+e], B[k][j=l&15], D[4(l>>4)+r][l&15];
+// products exact in f32, accumulated in k order (the hardware's internal order is not
+// documented: tests compare with a tolerance)
+template <int K, class V>
+inline f32x4_emul hipemul_mfma_bf16(V a, V b, f32x4_emul c) {
+    hipemul::Wave &w = hipemul::wave();
+    const int l = hipemul::lane();
+    for (int e = 0; e < K / 4; ++e) {
+        const uint32_t aw = a[e >> 1], bw = b[e >> 1];
+        const uint16_t ah = (e & 1) ? (uint16_t)(aw >> 16) : (uint16_t)aw;
+        const uint16_t bh = (e & 1) ? (uint16_t)(bw >> 16) : (uint16_t)bw;
+        w.A32[l & 15][(K / 4) * (l >> 4) + e] = hipemul_bf16_to_f32(ah);
+        w.B32[(K / 4) * (l >> 4) + e][l & 15] = hipemul_bf16_to_f32(bh);
+    }
+    w.bar.wait("mfma_bf16");
+    f32x4_emul d;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < K; ++k) acc += w.A32[row][k] * w.B32[k][col];
+        d[r] = acc;
+    }
+    w.bar.wait("mfma_bf16");
+    return d;
+}
+inline f32x4_emul mfma_bf16_k32(u32x4_emul a, u32x4_emul b, f32x4_emul c) {
+    return hipemul_mfma_bf16<32>(a, b, c);
+}
+inline f32x4_emul mfma_bf16_k16(u32x2_emul a, u32x2_emul b, f32x4_emul c) {
+    return hipemul_mfma_bf16<16>(a, b, c);
+}
+// ds_read_b64_tr_b16 (tile_bf16.h documents the lane map)
+inline u32x2_emul lds_read_tr16(const uint16_t *p) {
+    hipemul::Wave &w = hipemul::wave();
+    const int l = hipemul::lane();
+    if (((uintptr_t)p & 7) != 0) {
+        fprintf(stderr, "hipemul: ds_read_b64_tr_b16 address not 8-byte aligned\n");
+        abort();
+    }
+    uint64_t mine;
+    memcpy(&mine, p, 8);
+    w.xch[l] = mine;
+    w.bar.wait("tr16");
+    const int base = l & ~15, pcol = l & 15;
+    uint16_t out[4];
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t chunk = w.xch[base + 4 * j + (pcol >> 2)];
+        out[j] = (uint16_t)(chunk >> (16 * (pcol & 3)));
+    }
+    w.bar.wait("tr16");
+    u32x2_emul r;
+    r[0] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
+    r[1] = (uint32_t)out[2] | ((uint32_t)out[3] << 16);
+    return r;
+}
+}  // namespace gnntrk
 
 template <class T>
 inline T hipemul_shfl(T v, int srclane) {

@@ -353,3 +353,79 @@ def case_mlp_stress(device, rounds=3, seed=5, cases_per_round=12, row_choices=(1
             if want_dx:
                 for a, b in zip(dev_in, ref_in):
                     assert_close(a.grad, b.grad, TOL_GRAD, tag + " gx")
+
+
+# ------------------------------------------------------------------ bf16 storage mode
+# Tolerances: the kernels and oracle/ref_cpu.py:mlp_bf16_* round at the same points; they
+# differ by fp32 summation order only, which can move a value across a bf16 rounding
+# boundary (1 ulp = 2^-8 relative).  TOL16 bounds that; fp32 outputs (sigmoid) are tight.
+TOL16 = 2.0 ** -7
+
+
+def _rand_rows16(rows, dim, device, gen):
+    from gnn_tracking_amd import ops_bf16 as B
+    t = B.empty_rows(rows, dim, "cpu", zero=True)
+    t.copy_(torch.randn(rows, dim, generator=gen))
+    # poison the padding: the kernels must ignore it
+    buf = t.as_strided((rows, B.pad4(dim)), (B.pad4(dim), 1))
+    if B.pad4(dim) > dim:
+        buf[:, dim:] = float("nan")
+    return t.to(device) if device != "cpu" else t
+
+
+def case_mlp_bf16_forward(device, rows=75):
+    from gnn_tracking_amd import _capi, ops_bf16 as B
+    gen = torch.Generator().manual_seed(0)
+    cases = [
+        # (segment dims, gathered?, relu?, hidden, out, L, bias, epilogue)
+        ((5, 5, 4), (True, True, False), (True, True, True), 40, 4, 3, True, "none"),
+        ((5, 4), (False, False), (False, False), 40, 5, 3, True, "residual"),
+        ((14,), (False,), (False,), 40, 5, 2, False, "relu"),
+        ((4,), (True,), (False,), 40, 4, 2, False, "relu"),
+        ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, 40, 1, 3, True,
+         "sigmoid"),
+        ((3,), (False,), (False,), 7, 2, 3, True, "none"),
+        ((8, 8, 8, 8), (False,) * 4, (False,) * 4, 16, 16, 3, True, "none"),   # no free pad slot
+        ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, 62, 9, 3, True, "none"),  # KI=2, HT=4
+    ]
+    epi_code = {"none": _capi.EPI_NONE, "relu": _capi.EPI_RELU, "residual": _capi.EPI_RESIDUAL,
+                "sigmoid": _capi.EPI_SIGMOID}
+    for dims, gath, relu, hid, out, L, bias, epi in cases:
+        n_src = 31
+        segs, idxs, xs = [], [], []
+        for d, gflag in zip(dims, gath):
+            t = _rand_rows16(n_src if gflag else rows, d, device, gen)
+            idx = (torch.randint(0, n_src, (rows,), generator=gen).int().to(device) if gflag else None)
+            segs.append(t)
+            idxs.append(idx)
+        in_dim = sum(dims)
+        m = G.MLP(in_dim, out, hid, L=L, bias=bias)
+        weights = [l.weight.detach() for l in m.layers if hasattr(l, "weight")]
+        biases = [l.bias.detach() if bias else None for l in m.layers if hasattr(l, "weight")]
+        res = _rand_rows16(rows, out, device, gen) if epi == "residual" else None
+        out_idx = torch.randperm(rows, generator=gen).int().to(device) if epi == "sigmoid" else None
+        # oracle
+        xin = []
+        for t, idx, r in zip(segs, idxs, relu):
+            v = t.float().cpu()
+            if idx is not None:
+                v = v[idx.cpu().long()]
+            xin.append(torch.relu(v) if r else v)
+        z, _ = O.mlp_bf16_forward(torch.cat(xin, 1), weights, biases)
+        ca, cb = (0.6, 0.8) if epi == "residual" else ((0.001, 0.998) if epi == "sigmoid" else (0.0, 1.0))
+        yo = O.mlp_bf16_epilogue(z, epi, ca, cb, None if res is None else res.float().cpu())
+        if out_idx is not None:
+            tmp = torch.empty_like(yo)
+            tmp[out_idx.cpu().long()] = yo
+            yo = tmp
+        wd = [w.to(device).contiguous() for w in weights]
+        bd = [None if b is None else b.to(device).contiguous() for b in biases]
+        mlp = ops._fill_mlp(wd, bd)
+        y = B.mlp_forward_raw([B.rows16(s) for s in segs], idxs, relu, wd, bd, n_rows=rows,
+                              epilogue=epi_code[epi], ca=ca, cb=cb, res=res, out_idx=out_idx,
+                              out_rows=rows, mlp=mlp)
+        tag = f"bf16 MLP {dims}->{hid}->{out} L={L} bias={bias} {epi}"
+        assert_close(y.float(), yo, 1e-5 if epi == "sigmoid" else TOL16, tag)
+        if epi != "sigmoid" and B.pad4(out) > out:  # padding written as zeros
+            buf = y.as_strided((rows, B.pad4(out)), (B.pad4(out), 1))
+            assert (buf[:, out:] == 0).all(), tag + " padding"

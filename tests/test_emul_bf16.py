@@ -1,0 +1,15 @@
+"""bf16-storage kernels on the wave64 CPU emulator (tests/emul): the same .hip sources
+compiled with g++, checked against oracle/ref_cpu.py's restatement of the rounding
+contract.  The GPU versions of these cases are in test_gpu_parity.py."""
+
+import pytest
+
+import parity_cases as P
+from emul_util import emulated
+
+pytestmark = pytest.mark.emul
+
+
+def test_mlp_bf16_forward_emulated():
+    with emulated():
+        P.case_mlp_bf16_forward("cpu", rows=37)

@@ -79,8 +79,10 @@ _SIGNATURES = {
     "gnntrk_graph_index_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gnntrk_graph_index_build": (C.c_int, [_P, C.POINTER(GraphIndex), _P, C.c_size_t, _P]),
     "gnntrk_mlp_forward": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
-    "gnntrk_mlp_forward_bf16": (C.c_int, [C.POINTER(MlpFwdArgs), C.c_void_p]),
+    "gnntrk_mlp_forward_bf16": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
     "gnntrk_mlp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
+    "gnntrk_mlp_backward_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
+    "gnntrk_mlp_backward_bf16": (C.c_int, [C.POINTER(MlpBwdArgs), _P, C.c_size_t, _P]),
     "gnntrk_mlp_kernel_name": (C.c_int, [C.POINTER(Mlp), C.c_int32, C.POINTER(Seg), C.c_int32,
                                         C.c_char_p, C.c_size_t]),
     "gnntrk_mlp_backward": (C.c_int, [C.POINTER(MlpBwdArgs), _P, C.c_size_t, _P]),

@@ -103,6 +103,13 @@ int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream) {
 int gnntrk_mlp_forward_bf16(const gnntrk_mlp_fwd_args *args, void *stream) {
     return mlp_forward_bf16_launch(args, (hipStream_t)stream);
 }
+size_t gnntrk_mlp_backward_bf16_workspace_bytes(const gnntrk_mlp *mlp) {
+    return mlp_backward_bf16_ws_bytes(mlp);
+}
+int gnntrk_mlp_backward_bf16(const gnntrk_mlp_bwd_args *args, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+    return mlp_backward_bf16_launch(args, workspace, workspace_bytes, (hipStream_t)stream);
+}
 int gnntrk_mlp_kernel_name(const gnntrk_mlp *mlp, int32_t n_seg, const gnntrk_seg *seg,
                            int32_t backward, char *buf, size_t len) {
     if (backward & 2) return mlp16_kernel_name(mlp, n_seg, seg, backward & 1, buf, len);

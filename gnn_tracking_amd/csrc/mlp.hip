@@ -911,16 +911,22 @@ int mlp_backward_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes,
         rc = check_launch("mlp_backward");
         if (rc) return rc;
     }
-    if (want_dw && !(a->debug_flags & 32)) {
-        const int n_part = grid * wpb;
-        const int rgrid = (pl.total + 63) / 64;
-        auto rfn = reduce_partials_kernel;
-        hipLaunchKernelGGL(rfn, dim3(rgrid), dim3(kBlock), 0, stream,
-                           reinterpret_cast<const float *>(ws), n_part, pl.total, a->mlp, a->gW[0],
-                           a->gW[1], a->gW[2], a->gb[0], a->gb[1], a->gb[2], a->accumulate_params);
-        rc = check_launch("mlp_backward(reduce)");
-    }
+    if (want_dw && !(a->debug_flags & 32))
+        rc = reduce_partials_launch(reinterpret_cast<const float *>(ws), grid * wpb, &a->mlp, a->gW, a->gb,
+                                    a->accumulate_params, stream);
     return rc;
+}
+
+// Fixed-order sum of n_part partial blocks (parameter layout of part_layout()) into the
+// gradient tensors; n_part = 0 writes zeros.  Shared with the bf16 kernels (mlp_bf16.hip).
+int reduce_partials_launch(const float *part, int n_part, const gnntrk_mlp *mlp, float *const gW[3],
+                           float *const gb[3], int accumulate, hipStream_t stream) {
+    const BwdPartLayout pl = part_layout(*mlp);
+    const int rgrid = (pl.total + 63) / 64;
+    auto rfn = reduce_partials_kernel;
+    hipLaunchKernelGGL(rfn, dim3(rgrid), dim3(kBlock), 0, stream, part, n_part, pl.total, *mlp, gW[0], gW[1],
+                       gW[2], gb[0], gb[1], gb[2], accumulate);
+    return check_launch("mlp_backward(reduce)");
 }
 
 }  // namespace gnntrk

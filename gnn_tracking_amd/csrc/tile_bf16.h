@@ -76,6 +76,14 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t *p) {
         (lds_ptr)(__attribute__((address_space(3))) void *)p);
     return __builtin_bit_cast(u32x2, v);
 }
+// An offset of zero the optimiser cannot see through.  The backward kernel re-reads its
+// weight fragments from LDS in every tile (about 25 ds_read_b128): hoisted out of the tile
+// loop they would take 70+ registers next to the 72 weight-gradient accumulators.
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
 #endif  // GNNTRK_BF16_PRIMITIVES
 
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }

@@ -100,3 +100,51 @@ def mlp_forward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], rel
                     nbytes, M):
         _capi.check(lib.gnntrk_mlp_forward_bf16(C.byref(a), ops._stream(out)), lib)
     return out
+
+
+def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], relu: Sequence[bool],
+                     weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]], *, n_rows: int,
+                     epilogue: int, ca: float, cb: float, gout: Sequence[tuple], need_seg: Sequence[bool],
+                     want_dw: bool, mlp):
+    """One launch of gnntrk_mlp_backward_bf16.  ``gout``: 1-2 tuples (rows, idx) - padded
+    bf16 rows, or one fp32 ``[*, out]`` tensor for EPI_SIGMOID.  Returns (row-aligned
+    per-segment gradient slices ``[n_rows, dim]`` bf16 or None, gW list, gb list)."""
+    from . import ops
+    lib = _capi.load()
+    a = _capi.MlpBwdArgs()
+    a.mlp = mlp
+    a.n_seg, a.epilogue, a.n_rows = len(segs), epilogue, n_rows
+    a.ca, a.cb = ca, cb
+    for j, s in enumerate(segs):
+        a.seg[j] = _seg16(s, idx[j], relu[j])
+    a.n_gout = len(gout)
+    for t, (rows, gidx) in enumerate(gout):
+        a.gout[t] = _capi.GTerm(rows.data_ptr(), ops._p(gidx), rows.stride(0), 0)
+    dev = segs[0].device
+    slices = [None] * len(segs)
+    for j, s in enumerate(segs):
+        if need_seg[j]:
+            slices[j] = empty_rows(n_rows, s.shape[1], dev)
+            a.gseg[j] = _capi.GSeg(slices[j].data_ptr(), None, slices[j].stride(0), 0)
+    gW = [None] * len(weights)
+    gb = [None] * len(weights)
+    ws = None
+    if want_dw:
+        gW = [torch.empty_like(w) for w in weights]
+        gb = [None if b is None else torch.empty_like(b) for b in biases]
+        for i in range(len(weights)):
+            a.gW[i] = gW[i].data_ptr()
+            a.gb[i] = ops._p(gb[i])
+        ws = ops._ws(lib.gnntrk_mlp_backward_bf16_workspace_bytes(C.byref(a.mlp)), segs[0])
+    a.accumulate_params = 0
+    M = n_rows
+    nbytes = M * (sum(2 * s.shape[1] + (4 if idx[j] is not None else 0)
+                      + (2 * s.shape[1] if need_seg[j] else 0) for j, s in enumerate(segs))
+                  + sum((4 if epilogue == _capi.EPI_SIGMOID else 2) * mlp.out_dim
+                        + (4 if gi is not None else 0) for _, gi in gout))
+    ref = gout[0][0]
+    with ops._timed(ref, ops.kernel_key(lib, a, True, bf16=True), 3 * ops._mlp_flops_per_row(mlp) * M,
+                    nbytes, M):
+        _capi.check(lib.gnntrk_mlp_backward_bf16(C.byref(a), ops._p(ws), 0 if ws is None else ws.numel(),
+                                                 ops._stream(ref)), lib)
+    return slices, gW, gb

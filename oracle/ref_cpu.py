@@ -436,3 +436,30 @@ def mlp_bf16_epilogue(z: Tensor, epilogue: str, ca=0.0, cb=1.0, res=None) -> Ten
     if epilogue == "sigmoid":
         return ca + cb * torch.sigmoid(z)  # fp32 output
     raise ValueError(epilogue)
+
+
+def mlp_bf16_backward(x: Tensor, weights, biases, g: Tensor, epilogue: str, ca=0.0, cb=1.0):
+    """Backward of the bf16 fused MLP with the kernel's rounding points (include/gnntrk.h,
+    gnntrk_mlp_backward_bf16).  ``x`` [M, in] = inputs after their ReLU (bf16 values), ``g``
+    [M, out] fp32 = sum of the upstream terms.  Returns (gin [M, in] before the input-ReLU
+    gate, list of dW, list of db) - dW/db fp32."""
+    z, hidden = mlp_bf16_forward(x, weights, biases)
+    if epilogue == "relu":
+        g = g * (z > 0)
+    elif epilogue == "residual":
+        g = cb * g
+    elif epilogue == "sigmoid":
+        s = torch.sigmoid(z)
+        g = g * cb * s * (1 - s)
+    L = len(weights)
+    gk = bf16_round(g.float())
+    acts = [x] + hidden  # input of layer i
+    dW, db = [None] * L, [None] * L
+    for i in range(L - 1, -1, -1):
+        dW[i] = (gk.double().T @ acts[i].double()).float()
+        db[i] = gk.double().sum(0).float() if biases[i] is not None else None
+        gprev = bf16_round((gk.double() @ bf16_round(weights[i]).double()).float())
+        if i > 0:
+            gprev = gprev * (acts[i] > 0)
+        gk = gprev
+    return gk, dW, db

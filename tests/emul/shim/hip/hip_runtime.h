@@ -274,6 +274,7 @@ inline f32x4_emul mfma_bf16_k32(u32x4_emul a, u32x4_emul b, f32x4_emul c) {
 inline f32x4_emul mfma_bf16_k16(u32x2_emul a, u32x2_emul b, f32x4_emul c) {
     return hipemul_mfma_bf16<16>(a, b, c);
 }
+inline int opaque_zero() { return 0; }
 // ds_read_b64_tr_b16 (tile_bf16.h documents the lane map)
 inline u32x2_emul lds_read_tr16(const uint16_t *p) {
     hipemul::Wave &w = hipemul::wave();

@@ -402,7 +402,7 @@ def case_mlp_bf16_forward(device, rows=75):
         m = G.MLP(in_dim, out, hid, L=L, bias=bias)
         weights = [l.weight.detach() for l in m.layers if hasattr(l, "weight")]
         biases = [l.bias.detach() if bias else None for l in m.layers if hasattr(l, "weight")]
-        res = _rand_rows16(rows, out, device, gen) if epi == "residual" else None
+        res = B.rows16(_rand_rows16(rows, out, device, gen)) if epi == "residual" else None
         out_idx = torch.randperm(rows, generator=gen).int().to(device) if epi == "sigmoid" else None
         # oracle
         xin = []
@@ -429,3 +429,80 @@ def case_mlp_bf16_forward(device, rows=75):
         if epi != "sigmoid" and B.pad4(out) > out:  # padding written as zeros
             buf = y.as_strided((rows, B.pad4(out)), (B.pad4(out), 1))
             assert (buf[:, out:] == 0).all(), tag + " padding"
+
+
+def case_mlp_bf16_backward(device, rows=75, full=True):
+    from gnn_tracking_amd import _capi, ops_bf16 as B
+    gen = torch.Generator().manual_seed(1)
+    cases = [
+        # (segment dims, gathered?, relu?, need grad?, hidden, out, L, bias, epilogue, n_gout)
+        ((5, 5, 4), (True, True, False), (True, True, True), (True, True, True), 40, 4, 3, True, "none", 2),
+        ((5, 4), (False, False), (False, False), (True, True), 40, 5, 3, True, "residual", 1),
+        ((4,), (True,), (False,), (False,), 40, 4, 2, False, "relu", 1),
+        ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, (True,) * 6, 40, 1, 3,
+         True, "sigmoid", 1),
+    ]
+    if full:
+        cases += [
+            ((14,), (False,), (False,), (False,), 40, 5, 2, False, "relu", 1),
+            ((3,), (False,), (True,), (True,), 7, 2, 3, True, "none", 1),
+            ((8, 8, 8, 8), (False,) * 4, (False,) * 4, (True, False, True, False), 16, 16, 3, True, "none", 1),
+            ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, (True,) * 5, 30, 9, 3, True, "none", 1),
+        ]
+    epi_code = {"none": _capi.EPI_NONE, "relu": _capi.EPI_RELU, "residual": _capi.EPI_RESIDUAL,
+                "sigmoid": _capi.EPI_SIGMOID}
+    for dims, gath, relu, need, hid, out, L, bias, epi, n_gout in cases:
+        n_src = 31
+        segs, idxs = [], []
+        for d, gflag in zip(dims, gath):
+            segs.append(B.rows16(_rand_rows16(n_src if gflag else rows, d, device, gen)))
+            idxs.append(torch.randint(0, n_src, (rows,), generator=gen).int().to(device) if gflag else None)
+        m = G.MLP(sum(dims), out, hid, L=L, bias=bias)
+        weights = [l.weight.detach() for l in m.linears()]
+        biases = [l.bias.detach() if bias else None for l in m.linears()]
+        ca, cb = (0.6, 0.8) if epi == "residual" else ((0.001, 0.998) if epi == "sigmoid" else (0.0, 1.0))
+        # upstream gradient terms
+        gout, g_sum = [], torch.zeros(rows, out)
+        if epi == "sigmoid":
+            perm = torch.randperm(rows, generator=gen)
+            gfull = torch.randn(rows, out, generator=gen)
+            gout.append((gfull.to(device), perm.int().to(device)))
+            g_sum = gfull[perm]
+        else:
+            for t in range(n_gout):
+                if t == 0:
+                    gt = B.rows16(_rand_rows16(rows, out, device, gen))
+                    gout.append((gt, None))
+                    g_sum = g_sum + gt.float().cpu()
+                else:
+                    gt = B.rows16(_rand_rows16(n_src, out, device, gen))
+                    gi = torch.randint(0, n_src, (rows,), generator=gen)
+                    gout.append((gt, gi.int().to(device)))
+                    g_sum = g_sum + gt.float().cpu()[gi]
+        # oracle
+        xin, raw = [], []
+        for t, idx, r in zip(segs, idxs, relu):
+            v = t.float().cpu()
+            if idx is not None:
+                v = v[idx.cpu().long()]
+            raw.append(v)
+            xin.append(torch.relu(v) if r else v)
+        gin, dW, db = O.mlp_bf16_backward(torch.cat(xin, 1), weights, biases, g_sum, epi, ca, cb)
+        wd = [w.to(device).contiguous() for w in weights]
+        bd = [None if b is None else b.to(device).contiguous() for b in biases]
+        slices, gW, gb = B.mlp_backward_raw(segs, idxs, relu, wd, bd, n_rows=rows, epilogue=epi_code[epi],
+                                            ca=ca, cb=cb, gout=gout, need_seg=need, want_dw=True,
+                                            mlp=ops._fill_mlp(wd, bd))
+        tag = f"bf16 MLP bwd {dims}->{hid}->{out} L={L} bias={bias} {epi}"
+        col = 0
+        for j, d in enumerate(dims):
+            if need[j]:
+                want = gin[:, col:col + d] * ((raw[j] > 0) if relu[j] else 1.0)
+                assert_close(slices[j].float(), want, TOL16, f"{tag} gseg{j}")
+            else:
+                assert slices[j] is None
+            col += d
+        for i in range(L):
+            assert_close(gW[i], dW[i], TOL16, f"{tag} gW{i}")
+            if bias:
+                assert_close(gb[i], db[i], TOL16, f"{tag} gb{i}")

@@ -13,3 +13,8 @@ pytestmark = pytest.mark.emul
 def test_mlp_bf16_forward_emulated():
     with emulated():
         P.case_mlp_bf16_forward("cpu", rows=37)
+
+
+def test_mlp_bf16_backward_emulated():
+    with emulated():
+        P.case_mlp_bf16_backward("cpu", rows=37, full=False)

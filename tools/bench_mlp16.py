@@ -67,3 +67,18 @@ err = (y16 - y32).abs().max().item()
 alg16 = E * (8 + 8 + 8 + 2 * 16)  # ids + e + out + two gathered 16-byte rows
 print(f"rel fwd  E={E}: bf16 {t16:.3f} ms ({E / t16 / 1e6:.1f} G rows/s, alg {alg16 / t16 / 1e9:.2f} TB/s) | "
       f"fp32 {t32:.3f} ms | max|bf16-fp32| {err:.3e} (scale {y32.abs().max().item():.2f})")
+
+if args.bwd:
+    ge16 = B.empty_rows(E, 4, dev, zero=True)
+    ge16.copy_(torch.randn(E, 4, device=dev))
+    ga16 = B.empty_rows(N, 4, dev, zero=True)
+    ga16.copy_(torch.randn(N, 4, device=dev))
+
+    def bwd16():
+        return B.mlp_backward_raw([h16, h16, e16], [gi.tgt, gi.src, None], [True, True, True], W, b, n_rows=E,
+                                  epilogue=_capi.EPI_NONE, ca=0.0, cb=1.0, gout=[(ge16, None), (ga16, gi.tgt)],
+                                  need_seg=[True, True, True], want_dw=True, mlp=mlp)
+
+    tb = timeit(bwd16, args.iters)
+    alg = E * (8 + 8 + 32 + 8 + 8 + 8 + 32)
+    print(f"rel bwd  E={E}: bf16 {tb:.3f} ms ({E / tb / 1e6:.1f} G rows/s, alg {alg / tb / 1e9:.2f} TB/s)")

@@ -18,10 +18,11 @@ from .graph_masks import get_good_node_mask, get_good_node_mask_tensors
 from .losses_ec import EdgeWeightBCELoss, falsify_low_pt_edges
 from .losses_oc import CondensationLossRG, CondensationLossTiger, MultiLossFctReturn
 from .mlp import MLP
+from .precision import bf16_storage
 from .resin import ResIN
 
 __version__ = "0.1.0"
 __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphTCN",
            "EdgeWeightBCELoss", "falsify_low_pt_edges", "MLGraphConstruction",
            "knn_with_max_radius", "get_good_node_mask", "get_good_node_mask_tensors",
-           "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn"]
+           "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage"]

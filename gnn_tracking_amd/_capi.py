@@ -79,6 +79,11 @@ _SIGNATURES = {
     "gnntrk_graph_index_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gnntrk_graph_index_build": (C.c_int, [_P, C.POINTER(GraphIndex), _P, C.c_size_t, _P]),
     "gnntrk_mlp_forward": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
+    "gnntrk_rows_to_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P]),
+    "gnntrk_segment_sum_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32,
+                                          _P]),
+    "gnntrk_permute_rows_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32,
+                                           C.c_int32, _P]),
     "gnntrk_mlp_forward_bf16": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
     "gnntrk_mlp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
     "gnntrk_mlp_backward_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),

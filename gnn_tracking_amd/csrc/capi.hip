@@ -100,6 +100,21 @@ int gnntrk_graph_index_build(const int64_t *edge_index, const gnntrk_graph_index
 int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream) {
     return mlp_forward_launch(args, (hipStream_t)stream);
 }
+int gnntrk_rows_to_bf16(const float *in, int32_t dim, int32_t in_stride, const int32_t *idx, int64_t n_rows,
+                        uint16_t *out, int32_t out_stride, void *stream) {
+    return rows_to_bf16_launch(in, dim, in_stride, idx, n_rows, out, out_stride, (hipStream_t)stream);
+}
+int gnntrk_segment_sum_bf16(const uint16_t *rows, int32_t dim, int32_t row_stride, const int32_t *rowptr,
+                            const int32_t *pos, int64_t n_segments, uint16_t *out, int32_t out_stride,
+                            void *stream) {
+    return segment_sum_bf16_launch(rows, dim, row_stride, rowptr, pos, n_segments, out, out_stride,
+                                   (hipStream_t)stream);
+}
+int gnntrk_permute_rows_bf16(const uint16_t *in, int32_t dim, int32_t in_stride, const int32_t *idx,
+                             int64_t n_rows, uint16_t *out, int32_t out_stride, int32_t scatter, void *stream) {
+    return permute_rows_bf16_launch(in, dim, in_stride, idx, n_rows, out, out_stride, scatter,
+                                    (hipStream_t)stream);
+}
 int gnntrk_mlp_forward_bf16(const gnntrk_mlp_fwd_args *args, void *stream) {
     return mlp_forward_bf16_launch(args, (hipStream_t)stream);
 }

@@ -44,4 +44,14 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);
 size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m);
 int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes, hipStream_t stream);
 
+
+// rows_bf16.hip
+int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
+                        uint16_t *out, int out_stride, hipStream_t stream);
+int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const int32_t *rowptr,
+                            const int32_t *pos, int64_t n_seg, uint16_t *out, int out_stride,
+                            hipStream_t stream);
+int permute_rows_bf16_launch(const uint16_t *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
+                             uint16_t *out, int out_stride, int scatter, hipStream_t stream);
+
 }  // namespace gnntrk

@@ -791,6 +791,8 @@ int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int
     if (!m || !seg || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
     SlotPlan P;
     make_slot_plan(P, *m, n_seg, seg, nullptr);
+    // (the backward instantiation also depends on how many input gradients are wanted:
+    // GT = 1 or 2 KI gradient tiles; the name reports the k-step and hidden-tile counts)
     snprintf(buf, len, "mlp16_%s_kernel<%d, %d, %s>", backward ? "bwd" : "fwd", P.KI, P.HT,
              m->n_layers == 3 ? "true" : "false");
     return GNNTRK_OK;

@@ -1,0 +1,127 @@
+// HBM-bound helpers of the bf16-storage path: fp32 -> padded bf16 row conversion (with
+// optional row gather), deterministic CSR segment sums over bf16 rows (fp32 accumulate),
+// row permutations of padded bf16 rows.  Rows are handled in 8-byte chunks of four bf16
+// (the padding convention of gnntrk_mlp_forward_bf16).
+#include "host_util.h"
+#include "tile_bf16.h"
+
+namespace gnntrk {
+namespace {
+
+constexpr int kTpb16 = 256;
+
+int grid_for_threads(int64_t n) {
+    int64_t g = ceil_div(n, kTpb16);
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+// thread <-> (output row m, chunk ch)
+__global__ __launch_bounds__(kTpb16) void rows_to_bf16_kernel(const float *__restrict__ in, int dim,
+                                                               int in_stride,
+                                                               const int32_t *__restrict__ idx,
+                                                               int64_t n_rows, uint16_t *__restrict__ out,
+                                                               int out_stride) {
+    const int nch = (dim + 3) >> 2;
+    const int64_t total = n_rows * nch;
+    for (int64_t t = (int64_t)blockIdx.x * kTpb16 + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * kTpb16) {
+        const int64_t m = t / nch;
+        const int ch = (int)(t - m * nch);
+        const float *src = in + (idx ? (int64_t)idx[m] : m) * in_stride + 4 * ch;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (4 * ch + r < dim) ? src[r] : 0.f;
+        u32x2 o;
+        o[0] = bf16x2_pack(v[0], v[1]);
+        o[1] = bf16x2_pack(v[2], v[3]);
+        *reinterpret_cast<u32x2 *>(out + m * out_stride + 4 * ch) = o;
+    }
+}
+
+// thread <-> (segment n, chunk ch): out[n] = sum over CSR positions k of rows[pos ? pos[k] : k]
+__global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
+    const uint16_t *__restrict__ rows, int dim, int row_stride, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ pos, int64_t n_seg, uint16_t *__restrict__ out, int out_stride) {
+    const int nch = (dim + 3) >> 2;
+    const int64_t total = n_seg * nch;
+    for (int64_t t = (int64_t)blockIdx.x * kTpb16 + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * kTpb16) {
+        const int64_t n = t / nch;
+        const int ch = (int)(t - n * nch);
+        const int32_t k0 = rowptr[n], k1 = rowptr[n + 1];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int32_t k = k0; k < k1; ++k) {
+            const int64_t r = pos ? (int64_t)pos[k] : (int64_t)k;
+            const u32x2 v = *reinterpret_cast<const u32x2 *>(rows + r * row_stride + 4 * ch);
+            s0 += bf16_lo(v[0]);
+            s1 += bf16_hi(v[0]);
+            s2 += bf16_lo(v[1]);
+            s3 += bf16_hi(v[1]);
+        }
+        const int d = dim - 4 * ch;
+        u32x2 o;
+        o[0] = bf16x2_pack(s0, d >= 2 ? s1 : 0.f);
+        o[1] = bf16x2_pack(d >= 3 ? s2 : 0.f, d >= 4 ? s3 : 0.f);
+        *reinterpret_cast<u32x2 *>(out + n * out_stride + 4 * ch) = o;
+    }
+}
+
+// gather: out[m] = in[idx[m]];  scatter: out[idx[m]] = in[m]   (whole chunks are copied)
+__global__ __launch_bounds__(kTpb16) void permute_rows_bf16_kernel(
+    const uint16_t *__restrict__ in, int nch, int in_stride, const int32_t *__restrict__ idx,
+    int64_t n_rows, uint16_t *__restrict__ out, int out_stride, int scatter) {
+    const int64_t total = n_rows * nch;
+    for (int64_t t = (int64_t)blockIdx.x * kTpb16 + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * kTpb16) {
+        const int64_t m = t / nch;
+        const int ch = (int)(t - m * nch);
+        const int64_t j = idx[m];
+        const int64_t src = scatter ? m : j, dst = scatter ? j : m;
+        *reinterpret_cast<u32x2 *>(out + dst * out_stride + 4 * ch) =
+            *reinterpret_cast<const u32x2 *>(in + src * in_stride + 4 * ch);
+    }
+}
+
+bool rows_ok(const void *p, int dim, int stride) {
+    return p && dim >= 1 && stride % 4 == 0 && stride >= (dim + 3) / 4 * 4 && ((uintptr_t)p & 7) == 0;
+}
+
+}  // namespace
+
+int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
+                        uint16_t *out, int out_stride, hipStream_t stream) {
+    if (!in || dim < 1 || in_stride < dim || n_rows < 0 || !rows_ok(out, dim, out_stride))
+        return fail(GNNTRK_EINVAL, "rows_to_bf16: bad argument");
+    if (n_rows == 0) return GNNTRK_OK;
+    const int nch = (dim + 3) / 4;
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3(grid_for_threads(n_rows * nch)), dim3(kTpb16), 0, stream, in,
+                       dim, in_stride, idx, n_rows, out, out_stride);
+    return check_launch("rows_to_bf16");
+}
+
+int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const int32_t *rowptr,
+                            const int32_t *pos, int64_t n_seg, uint16_t *out, int out_stride,
+                            hipStream_t stream) {
+    if (!rowptr || n_seg < 0 || !rows_ok(rows, dim, row_stride) || !rows_ok(out, dim, out_stride))
+        return fail(GNNTRK_EINVAL, "segment_sum_bf16: bad argument");
+    if (n_seg == 0) return GNNTRK_OK;
+    const int nch = (dim + 3) / 4;
+    hipLaunchKernelGGL(segment_sum_bf16_kernel, dim3(grid_for_threads(n_seg * nch)), dim3(kTpb16), 0, stream,
+                       rows, dim, row_stride, rowptr, pos, n_seg, out, out_stride);
+    return check_launch("segment_sum_bf16");
+}
+
+int permute_rows_bf16_launch(const uint16_t *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
+                             uint16_t *out, int out_stride, int scatter, hipStream_t stream) {
+    if (!idx || n_rows < 0 || !rows_ok(in, dim, in_stride) || !rows_ok(out, dim, out_stride))
+        return fail(GNNTRK_EINVAL, "permute_rows_bf16: bad argument");
+    if (n_rows == 0) return GNNTRK_OK;
+    const int nch = (dim + 3) / 4;
+    hipLaunchKernelGGL(permute_rows_bf16_kernel, dim3(grid_for_threads(n_rows * nch)), dim3(kTpb16), 0, stream,
+                       in, nch, in_stride, idx, n_rows, out, out_stride, scatter);
+    return check_launch("permute_rows_bf16");
+}
+
+}  // namespace gnntrk

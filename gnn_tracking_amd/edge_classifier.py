@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor, nn
 
-from . import _capi, ops
+from . import _capi, ops, ops_bf16, precision
 from .hparams import HyperparametersMixin, assert_feat_dim
 from .mlp import MLP
 from .resin import ResIN
@@ -80,9 +80,16 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         gi = ops.graph_index(edge_index, x.shape[0])
         E = gi.n_edges
 
-        h = self.ec_node_encoder.fused([ops.Seg(x)], epilogue=_capi.EPI_RELU)
-        e = self.ec_edge_encoder.fused([ops.Seg(edge_attr, gi.perm, False, "perm")],
-                                       n_rows=E, epilogue=_capi.EPI_RELU)
+        if precision.use_bf16():
+            # bf16 storage: the dataset's fp32 features are converted once (edge_attr permuted
+            # into CSR order in the same pass); everything downstream is bf16 rows, W is fp32
+            h = self.ec_node_encoder.fused([ops.Seg(ops_bf16.to_rows16(x))], epilogue=_capi.EPI_RELU)
+            e = self.ec_edge_encoder.fused([ops.Seg(ops_bf16.to_rows16(edge_attr, gi.perm))],
+                                           n_rows=E, epilogue=_capi.EPI_RELU)
+        else:
+            h = self.ec_node_encoder.fused([ops.Seg(x)], epilogue=_capi.EPI_RELU)
+            e = self.ec_edge_encoder.fused([ops.Seg(edge_attr, gi.perm, False, "perm")],
+                                           n_rows=E, epilogue=_capi.EPI_RELU)
         h, e, es = self.ec_resin.forward_csr(gi, h, e)
 
         segs = []

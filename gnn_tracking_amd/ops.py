@@ -258,6 +258,9 @@ class _SegmentSum(torch.autograd.Function):
 def segment_sum(rows: Tensor, gi: GraphIndex, by: str = "tgt") -> Tensor:
     """``out[n] = sum of rows[k] over CSR positions k whose target (source) is n``.
     ``rows`` must be in CSR order.  PyG ``aggr="add"`` (interaction_network.py:36)."""
+    if rows.dtype == torch.bfloat16:
+        from . import ops_bf16
+        return ops_bf16.SegmentSum16.apply(rows, gi, by)
     return _SegmentSum.apply(rows, gi, by)
 
 
@@ -275,6 +278,9 @@ class _PermuteRows(torch.autograd.Function):
 
 def permute_rows(x: Tensor, idx: Tensor, scatter: bool = False) -> Tensor:
     """gather: ``out[m] = x[idx[m]]``; scatter: ``out[idx[m]] = x[m]`` (idx a permutation)."""
+    if x.dtype == torch.bfloat16:
+        from . import ops_bf16
+        return ops_bf16.PermuteRows16.apply(x, idx, scatter)
     return _PermuteRows.apply(x, idx, scatter)
 
 
@@ -503,6 +509,9 @@ def fused_mlp(segs: Sequence[Seg], weights: Sequence[Tensor],
                     [s.idx for s in segs], [s.relu for s in segs], [s.reduce for s in segs],
                     epilogue, float(ca), float(cb), out_idx,
                     int(out_rows if out_rows is not None else n_rows), int(n_rows))
+    if segs[0].t.dtype == torch.bfloat16:  # bf16-storage path (ops_bf16.py)
+        from . import ops_bf16
+        return ops_bf16.FusedMLP16.apply(spec, *[s.t for s in segs], *weights, *biases, res)
     return _FusedMLP.apply(spec, *[s.t for s in segs], *weights, *biases, res)
 
 

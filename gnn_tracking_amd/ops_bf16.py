@@ -148,3 +148,137 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
         _capi.check(lib.gnntrk_mlp_backward_bf16(C.byref(a), ops._p(ws), 0 if ws is None else ws.numel(),
                                                  ops._stream(ref)), lib)
     return slices, gW, gb
+
+
+# ------------------------------------------------------------------ plain helpers
+def segment_sum_raw(rows: Tensor, rowptr: Tensor, pos: Optional[Tensor], n_seg: int) -> Tensor:
+    from . import ops
+    lib = _capi.load()
+    rows = rows16(rows)
+    out = empty_rows(n_seg, rows.shape[1], rows.device)
+    _capi.check(lib.gnntrk_segment_sum_bf16(rows.data_ptr(), rows.shape[1], rows.stride(0), ops._p(rowptr),
+                                            ops._p(pos), n_seg, out.data_ptr(), out.stride(0),
+                                            ops._stream(rows)), lib)
+    return out
+
+
+def permute_raw(x: Tensor, idx: Tensor, scatter: bool) -> Tensor:
+    from . import ops
+    lib = _capi.load()
+    x2 = rows16(x)
+    m = int(idx.shape[0])
+    if scatter and m != x2.shape[0]:
+        raise ValueError("permute_rows(scatter): idx must be a permutation of the rows")
+    out = empty_rows(m, x2.shape[1], x2.device)
+    _capi.check(lib.gnntrk_permute_rows_bf16(x2.data_ptr(), x2.shape[1], x2.stride(0), ops._p(idx), m,
+                                             out.data_ptr(), out.stride(0), int(scatter),
+                                             ops._stream(x2)), lib)
+    return out.view(-1) if x.dim() == 1 else out
+
+
+class SegmentSum16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, gi, by: str):
+        _capi.require_device(rows)
+        ctx.gi, ctx.by = gi, by
+        if by == "tgt":
+            return segment_sum_raw(rows, gi.rowptr_t, None, gi.n_nodes)
+        if by == "src":
+            return segment_sum_raw(rows, gi.rowptr_s, gi.spos, gi.n_nodes)
+        raise ValueError(by)
+
+    @staticmethod
+    def backward(ctx, g):
+        gi = ctx.gi
+        return permute_raw(g, gi.tgt if ctx.by == "tgt" else gi.src, scatter=False), None, None
+
+
+class PermuteRows16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, scatter: bool):
+        _capi.require_device(x)
+        ctx.idx, ctx.scatter = idx, scatter
+        return permute_raw(x, idx, scatter)
+
+    @staticmethod
+    def backward(ctx, g):
+        return permute_raw(g, ctx.idx, not ctx.scatter), None, None
+
+
+# ------------------------------------------------------------------ fused MLP (autograd)
+class FusedMLP16(torch.autograd.Function):
+    """bf16-storage twin of ops._FusedMLP (same spec object, same reduce rules)."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        from . import ops
+        ns, nl = spec.n_seg, spec.n_layers
+        segs = [rows16(t) for t in tensors[:ns]]
+        weights = [w.contiguous() for w in tensors[ns:ns + nl]]
+        biases = [None if b is None else b.contiguous() for b in tensors[ns + nl:ns + 2 * nl]]
+        res = tensors[ns + 2 * nl]
+        _capi.require_device(*segs, *weights)
+        mlp = ops._fill_mlp(weights, biases)
+        if sum(s.shape[1] for s in segs) != mlp.in_dim:
+            raise AssertionError(
+                f"Expected feature dimension {mlp.in_dim}, got {sum(s.shape[1] for s in segs)}")
+        if spec.epilogue == _capi.EPI_RESIDUAL:
+            res = rows16(res)
+        out = mlp_forward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=spec.n_rows,
+                              epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb, res=res,
+                              out_idx=spec.out_idx, out_rows=spec.out_rows, mlp=mlp)
+        ctx.spec = spec
+        ctx.save_for_backward(*segs, *weights, *[b for b in biases if b is not None])
+        ctx.bias_mask = [b is not None for b in biases]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        from . import ops
+        spec = ctx.spec
+        ns, nl = spec.n_seg, spec.n_layers
+        saved = ctx.saved_tensors
+        segs, weights = list(saved[:ns]), list(saved[ns:ns + nl])
+        bl = list(saved[ns + nl:])
+        biases = [bl.pop(0) if m else None for m in ctx.bias_mask]
+        mlp = ops._fill_mlp(weights, biases)
+        if spec.epilogue == _capi.EPI_SIGMOID:
+            g_rows = ops._as_rows(g_out.float().contiguous())
+        else:
+            g_rows = rows16(g_out)
+        need = ctx.needs_input_grad  # [spec, segs..., W..., b..., res]
+        M = spec.n_rows
+        need_seg = [bool(need[1 + j]) for j in range(ns)]
+        for j in range(ns):
+            if need_seg[j] and spec.idx[j] is not None and spec.reduce[j] is None:
+                raise RuntimeError("gathered segment requires a `reduce` rule for backward")
+        want_dw = any(need[1 + ns:1 + ns + 2 * nl])
+        slices, gW, gb = mlp_backward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=M,
+                                          epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb,
+                                          gout=[(g_rows, spec.out_idx)], need_seg=need_seg,
+                                          want_dw=want_dw, mlp=mlp)
+        seg_grads = [None] * ns
+        for j, s in enumerate(segs):
+            if slices[j] is None:
+                continue
+            if spec.idx[j] is None:
+                if s.shape[0] != M:
+                    raise RuntimeError("identity segments must have n_rows rows")
+                seg_grads[j] = slices[j]
+            elif spec.reduce[j] == "perm":
+                if s.shape[0] != M:
+                    raise RuntimeError("'perm' segments must cover all source rows")
+                seg_grads[j] = permute_raw(slices[j], spec.idx[j], scatter=True)
+            else:
+                by, gi = spec.reduce[j]
+                rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
+                seg_grads[j] = segment_sum_raw(slices[j], rowptr, pos, s.shape[0])
+        g_res = None
+        if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
+            g_dense = g_rows if spec.out_idx is None else permute_raw(g_rows, spec.out_idx, False)
+            g_res = g_dense * spec.ca
+        outs = [None, *seg_grads]
+        outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
+        outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
+        outs.append(g_res)
+        return tuple(outs)

@@ -463,3 +463,35 @@ def mlp_bf16_backward(x: Tensor, weights, biases, g: Tensor, epilogue: str, ca=0
             gprev = gprev * (acts[i] > 0)
         gk = gprev
     return gk, dW, db
+
+
+def ec_for_graph_tcn_bf16(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *,
+                          L_ec: int = 3, alpha: float = 0.5) -> dict:
+    """``ec_for_graph_tcn`` (skip1, all embeddings fed to W) with the bf16-storage rounding
+    points of gnn_tracking_amd (edge_classifier.py bf16 branch): inputs, every stored
+    node/edge tensor and every hidden activation are bf16; sums are fp32."""
+    def run(prefix, L, xin, bias=True):
+        W = [p[f"{prefix}.layers.{2 * l}.weight"] for l in range(L)]
+        b = [p[f"{prefix}.layers.{2 * l}.bias"] if bias else None for l in range(L)]
+        return mlp_bf16_forward(xin, W, b)[0]
+
+    relu = lambda t: torch.clamp_min(t, 0.0)  # noqa: E731
+    src, tgt = edge_index[0], edge_index[1]
+    h = bf16_round(relu(run("ec_node_encoder", 2, bf16_round(x), bias=False)))
+    e = bf16_round(relu(run("ec_edge_encoder", 2, bf16_round(edge_attr), bias=False)))
+    es = [e]
+    ca, cb = math.sqrt(alpha), math.sqrt(1 - alpha)
+    for i in range(L_ec):
+        act = relu if i > 0 else (lambda t: t)
+        xi, ei = act(h), act(e)
+        pre = f"ec_resin.network.layers.{i}"
+        et = bf16_round(run(f"{pre}.relational_model", 3, torch.cat([xi[tgt], xi[src], ei], 1)))
+        aggr = bf16_round(torch.zeros(h.shape[0], et.shape[1]).index_add(0, tgt, et))
+        z = run(f"{pre}.object_model", 3, torch.cat([xi, aggr], 1))
+        h = bf16_round(z) if math.isclose(alpha, 0.0) else bf16_round(ca * h + cb * z)
+        e = et
+        es.append(e)
+    w_in = torch.cat([h[src], h[tgt], torch.cat(es, 1)], 1)
+    eps = 0.001
+    w = eps + (1 - 2 * eps) * torch.sigmoid(run("W", 3, w_in))
+    return {"W": w.squeeze(), "node_embedding": h, "edge_embedding": e}

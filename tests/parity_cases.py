@@ -506,3 +506,37 @@ def case_mlp_bf16_backward(device, rows=75, full=True):
             assert_close(gW[i], dW[i], TOL16, f"{tag} gW{i}")
             if bias:
                 assert_close(gb[i], db[i], TOL16, f"{tag} gb{i}")
+
+
+def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):
+    """ECForGraphTCN in bf16-storage mode on the golden inputs of g2: forward against the
+    bf16 restatement (oracle/ref_cpu.py:ec_for_graph_tcn_bf16, same rounding points) and
+    against the reference-pinned fp32 goldens with a bf16-sized tolerance; loss and
+    parameter gradients against the fp32 goldens (bf16 noise bound)."""
+    z = load("g2_ec_variants.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y, pt = tt(z["y"], device), tt(z["pt"], device)
+    for name in names:
+        kw = EC_VARIANTS[name]
+        model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **kw)
+        p = load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        with G.bf16_storage():
+            out = model(G.Data(x=x, edge_index=ei, edge_attr=ea))
+            loss = G.EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"], y=y.float(), pt=pt, edge_index=ei)
+            loss.backward()
+        assert out["W"].dtype == torch.float32 and out["node_embedding"].dtype == torch.bfloat16
+        ref = O.ec_for_graph_tcn_bf16(x.cpu(), ei.cpu(), ea.cpu(), p, L_ec=kw["L_ec"],
+                                      alpha=kw.get("alpha", 0.5))
+        # same rounding points: differences come from rare 1-ulp flips propagating
+        assert_close(out["W"], ref["W"], 4 * TOL16, name + " W vs bf16 oracle")
+        assert_close(out["node_embedding"].float(), ref["node_embedding"], 4 * TOL16, name + " node")
+        assert_close(out["edge_embedding"].float(), ref["edge_embedding"], 4 * TOL16, name + " edge")
+        # distance to the reference-pinned fp32 results
+        assert_close(out["W"], z[f"{name}/W"], 0.03, name + " W vs fp32 golden")
+        assert_close(loss, z[f"{name}/loss"], 0.01, name + " loss vs fp32 golden")
+        for k, v in model.named_parameters():
+            assert v.grad is not None and v.grad.dtype == torch.float32
+            gref = tt(z[f"{name}/grad/{k}"]).double()
+            err = (v.grad.detach().cpu().double() - gref).norm() / max(gref.norm().item(), 1e-6)
+            assert err < 0.1, f"{name} grad {k}: relative L2 error {err:.3f} vs fp32 golden"

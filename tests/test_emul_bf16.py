@@ -18,3 +18,8 @@ def test_mlp_bf16_forward_emulated():
 def test_mlp_bf16_backward_emulated():
     with emulated():
         P.case_mlp_bf16_backward("cpu", rows=37, full=False)
+
+
+def test_ec_bf16_emulated():
+    with emulated():
+        P.case_ec_bf16("cpu", names=("alpha0",))

@@ -1,778 +1,13 @@
-// Fused gather-concat-MLP kernels, bf16 storage / bf16 MFMA inputs / fp32 accumulate
-// (BASELINE configs 3 and 4).  Same operator as mlp.hip - reference models/mlp.py:18-62
-// applied to the concatenation the reference materialises with index_select + cat
-// (interaction_network.py:75-103, edge_classifier.py:103-116) - with every activation
-// tensor stored as bf16 and the contractions on v_mfma_f32_16x16x{32,16}_bf16.
-// Parameters, parameter gradients and the EPI_SIGMOID output stay fp32.
-//
-// Rounding points (what oracle/ref_cpu.py:mlp_bf16 restates): inputs are bf16 as stored;
-// weights and biases are rounded to bf16 (RNE) when the fragments are packed; every layer
-// accumulates in fp32; hidden activations are rounded to bf16 after the ReLU (the same
-// value as rounding before it); the output is rounded to bf16 after the epilogue.
-//
-// No LDS in the forward tile loop: a lane loads its own B-operand chunks straight from
-// HBM/L2 (8 bytes per chunk), the layer chain runs register to register (tile_bf16.h), the
-// weights are read-only LDS fragments.  Latency is covered by a one-tile software prefetch
-// plus the 4-6 waves per SIMD the small register footprint allows.
-#include <hip/hip_runtime.h>
-
-#include "host_util.h"
-#include "tile_bf16.h"
+// Launchers of the bf16-storage fused MLP kernels (mlp_bf16_kernels.h).  The backward
+// instantiations with an fp32 upstream gradient (EPI_SIGMOID: the edge-weight head) are
+// compiled in mlp_bf16_g32.hip so the two halves build in parallel.
+#include "mlp_bf16_kernels.h"
 
 namespace gnntrk {
-namespace {
 
-constexpr uint32_t kBf16One = 0x3f80u;
-constexpr int kFwdDepth = 4;  // tiles per wave and pipeline stage (forward)
-constexpr int kBwdDepth = 1;  // (backward: the dW accumulators take the registers)
+int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, int KI, int HT, int GT, int grid, float *part,
+                     uint8_t *trash, hipStream_t stream);  // mlp_bf16_g32.hip
 
-// floats of one partial block = all parameters in order W1, b1, [W2, b2,] W3, b3 (the layout
-// of part_layout() in mlp.hip: bias slots exist whether or not the layer has a bias)
-__host__ __device__ inline int part_total(const gnntrk_mlp &m) {
-    int n = m.hidden * m.in_dim + m.hidden + m.out_dim * m.hidden + m.out_dim;
-    if (m.n_layers == 3) n += m.hidden * m.hidden + m.hidden;
-    return n;
-}
-
-__device__ __forceinline__ void stage_seg_args(gnntrk_seg *dst, const gnntrk_seg (&seg)[GNNTRK_MAX_SEGS],
-                                               int tid) {
-#pragma unroll
-    for (int j = 0; j < GNNTRK_MAX_SEGS; ++j)
-        if (tid == j) dst[j] = seg[j];
-}
-
-// per-lane description of the chunks this lane loads: lane (g, c) owns chunks 8kk + 2g + h
-template <int KI>
-struct LaneChunks {
-    gch_ptr base[KI][2];
-    gci_ptr idx[KI][2];
-    int32_t stride[KI][2];
-    uint32_t keep[KI][2][2], ones[KI][2][2], rmin[KI][2];
-    bool on[KI][2];
-
-    __device__ __forceinline__ void init(const SlotPlan &P, const gnntrk_seg *seg, int g) {
-#pragma unroll
-        for (int kk = 0; kk < KI; ++kk)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int p = 8 * kk + 2 * g + h;
-                const int j = (p < P.n_chunks) ? P.seg[p] : -1;
-                on[kk][h] = j >= 0;
-                int d = 0;
-                base[kk][h] = nullptr;
-                idx[kk][h] = nullptr;
-                stride[kk][h] = 0;
-                rmin[kk][h] = 0x80008000u;
-                if (j >= 0) {
-                    d = seg[j].dim - 4 * P.first[p];
-                    d = d > 4 ? 4 : d;
-                    base[kk][h] = (gch_ptr)(reinterpret_cast<const uint16_t *>(seg[j].ptr) + 4 * P.first[p]);
-                    idx[kk][h] = (gci_ptr)seg[j].idx;
-                    stride[kk][h] = seg[j].stride;
-                    if (seg[j].relu) rmin[kk][h] = 0u;
-                }
-                keep[kk][h][0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
-                keep[kk][h][1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
-                ones[kk][h][0] = ones[kk][h][1] = 0u;
-                if (P.ones_slot >= 0 && (P.ones_slot >> 2) == p) {
-                    const int r = P.ones_slot & 3;
-                    ones[kk][h][0] = r < 2 ? kBf16One << (16 * (r & 1)) : 0u;
-                    ones[kk][h][1] = r >= 2 ? kBf16One << (16 * (r & 1)) : 0u;
-                }
-            }
-    }
-};
-
-template <int KI>
-struct RowIds {
-    int32_t v[KI][2];
-};
-template <int KI>
-struct RawTile {
-    u32x2 v[KI][2];
-};
-
-template <int KI>
-__device__ __forceinline__ void load_row_ids(const LaneChunks<KI> &L, int32_t row, RowIds<KI> &r) {
-#pragma unroll
-    for (int kk = 0; kk < KI; ++kk)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) r.v[kk][h] = L.idx[kk][h] ? L.idx[kk][h][row] : row;
-}
-template <int KI>
-__device__ __forceinline__ void load_raw(const LaneChunks<KI> &L, const RowIds<KI> &r, RawTile<KI> &t) {
-#pragma unroll
-    for (int kk = 0; kk < KI; ++kk)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            u32x2 v = {0u, 0u};
-            if (L.on[kk][h])
-                v = *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(
-                    L.base[kk][h] + (int64_t)r.v[kk][h] * L.stride[kk][h]);
-            t.v[kk][h] = v;
-        }
-}
-// pads -> 0, ones slot -> 1.0, optional ReLU: the B operand of layer 1
-template <int KI>
-__device__ __forceinline__ void finish_inputs(const LaneChunks<KI> &L, const RawTile<KI> &t,
-                                              u32x4 (&B)[KI]) {
-#pragma unroll
-    for (int kk = 0; kk < KI; ++kk) {
-        u32x2 h2[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int w = 0; w < 2; ++w)
-                h2[h][w] = i16x2_max((t.v[kk][h][w] & L.keep[kk][h][w]) | L.ones[kk][h][w], L.rmin[kk][h]);
-        B[kk] = join(h2[0], h2[1]);
-    }
-}
-
-// ---- weight fragment images -----------------------------------------------------------
-// forward:  A1 [HT][KI] K32 | A2 [HT] x hid_k | A3 [1] x hid_k          (dwords)
-template <int KI, int HT>
-struct FwdImg {
-    static constexpr int kA1 = 0;
-    static constexpr int kA2 = kA1 + HT * KI * 256;
-    static constexpr int kA3 = kA2 + HT * hid_k_dwords(HT);
-    static constexpr int kTotal = kA3 + hid_k_dwords(HT);
-};
-
-// image of `rows x hidden-k` fragments: element(o, f) for fragment row o (absolute) and
-// hidden feature f
-template <int HT, class F>
-__device__ __forceinline__ void pack_hidden_k(uint32_t *dst, int row0, F element, int tid, int nthreads) {
-#pragma unroll
-    for (int u = 0; u < HT / 2; ++u)
-        pack_frag_k32(dst + 256 * u,
-                      [&](int i, int g, int e) { return element(row0 + i, hid_feat_k32(u, g, e)); }, tid,
-                      nthreads);
-    if (HT % 2)  // odd last tile: K = 32 fragment with a zero upper half (see contract_hidden)
-        pack_frag_k32(dst + 256 * (HT / 2),
-                      [&](int i, int g, int e) {
-                          return e < 4 ? element(row0 + i, hid_feat_k16(HT - 1, g, e)) : 0.f;
-                      },
-                      tid, nthreads);
-}
-
-template <int KI, int HT, bool THREE>
-__device__ __forceinline__ void pack_forward_weights(uint32_t *img, const AugWeights &w, const SlotPlan &P,
-                                                     const gnntrk_seg *seg, int tid, int nthreads) {
-    using I = FwdImg<KI, HT>;
-    for (int t = 0; t < HT; ++t)
-        for (int kk = 0; kk < KI; ++kk)
-            pack_frag_k32(img + I::kA1 + (t * KI + kk) * 256,
-                          [&](int i, int g, int e) {
-                              return w.w1(16 * t + i, slot_col(P, seg, 32 * kk + 8 * g + e));
-                          },
-                          tid, nthreads);
-    if (THREE)
-        for (int t = 0; t < HT; ++t)
-            pack_hidden_k<HT>(img + I::kA2 + t * hid_k_dwords(HT), 16 * t,
-                              [&](int o, int f) { return w.wmid(o, f); }, tid, nthreads);
-    pack_hidden_k<HT>(img + I::kA3, 0, [&](int o, int f) { return w.wlast(o, f); }, tid, nthreads);
-}
-
-// layers 1..(last-1): inputs B -> packed hidden activations feeding the last layer
-template <int KI, int HT, bool THREE>
-__device__ __forceinline__ void hidden_chain(const uint32_t *img, const u32x4 (&B)[KI], int lane,
-                                             u32x2 (&P1)[HT], u32x2 (&P2)[HT]) {
-    using I = FwdImg<KI, HT>;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < HT; ++t) {
-        f32x4 acc = zero;
-#pragma unroll
-        for (int kk = 0; kk < KI; ++kk)
-            acc = mfma_bf16_k32(frag_k32(img + I::kA1 + (t * KI + kk) * 256, lane), B[kk], acc);
-        P1[t] = pack_tile_relu(acc);
-    }
-    if (THREE) {
-#pragma unroll
-        for (int t = 0; t < HT; ++t)
-            P2[t] = pack_tile_relu(contract_hidden<HT>(img + I::kA2 + t * hid_k_dwords(HT), P1, lane, zero));
-    }
-}
-
-template <int KI, int HT, bool THREE>
-__global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
-    using I = FwdImg<KI, HT>;
-    __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal];
-    __shared__ SlotPlan s_plan;
-    __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];  // kernel arguments cannot be indexed dynamically
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
-    stage_seg_args(s_seg, a.seg, tid);
-    __syncthreads();
-    if (tid == 0) make_slot_plan(s_plan, a.mlp, a.n_seg, s_seg, nullptr);
-    __syncthreads();
-    {
-        const AugWeights w = make_aug(a.mlp, s_plan);
-        pack_forward_weights<KI, HT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
-    }
-    LaneChunks<KI> L;
-    L.init(s_plan, s_seg, g);
-    __syncthreads();
-
-    const int out_dim = a.mlp.out_dim;
-    const bool out_lane = 4 * g < out_dim;  // this lane holds real output features
-    const gci_ptr out_idx = (gci_ptr)a.out_idx;
-    const int epi = a.epilogue;
-    const gch_ptr resp = (gch_ptr) reinterpret_cast<const uint16_t *>(a.res);
-    uint32_t okeep[2];
-    {
-        const int d = out_dim - 4 * g;
-        okeep[0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
-        okeep[1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
-    }
-
-    const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
-    const TileSched sch = make_sched(n_tiles);
-    if (sch.cur >= sch.end) return;
-    const int32_t last_row = (int32_t)(a.n_rows - 1);
-    auto clamp_row = [&](int64_t t) {
-        const int64_t r = t * kTileRows + c;
-        return (int32_t)(r < last_row ? r : last_row);
-    };
-
-    // Software pipeline over groups of kDepth tiles: the raw chunks of group n+1 and the row
-    // ids of group n+2 are in flight while group n computes - 16 * kDepth rows of loads per
-    // wave cover the gather latency (one tile per wave in flight left the kernel latency
-    // bound at 1/3 of the rate).  Tiles past the end of the schedule load clamped rows and
-    // are not computed.
-    constexpr int D = kFwdDepth;
-    RowIds<KI> rid[D];
-    RawTile<KI> cur[D], nxt[D];
-    int32_t orow_c[D], orow_n[D], orow_nn[D];
-    auto tile_of = [&](int64_t grp, int d) { return sch.cur + (grp * D + d) * sch.step; };
-    auto ids_of = [&](int64_t grp, int d, RowIds<KI> &r, int32_t &orow) {
-        const int32_t row = clamp_row(tile_of(grp, d));
-        load_row_ids<KI>(L, row, r);
-        orow = row;
-        if (out_lane && out_idx) orow = out_idx[row];
-    };
-#pragma unroll
-    for (int d = 0; d < D; ++d) ids_of(0, d, rid[d], orow_c[d]);
-#pragma unroll
-    for (int d = 0; d < D; ++d) load_raw<KI>(L, rid[d], cur[d]);
-#pragma unroll
-    for (int d = 0; d < D; ++d) ids_of(1, d, rid[d], orow_n[d]);
-
-    for (int64_t grp = 0; tile_of(grp, 0) < sch.end; ++grp) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) load_raw<KI>(L, rid[d], nxt[d]);
-#pragma unroll
-        for (int d = 0; d < D; ++d) ids_of(grp + 2, d, rid[d], orow_nn[d]);
-
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int64_t tile = tile_of(grp, d);
-            if (tile >= sch.end) break;
-            u32x4 B[KI];
-            finish_inputs<KI>(L, cur[d], B);
-            u32x2 P1[HT], P2[HT];
-            hidden_chain<KI, HT, THREE>(s_img, B, lane, P1, P2);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            f32x4 y = contract_hidden<HT>(s_img + I::kA3, THREE ? P2 : P1, lane, zero);
-
-            const int64_t row = tile * kTileRows + c;
-            if (out_lane && row < a.n_rows && !(a.debug_flags & 1)) {
-                if (epi == GNNTRK_EPI_SIGMOID) {
-                    float *outp = a.out + (int64_t)orow_c[d] * a.out_stride + 4 * g;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * g + r < out_dim) outp[r] = a.ca + a.cb * sigmoidf_(y[r]);
-                } else {
-                    if (epi == GNNTRK_EPI_RESIDUAL) {
-                        const u32x2 rv =
-                            *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(resp + row * a.res_stride + 4 * g);
-                        y[0] = a.ca * bf16_lo(rv[0]) + a.cb * y[0];
-                        y[1] = a.ca * bf16_hi(rv[0]) + a.cb * y[1];
-                        y[2] = a.ca * bf16_lo(rv[1]) + a.cb * y[2];
-                        y[3] = a.ca * bf16_hi(rv[1]) + a.cb * y[3];
-                    }
-                    u32x2 o = (epi == GNNTRK_EPI_RELU) ? pack_tile_relu(y) : pack_tile(y);
-                    o[0] &= okeep[0];
-                    o[1] &= okeep[1];
-                    uint16_t *outp =
-                        reinterpret_cast<uint16_t *>(a.out) + (int64_t)orow_c[d] * a.out_stride + 4 * g;
-                    *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>((gh_ptr)outp) = o;
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            cur[d] = nxt[d];
-            orow_c[d] = orow_n[d];
-            orow_n[d] = orow_nn[d];
-        }
-    }
-}
-
-// =========================================================================== backward
-// Full recompute (only the op inputs are saved), one wave per 16-row tile:
-//   S0  inputs -> B operand (as forward); recompute h1 (, h2) and, for the RELU / SIGMOID
-//       epilogues, the pre-activation output
-//   S1  upstream gradient: sum of the gout terms, epilogue derivative, rounded to bf16
-//   S2  dX chain on W^T fragments:  g_hidden = relu'(h) * (W^T g)  ->  input gradients,
-//       written per chunk (8 bytes per lane) to the row-aligned gradient slices
-//   S3  weight gradients: dW[o][i] += sum_rows g[row][o] * act[row][i] - a K = rows
-//       contraction; both operands go through a per-wave LDS image [row][feature] and come
-//       back transposed with ds_read_b64_tr_b16.  Accumulators stay in registers for the
-//       whole launch (fp32), are written once per wave as a partial block in parameter
-//       layout and reduced in a fixed order (reduce_partials in mlp.hip): bit-reproducible.
-// The bias gradients are the `ones` columns of the augmented dW tiles.
-template <int KI, int HT, int GT, bool THREE>
-struct BwdImg {
-    using F = FwdImg<KI, HT>;
-    static constexpr int kD3 = F::kTotal;                       // W_last'^T : [HT] x K16
-    static constexpr int kD2 = kD3 + HT * 128;                  // W_mid'^T  : [HT] x hid_k
-    static constexpr int kD1 = kD2 + (THREE ? HT * hid_k_dwords(HT) : 0);  // W1'^T : [GT] x hid_k
-    static constexpr int kTotal = kD1 + GT * hid_k_dwords(HT);
-};
-
-// per-wave staging images (bytes): X = activations (in / h1 / h2), Gs = gradients
-template <int KI, int HT>
-struct BwdStage {
-    static constexpr int kInRow = 64 * KI;  // bytes per row of the input image [row][32 KI slots]
-    static constexpr int kIn = 16 * kInRow;  // inputs: written in S0, read by the first-layer stage
-    static constexpr int kX = HT * 512;      // h2 / h1
-    static constexpr int kG = HT * 512;      // g_out / g_h2 / g_h1
-    static constexpr int kWave = kIn + kX + kG;
-};
-
-template <int KI, int HT, int GT, bool THREE>
-__device__ __forceinline__ void pack_backward_weights(uint32_t *img, const AugWeights &w, const SlotPlan &P,
-                                                      const gnntrk_seg *seg, int tid, int nthreads) {
-    using I = BwdImg<KI, HT, GT, THREE>;
-    for (int t = 0; t < HT; ++t)  // g_hidden_pre[f = 16t + i] = sum_o W_last'[o][f] g_out[o],  k = o = 4g + e
-        pack_frag_k16(img + I::kD3 + t * 128, [&](int i, int g, int e) { return w.wlast(4 * g + e, 16 * t + i); },
-                      tid, nthreads);
-    if (THREE)
-        for (int t = 0; t < HT; ++t)
-            pack_hidden_k<HT>(img + I::kD2 + t * hid_k_dwords(HT), 16 * t,
-                              [&](int f1, int f2) { return w.wmid(f2, f1); }, tid, nthreads);
-    for (int T = 0; T < GT; ++T)
-        pack_hidden_k<HT>(img + I::kD1 + T * hid_k_dwords(HT), 16 * T,
-                          [&](int m, int f) {
-                              const int q = m >> 2;
-                              if (q >= P.n_gchunks) return 0.f;
-                              return w.w1(f, slot_col(P, seg, 4 * P.gchunk[q] + (m & 3)));
-                          },
-                          tid, nthreads);
-}
-
-// upstream gradient terms of one tile, raw (bf16: two terms x 4 features; fp32: 4 floats)
-struct RawGout {
-    u32x4 v;
-};
-
-template <int KI, int HT, int GT, bool THREE>
-__global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part) {
-    using I = BwdImg<KI, HT, GT, THREE>;
-    using F = FwdImg<KI, HT>;
-    using S = BwdStage<KI, HT>;
-    __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves * S::kWave];
-    __shared__ SlotPlan s_plan;
-    __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];
-    __shared__ gnntrk_gseg s_gseg[GNNTRK_MAX_SEGS];
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15, wv = tid >> 6;
-    stage_seg_args(s_seg, a.seg, tid);
-#pragma unroll
-    for (int j = 0; j < GNNTRK_MAX_SEGS; ++j)
-        if (tid == 32 + j) s_gseg[j] = a.gseg[j];
-    __syncthreads();
-    if (tid == 0) make_slot_plan(s_plan, a.mlp, a.n_seg, s_seg, s_gseg);
-    __syncthreads();
-    {
-        const AugWeights w = make_aug(a.mlp, s_plan);
-        pack_forward_weights<KI, HT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
-        pack_backward_weights<KI, HT, GT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
-    }
-    LaneChunks<KI> L;
-    L.init(s_plan, s_seg, g);
-
-    // gradient chunk handled by this lane in dX tile T: q = 4T + g
-    gh_ptr gptr[GT];
-    int32_t gstride[GT], gin_off[GT];
-    uint32_t gkeep[GT][2];
-    bool gon[GT], grelu[GT];
-#pragma unroll
-    for (int T = 0; T < GT; ++T) {
-        const int q = 4 * T + g;
-        gon[T] = q < s_plan.n_gchunks;
-        gptr[T] = nullptr;
-        gstride[T] = 0;
-        gin_off[T] = 0;
-        grelu[T] = false;
-        int d = 0;
-        if (gon[T]) {
-            const int p = s_plan.gchunk[q], j = s_plan.seg[p];
-            d = s_seg[j].dim - 4 * s_plan.first[p];
-            d = d > 4 ? 4 : d;
-            gptr[T] = (gh_ptr)(reinterpret_cast<uint16_t *>(s_gseg[j].ptr) + 4 * s_plan.first[p]);
-            gstride[T] = s_gseg[j].stride;
-            gin_off[T] = 8 * p;  // byte offset of the chunk inside a row of the input image
-            grelu[T] = s_seg[j].relu != 0;
-        }
-        gkeep[T][0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
-        gkeep[T][1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
-    }
-    // W1 column of the input slot 16 ts + c (partials of dW1')
-    int32_t col1[2 * KI];
-#pragma unroll
-    for (int ts = 0; ts < 2 * KI; ++ts) col1[ts] = slot_col(s_plan, s_seg, 16 * ts + c);
-    const int hid_ones = s_plan.hid_ones;
-    __syncthreads();
-
-    const int out_dim = a.mlp.out_dim, hidden = a.mlp.hidden, in_dim = a.mlp.in_dim;
-    const bool out_lane = 4 * g < out_dim;
-    const int epi = a.epilogue;
-    const bool need_y = epi == GNNTRK_EPI_RELU || epi == GNNTRK_EPI_SIGMOID;
-    const bool g_f32 = epi == GNNTRK_EPI_SIGMOID;  // fp32 upstream gradient (edge weights)
-    const bool want_dw = a.gW[0] != nullptr;
-    uint32_t okeep[2];
-    {
-        const int d = out_dim - 4 * g;
-        okeep[0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
-        okeep[1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
-    }
-    const gci_ptr go_idx0 = (gci_ptr)a.gout[0].idx, go_idx1 = (gci_ptr)a.gout[1].idx;
-    const bool two_terms = a.n_gout > 1;
-
-    uint8_t *stIn = s_stage + wv * S::kWave, *stX = stIn + S::kIn, *stG = stX + S::kX;
-    // byte offsets inside the staging images
-    const int wr_tile = c * 32 + g * 8;                             // write [row c][4g..4g+3]
-    const int rd_tile = (4 * g + (c >> 2)) * 32 + (c & 3) * 8;      // transpose read, 16-feature tile
-    const int wr_in = c * S::kInRow + g * 16;                       // write [row c][8g..8g+7] (+64 kk)
-    const int rd_in = (4 * g + (c >> 2)) * S::kInRow + (c & 3) * 8; // (+32 ts)
-
-    f32x4 dW1[HT][2 * KI], dW2[THREE ? HT : 1][HT], dW3[HT];
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < HT; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2 * KI; ++j) dW1[i][j] = zero;
-        dW3[i] = zero;
-    }
-#pragma unroll
-    for (int i = 0; i < (THREE ? HT : 1); ++i)
-#pragma unroll
-        for (int j = 0; j < HT; ++j) dW2[i][j] = zero;
-
-    const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
-    const TileSched sch = make_sched(n_tiles);
-    const int32_t last_row = (int32_t)(a.n_rows - 1);
-    auto clamp_row = [&](int64_t t) {
-        const int64_t r = t * kTileRows + c;
-        return (int32_t)(r < last_row ? r : last_row);
-    };
-
-    constexpr int D = kBwdDepth;
-    RowIds<KI> rid[D];
-    int32_t grow[D][2];
-    RawTile<KI> cur[D], nxt[D];
-    RawGout gcur[D], gnxt[D];
-    auto tile_of = [&](int64_t grp, int d) { return sch.cur + (grp * D + d) * sch.step; };
-    auto ids_of = [&](int64_t grp, int d) {
-        const int32_t row = clamp_row(tile_of(grp, d));
-        load_row_ids<KI>(L, row, rid[d]);
-        grow[d][0] = grow[d][1] = row;
-        if (out_lane) {
-            if (go_idx0) grow[d][0] = go_idx0[row];
-            if (two_terms && go_idx1) grow[d][1] = go_idx1[row];
-        }
-    };
-    auto load_gout = [&](int d, RawGout &r) {
-        r.v = u32x4{0u, 0u, 0u, 0u};
-        if (!out_lane) return;
-        if (g_f32) {
-            const float GNNTRK_GLOBAL *p = (gcf_ptr)a.gout[0].ptr + (int64_t)grow[d][0] * a.gout[0].stride + 4 * g;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-                if (4 * g + r4 < out_dim) r.v[r4] = __float_as_uint(p[r4]);
-        } else {
-            const u32x2 t0 = *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(
-                (gch_ptr) reinterpret_cast<const uint16_t *>(a.gout[0].ptr) +
-                (int64_t)grow[d][0] * a.gout[0].stride + 4 * g);
-            r.v[0] = t0[0];
-            r.v[1] = t0[1];
-            if (two_terms) {
-                const u32x2 t1 = *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(
-                    (gch_ptr) reinterpret_cast<const uint16_t *>(a.gout[1].ptr) +
-                    (int64_t)grow[d][1] * a.gout[1].stride + 4 * g);
-                r.v[2] = t1[0];
-                r.v[3] = t1[1];
-            }
-        }
-    };
-
-    if (sch.cur < sch.end) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) ids_of(0, d);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            load_raw<KI>(L, rid[d], cur[d]);
-            load_gout(d, gcur[d]);
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) ids_of(1, d);
-    }
-
-    for (int64_t grp = 0; tile_of(grp, 0) < sch.end; ++grp) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            load_raw<KI>(L, rid[d], nxt[d]);
-            load_gout(d, gnxt[d]);
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) ids_of(grp + 2, d);
-
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int64_t tile = tile_of(grp, d);
-            if (tile >= sch.end) break;
-            const int64_t row = tile * kTileRows + c;
-            const bool valid = row < a.n_rows;
-
-            // ---- S0: recompute ------------------------------------------------------
-            const uint32_t *wimg = s_img + opaque_zero();
-            u32x4 B[KI];
-            finish_inputs<KI>(L, cur[d], B);
-            u32x2 P1[HT], P2[HT];
-            hidden_chain<KI, HT, THREE>(wimg, B, lane, P1, P2);
-            const u32x2(&PL)[HT] = THREE ? P2 : P1;  // input of the last layer
-#pragma unroll
-            for (int kk = 0; kk < KI; ++kk) *reinterpret_cast<u32x4 *>(stIn + wr_in + 64 * kk) = B[kk];
-
-            // ---- S1: upstream gradient ---------------------------------------------
-            f32x4 gy = zero;
-            if (out_lane && valid) {
-                if (g_f32) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gy[r] = __uint_as_float(gcur[d].v[r]);
-                } else {
-                    gy[0] = bf16_lo(gcur[d].v[0]) + bf16_lo(gcur[d].v[2]);
-                    gy[1] = bf16_hi(gcur[d].v[0]) + bf16_hi(gcur[d].v[2]);
-                    gy[2] = bf16_lo(gcur[d].v[1]) + bf16_lo(gcur[d].v[3]);
-                    gy[3] = bf16_hi(gcur[d].v[1]) + bf16_hi(gcur[d].v[3]);
-                }
-            }
-            if (need_y) {
-                const f32x4 y = contract_hidden<HT>(wimg + F::kA3, PL, lane, zero);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (epi == GNNTRK_EPI_RELU) {
-                        gy[r] = y[r] > 0.f ? gy[r] : 0.f;
-                    } else {
-                        const float sg = sigmoidf_(y[r]);
-                        gy[r] = gy[r] * a.cb * sg * (1.f - sg);
-                    }
-                }
-            } else if (epi == GNNTRK_EPI_RESIDUAL) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gy[r] *= a.cb;
-            }
-            u32x2 g3 = pack_tile(gy);
-            g3[0] &= okeep[0];
-            g3[1] &= okeep[1];
-
-            // ---- S2 / S3 interleaved: every dW stage reuses the two staging images ------
-            // last layer
-            u32x2 gh[HT];  // gradient at the input of the last layer (hidden, after relu')
-#pragma unroll
-            for (int t = 0; t < HT; ++t) {
-                const f32x4 acc = mfma_bf16_k16(frag_k16(wimg + I::kD3 + t * 128, lane), g3, zero);
-                gh[t] = pack_tile(acc);
-                gh[t][0] = gate_bf16x2(gh[t][0], PL[t][0]);
-                gh[t][1] = gate_bf16x2(gh[t][1], PL[t][1]);
-            }
-            if (want_dw) {
-#pragma unroll
-                for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stX + t * 512 + wr_tile) = PL[t];
-                *reinterpret_cast<u32x2 *>(stG + wr_tile) = g3;
-                lds_wave_sync();
-                const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + rd_tile));
-#pragma unroll
-                for (int t = 0; t < HT; ++t)
-                    dW3[t] = mfma_bf16_k16(
-                        at, lds_read_tr16(reinterpret_cast<const uint16_t *>(stX + t * 512 + rd_tile)), dW3[t]);
-            }
-            // middle layer
-            u32x2 g1[HT];
-            if (THREE) {
-#pragma unroll
-                for (int t = 0; t < HT; ++t) {
-                    const f32x4 acc = contract_hidden<HT>(wimg + I::kD2 + t * hid_k_dwords(HT), gh, lane, zero);
-                    g1[t] = pack_tile(acc);
-                    g1[t][0] = gate_bf16x2(g1[t][0], P1[t][0]);
-                    g1[t][1] = gate_bf16x2(g1[t][1], P1[t][1]);
-                }
-                if (want_dw) {
-                    lds_wave_sync();
-#pragma unroll
-                    for (int t = 0; t < HT; ++t) {
-                        *reinterpret_cast<u32x2 *>(stX + t * 512 + wr_tile) = P1[t];
-                        *reinterpret_cast<u32x2 *>(stG + t * 512 + wr_tile) = gh[t];
-                    }
-                    lds_wave_sync();
-                    u32x2 bt[HT];
-#pragma unroll
-                    for (int t = 0; t < HT; ++t)
-                        bt[t] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stX + t * 512 + rd_tile));
-#pragma unroll
-                    for (int to = 0; to < HT; ++to) {
-                        const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + to * 512 + rd_tile));
-#pragma unroll
-                        for (int t = 0; t < HT; ++t) dW2[to][t] = mfma_bf16_k16(at, bt[t], dW2[to][t]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < HT; ++t) g1[t] = gh[t];
-            }
-            // first layer: stage g1, input gradients, dW1
-            lds_wave_sync();
-            if (want_dw) {
-#pragma unroll
-                for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stG + t * 512 + wr_tile) = g1[t];
-            }
-            lds_wave_sync();
-#pragma unroll
-            for (int T = 0; T < GT; ++T) {
-                const f32x4 acc = contract_hidden<HT>(wimg + I::kD1 + T * hid_k_dwords(HT), g1, lane, zero);
-                u32x2 gi = pack_tile(acc);
-                const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn + c * S::kInRow + gin_off[T]);
-                gi[0] = grelu[T] ? gate_bf16x2(gi[0], xin[0]) : gi[0];
-                gi[1] = grelu[T] ? gate_bf16x2(gi[1], xin[1]) : gi[1];
-                gi[0] &= gkeep[T][0];
-                gi[1] &= gkeep[T][1];
-                if (gon[T] && valid && !(a.debug_flags & 1))
-                    *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(gptr[T] + row * gstride[T]) = gi;
-            }
-            if (want_dw) {
-                u32x2 bt[2 * KI];
-#pragma unroll
-                for (int ts = 0; ts < 2 * KI; ++ts)
-                    bt[ts] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stIn + rd_in + 32 * ts));
-#pragma unroll
-                for (int to = 0; to < HT; ++to) {
-                    const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + to * 512 + rd_tile));
-#pragma unroll
-                    for (int ts = 0; ts < 2 * KI; ++ts) dW1[to][ts] = mfma_bf16_k16(at, bt[ts], dW1[to][ts]);
-                }
-            }
-            lds_wave_sync();  // the next tile overwrites the images
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            cur[d] = nxt[d];
-            gcur[d] = gnxt[d];
-        }
-    }
-
-    // ---- partial block of this wave (parameter layout: W1, b1, [W2, b2,] W3, b3) --------
-    if (!want_dw) return;
-    float *pw = part + (int64_t)(blockIdx.x * kWaves + wv) * part_total(a.mlp);
-    int off = 0;
-    float *pW1 = pw + off;
-    off += hidden * in_dim;
-    float *pb1 = pw + off;
-    off += hidden;
-    float *pW2 = pw + off, *pb2 = nullptr;
-    if (THREE) {
-        off += hidden * hidden;
-        pb2 = pw + off;
-        off += hidden;
-    }
-    float *pW3 = pw + off;
-    off += out_dim * hidden;
-    float *pb3 = pw + off;
-#pragma unroll
-    for (int to = 0; to < HT; ++to)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 16 * to + 4 * g + r;
-            if (o >= hidden) continue;
-#pragma unroll
-            for (int ts = 0; ts < 2 * KI; ++ts) {
-                if (col1[ts] >= 0)
-                    pW1[o * in_dim + col1[ts]] = dW1[to][ts][r];
-                else if (col1[ts] == -2)
-                    pb1[o] = dW1[to][ts][r];
-            }
-            if (THREE) {
-#pragma unroll
-                for (int t = 0; t < HT; ++t) {
-                    const int f = 16 * t + c;
-                    if (f < hidden)
-                        pW2[o * hidden + f] = dW2[THREE ? to : 0][t][r];
-                    else if (f == hid_ones)
-                        pb2[o] = dW2[THREE ? to : 0][t][r];
-                }
-            }
-        }
-    if (s_plan.ones_slot < 0) {
-        // no bias column in dW1': the b1 slots of the partial block must still be defined
-        for (int o = lane; o < hidden; o += 64) pb1[o] = 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
-        if (o >= out_dim) continue;
-#pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            const int f = 16 * t + c;
-            if (f < hidden)
-                pW3[o * hidden + f] = dW3[t][r];
-            else if (f == hid_ones)
-                pb3[o] = dW3[t][r];
-        }
-    }
-    if (hid_ones < 0) {
-        if (THREE)
-            for (int o = lane; o < hidden; o += 64) pb2[o] = 0.f;
-        for (int o = lane; o < out_dim; o += 64) pb3[o] = 0.f;
-    }
-}
-
-// ------------------------------------------------------------------ launchers
-int check_bf16_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, const char *who) {
-    if (m.n_layers != 2 && m.n_layers != 3) return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): n_layers must be 2 or 3");
-    if (m.in_dim < 1 || m.hidden < 1 || m.hidden > 63 || m.out_dim < 1 || m.out_dim > 16)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): hidden must be in [1,63], out in [1,16]");
-    if (n_seg < 1 || n_seg > GNNTRK_MAX_SEGS) return fail(GNNTRK_EINVAL, "mlp(bf16): bad segment count");
-    int tot = 0;
-    for (int j = 0; j < n_seg; ++j) {
-        const int padded = (seg[j].dim + 3) / 4 * 4;
-        if (!seg[j].ptr || seg[j].dim < 1 || seg[j].stride < padded || seg[j].stride % 4 != 0 ||
-            ((uintptr_t)seg[j].ptr & 7) != 0)
-            return fail(GNNTRK_EINVAL,
-                        "mlp(bf16): segment rows must be 8-byte aligned bf16 with stride a multiple of 4 "
-                        "elements >= dim rounded up to 4");
-        tot += seg[j].dim;
-    }
-    if (tot != m.in_dim) return fail(GNNTRK_EINVAL, "mlp(bf16): segment dims do not sum to in_dim");
-    for (int i = 0; i < m.n_layers; ++i)
-        if (!m.W[i]) return fail(GNNTRK_EINVAL, "mlp(bf16): NULL weight pointer");
-    (void)who;
-    return GNNTRK_OK;
-}
-
-int grid16(int64_t n_rows, int blocks_per_cu, int waves) {
-    const int64_t tiles = (n_rows + kTileRows - 1) / kTileRows;
-    int64_t g = (tiles + waves - 1) / waves;
-    const int64_t cap = (int64_t)cu_count() * blocks_per_cu;
-    if (g > cap) g = cap;
-    if (g >= 8) g -= g % 8;
-    if (g < 1) g = 1;
-    return (int)g;
-}
-
-constexpr int kFwd16BlocksPerCu = 5;
-constexpr int kBwd16BlocksPerCu = 2;
-
-}  // namespace
 
 #define GNNTRK_FWD16_CASE(KI_, HT_)                                                         \
     if (P.KI == KI_ && P.HT == HT_) {                                                       \
@@ -836,25 +71,14 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     return check_launch("mlp_forward_bf16");
 }
 
+// workspace = one partial block per wave | one 8-byte trash slot per lane
+static size_t bwd16_partial_bytes(const gnntrk_mlp *m) {
+    return align_up((size_t)cu_count() * kBwd16BlocksPerCu * kWaves * (size_t)part_total(*m) * sizeof(float), 256);
+}
 size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m) {
     if (!m) return 0;
-    return (size_t)cu_count() * kBwd16BlocksPerCu * kWaves * (size_t)part_total(*m) * sizeof(float);
+    return bwd16_partial_bytes(m) + (size_t)cu_count() * kBwd16BlocksPerCu * kWaves * 64 * 8;
 }
-
-#define GNNTRK_BWD16_CASE(KI_, HT_, GT_)                                                    \
-    if (P.KI == KI_ && P.HT == HT_ && GT == GT_) {                                          \
-        if (three) {                                                                        \
-            auto kfn = mlp16_bwd_kernel<KI_, HT_, GT_, true>;                               \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part);         \
-        } else {                                                                            \
-            auto kfn = mlp16_bwd_kernel<KI_, HT_, GT_, false>;                              \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part);         \
-        }                                                                                   \
-        launched = true;                                                                    \
-    }
-#define GNNTRK_BWD16_HT(KI_, GT_) \
-    GNNTRK_BWD16_CASE(KI_, 1, GT_) GNNTRK_BWD16_CASE(KI_, 2, GT_) GNNTRK_BWD16_CASE(KI_, 3, GT_) \
-        GNNTRK_BWD16_CASE(KI_, 4, GT_)
 
 int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes, hipStream_t stream) {
     if (!a) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: NULL args");
@@ -882,12 +106,11 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     }
     if (a->n_rows < 0 || a->n_rows > 0x7fffffff) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad n_rows");
     const bool want_dw = a->gW[0] != nullptr;
-    if (want_dw) {
+    if (want_dw)
         for (int i = 0; i < a->mlp.n_layers; ++i)
             if (!a->gW[i]) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: gW must be all set or all NULL");
-        if (!ws || ws_bytes < mlp_backward_bf16_ws_bytes(&a->mlp))
-            return fail(GNNTRK_EINVAL, "mlp_backward_bf16: workspace too small");
-    }
+    if (!ws || ws_bytes < mlp_backward_bf16_ws_bytes(&a->mlp))
+        return fail(GNNTRK_EINVAL, "mlp_backward_bf16: workspace too small (always required)");
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
     if (!P.ok || P.KI > 2)
@@ -899,13 +122,10 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     if (a->n_rows > 0) {
         grid = grid16(a->n_rows, kBwd16BlocksPerCu, kWaves);
         float *part = reinterpret_cast<float *>(ws);
-        bool launched = false;
-        GNNTRK_BWD16_HT(1, 1)
-        GNNTRK_BWD16_HT(1, 2)
-        GNNTRK_BWD16_HT(2, 1)
-        GNNTRK_BWD16_HT(2, 4)
-        if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: no instantiation");
-        rc = check_launch("mlp_backward_bf16");
+        uint8_t *trash = reinterpret_cast<uint8_t *>(ws) + bwd16_partial_bytes(&a->mlp);
+        rc = (a->epilogue == GNNTRK_EPI_SIGMOID)
+                 ? launch_bwd16_g32(a, P.KI, P.HT, GT, grid, part, trash, stream)
+                 : launch_bwd16<false>(a, P, GT, grid, part, trash, stream);
         if (rc) return rc;
     }
     if (want_dw)

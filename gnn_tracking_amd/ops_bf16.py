@@ -128,14 +128,14 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
             a.gseg[j] = _capi.GSeg(slices[j].data_ptr(), None, slices[j].stride(0), 0)
     gW = [None] * len(weights)
     gb = [None] * len(weights)
-    ws = None
     if want_dw:
         gW = [torch.empty_like(w) for w in weights]
         gb = [None if b is None else torch.empty_like(b) for b in biases]
         for i in range(len(weights)):
             a.gW[i] = gW[i].data_ptr()
             a.gb[i] = ops._p(gb[i])
-        ws = ops._ws(lib.gnntrk_mlp_backward_bf16_workspace_bytes(C.byref(a.mlp)), segs[0])
+    # always needed: per-wave partial blocks + the store-redirect slots of masked lanes
+    ws = ops._ws(lib.gnntrk_mlp_backward_bf16_workspace_bytes(C.byref(a.mlp)), segs[0])
     a.accumulate_params = 0
     M = n_rows
     nbytes = M * (sum(2 * s.shape[1] + (4 if idx[j] is not None else 0)

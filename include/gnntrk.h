@@ -213,6 +213,37 @@ typedef struct gnntrk_mlp_bwd_args {
 } gnntrk_mlp_bwd_args;
 
 size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp);
+int gnntrk_mlp_backward(const gnntrk_mlp_bwd_args *args, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* Backward of gnntrk_mlp_forward_bf16 (same argument block as gnntrk_mlp_backward):
+ *   - seg[j].ptr, gout[t].ptr and gseg[j].ptr address padded bf16 rows (rules of
+ *     gnntrk_mlp_forward_bf16); with GNNTRK_EPI_SIGMOID the single upstream term is fp32;
+ *   - the forward is recomputed with the forward's rounding; the upstream gradient (after
+ *     the epilogue derivative) and the gradient at every hidden layer are rounded to bf16
+ *     before they feed the next MFMA; input gradients are written as bf16 (padding
+ *     elements as 0); weight / bias gradients are fp32, accumulated in fp32 per wave and
+ *     reduced in a fixed order (bit-reproducible). */
+size_t gnntrk_mlp_backward_bf16_workspace_bytes(const gnntrk_mlp *mlp);
+int gnntrk_mlp_backward_bf16(const gnntrk_mlp_bwd_args *args, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
+/* Helpers of the bf16-storage path.  All bf16 row tensors follow the padding rules of
+ * gnntrk_mlp_forward_bf16 (uint16_t storage, stride in elements, multiple of 4).
+ *  rows_to_bf16:      out[m] = bf16(in[idx ? idx[m] : m]) (RNE), padding written as 0: how the
+ *                     dataset's fp32 x / edge_attr (graph_builder.py:440-455) enter the stack,
+ *                     edge_attr permuted into CSR order in the same pass.
+ *  segment_sum_bf16:  gnntrk_segment_sum over bf16 rows, fp32 accumulation in CSR order, one
+ *                     rounding at the end (aggregation and node-gradient folds).
+ *  permute_rows_bf16: gnntrk_permute_rows for padded bf16 rows. */
+int gnntrk_rows_to_bf16(const float *in, int32_t dim, int32_t in_stride, const int32_t *idx,
+                        int64_t n_rows, uint16_t *out, int32_t out_stride, void *stream);
+int gnntrk_segment_sum_bf16(const uint16_t *rows, int32_t dim, int32_t row_stride,
+                            const int32_t *rowptr, const int32_t *pos, int64_t n_segments,
+                            uint16_t *out, int32_t out_stride, void *stream);
+int gnntrk_permute_rows_bf16(const uint16_t *in, int32_t dim, int32_t in_stride, const int32_t *idx,
+                             int64_t n_rows, uint16_t *out, int32_t out_stride, int32_t scatter,
+                             void *stream);
 
 /* Name (as rocprofv3 prints it) of the kernel instantiation gnntrk_mlp_forward /
  * gnntrk_mlp_backward dispatch to for this MLP and input-segment list; written
@@ -220,8 +251,6 @@ size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp);
  * points.  For matching host-side timings with profiles. */
 int gnntrk_mlp_kernel_name(const gnntrk_mlp *mlp, int32_t n_seg, const gnntrk_seg *seg,
                            int32_t backward, char *buf, size_t len);
-int gnntrk_mlp_backward(const gnntrk_mlp_bwd_args *args, void *workspace,
-                        size_t workspace_bytes, void *stream);
 
 /* --------------------------------------------------------------- segment sums
  * out[n][0..dim) (=|+=) sum_{k in [rowptr[n], rowptr[n+1])} rows[(pos ? pos[k] : k)][0..dim)

@@ -13,6 +13,7 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name).replace("void ", "").replace("gnntrk::", "")
     return name if len(name) <= 80 else name[:77] + "..."
 

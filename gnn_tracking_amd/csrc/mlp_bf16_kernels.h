@@ -341,7 +341,11 @@ struct BwdImg {
 // per-wave staging images (bytes): X = activations (in / h1 / h2), Gs = gradients
 template <int KI, int HT>
 struct BwdStage {
-    static constexpr int kInRow = 64 * KI;  // bytes per row of the input image [row][32 KI slots]
+    // Bank-conflict-free images (64 banks x 4 bytes; b64 accesses are served 32 lanes per
+    // cycle, b128 16 lanes): a 16-feature tile is [row][4 chunks of 8 bytes] with the chunk
+    // position XORed with (row >> 2) & 3; the input image is [row][4 KI units of 16 bytes]
+    // with a 32-byte row pad and the unit position XORed with (row >> 3) & 1.
+    static constexpr int kInRow = 64 * KI + 32;  // bytes per row of the input image
     static constexpr int kIn = 16 * kInRow;  // inputs: written in S0, read by the first-layer stage
     static constexpr int kX = HT * 512;      // h2 / h1
     static constexpr int kG = HT * 512;      // g_out / g_h2 / g_h1
@@ -464,10 +468,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 
     uint8_t *stIn = s_stage + wv * S::kWave, *stX = stIn + S::kIn, *stG = stX + S::kX;
     // byte offsets inside the staging images
-    const int wr_tile = c * 32 + g * 8;                             // write [row c][4g..4g+3]
-    const int rd_tile = (4 * g + (c >> 2)) * 32 + (c & 3) * 8;      // transpose read, 16-feature tile
-    const int wr_in = c * S::kInRow + g * 16;                       // write [row c][8g..8g+7] (+64 kk)
-    const int rd_in = (4 * g + (c >> 2)) * S::kInRow + (c & 3) * 8; // (+32 ts)
+    const int wr_tile = c * 32 + 8 * (g ^ ((c >> 2) & 3));                  // write [row c][4g..4g+3]
+    const int rd_tile = (4 * g + (c >> 2)) * 32 + 8 * ((c & 3) ^ g);        // transpose read (row >> 2 = g)
+    const int in_swz = 16 * ((c >> 3) & 1);                                 // unit swizzle of row c
+    const int rd_row = 4 * g + (c >> 2);                                    // row this lane addresses in reads
 
     f32x4 dW1[HT][2 * KI], dW2[THREE ? HT : 1][HT], dW3[HT];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -543,10 +547,11 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 
 #pragma unroll
         for (int d = 0; d < D; ++d) {
+            // (tiles past the end of the schedule run as all-invalid rows: zero upstream
+            // gradient, stores redirected - no second loop exit for the accumulators)
             const int64_t tile = tile_of(grp, d);
-            if (tile >= sch.end) break;
             const int64_t row = tile * kTileRows + c;
-            const bool valid = row < a.n_rows;
+            const bool valid = tile < sch.end && row < a.n_rows;
 
             // ---- S0: recompute ------------------------------------------------------
             const uint32_t *wimg = s_img + opaque_zero();
@@ -556,7 +561,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             hidden_chain<KI, HT, THREE>(wimg, B, lane, P1, P2);
             const u32x2(&PL)[HT] = THREE ? P2 : P1;  // input of the last layer
 #pragma unroll
-            for (int kk = 0; kk < KI; ++kk) *reinterpret_cast<u32x4 *>(stIn + wr_in + 64 * kk) = B[kk];
+            for (int kk = 0; kk < KI; ++kk)
+                *reinterpret_cast<u32x4 *>(stIn + c * S::kInRow + ((64 * kk + 16 * g) ^ in_swz)) = B[kk];
 
             // ---- S1: upstream gradient ---------------------------------------------
             f32x4 gy;
@@ -599,7 +605,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 gh[t][0] = gate_bf16x2(gh[t][0], PL[t][0]);
                 gh[t][1] = gate_bf16x2(gh[t][1], PL[t][1]);
             }
-            if (want_dw) {
+            {   // weight gradients are always accumulated (a branch here would turn the
+                // loop-carried accumulators into phi copies); only the final write is optional
 #pragma unroll
                 for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stX + t * 512 + wr_tile) = PL[t];
                 *reinterpret_cast<u32x2 *>(stG + wr_tile) = g3;
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + rd_tile));
 #pragma unroll
                 for (int t = 0; t < HT; ++t)
-                    dW3[t] = mfma_bf16_k16(
+                    mfma_bf16_k16_acc(
                         at, lds_read_tr16(reinterpret_cast<const uint16_t *>(stX + t * 512 + rd_tile)), dW3[t]);
             }
             // middle layer
@@ -620,7 +627,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                     g1[t][0] = gate_bf16x2(g1[t][0], P1[t][0]);
                     g1[t][1] = gate_bf16x2(g1[t][1], P1[t][1]);
                 }
-                if (want_dw) {
+                {
                     lds_wave_sync();
 #pragma unroll
                     for (int t = 0; t < HT; ++t) {
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                     for (int to = 0; to < HT; ++to) {
                         const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + to * 512 + rd_tile));
 #pragma unroll
-                        for (int t = 0; t < HT; ++t) dW2[to][t] = mfma_bf16_k16(at, bt[t], dW2[to][t]);
+                        for (int t = 0; t < HT; ++t) mfma_bf16_k16_acc(at, bt[t], dW2[to][t]);
                     }
                 }
             } else {
@@ -645,16 +652,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             }
             // first layer: stage g1, input gradients, dW1
             lds_wave_sync();
-            if (want_dw) {
 #pragma unroll
-                for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stG + t * 512 + wr_tile) = g1[t];
-            }
+            for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stG + t * 512 + wr_tile) = g1[t];
             lds_wave_sync();
 #pragma unroll
             for (int T = 0; T < GT; ++T) {
                 const f32x4 acc = contract_hidden<HT>(wimg + I::kD1 + T * hid_k_dwords(HT), g1, lane, zero);
                 u32x2 gi = pack_tile(acc);
-                const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn + c * S::kInRow + gin_off[T]);
+                const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn + c * S::kInRow + (gin_off[T] ^ in_swz));
                 gi[0] = grelu[T] ? gate_bf16x2(gi[0], xin[0]) : gi[0];
                 gi[1] = grelu[T] ? gate_bf16x2(gi[1], xin[1]) : gi[1];
                 gi[0] &= gkeep[T][0];
@@ -662,16 +667,17 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 const bool st = gon[T] && valid;
                 *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(st ? gptr[T] + row * gstride[T] : my_trash) = gi;
             }
-            if (want_dw) {
+            {
                 u32x2 bt[2 * KI];
 #pragma unroll
                 for (int ts = 0; ts < 2 * KI; ++ts)
-                    bt[ts] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stIn + rd_in + 32 * ts));
+                    bt[ts] = lds_read_tr16(reinterpret_cast<const uint16_t *>(
+                        stIn + rd_row * S::kInRow + ((32 * ts + 8 * (c & 3)) ^ (16 * (g >> 1)))));
 #pragma unroll
                 for (int to = 0; to < HT; ++to) {
                     const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + to * 512 + rd_tile));
 #pragma unroll
-                    for (int ts = 0; ts < 2 * KI; ++ts) dW1[to][ts] = mfma_bf16_k16(at, bt[ts], dW1[to][ts]);
+                    for (int ts = 0; ts < 2 * KI; ++ts) mfma_bf16_k16_acc(at, bt[ts], dW1[to][ts]);
                 }
             }
             lds_wave_sync();  // the next tile overwrites the images
@@ -685,6 +691,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 
     // ---- partial block of this wave (parameter layout: W1, b1, [W2, b2,] W3, b3) --------
     if (!want_dw) return;
+    drain_mfma();
     float *pw = part + (int64_t)(blockIdx.x * kWaves + wv) * part_total(a.mlp);
     int off = 0;
     float *pW1 = pw + off;

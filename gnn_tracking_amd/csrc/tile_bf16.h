@@ -84,15 +84,35 @@ __device__ __forceinline__ int opaque_zero() {
     asm volatile("v_mov_b32 %0, 0" : "=v"(z));
     return z;
 }
+// x where the matching 16-bit half of p is a positive bf16, else 0 (p is a ReLU output, >= +0):
+// x * min(p, 1) per half as integers.  Written as two instructions because the optimiser
+// expands the C form into five compares / selects / permutes per register.
+__device__ __forceinline__ uint32_t gate_bf16x2(uint32_t x, uint32_t p) {
+    uint32_t t, r;
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(p), "v"(0x00010001u));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
+    return r;
+}
+// acc += A * B (K = 16) for the weight-gradient accumulators that live across the whole
+// tile loop.  The product goes to a scratch tile (C = 0) and is added with VALU adds: the
+// VGPR-destination MFMA form the compiler selects here cannot write its own SrcC tuple, so
+// "acc = mfma(a, b, acc)" allocates a second tuple per accumulator and copies it back every
+// iteration - the same instruction count as the adds, but twice the registers (144 instead
+// of 72 for the default shape), which costs a wave of occupancy.
+__device__ __forceinline__ void mfma_bf16_k16_acc(u32x2 a, u32x2 b, f32x4 &acc) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 t = mfma_bf16_k16(a, b, zero);
+    acc[0] += t[0];
+    acc[1] += t[1];
+    acc[2] += t[2];
+    acc[3] += t[3];
+}
+__device__ __forceinline__ void drain_mfma() {}
 #endif  // GNNTRK_BF16_PRIMITIVES
 
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) { return i16x2_max(v, 0u); }
-// x where the matching half of p is a positive bf16 (p is a ReLU output: >= +0), else 0
-__device__ __forceinline__ uint32_t gate_bf16x2(uint32_t x, uint32_t p) {
-    return u16x2_mul(x, i16x2_min(p, 0x00010001u));
-}
 __device__ __forceinline__ u32x2 pack_tile(const f32x4 &v) {
     u32x2 r;
     r[0] = bf16x2_pack(v[0], v[1]);

@@ -540,3 +540,22 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):
             gref = tt(z[f"{name}/grad/{k}"]).double()
             err = (v.grad.detach().cpu().double() - gref).norm() / max(gref.norm().item(), 1e-6)
             assert err < 0.1, f"{name} grad {k}: relative L2 error {err:.3f} vs fp32 golden"
+
+
+def case_bf16_reproducible(device):
+    z = load("g2_ec_variants.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y = tt(z["y"], device)
+    name = "skip1_L3_h40"
+    model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_VARIANTS[name])
+    load_params(model, z, f"{name}/p0/")
+    model = model.to(device)
+    grads = []
+    for _ in range(2):
+        model.zero_grad()
+        with G.bf16_storage():
+            out = model(G.Data(x=x, edge_index=ei, edge_attr=ea))
+            G.EdgeWeightBCELoss()(w=out["W"], y=y.float()).backward()
+        grads.append({k: v.grad.clone() for k, v in model.named_parameters()})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), f"{k}: run-to-run difference"

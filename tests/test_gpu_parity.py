@@ -73,3 +73,23 @@ def test_cpu_tensor_is_rejected(dev):
     m = G.MLP(4, 2, 8)
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         m(torch.zeros(3, 4))
+
+
+# ---- bf16-storage mode (BASELINE configs 3/4) ------------------------------------------
+def test_bf16_mlp_forward(dev):
+    P.case_mlp_bf16_forward(dev, rows=1000)
+    P.case_mlp_bf16_forward(dev, rows=16 * 4 * 8 * 5 + 3)  # several tile groups per wave
+
+
+def test_bf16_mlp_backward(dev):
+    P.case_mlp_bf16_backward(dev, rows=1000)
+    P.case_mlp_bf16_backward(dev, rows=100_000, full=False)
+
+
+def test_bf16_edge_classifier(dev):
+    P.case_ec_bf16(dev)
+
+
+def test_bf16_backward_is_reproducible(dev):
+    """Fixed-order partial reduction: two runs give bit-identical parameter gradients."""
+    P.case_bf16_reproducible(dev)

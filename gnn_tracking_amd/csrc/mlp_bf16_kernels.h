@@ -439,6 +439,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 #pragma unroll
     for (int ts = 0; ts < 2 * KI; ++ts) col1[ts] = slot_col(s_plan, s_seg, 16 * ts + c);
     const int hid_ones = s_plan.hid_ones;
+    const uint32_t k_one = opaque_u32(0x00010001u);
     __syncthreads();
 
     const int out_dim = a.mlp.out_dim, hidden = a.mlp.hidden, in_dim = a.mlp.in_dim;
@@ -602,8 +603,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             for (int t = 0; t < HT; ++t) {
                 const f32x4 acc = mfma_bf16_k16(frag_k16(wimg + I::kD3 + t * 128, lane), g3, zero);
                 gh[t] = pack_tile(acc);
-                gh[t][0] = gate_bf16x2(gh[t][0], PL[t][0]);
-                gh[t][1] = gate_bf16x2(gh[t][1], PL[t][1]);
+                gh[t][0] = gate_bf16x2(gh[t][0], PL[t][0], k_one);
+                gh[t][1] = gate_bf16x2(gh[t][1], PL[t][1], k_one);
             }
             {   // weight gradients are always accumulated (a branch here would turn the
                 // loop-carried accumulators into phi copies); only the final write is optional
@@ -624,8 +625,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 for (int t = 0; t < HT; ++t) {
                     const f32x4 acc = contract_hidden<HT>(wimg + I::kD2 + t * hid_k_dwords(HT), gh, lane, zero);
                     g1[t] = pack_tile(acc);
-                    g1[t][0] = gate_bf16x2(g1[t][0], P1[t][0]);
-                    g1[t][1] = gate_bf16x2(g1[t][1], P1[t][1]);
+                    g1[t][0] = gate_bf16x2(g1[t][0], P1[t][0], k_one);
+                    g1[t][1] = gate_bf16x2(g1[t][1], P1[t][1], k_one);
                 }
                 {
                     lds_wave_sync();
@@ -660,8 +661,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 const f32x4 acc = contract_hidden<HT>(wimg + I::kD1 + T * hid_k_dwords(HT), g1, lane, zero);
                 u32x2 gi = pack_tile(acc);
                 const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn + c * S::kInRow + (gin_off[T] ^ in_swz));
-                gi[0] = grelu[T] ? gate_bf16x2(gi[0], xin[0]) : gi[0];
-                gi[1] = grelu[T] ? gate_bf16x2(gi[1], xin[1]) : gi[1];
+                gi[0] = grelu[T] ? gate_bf16x2(gi[0], xin[0], k_one) : gi[0];
+                gi[1] = grelu[T] ? gate_bf16x2(gi[1], xin[1], k_one) : gi[1];
                 gi[0] &= gkeep[T][0];
                 gi[1] &= gkeep[T][1];
                 const bool st = gon[T] && valid;

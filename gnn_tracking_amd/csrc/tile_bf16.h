@@ -84,14 +84,13 @@ __device__ __forceinline__ int opaque_zero() {
     asm volatile("v_mov_b32 %0, 0" : "=v"(z));
     return z;
 }
-// x where the matching 16-bit half of p is a positive bf16, else 0 (p is a ReLU output, >= +0):
-// x * min(p, 1) per half as integers.  Written as two instructions because the optimiser
-// expands the C form into five compares / selects / permutes per register.
-__device__ __forceinline__ uint32_t gate_bf16x2(uint32_t x, uint32_t p) {
-    uint32_t t, r;
-    asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(p), "v"(0x00010001u));
-    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
-    return r;
+// A value the optimiser cannot see through (no instruction is emitted).  gate_bf16x2 takes
+// its constant 0x00010001 through it: knowing the constant, the optimiser expands
+// "x * min(p, 1)" into five compares / selects / permutes per register instead of
+// v_pk_min_i16 + v_pk_mul_lo_u16.
+__device__ __forceinline__ uint32_t opaque_u32(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
 }
 // acc += A * B (K = 16) for the weight-gradient accumulators that live across the whole
 // tile loop.  The product goes to a scratch tile (C = 0) and is added with VALU adds: the
@@ -113,6 +112,11 @@ __device__ __forceinline__ void drain_mfma() {}
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) { return i16x2_max(v, 0u); }
+// x where the matching half of p is a positive bf16 (p is a ReLU output: >= +0), else 0:
+// x * min(p, 1) per 16-bit half as integers; `one` = opaque_u32(0x00010001)
+__device__ __forceinline__ uint32_t gate_bf16x2(uint32_t x, uint32_t p, uint32_t one) {
+    return u16x2_mul(x, i16x2_min(p, one));
+}
 __device__ __forceinline__ u32x2 pack_tile(const f32x4 &v) {
     u32x2 r;
     r[0] = bf16x2_pack(v[0], v[1]);

@@ -275,7 +275,7 @@ inline f32x4_emul mfma_bf16_k16(u32x2_emul a, u32x2_emul b, f32x4_emul c) {
     return hipemul_mfma_bf16<16>(a, b, c);
 }
 inline int opaque_zero() { return 0; }
-inline uint32_t gate_bf16x2(uint32_t x, uint32_t p) { return u16x2_mul(x, i16x2_min(p, 0x00010001u)); }
+inline uint32_t opaque_u32(uint32_t v) { return v; }
 inline void drain_mfma() {}
 inline void mfma_bf16_k16_acc(u32x2_emul a, u32x2_emul b, f32x4_emul &acc) {
     acc = hipemul_mfma_bf16<16>(a, b, acc);

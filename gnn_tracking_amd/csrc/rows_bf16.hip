@@ -40,31 +40,50 @@ __global__ __launch_bounds__(kTpb16) void rows_to_bf16_kernel(const float *__res
     }
 }
 
-// thread <-> (segment n, chunk ch): out[n] = sum over CSR positions k of rows[pos ? pos[k] : k]
+// Four lanes per segment: lane j of the group sums rows k0 + j, k0 + j + 4, ... (whole
+// rows: 8 or 16 bytes per load), the group combines with two xor-shuffles, lane 0 rounds
+// and stores.  Neighbouring lanes read neighbouring rows, so a CSR-ordered input streams
+// through full sectors; with `pos` (source-sorted folds) the rows are random 8/16-byte
+// gathers and the kernel is sector-bound.  The order of the fp32 additions is fixed.
+template <int NCH>
 __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
     const uint16_t *__restrict__ rows, int dim, int row_stride, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ pos, int64_t n_seg, uint16_t *__restrict__ out, int out_stride) {
-    const int nch = (dim + 3) >> 2;
-    const int64_t total = n_seg * nch;
-    for (int64_t t = (int64_t)blockIdx.x * kTpb16 + threadIdx.x; t < total;
-         t += (int64_t)gridDim.x * kTpb16) {
-        const int64_t n = t / nch;
-        const int ch = (int)(t - n * nch);
-        const int32_t k0 = rowptr[n], k1 = rowptr[n + 1];
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int32_t k = k0; k < k1; ++k) {
+    const int j = threadIdx.x & 3;
+    for (int64_t n = ((int64_t)blockIdx.x * kTpb16 + threadIdx.x) >> 2; n < ((n_seg + 63) & ~(int64_t)63);
+         n += ((int64_t)gridDim.x * kTpb16) >> 2) {
+        float s[4 * NCH];
+#pragma unroll
+        for (int i = 0; i < 4 * NCH; ++i) s[i] = 0.f;
+        const bool on = n < n_seg;
+        const int32_t k0 = on ? rowptr[n] : 0, k1 = on ? rowptr[n + 1] : 0;
+        for (int32_t k = k0 + j; k < k1; k += 4) {
             const int64_t r = pos ? (int64_t)pos[k] : (int64_t)k;
-            const u32x2 v = *reinterpret_cast<const u32x2 *>(rows + r * row_stride + 4 * ch);
-            s0 += bf16_lo(v[0]);
-            s1 += bf16_hi(v[0]);
-            s2 += bf16_lo(v[1]);
-            s3 += bf16_hi(v[1]);
+            const uint16_t *p = rows + r * row_stride;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const u32x2 v = *reinterpret_cast<const u32x2 *>(p + 4 * ch);
+                s[4 * ch + 0] += bf16_lo(v[0]);
+                s[4 * ch + 1] += bf16_hi(v[0]);
+                s[4 * ch + 2] += bf16_lo(v[1]);
+                s[4 * ch + 3] += bf16_hi(v[1]);
+            }
         }
-        const int d = dim - 4 * ch;
-        u32x2 o;
-        o[0] = bf16x2_pack(s0, d >= 2 ? s1 : 0.f);
-        o[1] = bf16x2_pack(d >= 3 ? s2 : 0.f, d >= 4 ? s3 : 0.f);
-        *reinterpret_cast<u32x2 *>(out + n * out_stride + 4 * ch) = o;
+#pragma unroll
+        for (int i = 0; i < 4 * NCH; ++i) {
+            s[i] += __shfl_xor(s[i], 1);
+            s[i] += __shfl_xor(s[i], 2);
+        }
+        if (on && j == 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int d = dim - 4 * ch;
+                u32x2 o;
+                o[0] = bf16x2_pack(d >= 1 ? s[4 * ch] : 0.f, d >= 2 ? s[4 * ch + 1] : 0.f);
+                o[1] = bf16x2_pack(d >= 3 ? s[4 * ch + 2] : 0.f, d >= 4 ? s[4 * ch + 3] : 0.f);
+                *reinterpret_cast<u32x2 *>(out + n * out_stride + 4 * ch) = o;
+            }
+        }
     }
 }
 
@@ -92,9 +111,9 @@ bool rows_ok(const void *p, int dim, int stride) {
 
 int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
                         uint16_t *out, int out_stride, hipStream_t stream) {
+    if (n_rows == 0) return GNNTRK_OK;  // empty tensors may carry NULL pointers
     if (!in || dim < 1 || in_stride < dim || n_rows < 0 || !rows_ok(out, dim, out_stride))
         return fail(GNNTRK_EINVAL, "rows_to_bf16: bad argument");
-    if (n_rows == 0) return GNNTRK_OK;
     const int nch = (dim + 3) / 4;
     hipLaunchKernelGGL(rows_to_bf16_kernel, dim3(grid_for_threads(n_rows * nch)), dim3(kTpb16), 0, stream, in,
                        dim, in_stride, idx, n_rows, out, out_stride);
@@ -104,20 +123,27 @@ int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *
 int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const int32_t *rowptr,
                             const int32_t *pos, int64_t n_seg, uint16_t *out, int out_stride,
                             hipStream_t stream) {
-    if (!rowptr || n_seg < 0 || !rows_ok(rows, dim, row_stride) || !rows_ok(out, dim, out_stride))
-        return fail(GNNTRK_EINVAL, "segment_sum_bf16: bad argument");
     if (n_seg == 0) return GNNTRK_OK;
+    // rows may be NULL when there are no rows at all (every segment empty)
+    if (!rowptr || n_seg < 0 || (rows && !rows_ok(rows, dim, row_stride)) || !rows_ok(out, dim, out_stride))
+        return fail(GNNTRK_EINVAL, "segment_sum_bf16: bad argument");
     const int nch = (dim + 3) / 4;
-    hipLaunchKernelGGL(segment_sum_bf16_kernel, dim3(grid_for_threads(n_seg * nch)), dim3(kTpb16), 0, stream,
-                       rows, dim, row_stride, rowptr, pos, n_seg, out, out_stride);
+    if (nch > 4) return fail(GNNTRK_EUNSUPPORTED, "segment_sum_bf16: dim > 16");
+    const int grid = grid_for_threads(n_seg * 4);
+#define GNNTRK_SEGSUM16(N)                                                                          \
+    if (nch == N)                                                                                   \
+        hipLaunchKernelGGL(segment_sum_bf16_kernel<N>, dim3(grid), dim3(kTpb16), 0, stream, rows, dim, \
+                           row_stride, rowptr, pos, n_seg, out, out_stride);
+    GNNTRK_SEGSUM16(1) GNNTRK_SEGSUM16(2) GNNTRK_SEGSUM16(3) GNNTRK_SEGSUM16(4)
+#undef GNNTRK_SEGSUM16
     return check_launch("segment_sum_bf16");
 }
 
 int permute_rows_bf16_launch(const uint16_t *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
                              uint16_t *out, int out_stride, int scatter, hipStream_t stream) {
+    if (n_rows == 0) return GNNTRK_OK;
     if (!idx || n_rows < 0 || !rows_ok(in, dim, in_stride) || !rows_ok(out, dim, out_stride))
         return fail(GNNTRK_EINVAL, "permute_rows_bf16: bad argument");
-    if (n_rows == 0) return GNNTRK_OK;
     const int nch = (dim + 3) / 4;
     hipLaunchKernelGGL(permute_rows_bf16_kernel, dim3(grid_for_threads(n_rows * nch)), dim3(kTpb16), 0, stream,
                        in, nch, in_stride, idx, n_rows, out, out_stride, scatter);

@@ -559,3 +559,31 @@ def case_bf16_reproducible(device):
         grads.append({k: v.grad.clone() for k, v in model.named_parameters()})
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), f"{k}: run-to-run difference"
+
+
+def case_rows_bf16(device):
+    """bf16 helper kernels: conversion (+gather), CSR segment sums (both orders, dims that are
+    not multiples of 4), row permutations - against torch on the same bf16 values."""
+    from gnn_tracking_amd import ops_bf16 as B
+    g = np.random.default_rng(4)
+    for N, E, D in ((1, 0, 4), (7, 20, 5), (300, 4000, 4), (1000, 9000, 9)):
+        ei = tt(g.integers(0, N, size=(2, E)), device).long()
+        gi = ops.graph_index(ei, N, cache=False)
+        x32 = tt(g.normal(size=(E, D)).astype(np.float32), device)
+        rows = B.to_rows16(x32)
+        assert rows.dtype == torch.bfloat16 and rows.stride(0) == B.pad4(D)
+        assert torch.equal(rows.float().cpu(), x32.cpu().to(torch.bfloat16).float()), "RNE conversion"
+        if E:
+            perm = gi.perm
+            got = B.to_rows16(x32, perm)
+            assert torch.equal(got.float().cpu(), x32.cpu()[perm.cpu().long()].to(torch.bfloat16).float())
+            back = B.permute_raw(got, perm, scatter=True)
+            assert torch.equal(back.float().cpu(), rows.float().cpu()), "permute scatter inverts gather"
+        csr = rows  # treat the rows as already CSR ordered
+        for by, ids in (("tgt", gi.tgt), ("src", None)):
+            out = ops.segment_sum(csr, gi, by)
+            ref = torch.zeros(N, D)
+            if E:
+                node = gi.tgt.cpu().long() if by == "tgt" else gi.src.cpu().long()
+                ref.index_add_(0, node, csr.float().cpu())
+            assert_close(out.float(), ref.to(torch.bfloat16).float(), TOL16, f"segment_sum16 {by} N={N} D={D}")

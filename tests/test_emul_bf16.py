@@ -23,3 +23,8 @@ def test_mlp_bf16_backward_emulated():
 def test_ec_bf16_emulated():
     with emulated():
         P.case_ec_bf16("cpu", names=("alpha0",))
+
+
+def test_rows_bf16_emulated():
+    with emulated():
+        P.case_rows_bf16("cpu")

@@ -93,3 +93,7 @@ def test_bf16_edge_classifier(dev):
 def test_bf16_backward_is_reproducible(dev):
     """Fixed-order partial reduction: two runs give bit-identical parameter gradients."""
     P.case_bf16_reproducible(dev)
+
+
+def test_bf16_row_helpers(dev):
+    P.case_rows_bf16(dev)

@@ -39,7 +39,7 @@ from gnn_tracking_amd import ops, synthetic  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
 PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
-TRAFFIC_PROFILE = "r01_hbm_traffic_v5.json"
+TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r01_hbm_traffic_bf16_v6.json"}
 
 WORKLOADS = {
     # name: (events per GPU, hits per event, edges per event, model kwargs)
@@ -107,11 +107,11 @@ def cpu_baseline(event, model, iters: int) -> dict:
             "s_per_iter": dt, "thread_probe_s": probe}
 
 
-def measured_traffic(kernel: str, rows_per_launch: float):
+def measured_traffic(kernel: str, rows_per_launch: float, dtype: str):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and
     WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; see the JSON's _about),
     scaled by rows when this run's launch size differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
+    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILES[dtype])
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -198,7 +198,7 @@ def main():
             common = {"kernel": dom, "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
                       "alg_flops_per_launch": d["flops"] / d["launches"],
                       "alg_bytes_per_launch": d["bytes"] / d["launches"],
-                      "traffic": measured_traffic(dom, d["rows"] / d["launches"])}
+                      "traffic": measured_traffic(dom, d["rows"] / d["launches"], args.dtype)}
             if args.dtype == "bf16":
                 # bf16 MFMA (2.5 PFLOP/s) leaves the fused kernels HBM / issue bound: the
                 # roofline that bounds them is HBM bandwidth

@@ -125,6 +125,9 @@ int gnntrk_mlp_backward_bf16(const gnntrk_mlp_bwd_args *args, void *workspace, s
                              void *stream) {
     return mlp_backward_bf16_launch(args, workspace, workspace_bytes, (hipStream_t)stream);
 }
+int gnntrk_mlp_backward_bf16_kernel_name(const gnntrk_mlp_bwd_args *args, char *buf, size_t len) {
+    return mlp16_bwd_kernel_name(args, buf, len);
+}
 int gnntrk_mlp_kernel_name(const gnntrk_mlp *mlp, int32_t n_seg, const gnntrk_seg *seg,
                            int32_t backward, char *buf, size_t len) {
     if (backward & 2) return mlp16_kernel_name(mlp, n_seg, seg, backward & 1, buf, len);

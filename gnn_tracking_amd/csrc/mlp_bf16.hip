@@ -33,6 +33,17 @@ int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int
     return GNNTRK_OK;
 }
 
+// exact backward instantiation (needs the gradient slices and the epilogue)
+int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
+    if (!a || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
+    SlotPlan P;
+    make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
+    const int GT = (P.GT <= 1) ? 1 : 2 * P.KI;
+    snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s>", P.KI, P.HT, GT,
+             a->mlp.n_layers == 3 ? "true" : "false", a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false");
+    return GNNTRK_OK;
+}
+
 int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     if (!a) return fail(GNNTRK_EINVAL, "mlp_forward_bf16: NULL args");
     int rc = check_bf16_mlp(a->mlp, a->n_seg, a->seg, "mlp_forward_bf16");

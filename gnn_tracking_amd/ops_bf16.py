@@ -143,8 +143,12 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
                   + sum((4 if epilogue == _capi.EPI_SIGMOID else 2) * mlp.out_dim
                         + (4 if gi is not None else 0) for _, gi in gout))
     ref = gout[0][0]
-    with ops._timed(ref, ops.kernel_key(lib, a, True, bf16=True), 3 * ops._mlp_flops_per_row(mlp) * M,
-                    nbytes, M):
+    key = ""
+    if ops._TIMER is not None:
+        buf = C.create_string_buffer(160)
+        _capi.check(lib.gnntrk_mlp_backward_bf16_kernel_name(C.byref(a), buf, len(buf)), lib)
+        key = buf.value.decode()
+    with ops._timed(ref, key, 3 * ops._mlp_flops_per_row(mlp) * M, nbytes, M):
         _capi.check(lib.gnntrk_mlp_backward_bf16(C.byref(a), ops._p(ws), 0 if ws is None else ws.numel(),
                                                  ops._stream(ref)), lib)
     return slices, gW, gb

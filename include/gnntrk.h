@@ -251,6 +251,9 @@ int gnntrk_permute_rows_bf16(const uint16_t *in, int32_t dim, int32_t in_stride,
  * points.  For matching host-side timings with profiles. */
 int gnntrk_mlp_kernel_name(const gnntrk_mlp *mlp, int32_t n_seg, const gnntrk_seg *seg,
                            int32_t backward, char *buf, size_t len);
+/* same for gnntrk_mlp_backward_bf16, whose instantiation also depends on the gradient
+ * slices requested and on the epilogue */
+int gnntrk_mlp_backward_bf16_kernel_name(const gnntrk_mlp_bwd_args *args, char *buf, size_t len);
 
 /* --------------------------------------------------------------- segment sums
  * out[n][0..dim) (=|+=) sum_{k in [rowptr[n], rowptr[n+1])} rows[(pos ? pos[k] : k)][0..dim)

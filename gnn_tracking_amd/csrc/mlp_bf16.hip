@@ -9,16 +9,22 @@ int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, int KI, int HT, int GT, int g
                      uint8_t *trash, hipStream_t stream);  // mlp_bf16_g32.hip
 
 
-#define GNNTRK_FWD16_CASE(KI_, HT_)                                                         \
-    if (P.KI == KI_ && P.HT == HT_) {                                                       \
-        if (three) {                                                                        \
-            auto kfn = mlp16_fwd_kernel<KI_, HT_, true>;                                    \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);               \
-        } else {                                                                            \
-            auto kfn = mlp16_fwd_kernel<KI_, HT_, false>;                                   \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);               \
-        }                                                                                   \
-        launched = true;                                                                    \
+#define GNNTRK_FWD16_LAUNCH(KI_, HT_, T_, S_, R_)                                       \
+    {                                                                                   \
+        auto kfn = mlp16_fwd_kernel<KI_, HT_, T_, S_, R_>;                              \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);               \
+    }
+#define GNNTRK_FWD16_CASE(KI_, HT_)                                                     \
+    if (P.KI == KI_ && P.HT == HT_) {                                                   \
+        if (three && sig && share) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, true, 4)         \
+        else if (three && sig) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, true, 1)             \
+        else if (three && share) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, false, 4)          \
+        else if (three) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, false, 1)                   \
+        else if (sig && share) GNNTRK_FWD16_LAUNCH(KI_, HT_, false, true, 4)            \
+        else if (sig) GNNTRK_FWD16_LAUNCH(KI_, HT_, false, true, 1)                     \
+        else if (share) GNNTRK_FWD16_LAUNCH(KI_, HT_, false, false, 4)                  \
+        else GNNTRK_FWD16_LAUNCH(KI_, HT_, false, false, 1)                             \
+        launched = true;                                                                \
     }
 
 int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int backward, char *buf,
@@ -29,7 +35,7 @@ int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int
     // (the backward instantiation also depends on how many input gradients are wanted:
     // GT = 1 or 2 KI gradient tiles; the name reports the k-step and hidden-tile counts)
     snprintf(buf, len, "mlp16_%s_kernel<%d, %d, %s>", backward ? "bwd" : "fwd", P.KI, P.HT,
-             m->n_layers == 3 ? "true" : "false");
+             m->n_layers == 3 ? "true" : "false");  // (forward: + the sigmoid flag, see ops_bf16.py)
     return GNNTRK_OK;
 }
 
@@ -67,8 +73,10 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
     if (!P.ok || P.KI > 2)
         return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: more than 16 input chunks / 4 hidden tiles");
-    const bool three = a->mlp.n_layers == 3;
-    const int grid = grid16(a->n_rows, kFwd16BlocksPerCu, kWaves);
+    const bool three = a->mlp.n_layers == 3, sig = a->epilogue == GNNTRK_EPI_SIGMOID;
+    const bool share = a->mlp.out_dim <= 4;  // four tiles share one output tile and one store
+    int grid = grid16(a->n_rows, kFwd16BlocksPerCu, kWaves);
+    if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
     bool launched = false;
     GNNTRK_FWD16_CASE(1, 1)
     GNNTRK_FWD16_CASE(1, 2)

@@ -202,10 +202,21 @@ __device__ __forceinline__ void hidden_chain(const uint32_t *img, const u32x4 (&
     }
 }
 
-template <int KI, int HT, bool THREE>
+// Store-redirect slots of the forward kernel (16 bytes per lane of the largest grid): the
+// forward C ABI has no workspace argument.  Contents are never read.
+constexpr int kFwdMaxBlocks = 2048;
+__device__ uint8_t g_fwd_trash[(size_t)kFwdMaxBlocks * kBlock * 16];
+
+// R = tiles sharing one output tile.  With at most four output features (the edge
+// embeddings, the edge weight) only lane group 0 of the last layer's D tile carries data;
+// R = 4 gives every tile of a group its own copy of the last-layer fragments with the
+// rows rotated by 4v, so tile v lands in lane group v, the four last-layer MFMA chains
+// accumulate into ONE tile (the other row blocks of each fragment are zero: exact), and a
+// single full-wave store writes 4 x 16 rows.  R = 1 is the plain layout (wider outputs).
+template <int KI, int HT, bool THREE, bool SIG, int R>
 __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
     using I = FwdImg<KI, HT>;
-    __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal];
+    __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal + (R - 1) * hid_k_dwords(HT)];
     __shared__ SlotPlan s_plan;
     __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];  // kernel arguments cannot be indexed dynamically
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
@@ -216,19 +227,29 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
     {
         const AugWeights w = make_aug(a.mlp, s_plan);
         pack_forward_weights<KI, HT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
+        for (int v = 1; v < R; ++v)  // rotated copies of the last layer
+            pack_hidden_k<HT>(s_img + I::kA3 + v * hid_k_dwords(HT), 0,
+                              [&](int o, int f) { return (o >> 2) == v ? w.wlast(o & 3, f) : 0.f; }, tid, kBlock);
     }
     LaneChunks<KI> L;
     L.init(s_plan, s_seg, g);
     __syncthreads();
 
     const int out_dim = a.mlp.out_dim;
-    const bool out_lane = 4 * g < out_dim;  // this lane holds real output features
-    const gci_ptr out_idx = (gci_ptr)a.out_idx;
+    // (R = 4: lane group g holds output chunk 0 of tile g; R = 1: chunk g of the tile)
+    const int chunk = R == 1 ? g : 0;
+    const bool out_lane = 4 * chunk < out_dim;
+    // branch-free VMEM (see LaneChunks): a missing out_idx reads the output buffer as int32
+    // and is discarded, masked lanes load from / store to a private trash slot
+    const bool oi_on = a.out_idx != nullptr;
+    const gci_ptr out_idx = oi_on ? (gci_ptr)a.out_idx : (gci_ptr) reinterpret_cast<const int32_t *>(a.out);
     const int epi = a.epilogue;
-    const gch_ptr resp = (gch_ptr) reinterpret_cast<const uint16_t *>(a.res);
+    const bool res_on = epi == GNNTRK_EPI_RESIDUAL;
+    uint8_t GNNTRK_GLOBAL *my_trash =
+        (uint8_t GNNTRK_GLOBAL *)g_fwd_trash + ((size_t)(blockIdx.x % kFwdMaxBlocks) * kBlock + tid) * 16;
     uint32_t okeep[2];
     {
-        const int d = out_dim - 4 * g;
+        const int d = out_dim - 4 * chunk;
         okeep[0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
         okeep[1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
     }
@@ -246,72 +267,86 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
     // ids of group n+2 are in flight while group n computes - 16 * kDepth rows of loads per
     // wave cover the gather latency (one tile per wave in flight left the kernel latency
     // bound at 1/3 of the rate).  Tiles past the end of the schedule load clamped rows and
-    // are not computed.
+    // run with masked stores.
     constexpr int D = kFwdDepth;
+    static_assert(D % R == 0, "group depth must be a multiple of the output sharing factor");
     RowIds<KI> rid[D];
     RawTile<KI> cur[D], nxt[D];
-    int32_t orow_c[D], orow_n[D], orow_nn[D];
+    // output row of this lane for sub-batch b (R = 4: of tile b*R + g; R = 1: of tile b)
+    int32_t orow_c[D / R], orow_n[D / R], orow_nn[D / R];
     auto tile_of = [&](int64_t grp, int d) { return sch.cur + (grp * D + d) * sch.step; };
-    auto ids_of = [&](int64_t grp, int d, RowIds<KI> &r, int32_t &orow) {
-        const int32_t row = clamp_row(tile_of(grp, d));
-        load_row_ids<KI>(L, row, r);
-        orow = row;
-        if (out_lane && out_idx) orow = out_idx[row];
-    };
+    auto my_tile = [&](int64_t grp, int b) { return tile_of(grp, 0) + (int64_t)(b * R + (R == 1 ? 0 : g)) * sch.step; };
+    auto ids_of = [&](int64_t grp) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) ids_of(0, d, rid[d], orow_c[d]);
+        for (int d = 0; d < D; ++d) load_row_ids<KI>(L, clamp_row(tile_of(grp, d)), rid[d]);
+    };
+    auto orows_of = [&](int64_t grp, int32_t (&orow)[D / R]) {
+#pragma unroll
+        for (int b = 0; b < D / R; ++b) {
+            const int32_t row = clamp_row(my_tile(grp, b));
+            const int32_t v = out_idx[row];
+            orow[b] = oi_on ? v : row;
+        }
+    };
+    ids_of(0);
+    orows_of(0, orow_c);
 #pragma unroll
     for (int d = 0; d < D; ++d) load_raw<KI>(L, rid[d], cur[d]);
-#pragma unroll
-    for (int d = 0; d < D; ++d) ids_of(1, d, rid[d], orow_n[d]);
+    ids_of(1);
+    orows_of(1, orow_n);
 
     for (int64_t grp = 0; tile_of(grp, 0) < sch.end; ++grp) {
 #pragma unroll
         for (int d = 0; d < D; ++d) load_raw<KI>(L, rid[d], nxt[d]);
-#pragma unroll
-        for (int d = 0; d < D; ++d) ids_of(grp + 2, d, rid[d], orow_nn[d]);
+        ids_of(grp + 2);
+        orows_of(grp + 2, orow_nn);
 
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int64_t tile = tile_of(grp, d);
-            if (tile >= sch.end) break;
-            u32x4 B[KI];
-            finish_inputs<KI>(L, cur[d], B);
-            u32x2 P1[HT], P2[HT];
-            hidden_chain<KI, HT, THREE>(s_img, B, lane, P1, P2);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            f32x4 y = contract_hidden<HT>(s_img + I::kA3, THREE ? P2 : P1, lane, zero);
-
+        for (int b = 0; b < D / R; ++b) {
+            f32x4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < R; ++v) {
+                u32x4 B[KI];
+                finish_inputs<KI>(L, cur[b * R + v], B);
+                u32x2 P1[HT], P2[HT];
+                hidden_chain<KI, HT, THREE>(s_img, B, lane, P1, P2);
+                y = contract_hidden<HT>(s_img + I::kA3 + v * hid_k_dwords(HT), THREE ? P2 : P1, lane, y);
+            }
+            const int64_t tile = my_tile(grp, b);
             const int64_t row = tile * kTileRows + c;
-            if (out_lane && row < a.n_rows && !(a.debug_flags & 1)) {
-                if (epi == GNNTRK_EPI_SIGMOID) {
-                    float *outp = a.out + (int64_t)orow_c[d] * a.out_stride + 4 * g;
+            const bool st = out_lane && tile < sch.end && row < a.n_rows;
+            if (SIG) {
+                float GNNTRK_GLOBAL *outp = (gf_ptr)a.out + (int64_t)orow_c[b] * a.out_stride + 4 * chunk;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * g + r < out_dim) outp[r] = a.ca + a.cb * sigmoidf_(y[r]);
-                } else {
-                    if (epi == GNNTRK_EPI_RESIDUAL) {
-                        const u32x2 rv =
-                            *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(resp + row * a.res_stride + 4 * g);
-                        y[0] = a.ca * bf16_lo(rv[0]) + a.cb * y[0];
-                        y[1] = a.ca * bf16_hi(rv[0]) + a.cb * y[1];
-                        y[2] = a.ca * bf16_lo(rv[1]) + a.cb * y[2];
-                        y[3] = a.ca * bf16_hi(rv[1]) + a.cb * y[3];
-                    }
-                    u32x2 o = (epi == GNNTRK_EPI_RELU) ? pack_tile_relu(y) : pack_tile(y);
-                    o[0] &= okeep[0];
-                    o[1] &= okeep[1];
-                    uint16_t *outp =
-                        reinterpret_cast<uint16_t *>(a.out) + (int64_t)orow_c[d] * a.out_stride + 4 * g;
-                    *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>((gh_ptr)outp) = o;
+                for (int r = 0; r < 4; ++r) {
+                    float GNNTRK_GLOBAL *dst =
+                        (st && 4 * chunk + r < out_dim) ? outp + r : (float GNNTRK_GLOBAL *)(my_trash + 4 * r);
+                    *dst = a.ca + a.cb * sigmoidf_(y[r]);
                 }
+            } else {
+                const gch_ptr rp = (res_on && st)
+                                       ? (gch_ptr) reinterpret_cast<const uint16_t *>(a.res) + row * a.res_stride + 4 * chunk
+                                       : (gch_ptr)(const uint16_t GNNTRK_GLOBAL *)my_trash;
+                const u32x2 rv = *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(rp);
+                if (res_on) {
+                    y[0] = a.ca * bf16_lo(rv[0]) + a.cb * y[0];
+                    y[1] = a.ca * bf16_hi(rv[0]) + a.cb * y[1];
+                    y[2] = a.ca * bf16_lo(rv[1]) + a.cb * y[2];
+                    y[3] = a.ca * bf16_hi(rv[1]) + a.cb * y[3];
+                }
+                u32x2 o = (epi == GNNTRK_EPI_RELU) ? pack_tile_relu(y) : pack_tile(y);
+                o[0] &= okeep[0];
+                o[1] &= okeep[1];
+                gh_ptr outp = (gh_ptr) reinterpret_cast<uint16_t *>(a.out) + (int64_t)orow_c[b] * a.out_stride + 4 * chunk;
+                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(st ? outp : (gh_ptr)(uint16_t GNNTRK_GLOBAL *)my_trash) = o;
             }
         }
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            cur[d] = nxt[d];
-            orow_c[d] = orow_n[d];
-            orow_n[d] = orow_nn[d];
+        for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+#pragma unroll
+        for (int b = 0; b < D / R; ++b) {
+            orow_c[b] = orow_n[b];
+            orow_n[b] = orow_nn[b];
         }
     }
 }

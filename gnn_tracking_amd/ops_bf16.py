@@ -96,8 +96,11 @@ def mlp_forward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], rel
                   + (4 if epilogue == _capi.EPI_SIGMOID else 2) * mlp.out_dim
                   + (4 if out_idx is not None else 0)
                   + (2 * mlp.out_dim if epilogue == _capi.EPI_RESIDUAL else 0))
-    with ops._timed(out, ops.kernel_key(lib, a, False, bf16=True), ops._mlp_flops_per_row(mlp) * M,
-                    nbytes, M):
+    key = ops.kernel_key(lib, a, False, bf16=True)
+    if key:  # the instantiation also carries the fp32-output (sigmoid) flag
+        key = key[:-1] + (", true" if epilogue == _capi.EPI_SIGMOID else ", false") + (
+            ", 4>" if mlp.out_dim <= 4 else ", 1>")
+    with ops._timed(out, key, ops._mlp_flops_per_row(mlp) * M, nbytes, M):
         _capi.check(lib.gnntrk_mlp_forward_bf16(C.byref(a), ops._stream(out)), lib)
     return out
 

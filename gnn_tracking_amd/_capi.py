@@ -59,7 +59,7 @@ class MlpBwdArgs(C.Structure):
 class GraphIndex(C.Structure):
     _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("perm", C.c_void_p),
                 ("tgt", C.c_void_p), ("src", C.c_void_p), ("rowptr_t", C.c_void_p),
-                ("rowptr_s", C.c_void_p), ("spos", C.c_void_p)]
+                ("rowptr_s", C.c_void_p), ("spos", C.c_void_p), ("spos_inv", C.c_void_p)]
 
 
 class OcArgs(C.Structure):

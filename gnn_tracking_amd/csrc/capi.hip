@@ -10,7 +10,7 @@ static_assert(sizeof(gnntrk_seg) == 32, "gnntrk_seg layout");
 static_assert(sizeof(gnntrk_mlp) == 64, "gnntrk_mlp layout");
 static_assert(sizeof(gnntrk_mlp_fwd_args) == 448, "gnntrk_mlp_fwd_args layout");
 static_assert(sizeof(gnntrk_mlp_bwd_args) == 760, "gnntrk_mlp_bwd_args layout");
-static_assert(sizeof(gnntrk_graph_index) == 64, "gnntrk_graph_index layout");
+static_assert(sizeof(gnntrk_graph_index) == 72, "gnntrk_graph_index layout");
 
 namespace gnntrk {
 

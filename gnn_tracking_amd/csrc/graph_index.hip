@@ -47,6 +47,13 @@ __global__ __launch_bounds__(kTpb) void gi_rowptr_kernel(const uint32_t *__restr
     }
 }
 
+// inv[spos[k]] = k
+__global__ __launch_bounds__(kTpb) void gi_invert_kernel(const int32_t *__restrict__ spos, int64_t E,
+                                                         int32_t *__restrict__ inv) {
+    for (int64_t k = (int64_t)blockIdx.x * kTpb + threadIdx.x; k < E; k += (int64_t)gridDim.x * kTpb)
+        inv[spos[k]] = (int32_t)k;
+}
+
 static int stream_grid(int64_t n) {
     int64_t g = ceil_div(n, kTpb);
     const int64_t cap = (int64_t)cu_count() * 8;
@@ -114,6 +121,8 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, vo
         if (rc) return rc;
         hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, keys_b, E, N,
                            o->rowptr_s);
+        if (o->spos_inv)
+            hipLaunchKernelGGL(gi_invert_kernel, dim3(grid), dim3(kTpb), 0, stream, o->spos, E, o->spos_inv);
     } else {
         rc = check_hip(hipMemsetAsync(o->rowptr_t, 0, (size_t)(N + 1) * 4, stream), "memset");
         if (rc) return rc;

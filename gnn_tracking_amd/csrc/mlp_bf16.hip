@@ -118,8 +118,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     for (int j = 0; j < a->n_seg; ++j) {
         const gnntrk_gseg &gs = a->gseg[j];
         if (!gs.ptr) continue;
-        if (gs.idx || gs.accumulate)
-            return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: gseg.idx / gseg.accumulate are reserved");
+        if (gs.accumulate) return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: gseg.accumulate is reserved");
         if (gs.stride < (a->seg[j].dim + 3) / 4 * 4 || gs.stride % 4 != 0 || ((uintptr_t)gs.ptr & 7) != 0)
             return fail(GNNTRK_EINVAL, "mlp_backward_bf16: gradient slices must be padded bf16 rows");
     }

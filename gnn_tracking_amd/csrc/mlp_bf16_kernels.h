@@ -444,15 +444,18 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
     // (and rows past the end) store to a private 8-byte slot of the trash area instead, so
     // that the store is unconditional (see LaneChunks).
     gh_ptr gptr[GT];
+    gci_ptr gidx[GT];  // optional row permutation of the gradient slice (never NULL, see LaneChunks)
     int32_t gstride[GT], gin_off[GT];
     uint32_t gkeep[GT][2];
-    bool gon[GT], grelu[GT];
+    bool gon[GT], grelu[GT], gidx_on[GT];
     gh_ptr my_trash = (gh_ptr) reinterpret_cast<uint16_t *>(trash + ((int64_t)(blockIdx.x * kWaves + wv) * 64 + lane) * 8);
 #pragma unroll
     for (int T = 0; T < GT; ++T) {
         const int q = 4 * T + g;
         gon[T] = q < s_plan.n_gchunks;
         gptr[T] = my_trash;
+        gidx[T] = (gci_ptr) reinterpret_cast<const int32_t *>(a.gout[0].ptr);  // readable int32[n_rows]
+        gidx_on[T] = false;
         gstride[T] = 0;
         gin_off[T] = 0;
         grelu[T] = false;
@@ -463,6 +466,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             d = d > 4 ? 4 : d;
             gptr[T] = (gh_ptr)(reinterpret_cast<uint16_t *>(s_gseg[j].ptr) + 4 * s_plan.first[p]);
             gstride[T] = s_gseg[j].stride;
+            if (s_gseg[j].idx) {
+                gidx[T] = (gci_ptr)s_gseg[j].idx;
+                gidx_on[T] = true;
+            }
             gin_off[T] = 8 * p;  // byte offset of the chunk inside a row of the input image
             grelu[T] = s_seg[j].relu != 0;
         }
@@ -589,6 +596,15 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             const int64_t row = tile * kTileRows + c;
             const bool valid = tile < sch.end && row < a.n_rows;
 
+            // destination rows of the input-gradient slices (used at the end of the tile)
+            int32_t srow[GT];
+#pragma unroll
+            for (int T = 0; T < GT; ++T) {
+                const int32_t rc = clamp_row(tile < sch.end ? tile : sch.cur);
+                const int32_t v = gidx[T][rc];
+                srow[T] = gidx_on[T] ? v : rc;
+            }
+
             // ---- S0: recompute ------------------------------------------------------
             const uint32_t *wimg = s_img + opaque_zero();
             u32x4 B[KI];
@@ -701,7 +717,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 gi[0] &= gkeep[T][0];
                 gi[1] &= gkeep[T][1];
                 const bool st = gon[T] && valid;
-                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(st ? gptr[T] + row * gstride[T] : my_trash) = gi;
+                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(st ? gptr[T] + (int64_t)srow[T] * gstride[T] : my_trash) = gi;
             }
             {
                 u32x2 bt[2 * KI];

@@ -148,6 +148,7 @@ class GraphIndex:
     rowptr_t: Tensor  # [N+1] int32
     rowptr_s: Tensor  # [N+1] int32
     spos: Tensor      # [E] int32: source-sorted order -> CSR position
+    spos_inv: Tensor  # [E] int32: CSR position -> position in the source-sorted order
 
 
 _GI_CACHE: dict[int, tuple] = {}
@@ -180,9 +181,9 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True) -> Grap
     E = int(ei.shape[1])
     dev = ei.device
     mk = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
-    gi = GraphIndex(n_nodes, E, mk(E), mk(E), mk(E), mk(n_nodes + 1), mk(n_nodes + 1), mk(E))
+    gi = GraphIndex(n_nodes, E, mk(E), mk(E), mk(E), mk(n_nodes + 1), mk(n_nodes + 1), mk(E), mk(E))
     d = _capi.GraphIndex(n_nodes, E, _p(gi.perm), _p(gi.tgt), _p(gi.src), _p(gi.rowptr_t),
-                         _p(gi.rowptr_s), _p(gi.spos))
+                         _p(gi.rowptr_s), _p(gi.spos), _p(gi.spos_inv))
     ws = _ws(lib.gnntrk_graph_index_workspace_bytes(n_nodes, E), ei)
     _capi.check(lib.gnntrk_graph_index_build(_p(ei), C.byref(d), _p(ws), ws.numel(),
                                              _stream(ei)), lib)

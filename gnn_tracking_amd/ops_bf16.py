@@ -108,7 +108,7 @@ def mlp_forward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], rel
 def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], relu: Sequence[bool],
                      weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]], *, n_rows: int,
                      epilogue: int, ca: float, cb: float, gout: Sequence[tuple], need_seg: Sequence[bool],
-                     want_dw: bool, mlp):
+                     want_dw: bool, mlp, gidx: Optional[Sequence[Optional[Tensor]]] = None):
     """One launch of gnntrk_mlp_backward_bf16.  ``gout``: 1-2 tuples (rows, idx) - padded
     bf16 rows, or one fp32 ``[*, out]`` tensor for EPI_SIGMOID.  Returns (row-aligned
     per-segment gradient slices ``[n_rows, dim]`` bf16 or None, gW list, gb list)."""
@@ -121,14 +121,15 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
     for j, s in enumerate(segs):
         a.seg[j] = _seg16(s, idx[j], relu[j])
     a.n_gout = len(gout)
-    for t, (rows, gidx) in enumerate(gout):
-        a.gout[t] = _capi.GTerm(rows.data_ptr(), ops._p(gidx), rows.stride(0), 0)
+    for t, (rows, term_idx) in enumerate(gout):
+        a.gout[t] = _capi.GTerm(rows.data_ptr(), ops._p(term_idx), rows.stride(0), 0)
     dev = segs[0].device
     slices = [None] * len(segs)
     for j, s in enumerate(segs):
         if need_seg[j]:
             slices[j] = empty_rows(n_rows, s.shape[1], dev)
-            a.gseg[j] = _capi.GSeg(slices[j].data_ptr(), None, slices[j].stride(0), 0)
+            gi_j = None if gidx is None else gidx[j]
+            a.gseg[j] = _capi.GSeg(slices[j].data_ptr(), ops._p(gi_j), slices[j].stride(0), 0)
     gW = [None] * len(weights)
     gb = [None] * len(weights)
     if want_dw:
@@ -260,10 +261,16 @@ class FusedMLP16(torch.autograd.Function):
             if need_seg[j] and spec.idx[j] is not None and spec.reduce[j] is None:
                 raise RuntimeError("gathered segment requires a `reduce` rule for backward")
         want_dw = any(need[1 + ns:1 + ns + 2 * nl])
+        # source-gathered node rows: the kernel writes their per-edge gradients already in
+        # source-sorted order (a permuted 16-byte store), so the fold below streams instead of
+        # gathering random rows
+        gidx = [spec.reduce[j][1].spos_inv
+                if (need_seg[j] and isinstance(spec.reduce[j], tuple) and spec.reduce[j][0] == "src")
+                else None for j in range(ns)]
         slices, gW, gb = mlp_backward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=M,
                                           epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb,
                                           gout=[(g_rows, spec.out_idx)], need_seg=need_seg,
-                                          want_dw=want_dw, mlp=mlp)
+                                          want_dw=want_dw, mlp=mlp, gidx=gidx)
         seg_grads = [None] * ns
         for j, s in enumerate(segs):
             if slices[j] is None:
@@ -278,8 +285,8 @@ class FusedMLP16(torch.autograd.Function):
                 seg_grads[j] = permute_raw(slices[j], spec.idx[j], scatter=True)
             else:
                 by, gi = spec.reduce[j]
-                rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
-                seg_grads[j] = segment_sum_raw(slices[j], rowptr, pos, s.shape[0])
+                rowptr = gi.rowptr_t if by == "tgt" else gi.rowptr_s  # (src rows are pre-sorted)
+                seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0])
         g_res = None
         if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
             g_dense = g_rows if spec.out_idx is None else permute_raw(g_rows, spec.out_idx, False)

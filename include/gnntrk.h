@@ -76,6 +76,9 @@ typedef struct gnntrk_graph_index {
     int32_t *rowptr_t; /* [N+1] */
     int32_t *rowptr_s; /* [N+1] */
     int32_t *spos;     /* [E]   */
+    int32_t *spos_inv; /* [E] or NULL: inverse of spos (CSR position -> position in the
+                          source-sorted order): lets a backward kernel write per-edge source
+                          gradients already source-sorted, so their fold streams */
 } gnntrk_graph_index;
 
 size_t gnntrk_graph_index_workspace_bytes(int64_t n_nodes, int64_t n_edges);
@@ -170,7 +173,9 @@ int gnntrk_mlp_forward_bf16(const gnntrk_mlp_fwd_args *args, void *stream);
  * Per-row input gradients are written row-aligned: for segment j, if
  * gseg[j].ptr != NULL, row m of the segment's gradient slice goes to
  *     gseg[j].ptr[m * gseg[j].stride + 0..dim)      (ReLU masks of the segment applied;
- * gseg[j].idx and gseg[j].accumulate are reserved and must be NULL / 0).
+ * gseg[j].idx and gseg[j].accumulate are reserved and must be NULL / 0 in the fp32 entry
+ * point; gnntrk_mlp_backward_bf16 accepts gseg[j].idx (int32[M], a permutation): row m is
+ * then written at gseg[j].ptr[gseg[j].idx[m] * stride + ...]).
  * Gathered segments are reduced onto their source rows afterwards with
  * gnntrk_segment_sum (deterministic).  gres (EPI_RESIDUAL) is NOT produced here:
  * it is ca * g, an elementwise op of the caller.

@@ -490,9 +490,15 @@ def case_mlp_bf16_backward(device, rows=75, full=True):
         gin, dW, db = O.mlp_bf16_backward(torch.cat(xin, 1), weights, biases, g_sum, epi, ca, cb)
         wd = [w.to(device).contiguous() for w in weights]
         bd = [None if b is None else b.to(device).contiguous() for b in biases]
+        # the second segment's gradient rows are written through a row permutation when it is
+        # wanted (how source-ordered folds receive pre-sorted rows)
+        gperm = torch.randperm(rows, generator=gen) if (len(dims) > 1 and need[1]) else None
+        gidx = [gperm.int().to(device) if (j == 1 and gperm is not None) else None for j in range(len(dims))]
         slices, gW, gb = B.mlp_backward_raw(segs, idxs, relu, wd, bd, n_rows=rows, epilogue=epi_code[epi],
                                             ca=ca, cb=cb, gout=gout, need_seg=need, want_dw=True,
-                                            mlp=ops._fill_mlp(wd, bd))
+                                            mlp=ops._fill_mlp(wd, bd), gidx=gidx)
+        if gperm is not None:
+            slices[1] = slices[1][gperm.to(slices[1].device)]
         tag = f"bf16 MLP bwd {dims}->{hid}->{out} L={L} bias={bias} {epi}"
         col = 0
         for j, d in enumerate(dims):

@@ -46,7 +46,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.Mlp) == 64
     assert ctypes.sizeof(_capi.MlpFwdArgs) == 448
     assert _capi.MlpFwdArgs.n_rows.offset == 392
-    assert ctypes.sizeof(_capi.GraphIndex) == 64
+    assert ctypes.sizeof(_capi.GraphIndex) == 72
     assert ctypes.sizeof(_capi.MlpBwdArgs) == 760
 
 

@@ -317,11 +317,15 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
             const bool st = out_lane && tile < sch.end && row < a.n_rows;
             if (SIG) {
                 float GNNTRK_GLOBAL *outp = (gf_ptr)a.out + (int64_t)orow_c[b] * a.out_stride + 4 * chunk;
+                if (out_dim == 1) {  // the edge-weight head: one store per lane (uniform branch)
+                    *(st ? outp : (float GNNTRK_GLOBAL *)my_trash) = a.ca + a.cb * sigmoidf_(y[0]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float GNNTRK_GLOBAL *dst =
-                        (st && 4 * chunk + r < out_dim) ? outp + r : (float GNNTRK_GLOBAL *)(my_trash + 4 * r);
-                    *dst = a.ca + a.cb * sigmoidf_(y[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        float GNNTRK_GLOBAL *dst =
+                            (st && 4 * chunk + r < out_dim) ? outp + r : (float GNNTRK_GLOBAL *)(my_trash + 4 * r);
+                        *dst = a.ca + a.cb * sigmoidf_(y[r]);
+                    }
                 }
             } else {
                 const gch_ptr rp = (res_on && st)

@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor, nn
 
-from . import _capi, ops
+from . import _capi, ops, ops_bf16
 from .hparams import HyperparametersMixin, assert_feat_dim
 from .mlp import MLP
 
@@ -53,12 +53,20 @@ class InteractionNetwork(nn.Module, HyperparametersMixin):
         residual stacks apply to both inputs (resin.py:103-104).  With ``residue`` the
         node output is ``sqrt(a)*residue + sqrt(1-a)*x~`` (resin.py:26), fused as the
         object model's epilogue.  Returns ``(x_out, e_tilde_csr)``."""
-        e_tilde = self.relational_model.fused([
+        rel_segs = [
             ops.Seg(x, gi.tgt, relu_in, ("tgt", gi)),
             ops.Seg(x, gi.src, relu_in, ("src", gi)),
             ops.Seg(e_csr, None, relu_in),
-        ], n_rows=gi.n_edges)
-        aggr = ops.segment_sum(e_tilde, gi, "tgt")
+        ]
+        if x.dtype == torch.bfloat16:
+            # bf16 storage: relational model + aggregation as one autograd node, so that the
+            # backward kernel takes "direct" and "through aggr" gradients as two terms
+            lin = self.relational_model.linears()
+            e_tilde, aggr = ops_bf16.in_edge(rel_segs, [m.weight for m in lin], [m.bias for m in lin],
+                                             gi, gi.n_edges)
+        else:
+            e_tilde = self.relational_model.fused(rel_segs, n_rows=gi.n_edges)
+            aggr = ops.segment_sum(e_tilde, gi, "tgt")
         segs = [ops.Seg(x, None, relu_in), ops.Seg(aggr)]
         if residue is not None:
             ca, cb = float(alpha_residue) ** 0.5, (1.0 - float(alpha_residue)) ** 0.5

@@ -244,55 +244,114 @@ class FusedMLP16(torch.autograd.Function):
     def backward(ctx, g_out):
         from . import ops
         spec = ctx.spec
-        ns, nl = spec.n_seg, spec.n_layers
-        saved = ctx.saved_tensors
-        segs, weights = list(saved[:ns]), list(saved[ns:ns + nl])
-        bl = list(saved[ns + nl:])
-        biases = [bl.pop(0) if m else None for m in ctx.bias_mask]
-        mlp = ops._fill_mlp(weights, biases)
         if spec.epilogue == _capi.EPI_SIGMOID:
             g_rows = ops._as_rows(g_out.float().contiguous())
         else:
             g_rows = rows16(g_out)
-        need = ctx.needs_input_grad  # [spec, segs..., W..., b..., res]
-        M = spec.n_rows
-        need_seg = [bool(need[1 + j]) for j in range(ns)]
-        for j in range(ns):
-            if need_seg[j] and spec.idx[j] is not None and spec.reduce[j] is None:
-                raise RuntimeError("gathered segment requires a `reduce` rule for backward")
-        want_dw = any(need[1 + ns:1 + ns + 2 * nl])
-        # source-gathered node rows: the kernel writes their per-edge gradients already in
-        # source-sorted order (a permuted 16-byte store), so the fold below streams instead of
-        # gathering random rows
-        gidx = [spec.reduce[j][1].spos_inv
-                if (need_seg[j] and isinstance(spec.reduce[j], tuple) and spec.reduce[j][0] == "src")
-                else None for j in range(ns)]
-        slices, gW, gb = mlp_backward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=M,
-                                          epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb,
-                                          gout=[(g_rows, spec.out_idx)], need_seg=need_seg,
-                                          want_dw=want_dw, mlp=mlp, gidx=gidx)
-        seg_grads = [None] * ns
-        for j, s in enumerate(segs):
-            if slices[j] is None:
-                continue
-            if spec.idx[j] is None:
-                if s.shape[0] != M:
-                    raise RuntimeError("identity segments must have n_rows rows")
-                seg_grads[j] = slices[j]
-            elif spec.reduce[j] == "perm":
-                if s.shape[0] != M:
-                    raise RuntimeError("'perm' segments must cover all source rows")
-                seg_grads[j] = permute_raw(slices[j], spec.idx[j], scatter=True)
-            else:
-                by, gi = spec.reduce[j]
-                rowptr = gi.rowptr_t if by == "tgt" else gi.rowptr_s  # (src rows are pre-sorted)
-                seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0])
-        g_res = None
-        if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
-            g_dense = g_rows if spec.out_idx is None else permute_raw(g_rows, spec.out_idx, False)
-            g_res = g_dense * spec.ca
-        outs = [None, *seg_grads]
-        outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
-        outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
-        outs.append(g_res)
-        return tuple(outs)
+        outs, g_res = _backward_common(ctx, [(g_rows, spec.out_idx)], ctx.needs_input_grad, g_rows)
+        return (None, *outs, g_res)
+
+
+def _backward_common(ctx, gout, need, g_rows):
+    """Shared by FusedMLP16 and FusedINEdge16: one gnntrk_mlp_backward_bf16 launch for the
+    upstream terms ``gout`` + the folds of the gathered input gradients.  ``need`` is laid
+    out as [spec, segs..., W..., b..., res].  Returns (grads of segs/W/b, grad of res)."""
+    from . import ops
+    spec = ctx.spec
+    ns, nl = spec.n_seg, spec.n_layers
+    saved = ctx.saved_tensors
+    segs, weights = list(saved[:ns]), list(saved[ns:ns + nl])
+    bl = list(saved[ns + nl:ns + nl + sum(ctx.bias_mask)])
+    biases = [bl.pop(0) if m else None for m in ctx.bias_mask]
+    mlp = ops._fill_mlp(weights, biases)
+    M = spec.n_rows
+    need_seg = [bool(need[1 + j]) for j in range(ns)]
+    for j in range(ns):
+        if need_seg[j] and spec.idx[j] is not None and spec.reduce[j] is None:
+            raise RuntimeError("gathered segment requires a `reduce` rule for backward")
+    want_dw = any(need[1 + ns:1 + ns + 2 * nl])
+    # source-gathered node rows: the kernel writes their per-edge gradients already in
+    # source-sorted order (a permuted 16-byte store), so the fold below streams instead of
+    # gathering random rows
+    gidx = [spec.reduce[j][1].spos_inv
+            if (need_seg[j] and isinstance(spec.reduce[j], tuple) and spec.reduce[j][0] == "src")
+            else None for j in range(ns)]
+    slices, gW, gb = mlp_backward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=M,
+                                      epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb, gout=gout,
+                                      need_seg=need_seg, want_dw=want_dw, mlp=mlp, gidx=gidx)
+    seg_grads = [None] * ns
+    for j, s in enumerate(segs):
+        if slices[j] is None:
+            continue
+        if spec.idx[j] is None:
+            if s.shape[0] != M:
+                raise RuntimeError("identity segments must have n_rows rows")
+            seg_grads[j] = slices[j]
+        elif spec.reduce[j] == "perm":
+            if s.shape[0] != M:
+                raise RuntimeError("'perm' segments must cover all source rows")
+            seg_grads[j] = permute_raw(slices[j], spec.idx[j], scatter=True)
+        else:
+            by, gi = spec.reduce[j]
+            rowptr = gi.rowptr_t if by == "tgt" else gi.rowptr_s  # (src rows are pre-sorted)
+            seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0])
+    g_res = None
+    if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
+        g_dense = g_rows if spec.out_idx is None else permute_raw(g_rows, spec.out_idx, False)
+        g_res = g_dense * spec.ca
+    outs = list(seg_grads)
+    outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
+    outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
+    return outs, g_res
+
+
+class FusedINEdge16(torch.autograd.Function):
+    """Relational model + sum aggregation of one interaction-network layer
+    (interaction_network.py:67-89) as ONE autograd node: ``(e~, aggr) = f(segments, params)``.
+    The backward feeds the kernel both upstream terms - ``g_e~[k] + g_aggr[tgt[k]]`` - so the
+    gathered aggregation gradient and the sum are never materialised (include/gnntrk.h:
+    gout[2])."""
+
+    @staticmethod
+    def forward(ctx, spec, gi, *tensors):
+        from . import ops
+        ns, nl = spec.n_seg, spec.n_layers
+        segs = [rows16(t) for t in tensors[:ns]]
+        weights = [w.contiguous() for w in tensors[ns:ns + nl]]
+        biases = [None if b is None else b.contiguous() for b in tensors[ns + nl:ns + 2 * nl]]
+        _capi.require_device(*segs, *weights)
+        mlp = ops._fill_mlp(weights, biases)
+        if sum(s.shape[1] for s in segs) != mlp.in_dim:
+            raise AssertionError(
+                f"Expected feature dimension {mlp.in_dim}, got {sum(s.shape[1] for s in segs)}")
+        e_tilde = mlp_forward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=spec.n_rows,
+                                  epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb, res=None,
+                                  out_idx=None, out_rows=spec.out_rows, mlp=mlp)
+        aggr = segment_sum_raw(e_tilde, gi.rowptr_t, None, gi.n_nodes)
+        ctx.spec, ctx.gi = spec, gi
+        ctx.save_for_backward(*segs, *weights, *[b for b in biases if b is not None])
+        ctx.bias_mask = [b is not None for b in biases]
+        return e_tilde, aggr
+
+    @staticmethod
+    def backward(ctx, g_et, g_aggr):
+        gi = ctx.gi
+        gout = []
+        if g_et is not None:
+            gout.append((rows16(g_et), None))
+        if g_aggr is not None:
+            gout.append((rows16(g_aggr), gi.tgt))
+        if not gout:
+            raise RuntimeError("FusedINEdge16.backward without upstream gradients")
+        need = ctx.needs_input_grad  # [spec, gi, segs..., W..., b...]
+        outs, _ = _backward_common(ctx, gout, (need[0],) + tuple(need[2:]) + (False,), None)
+        return (None, None, *outs)
+
+
+def in_edge(segs, weights, biases, gi, n_rows: int):
+    """``(e~, aggr)`` of one interaction-network layer in bf16 storage (see FusedINEdge16)."""
+    from . import ops
+    spec = ops._MlpSpec(len(segs), len(weights), any(b is not None for b in biases),
+                        [s.idx for s in segs], [s.relu for s in segs], [s.reduce for s in segs],
+                        _capi.EPI_NONE, 0.0, 1.0, None, int(n_rows), int(n_rows))
+    return FusedINEdge16.apply(spec, gi, *[s.t for s in segs], *weights, *biases)

@@ -146,9 +146,12 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
                  : launch_bwd16<false>(a, P, GT, grid, part, trash, stream);
         if (rc) return rc;
     }
-    if (want_dw)
-        rc = reduce_partials_launch(reinterpret_cast<const float *>(ws), grid * kWaves, &a->mlp, a->gW, a->gb,
-                                    a->accumulate_params, stream);
+    if (want_dw) {
+        // one partial block per workgroup when the parameters fit the kernel's LDS image
+        const bool via_lds = part_total(a->mlp) <= bwd16_img_dwords(P.KI, P.HT, GT, three);
+        rc = reduce_partials_launch(reinterpret_cast<const float *>(ws), via_lds ? grid : grid * kWaves, &a->mlp,
+                                    a->gW, a->gb, a->accumulate_params, stream);
+    }
     return rc;
 }
 

@@ -368,6 +368,13 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
 //       whole launch (fp32), are written once per wave as a partial block in parameter
 //       layout and reduced in a fixed order (reduce_partials in mlp.hip): bit-reproducible.
 // The bias gradients are the `ones` columns of the augmented dW tiles.
+// dwords of the backward kernel's weight-fragment image (also the capacity of the in-LDS
+// reduction of the partial blocks, see the end of mlp16_bwd_kernel)
+__host__ __device__ constexpr int bwd16_img_dwords(int KI, int HT, int GT, bool three) {
+    return HT * KI * 256 + (1 + HT) * hid_k_dwords(HT) /* forward A1 | A2 | A3 */ + HT * 128 +
+           (three ? HT * hid_k_dwords(HT) : 0) + GT * hid_k_dwords(HT);
+}
+
 template <int KI, int HT, int GT, bool THREE>
 struct BwdImg {
     using F = FwdImg<KI, HT>;
@@ -375,6 +382,7 @@ struct BwdImg {
     static constexpr int kD2 = kD3 + HT * 128;                  // W_mid'^T  : [HT] x hid_k
     static constexpr int kD1 = kD2 + (THREE ? HT * hid_k_dwords(HT) : 0);  // W1'^T : [GT] x hid_k
     static constexpr int kTotal = kD1 + GT * hid_k_dwords(HT);
+    static_assert(kTotal == bwd16_img_dwords(KI, HT, GT, THREE), "image size formula out of sync");
 };
 
 // per-wave staging images (bytes): X = activations (in / h1 / h2), Gs = gradients
@@ -745,69 +753,90 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         }
     }
 
-    // ---- partial block of this wave (parameter layout: W1, b1, [W2, b2,] W3, b3) --------
+    // ---- partial block (parameter layout: W1, b1, [W2, b2,] W3, b3) ------------------------
+    // The four waves of the workgroup are summed in wave order through LDS (the weight-fragment
+    // image is free by now) and ONE block per workgroup goes to the workspace; shapes whose
+    // parameter count exceeds the image fall back to one block per wave.
     if (!want_dw) return;
     drain_mfma();
-    float *pw = part + (int64_t)(blockIdx.x * kWaves + wv) * part_total(a.mlp);
-    int off = 0;
-    float *pW1 = pw + off;
-    off += hidden * in_dim;
-    float *pb1 = pw + off;
-    off += hidden;
-    float *pW2 = pw + off, *pb2 = nullptr;
-    if (THREE) {
-        off += hidden * hidden;
-        pb2 = pw + off;
+    const int PT = part_total(a.mlp);
+    const bool via_lds = PT <= I::kTotal;
+    auto emit = [&](float *pw, bool add) {
+        auto put = [&](float *dst, float v) { *dst = add ? *dst + v : v; };
+        int off = 0;
+        float *pW1 = pw + off;
+        off += hidden * in_dim;
+        float *pb1 = pw + off;
         off += hidden;
-    }
-    float *pW3 = pw + off;
-    off += out_dim * hidden;
-    float *pb3 = pw + off;
+        float *pW2 = pw + off, *pb2 = nullptr;
+        if (THREE) {
+            off += hidden * hidden;
+            pb2 = pw + off;
+            off += hidden;
+        }
+        float *pW3 = pw + off;
+        off += out_dim * hidden;
+        float *pb3 = pw + off;
 #pragma unroll
-    for (int to = 0; to < HT; ++to)
+        for (int to = 0; to < HT; ++to)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 16 * to + 4 * g + r;
-            if (o >= hidden) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * to + 4 * g + r;
+                if (o >= hidden) continue;
 #pragma unroll
-            for (int ts = 0; ts < 2 * KI; ++ts) {
-                if (col1[ts] >= 0)
-                    pW1[o * in_dim + col1[ts]] = dW1[to][ts][r];
-                else if (col1[ts] == -2)
-                    pb1[o] = dW1[to][ts][r];
-            }
-            if (THREE) {
+                for (int ts = 0; ts < 2 * KI; ++ts) {
+                    if (col1[ts] >= 0)
+                        put(pW1 + o * in_dim + col1[ts], dW1[to][ts][r]);
+                    else if (col1[ts] == -2)
+                        put(pb1 + o, dW1[to][ts][r]);
+                }
+                if (THREE) {
 #pragma unroll
-                for (int t = 0; t < HT; ++t) {
-                    const int f = 16 * t + c;
-                    if (f < hidden)
-                        pW2[o * hidden + f] = dW2[THREE ? to : 0][t][r];
-                    else if (f == hid_ones)
-                        pb2[o] = dW2[THREE ? to : 0][t][r];
+                    for (int t = 0; t < HT; ++t) {
+                        const int f = 16 * t + c;
+                        if (f < hidden)
+                            put(pW2 + o * hidden + f, dW2[THREE ? to : 0][t][r]);
+                        else if (f == hid_ones)
+                            put(pb2 + o, dW2[THREE ? to : 0][t][r]);
+                    }
                 }
             }
-        }
-    if (s_plan.ones_slot < 0) {
-        // no bias column in dW1': the b1 slots of the partial block must still be defined
-        for (int o = lane; o < hidden; o += 64) pb1[o] = 0.f;
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
-        if (o >= out_dim) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int o = 4 * g + r;
+            if (o >= out_dim) continue;
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            const int f = 16 * t + c;
-            if (f < hidden)
-                pW3[o * hidden + f] = dW3[t][r];
-            else if (f == hid_ones)
-                pb3[o] = dW3[t][r];
+            for (int t = 0; t < HT; ++t) {
+                const int f = 16 * t + c;
+                if (f < hidden)
+                    put(pW3 + o * hidden + f, dW3[t][r]);
+                else if (f == hid_ones)
+                    put(pb3 + o, dW3[t][r]);
+            }
         }
-    }
-    if (hid_ones < 0) {
-        if (THREE)
-            for (int o = lane; o < hidden; o += 64) pb2[o] = 0.f;
-        for (int o = lane; o < out_dim; o += 64) pb3[o] = 0.f;
+        if (!add) {  // bias slots without a ones column must still be defined
+            if (s_plan.ones_slot < 0)
+                for (int o = lane; o < hidden; o += 64) pb1[o] = 0.f;
+            if (hid_ones < 0) {
+                if (THREE)
+                    for (int o = lane; o < hidden; o += 64) pb2[o] = 0.f;
+                for (int o = lane; o < out_dim; o += 64) pb3[o] = 0.f;
+            }
+        }
+    };
+    if (via_lds) {
+        float *buf = reinterpret_cast<float *>(s_img);
+        __syncthreads();  // every wave is done with the fragments
+        for (int i = tid; i < PT; i += kBlock) buf[i] = 0.f;
+        __syncthreads();
+        for (int w = 0; w < kWaves; ++w) {
+            if (wv == w) emit(buf, true);
+            __syncthreads();
+        }
+        float *dst = part + (int64_t)blockIdx.x * PT;
+        for (int i = tid; i < PT; i += kBlock) dst[i] = buf[i];
+    } else {
+        emit(part + (int64_t)(blockIdx.x * kWaves + wv) * PT, false);
     }
 }
 

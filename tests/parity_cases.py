@@ -532,18 +532,24 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):
             loss = G.EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"], y=y.float(), pt=pt, edge_index=ei)
             loss.backward()
         assert out["W"].dtype == torch.float32 and out["node_embedding"].dtype == torch.bfloat16
-        ref = O.ec_for_graph_tcn_bf16(x.cpu(), ei.cpu(), ea.cpu(), p, L_ec=kw["L_ec"],
-                                      alpha=kw.get("alpha", 0.5))
-        # same rounding points: differences come from rare 1-ulp flips propagating
-        assert_close(out["W"], ref["W"], 4 * TOL16, name + " W vs bf16 oracle")
-        assert_close(out["node_embedding"].float(), ref["node_embedding"], 4 * TOL16, name + " node")
-        assert_close(out["edge_embedding"].float(), ref["edge_embedding"], 4 * TOL16, name + " edge")
+        plain = (kw.get("residual_type", "skip1") == "skip1" and kw.get("use_node_embedding", True)
+                 and kw.get("use_intermediate_edge_embeddings", True))
+        if plain:  # the bf16 restatement covers the default wiring
+            ref = O.ec_for_graph_tcn_bf16(x.cpu(), ei.cpu(), ea.cpu(), p, L_ec=kw["L_ec"],
+                                          alpha=kw.get("alpha", 0.5))
+            # same rounding points: differences come from rare 1-ulp flips propagating
+            assert_close(out["W"], ref["W"], 4 * TOL16, name + " W vs bf16 oracle")
+            assert_close(out["node_embedding"].float(), ref["node_embedding"], 4 * TOL16, name + " node")
+            assert_close(out["edge_embedding"].float(), ref["edge_embedding"], 4 * TOL16, name + " edge")
         # distance to the reference-pinned fp32 results
         assert_close(out["W"], z[f"{name}/W"], 0.03, name + " W vs fp32 golden")
         assert_close(loss, z[f"{name}/loss"], 0.01, name + " loss vs fp32 golden")
         for k, v in model.named_parameters():
-            assert v.grad is not None and v.grad.dtype == torch.float32
             gref = tt(z[f"{name}/grad/{k}"]).double()
+            if v.grad is None:  # parameter without a path to the loss in this variant
+                assert gref.abs().max().item() == 0.0, f"{name} grad {k} missing"
+                continue
+            assert v.grad.dtype == torch.float32
             err = (v.grad.detach().cpu().double() - gref).norm() / max(gref.norm().item(), 1e-6)
             assert err < 0.1, f"{name} grad {k}: relative L2 error {err:.3f} vs fp32 golden"
 

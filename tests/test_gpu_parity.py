@@ -87,7 +87,7 @@ def test_bf16_mlp_backward(dev):
 
 
 def test_bf16_edge_classifier(dev):
-    P.case_ec_bf16(dev)
+    P.case_ec_bf16(dev, names=tuple(P.EC_VARIANTS))  # all residual layouts / head inputs
 
 
 def test_bf16_backward_is_reproducible(dev):

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "gnntrk_mlp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
     "gnntrk_mlp_backward_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
     "gnntrk_mlp_backward_bf16": (C.c_int, [C.POINTER(MlpBwdArgs), _P, C.c_size_t, _P]),
+    "gnntrk_mlp_forward_bf16_kernel_name": (C.c_int, [C.POINTER(MlpFwdArgs), C.c_char_p, C.c_size_t]),
     "gnntrk_mlp_backward_bf16_kernel_name": (C.c_int, [C.POINTER(MlpBwdArgs), C.c_char_p, C.c_size_t]),
     "gnntrk_mlp_kernel_name": (C.c_int, [C.POINTER(Mlp), C.c_int32, C.POINTER(Seg), C.c_int32,
                                         C.c_char_p, C.c_size_t]),

@@ -125,6 +125,9 @@ int gnntrk_mlp_backward_bf16(const gnntrk_mlp_bwd_args *args, void *workspace, s
                              void *stream) {
     return mlp_backward_bf16_launch(args, workspace, workspace_bytes, (hipStream_t)stream);
 }
+int gnntrk_mlp_forward_bf16_kernel_name(const gnntrk_mlp_fwd_args *args, char *buf, size_t len) {
+    return mlp16_fwd_kernel_name(args, buf, len);
+}
 int gnntrk_mlp_backward_bf16_kernel_name(const gnntrk_mlp_bwd_args *args, char *buf, size_t len) {
     return mlp16_bwd_kernel_name(args, buf, len);
 }

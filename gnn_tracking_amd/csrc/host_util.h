@@ -40,6 +40,7 @@ int reduce_partials_launch(const float *part, int n_part, const gnntrk_mlp *mlp,
 // mlp_bf16.hip
 int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int backward, char *buf,
                       size_t len);
+int mlp16_fwd_kernel_name(const gnntrk_mlp_fwd_args *a, char *buf, size_t len);
 int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len);
 int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);
 size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m);

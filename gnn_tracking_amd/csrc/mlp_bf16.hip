@@ -11,8 +11,13 @@ int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, int KI, int HT, int GT, int g
 
 #define GNNTRK_FWD16_LAUNCH(KI_, HT_, T_, S_, R_)                                       \
     {                                                                                   \
-        auto kfn = mlp16_fwd_kernel<KI_, HT_, T_, S_, R_>;                              \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);               \
+        if (wide) {                                                                     \
+            auto kfn = mlp16_fwd_kernel<KI_, HT_, T_, S_, R_, true>;                    \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);           \
+        } else {                                                                        \
+            auto kfn = mlp16_fwd_kernel<KI_, HT_, T_, S_, R_, false>;                   \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);           \
+        }                                                                               \
     }
 #define GNNTRK_FWD16_CASE(KI_, HT_)                                                     \
     if (P.KI == KI_ && P.HT == HT_) {                                                   \
@@ -36,6 +41,17 @@ int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int
     // GT = 1 or 2 KI gradient tiles; the name reports the k-step and hidden-tile counts)
     snprintf(buf, len, "mlp16_%s_kernel<%d, %d, %s>", backward ? "bwd" : "fwd", P.KI, P.HT,
              m->n_layers == 3 ? "true" : "false");  // (forward: + the sigmoid flag, see ops_bf16.py)
+    return GNNTRK_OK;
+}
+
+// exact forward instantiation
+int mlp16_fwd_kernel_name(const gnntrk_mlp_fwd_args *a, char *buf, size_t len) {
+    if (!a || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
+    SlotPlan P;
+    make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
+    snprintf(buf, len, "mlp16_fwd_kernel<%d, %d, %s, %s, %d, %s>", P.KI, P.HT, a->mlp.n_layers == 3 ? "true" : "false",
+             a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false", a->mlp.out_dim <= 4 ? 4 : 1,
+             wide_ok(P, a->seg, a->n_rows) ? "true" : "false");
     return GNNTRK_OK;
 }
 
@@ -75,6 +91,7 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
         return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: more than 16 input chunks / 4 hidden tiles");
     const bool three = a->mlp.n_layers == 3, sig = a->epilogue == GNNTRK_EPI_SIGMOID;
     const bool share = a->mlp.out_dim <= 4;  // four tiles share one output tile and one store
+    const bool wide = wide_ok(P, a->seg, a->n_rows);  // one 16-byte load per lane and k-step
     int grid = grid16(a->n_rows, kFwd16BlocksPerCu, kWaves);
     if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
     bool launched = false;

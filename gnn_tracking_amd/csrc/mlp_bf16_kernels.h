@@ -58,6 +58,7 @@ struct LaneChunks {
     int32_t stride[KI][2];
     uint32_t keep[KI][2][2], ones[KI][2][2], rmin[KI][2];
     bool has_idx[KI][2];
+    bool pair8[KI];  // wide mode: the 16-byte load covers rows (r & ~1, r | 1) of an 8-byte-row tensor
 
     __device__ __forceinline__ void init(const SlotPlan &P, const gnntrk_seg *seg, int g) {
 #pragma unroll
@@ -80,6 +81,12 @@ struct LaneChunks {
                 has_idx[kk][h] = seg[js].idx != nullptr;
                 // identity segment: n_rows rows of >= 8 bytes -> its own data is a valid int32[n_rows]
                 idx[kk][h] = has_idx[kk][h] ? (gci_ptr)seg[js].idx : (gci_ptr) reinterpret_cast<const int32_t *>(seg[js].ptr);
+                if (h == 0) {
+                    // wide mode (see wide_ok()): lanes without chunks mirror pair 0 of the layout
+                    const int p0 = j >= 0 ? p : 0;
+                    const bool second = (p0 + 1 < P.n_chunks) && P.seg[p0 + 1] >= 0;
+                    pair8[kk] = !second;
+                }
                 keep[kk][h][0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
                 keep[kk][h][1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
                 ones[kk][h][0] = ones[kk][h][1] = 0u;
@@ -120,6 +127,57 @@ __device__ __forceinline__ void load_raw(const LaneChunks<KI> &L, const RowIds<K
             t.v[kk][h] = *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(
                 L.base[kk][h] + (int64_t)r.v[kk][h] * L.stride[kk][h]);
 }
+// Wide mode: ONE 16-byte load per lane and k-step (8-byte-per-lane streams top out near
+// 3.2 TB/s on MI355X, 16-byte ones reach 6 TB/s).  Every chunk pair (2g, 2g+1) is either
+// one 16-byte row of a segment ("row16") or a single 4-feature chunk of an identity segment
+// with 8-byte rows ("pair8": the load covers two adjacent rows, the lane keeps its half).
+// Host-side eligibility: wide_ok().
+template <int KI>
+__device__ __forceinline__ void load_row_ids_wide(const LaneChunks<KI> &L, int32_t row, RowIds<KI> &r) {
+#pragma unroll
+    for (int kk = 0; kk < KI; ++kk) {
+        const int32_t v = L.idx[kk][0][row];
+        r.v[kk][0] = L.has_idx[kk][0] ? v : row;
+        r.v[kk][1] = row;
+    }
+}
+template <int KI>
+__device__ __forceinline__ void load_raw_wide(const LaneChunks<KI> &L, const RowIds<KI> &r, int32_t pair_cap,
+                                              RawTile<KI> &t) {
+#pragma unroll
+    for (int kk = 0; kk < KI; ++kk) {
+        const int32_t row = r.v[kk][0];
+        int32_t base_row = row & ~1;
+        base_row = base_row < pair_cap ? base_row : pair_cap;  // keep both rows of the pair in bounds
+        const int32_t rr = L.pair8[kk] ? base_row : row;
+        // (a pair capped at the end of an odd-length tensor starts on an odd row: 8-byte aligned)
+        typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+        const u32x4 w = *reinterpret_cast<const u32x4_a8 GNNTRK_GLOBAL *>(L.base[kk][0] + (int64_t)rr * L.stride[kk][0]);
+        const bool hi = L.pair8[kk] && (row != base_row);
+        t.v[kk][0][0] = hi ? w[2] : w[0];
+        t.v[kk][0][1] = hi ? w[3] : w[1];
+        t.v[kk][1][0] = w[2];
+        t.v[kk][1][1] = w[3];
+    }
+}
+// the host-side condition for wide mode
+inline bool wide_ok(const SlotPlan &P, const gnntrk_seg *seg, int64_t n_rows) {
+    for (int p = 0; p < 8 * P.KI; p += 2) {
+        const int j0 = p < P.n_chunks ? P.seg[p] : -1, j1 = p + 1 < P.n_chunks ? P.seg[p + 1] : -1;
+        if (j0 < 0) {
+            if (j1 >= 0) return false;
+            continue;  // empty pair (or the ones-only chunk): mirrors pair 0
+        }
+        if (((uintptr_t)seg[j0].ptr & 15) != 0) return false;
+        if (j1 == j0 && P.first[p + 1] == P.first[p] + 1 && (P.first[p] & 1) == 0 && seg[j0].stride % 8 == 0)
+            continue;  // row16
+        if (j1 < 0 && seg[j0].idx == nullptr && seg[j0].stride == 4 && P.first[p] == 0 && n_rows >= 2)
+            continue;  // pair8
+        return false;
+    }
+    return true;
+}
+
 // pads -> 0, ones slot -> 1.0, optional ReLU: the B operand of layer 1
 template <int KI>
 __device__ __forceinline__ void finish_inputs(const LaneChunks<KI> &L, const RawTile<KI> &t,
@@ -213,7 +271,7 @@ __device__ uint8_t g_fwd_trash[(size_t)kFwdMaxBlocks * kBlock * 16];
 // rows rotated by 4v, so tile v lands in lane group v, the four last-layer MFMA chains
 // accumulate into ONE tile (the other row blocks of each fragment are zero: exact), and a
 // single full-wave store writes 4 x 16 rows.  R = 1 is the plain layout (wider outputs).
-template <int KI, int HT, bool THREE, bool SIG, int R>
+template <int KI, int HT, bool THREE, bool SIG, int R, bool WIDE>
 __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
     using I = FwdImg<KI, HT>;
     __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal + (R - 1) * hid_k_dwords(HT)];
@@ -276,9 +334,21 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
     int32_t orow_c[D / R], orow_n[D / R], orow_nn[D / R];
     auto tile_of = [&](int64_t grp, int d) { return sch.cur + (grp * D + d) * sch.step; };
     auto my_tile = [&](int64_t grp, int b) { return tile_of(grp, 0) + (int64_t)(b * R + (R == 1 ? 0 : g)) * sch.step; };
+    const int32_t pair_cap = last_row >= 1 ? ((last_row - 1) & ~0) : 0;  // largest valid pair base
     auto ids_of = [&](int64_t grp) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) load_row_ids<KI>(L, clamp_row(tile_of(grp, d)), rid[d]);
+        for (int d = 0; d < D; ++d) {
+            if (WIDE)
+                load_row_ids_wide<KI>(L, clamp_row(tile_of(grp, d)), rid[d]);
+            else
+                load_row_ids<KI>(L, clamp_row(tile_of(grp, d)), rid[d]);
+        }
+    };
+    auto raw_of = [&](int d, RawTile<KI> &t) {
+        if (WIDE)
+            load_raw_wide<KI>(L, rid[d], pair_cap, t);
+        else
+            load_raw<KI>(L, rid[d], t);
     };
     auto orows_of = [&](int64_t grp, int32_t (&orow)[D / R]) {
 #pragma unroll
@@ -291,13 +361,13 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
     ids_of(0);
     orows_of(0, orow_c);
 #pragma unroll
-    for (int d = 0; d < D; ++d) load_raw<KI>(L, rid[d], cur[d]);
+    for (int d = 0; d < D; ++d) raw_of(d, cur[d]);
     ids_of(1);
     orows_of(1, orow_n);
 
     for (int64_t grp = 0; tile_of(grp, 0) < sch.end; ++grp) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) load_raw<KI>(L, rid[d], nxt[d]);
+        for (int d = 0; d < D; ++d) raw_of(d, nxt[d]);
         ids_of(grp + 2);
         orows_of(grp + 2, orow_nn);
 

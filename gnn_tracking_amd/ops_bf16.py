@@ -96,10 +96,11 @@ def mlp_forward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], rel
                   + (4 if epilogue == _capi.EPI_SIGMOID else 2) * mlp.out_dim
                   + (4 if out_idx is not None else 0)
                   + (2 * mlp.out_dim if epilogue == _capi.EPI_RESIDUAL else 0))
-    key = ops.kernel_key(lib, a, False, bf16=True)
-    if key:  # the instantiation also carries the fp32-output (sigmoid) flag
-        key = key[:-1] + (", true" if epilogue == _capi.EPI_SIGMOID else ", false") + (
-            ", 4>" if mlp.out_dim <= 4 else ", 1>")
+    key = ""
+    if ops._TIMER is not None:
+        buf = C.create_string_buffer(160)
+        _capi.check(lib.gnntrk_mlp_forward_bf16_kernel_name(C.byref(a), buf, len(buf)), lib)
+        key = buf.value.decode()
     with ops._timed(out, key, ops._mlp_flops_per_row(mlp) * M, nbytes, M):
         _capi.check(lib.gnntrk_mlp_forward_bf16(C.byref(a), ops._stream(out)), lib)
     return out

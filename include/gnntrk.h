@@ -256,8 +256,9 @@ int gnntrk_permute_rows_bf16(const uint16_t *in, int32_t dim, int32_t in_stride,
  * points.  For matching host-side timings with profiles. */
 int gnntrk_mlp_kernel_name(const gnntrk_mlp *mlp, int32_t n_seg, const gnntrk_seg *seg,
                            int32_t backward, char *buf, size_t len);
-/* same for gnntrk_mlp_backward_bf16, whose instantiation also depends on the gradient
- * slices requested and on the epilogue */
+/* same for the bf16 entry points, whose instantiations also depend on the epilogue, the
+ * segment layout (16-byte loads when every chunk pair allows them) and the gradient slices */
+int gnntrk_mlp_forward_bf16_kernel_name(const gnntrk_mlp_fwd_args *args, char *buf, size_t len);
 int gnntrk_mlp_backward_bf16_kernel_name(const gnntrk_mlp_bwd_args *args, char *buf, size_t len);
 
 /* --------------------------------------------------------------- segment sums

@@ -106,13 +106,12 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, vo
         const int64_t *src = edge_index, *tgt = edge_index + E;
         hipLaunchKernelGGL(gi_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt, E, N, keys_a,
                            vals_a, bad);
-        rc = sort_pairs_u32(keys_a, keys_b, vals_a, reinterpret_cast<uint32_t *>(o->perm), E, bits,
+        // the sorted keys ARE the CSR targets: sort straight into the output array
+        uint32_t *tgt_sorted = reinterpret_cast<uint32_t *>(o->tgt);
+        rc = sort_pairs_u32(keys_a, tgt_sorted, vals_a, reinterpret_cast<uint32_t *>(o->perm), E, bits,
                             temp, temp_bytes, stream);
         if (rc) return rc;
-        rc = check_hip(hipMemcpyAsync(o->tgt, keys_b, (size_t)E * 4, hipMemcpyDeviceToDevice, stream),
-                       "graph_index_build(copy tgt)");
-        if (rc) return rc;
-        hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, keys_b, E, N,
+        hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt_sorted, E, N,
                            o->rowptr_t);
         hipLaunchKernelGGL(gi_gather_src_kernel, dim3(grid), dim3(kTpb), 0, stream, src,
                            reinterpret_cast<const uint32_t *>(o->perm), E, o->src, keys_a, vals_a);

@@ -93,18 +93,13 @@ __device__ __forceinline__ uint32_t opaque_u32(uint32_t v) {
     return v;
 }
 // acc += A * B (K = 16) for the weight-gradient accumulators that live across the whole
-// tile loop.  The product goes to a scratch tile (C = 0) and is added with VALU adds: the
-// VGPR-destination MFMA form the compiler selects here cannot write its own SrcC tuple, so
-// "acc = mfma(a, b, acc)" allocates a second tuple per accumulator and copies it back every
-// iteration - the same instruction count as the adds, but twice the registers (144 instead
-// of 72 for the default shape), which costs a wave of occupancy.
+// tile loop.  Known cost: the VGPR-destination MFMA form the compiler selects
+// is not tied to its SrcC; in the large backward loop the register allocator gives most
+// accumulators a second tuple and copies it back every iteration (v_mov per register per
+// tile).  Written as a separate add it is folded back into the same MFMA; inline-asm /
+// AGPR pinning either spills or halves the VGPR budget.
 __device__ __forceinline__ void mfma_bf16_k16_acc(u32x2 a, u32x2 b, f32x4 &acc) {
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 t = mfma_bf16_k16(a, b, zero);
-    acc[0] += t[0];
-    acc[1] += t[1];
-    acc[2] += t[2];
-    acc[3] += t[3];
+    acc = mfma_bf16_k16(a, b, acc);
 }
 __device__ __forceinline__ void drain_mfma() {}
 #endif  // GNNTRK_BF16_PRIMITIVES

@@ -599,3 +599,46 @@ def case_rows_bf16(device):
                 node = gi.tgt.cpu().long() if by == "tgt" else gi.src.cpu().long()
                 ref.index_add_(0, node, csr.float().cpu())
             assert_close(out.float(), ref.to(torch.bfloat16).float(), TOL16, f"segment_sum16 {by} N={N} D={D}")
+
+
+def case_hipgraph_capture(device):
+    """The training step is capturable as a HIP graph (every gnntrk_* call is stream
+    ordered, allocation- and sync-free); a replay reproduces the eager gradients bit for bit."""
+    z = load("g2_ec_variants.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y = tt(z["y"], device).float()
+    name = "skip1_L3_h40"
+    for bf16 in (False, True):
+        model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_VARIANTS[name])
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        data = G.Data(x=x, edge_index=ei, edge_attr=ea)
+
+        def step():
+            ops.clear_graph_index_cache()
+            for p_ in model.parameters():
+                if p_.grad is not None:
+                    p_.grad.zero_()
+            with G.bf16_storage(bf16):
+                out = model(data)
+                loss = G.EdgeWeightBCELoss()(w=out["W"], y=y)
+                loss.backward()
+            return loss
+
+        for _ in range(2):
+            step()
+        eager = {k: v.grad.clone() for k, v in model.named_parameters()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        for p_ in model.parameters():
+            p_.grad.fill_(7.0)  # must be overwritten by the replay
+        g.replay()
+        torch.cuda.synchronize()
+        for k, v in model.named_parameters():
+            assert torch.equal(v.grad, eager[k]), f"hipGraph replay differs from eager: {k} (bf16={bf16})"

@@ -97,3 +97,7 @@ def test_bf16_backward_is_reproducible(dev):
 
 def test_bf16_row_helpers(dev):
     P.case_rows_bf16(dev)
+
+
+def test_training_step_is_hipgraph_capturable(dev):
+    P.case_hipgraph_capture(dev)

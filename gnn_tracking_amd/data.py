@@ -71,6 +71,43 @@ class Data:
     def detach(self):
         return self._map(lambda t: t.detach())
 
+    # -- PyG ``Data.edge_subgraph`` / ``Data.subgraph`` as the reference uses them
+    # (models/track_condensation_networks.py:252,259): every edge-level attribute is
+    # filtered by the edge mask; ``subgraph`` keeps a node subset, filters node-level
+    # attributes, drops edges touching removed nodes and relabels ``edge_index``.
+    def edge_subgraph(self, mask: Tensor) -> "Data":
+        out = copy.copy(self)
+        for k in self.keys():
+            v = getattr(self, k)
+            if k == "edge_index":
+                out.edge_index = v[:, mask]
+            elif self.is_edge_attr(k):
+                setattr(out, k, v[mask])
+        return out
+
+    def subgraph(self, subset: Tensor) -> "Data":
+        n = self.num_nodes
+        dev = self.edge_index.device
+        if subset.dtype == torch.bool:
+            node_mask = subset
+        else:
+            node_mask = torch.zeros(n, dtype=torch.bool, device=dev)
+            node_mask[subset] = True
+        relabel = torch.full((n,), -1, dtype=torch.long, device=dev)
+        relabel[node_mask] = torch.arange(int(node_mask.sum()), device=dev)
+        ei = self.edge_index
+        emask = node_mask[ei[0]] & node_mask[ei[1]]
+        out = copy.copy(self)
+        for k in self.keys():
+            v = getattr(self, k)
+            if k == "edge_index":
+                out.edge_index = relabel[ei[:, emask]]
+            elif self.is_edge_attr(k):
+                setattr(out, k, v[emask])
+            elif self.is_node_attr(k):
+                setattr(out, k, v[node_mask])
+        return out
+
     def is_edge_attr(self, key: str) -> bool:
         if key == "edge_index" or "index" in key:
             return False

@@ -1,0 +1,188 @@
+"""Graph track-condensation networks on the fused HIP kernels.
+
+Reference: models/track_condensation_networks.py:118-403 (``ModularGraphTCN``, ``GraphTCN``,
+``PreTrainedECGraphTCN``) and models/mlp.py:65-123 (``ResFCNN``).  Same constructor
+keywords, ``hparams``, ``state_dict`` keys and output dict
+``{"W", "H", "B", "ec_hit_mask", "ec_edge_mask"}``.
+
+Data flow: edge classifier -> threshold cut on ``W`` (edge compaction,
+``Data.edge_subgraph``) -> optional orphan-node masking (``Data.subgraph``: relabelled
+``edge_index``) -> node / edge encoders -> track-condenser ``ResIN`` on the pruned graph
+-> beta head (clamped sigmoid, fused epilogue) and cluster-coordinate head.  The MLPs and
+interaction networks are the fused kernels of this package; the mask / compaction /
+relabel bookkeeping between them uses torch's device ops (boolean indexing, unique).
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import Tensor, nn
+
+from . import _capi, ops, precision
+from .edge_classifier import ECForGraphTCN
+from .hparams import HyperparametersMixin, obj_from_or_to_hparams
+from .mlp import MLP
+from .resin import ResIN
+
+
+class ResFCNN(nn.Module):
+    def __init__(self, *, in_dim: int, hidden_dim: int, out_dim: int, depth: int, alpha: float = 0.6,
+                 bias: bool = True):
+        """Fully connected network with residual connections (models/mlp.py:65-123):
+        L2-normalised input -> encoder -> ``depth-1`` residual hidden layers -> decoder.
+
+        Only ``depth == 1`` (normalise -> Linear -> ReLU -> Linear: the node encoder of
+        ``ModularGraphTCN``) runs on the fused kernels; deeper stacks raise
+        ``NotImplementedError`` (not on the reference's default path).
+        """
+        super().__init__()
+        if depth < 1:
+            raise ValueError("Depth must be at least 1")
+        if depth != 1:
+            raise NotImplementedError("ResFCNN: only depth=1 is implemented on the fused kernels")
+        self._encoder = nn.Linear(in_dim, hidden_dim, bias=bias)
+        self._decoder = nn.Linear(hidden_dim, out_dim, bias=bias)
+        self._layers = nn.ModuleList([])
+        self._reset_layer_parameters(self._encoder, var=1 / in_dim)
+        self._reset_layer_parameters(self._decoder, var=2 / hidden_dim)
+        self._alpha = alpha
+
+    @staticmethod
+    def _reset_layer_parameters(layer, var: float):
+        layer.reset_parameters()
+        for p in layer.parameters():
+            nn.init.normal_(p.data, mean=0, std=math.sqrt(var))
+
+    def forward(self, x: Tensor, *, epilogue: int = _capi.EPI_NONE, **ignore) -> Tensor:
+        x = nn.functional.normalize(x.float(), p=2.0, dim=1, eps=1e-12)
+        if precision.use_bf16():  # bf16 storage: the normalised rows enter the kernels as bf16
+            x = x.to(torch.bfloat16)
+        return ops.fused_mlp([ops.Seg(x)], [self._encoder.weight, self._decoder.weight],
+                             [self._encoder.bias, self._decoder.bias], epilogue=epilogue)
+
+
+class ModularGraphTCN(nn.Module, HyperparametersMixin):
+    def __init__(self, *, ec: nn.Module | None = None, hc_in: nn.Module, node_indim: int,
+                 edge_indim: int, h_dim: int = 5, e_dim: int = 4, h_outdim: int = 2,
+                 hidden_dim: int = 40, feed_edge_weights: bool = False, ec_threshold: float = 0.5,
+                 mask_orphan_nodes: bool = False, use_ec_embeddings_for_hc: bool = False,
+                 alpha_latent: float = 0.0, n_embedding_coords: int = 0,
+                 heterogeneous_node_encoder: bool = False):
+        """Track condensation network on pre-constructed graphs: optional edge classifier,
+        node / edge encoders to ``(h_dim, e_dim)``, a track condenser ``hc_in`` and the
+        beta / cluster heads (arguments as models/track_condensation_networks.py:118-170).
+        """
+        super().__init__()
+        self.save_hyperparameters(ignore=["ec", "hc_in"])
+        if heterogeneous_node_encoder:
+            raise NotImplementedError("heterogeneous_node_encoder=True is not implemented")
+        self.relu = nn.ReLU()
+        self.ec = obj_from_or_to_hparams(self, "ec", ec)
+        self.hc_in = obj_from_or_to_hparams(self, "hc_in", hc_in)
+        node_enc_indim, edge_enc_indim = node_indim, edge_indim
+        if use_ec_embeddings_for_hc:
+            ec_node_latent_dim, ec_edge_latent_dim = ec.latent_dim
+            node_enc_indim += int(ec_node_latent_dim)
+            edge_enc_indim += int(ec_edge_latent_dim)
+        edge_enc_indim += int(feed_edge_weights)
+        self.hc_edge_encoder = MLP(edge_enc_indim, e_dim, hidden_dim=hidden_dim, L=2, bias=False)
+        self.hc_node_encoder = ResFCNN(in_dim=node_enc_indim, out_dim=h_dim, hidden_dim=hidden_dim,
+                                       depth=1, bias=False, alpha=0)
+        self.p_beta = MLP(h_dim, 1, hidden_dim, L=3)
+        self.p_cluster = MLP(h_dim, h_outdim, hidden_dim, L=3)
+        self._latent_normalization = nn.Parameter(torch.Tensor([1.0]), requires_grad=True)
+
+    def forward(self, data) -> dict[str, Tensor | None]:
+        edge_weights_unmasked = edge_mask = hit_mask = None
+        if self.ec is not None:
+            ec_result = self.ec(data)
+            data.edge_weights = ec_result["W"].reshape((-1, 1))
+            data.ec_node_embedding = ec_result.get("node_embedding", None)
+            data.ec_edge_embedding = ec_result.get("edge_embedding", None)
+            edge_weights_unmasked = data.edge_weights.squeeze()
+            edge_mask = (data.edge_weights > self.hparams.ec_threshold).squeeze()
+            data = data.edge_subgraph(edge_mask)
+            if self.hparams.mask_orphan_nodes:
+                connected_nodes = data.edge_index.flatten().unique()
+                hit_mask = torch.zeros(data.num_nodes, dtype=torch.bool, device=data.x.device)
+                hit_mask[connected_nodes] = True
+                data = data.subgraph(connected_nodes)
+            else:
+                hit_mask = torch.ones(data.num_nodes, dtype=torch.bool, device=data.x.device)
+        if self.ec is None and self.hparams.feed_edge_weights:
+            data.edge_weights = data.ec_score.reshape((-1, 1))
+
+        _edge_attrs, _xs = [data.edge_attr], [data.x]
+        if self.hparams.use_ec_embeddings_for_hc:
+            assert data.ec_edge_embedding is not None
+            assert data.ec_node_embedding is not None
+            _edge_attrs.append(data.ec_edge_embedding)
+            _xs.append(data.ec_node_embedding)
+        if self.hparams.feed_edge_weights:
+            _edge_attrs.append(data.edge_weights)
+        # (in bf16 storage mode the EC embeddings are bf16: concatenate in one dtype)
+        cdt = torch.bfloat16 if precision.use_bf16() else torch.float32
+        x = torch.cat([t.to(cdt) for t in _xs], dim=1) if len(_xs) > 1 else _xs[0]
+        edge_attrs = (torch.cat([t.to(cdt) for t in _edge_attrs], dim=1) if len(_edge_attrs) > 1
+                      else _edge_attrs[0]).to(cdt)
+        # relu(encoder(.)) with the ReLU fused as the kernels' epilogue
+        h_hc = self.hc_node_encoder(x, epilogue=_capi.EPI_RELU)
+        edge_attr_hc = self.hc_edge_encoder.fused([ops.Seg(edge_attrs)], epilogue=_capi.EPI_RELU)
+
+        h_hc, _, _ = self.hc_in(h_hc, data.edge_index, edge_attr_hc)
+        # epsilon + (1 - 2 epsilon) * sigmoid(.): the clamped-sigmoid epilogue
+        epsilon = 1e-6
+        beta = self.p_beta.fused([ops.Seg(h_hc)], epilogue=_capi.EPI_SIGMOID, ca=epsilon,
+                                 cb=1 - 2 * epsilon)
+        assert not torch.isnan(beta).any()
+        h = self.p_cluster(h_hc).float()  # H, B and W leave in fp32 in both storage modes
+        if alpha_residue := self.hparams.alpha_latent:
+            nec: int = self.hparams.n_embedding_coords
+            assert nec > 0
+            assert nec <= h.shape[1]
+            residual = nn.functional.pad(data.x[:, :nec], (0, h.shape[1] - nec))
+            h = math.sqrt(alpha_residue) * residual + math.sqrt(1 - alpha_residue) * h
+        h = h * self._latent_normalization
+        return {"W": edge_weights_unmasked, "H": h, "B": beta.squeeze(), "ec_hit_mask": hit_mask,
+                "ec_edge_mask": edge_mask}
+
+
+class GraphTCN(nn.Module, HyperparametersMixin):
+    def __init__(self, node_indim: int, edge_indim: int, *, h_dim=5, e_dim=4, h_outdim=2,
+                 hidden_dim=40, L_ec=3, L_hc=3, alpha_ec: float = 0.5, alpha_hc: float = 0.5,
+                 **kwargs):
+        """``ModularGraphTCN`` with ``ECForGraphTCN`` as edge classifier and a ``ResIN``
+        stack as track condenser (models/track_condensation_networks.py:311-385)."""
+        super().__init__()
+        self.save_hyperparameters()
+        ec = ECForGraphTCN(node_indim=node_indim, edge_indim=edge_indim, hidden_dim=hidden_dim,
+                           interaction_node_dim=h_dim, interaction_edge_dim=e_dim, L_ec=L_ec,
+                           alpha=alpha_ec)
+        hc_in = ResIN(node_dim=h_dim, edge_dim=e_dim, object_hidden_dim=hidden_dim,
+                      relational_hidden_dim=hidden_dim, alpha=alpha_hc, n_layers=L_hc)
+        self._gtcn = ModularGraphTCN(ec=ec, hc_in=hc_in, node_indim=node_indim,
+                                     edge_indim=edge_indim, h_dim=h_dim, e_dim=e_dim,
+                                     h_outdim=h_outdim, hidden_dim=hidden_dim, **kwargs)
+
+    def forward(self, data) -> dict[str, Tensor | None]:
+        return self._gtcn.forward(data=data)
+
+
+class PreTrainedECGraphTCN(nn.Module, HyperparametersMixin):
+    def __init__(self, ec, *, node_indim: int, edge_indim: int, h_dim=5, e_dim=4, h_outdim=2,
+                 hidden_dim=40, L_hc=3, alpha_hc: float = 0.5, **kwargs):
+        """``GraphTCN`` with a given (pre-trained) edge classifier
+        (models/track_condensation_networks.py:457-517)."""
+        super().__init__()
+        self.save_hyperparameters(ignore=["ec"])
+        ec = obj_from_or_to_hparams(self, "ec", ec)
+        hc_in = ResIN(node_dim=h_dim, edge_dim=e_dim, object_hidden_dim=hidden_dim,
+                      relational_hidden_dim=hidden_dim, alpha=alpha_hc, n_layers=L_hc)
+        self._gtcn = ModularGraphTCN(ec=ec, hc_in=hc_in, node_indim=node_indim,
+                                     edge_indim=edge_indim, h_dim=h_dim, e_dim=e_dim,
+                                     h_outdim=h_outdim, hidden_dim=hidden_dim, **kwargs)
+
+    def forward(self, data) -> dict[str, Tensor | None]:
+        return self._gtcn.forward(data=data)

@@ -62,6 +62,7 @@ from gnn_tracking.models.graph_construction import (  # noqa: E402
 )
 from gnn_tracking.models.interaction_network import InteractionNetwork  # noqa: E402
 from gnn_tracking.models.resin import ResIN  # noqa: E402
+from gnn_tracking.models.track_condensation_networks import GraphTCN  # noqa: E402
 
 Data = _ref_standins.Data
 torch.set_num_threads(4)
@@ -422,6 +423,75 @@ def g6_mlgc(test_graph):
     npz("g6_mlgc.npz", **arrs)
 
 
+GTCN_VARIANTS = {
+    # tests/test_tcn_training.py:109-117 builds GraphTCN(h_dim=2, hidden_dim=2, L_ec=2, L_hc=2)
+    "test_cfg": dict(h_dim=2, hidden_dim=2, L_ec=2, L_hc=2),
+    "default": dict(),
+    "orphans_ecfeed": dict(L_ec=2, L_hc=2, hidden_dim=16, mask_orphan_nodes=True,
+                           use_ec_embeddings_for_hc=True, feed_edge_weights=True),
+    "latent": dict(L_ec=1, L_hc=2, hidden_dim=8, h_outdim=4, alpha_latent=0.4, n_embedding_coords=3),
+}
+
+
+def g7_graph_tcn():
+    """GraphTCN (ModularGraphTCN: EC -> threshold cut -> orphan masking -> encoders -> ResIN
+    track condenser -> beta / cluster heads) on the G2 graph: outputs, masks and the
+    gradients of sum(H*rH) + sum(B*rB) + BCE(W, y)."""
+    print("G7 GraphTCN variants")
+    x, ei, ea, y, pt = synth_graph(2, 300, 2000, 14, 4)
+    g = np.random.default_rng(77)
+    arrs = dict(x=x, edge_index=ei, edge_attr=ea, y=y)
+    worst = 0.0
+    for name, kw in GTCN_VARIANTS.items():
+        # the cut must remove a real fraction of the edges: put the threshold at the 40 %
+        # quantile of this model's edge weights (they do not depend on it), away from any weight
+        torch.manual_seed(11)
+        probe = GraphTCN(14, 4, **kw)
+        wq = probe._gtcn.ec(Data(x=x, edge_index=ei, edge_attr=ea))["W"].detach().sort().values
+        gaps = wq[int(0.25 * len(wq)):int(0.55 * len(wq))].double()
+        j = int((gaps[1:] - gaps[:-1]).argmax())
+        kw = dict(kw, ec_threshold=float((gaps[j] + gaps[j + 1]) / 2))
+        torch.manual_seed(11)
+        model = GraphTCN(14, 4, **kw)
+        p0 = sd(model)
+        data = Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=torch.zeros(x.shape[0], dtype=torch.long))
+        out = model(data)
+        thr = kw["ec_threshold"]
+        arrs[f"{name}/ec_threshold"] = np.float64(thr)
+        margin = (out["W"].detach() - thr).abs().min().item()
+        assert margin > 1e-6, f"{name}: an edge weight sits {margin:.1e} from the threshold"
+        rH = torch.from_numpy(g.normal(size=tuple(out["H"].shape))).float()
+        rB = torch.from_numpy(g.normal(size=tuple(out["B"].shape))).float()
+        loss = (out["H"] * rH).sum() + (out["B"] * rB).sum() + EdgeWeightBCELoss()(w=out["W"], y=y.float())
+        loss.backward()
+        okw = dict(L_ec=kw.get("L_ec", 3), L_hc=kw.get("L_hc", 3))
+        for k in ("ec_threshold", "mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc",
+                  "alpha_latent", "n_embedding_coords"):
+            if k in kw:
+                okw[k] = kw[k]
+        po = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+        oo = O.graph_tcn(x, ei, ea, po, **okw)
+        assert torch.equal(oo["ec_edge_mask"], out["ec_edge_mask"]) and torch.equal(oo["ec_hit_mask"], out["ec_hit_mask"])
+        worst = max(worst, close(oo["W"], out["W"], 1e-6, name + " W"), close(oo["H"], out["H"], 1e-5, name + " H"),
+                    close(oo["B"], out["B"], 1e-6, name + " B"))
+        ol = (oo["H"] * rH).sum() + (oo["B"] * rB).sum() + O.edge_weight_bce_loss(oo["W"], y.float())
+        og = torch.autograd.grad(ol, list(po.values()), allow_unused=True)
+        for (k, v), gk in zip(model.named_parameters(), og):
+            gm = v.grad if v.grad is not None else torch.zeros_like(v)
+            gk = gk if gk is not None else torch.zeros_like(v)
+            worst = max(worst, close(gk, gm, 1e-5, f"{name} grad {k}"))
+            arrs[f"{name}/p0/{k}"] = p0[k]
+            arrs[f"{name}/grad/{k}"] = gm
+        for k in ("W", "H", "B", "ec_hit_mask", "ec_edge_mask"):
+            arrs[f"{name}/{k}"] = out[k]
+        arrs[f"{name}/rH"], arrs[f"{name}/rB"] = rH, rB
+        arrs[f"{name}/loss"] = loss
+        print(f"   {name}: {int(out['ec_edge_mask'].sum())} of {ei.shape[1]} edges kept, "
+              f"{int(out['ec_hit_mask'].sum())} of {x.shape[0]} hits, threshold margin {margin:.1e}")
+    print(f"  oracle == reference (max diff {worst:.2e})")
+    npz("g7_graph_tcn.npz", **arrs)
+
+
 if __name__ == "__main__":
     assert REF.is_dir(), "needs /root/reference (build container only)"
     tg = g1_ec_testgraph()
@@ -431,4 +501,5 @@ if __name__ == "__main__":
     g4_knn(tg)
     g5_oc()
     g6_mlgc(tg)
+    g7_graph_tcn()
     print("all goldens written; oracle pinned against the reference.")

@@ -495,3 +495,60 @@ def ec_for_graph_tcn_bf16(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: d
     eps = 0.001
     w = eps + (1 - 2 * eps) * torch.sigmoid(run("W", 3, w_in))
     return {"W": w.squeeze(), "node_embedding": h, "edge_embedding": e}
+
+
+# ---------------------------------------------------------------------------------------
+# Graph track-condensation network
+def res_fcnn_depth1(x: Tensor, p: dict, prefix: str) -> Tensor:
+    """models/mlp.py:65-123 with depth=1, bias=False: normalise -> Linear -> ReLU -> Linear."""
+    x = torch.nn.functional.normalize(x, p=2.0, dim=1, eps=1e-12)
+    h = torch.clamp_min(x @ p[f"{prefix}._encoder.weight"].t(), 0.0)
+    return h @ p[f"{prefix}._decoder.weight"].t()
+
+
+def graph_tcn(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *, L_ec: int, L_hc: int,
+              alpha_ec: float = 0.5, alpha_hc: float = 0.5, ec_threshold: float = 0.5,
+              mask_orphan_nodes: bool = False, feed_edge_weights: bool = False,
+              use_ec_embeddings_for_hc: bool = False, alpha_latent: float = 0.0,
+              n_embedding_coords: int = 0, prefix: str = "_gtcn") -> dict:
+    """models/track_condensation_networks.py:236-308 (``ModularGraphTCN.forward`` as built by
+    ``GraphTCN``, homogeneous node encoder)."""
+    relu = lambda t: torch.clamp_min(t, 0.0)  # noqa: E731
+    pe = {k[len(prefix) + 4:]: v for k, v in p.items() if k.startswith(prefix + ".ec.")}
+    ec = ec_for_graph_tcn(x, edge_index, edge_attr, pe, L_ec=L_ec, alpha=alpha_ec)
+    w = ec["W"].reshape(-1, 1)
+    edge_mask = (w > ec_threshold).squeeze(1)
+    ei = edge_index[:, edge_mask]
+    ea = edge_attr[edge_mask]
+    w_m = w[edge_mask]
+    ee = ec["edge_embedding"][edge_mask]
+    xn, en = x, ec["node_embedding"]
+    n = x.shape[0]
+    if mask_orphan_nodes:
+        connected = ei.flatten().unique()
+        hit_mask = torch.zeros(n, dtype=torch.bool)
+        hit_mask[connected] = True
+        relabel = torch.full((n,), -1, dtype=torch.long)
+        relabel[hit_mask] = torch.arange(int(hit_mask.sum()))
+        ei = relabel[ei]
+        xn, en = x[hit_mask], en[hit_mask]
+    else:
+        hit_mask = torch.ones(n, dtype=torch.bool)
+    xs, eas = [xn], [ea]
+    if use_ec_embeddings_for_hc:
+        xs.append(en)
+        eas.append(ee)
+    if feed_edge_weights:
+        eas.append(w_m)
+    h = relu(res_fcnn_depth1(torch.cat(xs, 1), p, f"{prefix}.hc_node_encoder"))
+    e = relu(mlp(torch.cat(eas, 1), p, f"{prefix}.hc_edge_encoder", 2, bias=False))
+    h, _, _ = resin(h, ei, e, p, f"{prefix}.hc_in", n_layers=L_hc, alpha=alpha_hc)
+    eps = 1e-6
+    beta = eps + (1 - 2 * eps) * torch.sigmoid(mlp(h, p, f"{prefix}.p_beta", 3))
+    hh = mlp(h, p, f"{prefix}.p_cluster", 3)
+    if alpha_latent:
+        res = torch.nn.functional.pad(xn[:, :n_embedding_coords], (0, hh.shape[1] - n_embedding_coords))
+        hh = math.sqrt(alpha_latent) * res + math.sqrt(1 - alpha_latent) * hh
+    hh = hh * p[f"{prefix}._latent_normalization"]
+    return {"W": w.squeeze(1), "H": hh, "B": beta.squeeze(1), "ec_hit_mask": hit_mask,
+            "ec_edge_mask": edge_mask}

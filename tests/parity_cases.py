@@ -642,3 +642,78 @@ def case_hipgraph_capture(device):
         torch.cuda.synchronize()
         for k, v in model.named_parameters():
             assert torch.equal(v.grad, eager[k]), f"hipGraph replay differs from eager: {k} (bf16={bf16})"
+
+
+# ------------------------------------------------ graph track-condensation network (8f-1)
+GTCN_VARIANTS = {
+    "test_cfg": dict(h_dim=2, hidden_dim=2, L_ec=2, L_hc=2),
+    "default": dict(),
+    "orphans_ecfeed": dict(L_ec=2, L_hc=2, hidden_dim=16, mask_orphan_nodes=True,
+                           use_ec_embeddings_for_hc=True, feed_edge_weights=True),
+    "latent": dict(L_ec=1, L_hc=2, hidden_dim=8, h_outdim=4, alpha_latent=0.4, n_embedding_coords=3),
+}
+
+
+def gtcn_oracle_kwargs(kw, thr):
+    okw = dict(L_ec=kw.get("L_ec", 3), L_hc=kw.get("L_hc", 3), ec_threshold=thr)
+    for k in ("mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc", "alpha_latent",
+              "n_embedding_coords"):
+        if k in kw:
+            okw[k] = kw[k]
+    return okw
+
+
+def case_graph_tcn(device, names=None):
+    """GraphTCN (EC -> threshold cut -> orphan masking -> encoders -> ResIN -> beta / cluster
+    heads) against the reference-generated golden G7: masks bit-exact, W/H/B 1e-5, gradients
+    of sum(H rH) + sum(B rB) + BCE(W, y) 1e-4."""
+    z = load("g7_graph_tcn.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y = tt(z["y"], device)
+    for name, kw in GTCN_VARIANTS.items():
+        if names is not None and name not in names:
+            continue
+        thr = float(z[f"{name}/ec_threshold"])
+        model = G.GraphTCN(14, 4, ec_threshold=thr, **kw)
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y))
+        assert torch.equal(out["ec_edge_mask"].cpu(), tt(z[f"{name}/ec_edge_mask"])), name + " edge mask"
+        assert torch.equal(out["ec_hit_mask"].cpu(), tt(z[f"{name}/ec_hit_mask"])), name + " hit mask"
+        assert_close(out["W"], z[f"{name}/W"], TOL_OUT, name + " W")
+        assert_close(out["H"], z[f"{name}/H"], TOL_OUT, name + " H")
+        assert_close(out["B"], z[f"{name}/B"], TOL_OUT, name + " B")
+        loss = ((out["H"] * tt(z[f"{name}/rH"], device)).sum() + (out["B"] * tt(z[f"{name}/rB"], device)).sum()
+                + G.EdgeWeightBCELoss()(w=out["W"], y=y.float()))
+        assert_close(loss, z[f"{name}/loss"], TOL_OUT, name + " loss")
+        loss.backward()
+        for k, v in model.named_parameters():
+            gk = v.grad if v.grad is not None else torch.zeros_like(v)
+            assert_close(gk, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
+
+
+def case_graph_tcn_bf16(device):
+    """bf16 storage through the whole GraphTCN: runs, fp32 outputs, finite, every parameter
+    with a path to the loss gets an fp32 gradient.  (No value comparison: the threshold cut
+    can differ from the fp32 golden once W moves by a bf16-sized amount.)"""
+    z = load("g7_graph_tcn.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y = tt(z["y"], device)
+    for name, kw in GTCN_VARIANTS.items():
+        model = G.GraphTCN(14, 4, ec_threshold=float(z[f"{name}/ec_threshold"]), **kw)
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        with G.bf16_storage():
+            out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y))
+            loss = out["H"].square().sum() + out["B"].sum() + G.EdgeWeightBCELoss()(w=out["W"], y=y.float())
+            loss.backward()
+        for k in ("W", "H", "B"):
+            assert out[k].dtype == torch.float32 and torch.isfinite(out[k]).all(), f"{name} {k}"
+        # (the golden thresholds sit inside a dense cluster of weights, so the kept fraction
+        # itself moves with bf16 noise; it only has to stay a genuine cut)
+        kept = out["ec_edge_mask"].float().mean().item()
+        assert 0.02 < kept < 0.98, f"{name}: cut keeps {kept:.2f} of the edges"
+        for k, v in model.named_parameters():
+            gref = tt(z[f"{name}/grad/{k}"])
+            if gref.abs().max() > 0:
+                assert v.grad is not None and v.grad.dtype == torch.float32 and torch.isfinite(v.grad).all(), k

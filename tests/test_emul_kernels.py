@@ -58,3 +58,8 @@ def test_condensation_losses_and_mask():
     with emulated():
         P.case_good_node_mask("cpu")
         P.case_condensation_losses("cpu")
+
+
+def test_graph_tcn_emulated():
+    with emulated():
+        P.case_graph_tcn("cpu", names=("latent",))

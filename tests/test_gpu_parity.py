@@ -101,3 +101,11 @@ def test_bf16_row_helpers(dev):
 
 def test_training_step_is_hipgraph_capturable(dev):
     P.case_hipgraph_capture(dev)
+
+
+def test_graph_tcn(dev):
+    P.case_graph_tcn(dev)
+
+
+def test_graph_tcn_bf16_storage(dev):
+    P.case_graph_tcn_bf16(dev)

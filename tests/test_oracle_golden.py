@@ -98,3 +98,21 @@ def test_ml_graph_construction_edges():
         assert torch.equal(ei, tt(z[f"k{k}_r{r}/edge_index"]))
         assert torch.equal(y, tt(z[f"k{k}_r{r}/y"]))
         assert torch.equal(f, tt(z[f"k{k}_r{r}/edge_attr"]))
+
+
+def test_graph_tcn():
+    z = load("g7_graph_tcn.npz")
+    x, ei, ea, y = (tt(z[k]) for k in ("x", "edge_index", "edge_attr", "y"))
+    for name, kw in P.GTCN_VARIANTS.items():
+        p0 = {k: v.clone().requires_grad_(True) for k, v in _params(z, f"{name}/p0/").items()}
+        out = O.graph_tcn(x, ei, ea, p0, **P.gtcn_oracle_kwargs(kw, float(z[f"{name}/ec_threshold"])))
+        assert torch.equal(out["ec_edge_mask"], tt(z[f"{name}/ec_edge_mask"]))
+        assert torch.equal(out["ec_hit_mask"], tt(z[f"{name}/ec_hit_mask"]))
+        for k in ("W", "H", "B"):
+            assert_close(out[k], z[f"{name}/{k}"], 1e-6 if k != "H" else 1e-5, f"{name} {k}")
+        loss = ((out["H"] * tt(z[f"{name}/rH"])).sum() + (out["B"] * tt(z[f"{name}/rB"])).sum()
+                + O.edge_weight_bce_loss(out["W"], y.float()))
+        grads = torch.autograd.grad(loss, list(p0.values()), allow_unused=True)
+        for (k, v), g in zip(p0.items(), grads):
+            g = g if g is not None else torch.zeros_like(v)
+            assert_close(g, z[f"{name}/grad/{k}"], 1e-5, f"{name} grad {k}")

@@ -16,6 +16,7 @@ from .interaction_network import InteractionNetwork
 from .graph_construction import MLGraphConstruction, knn_with_max_radius
 from .graph_masks import get_good_node_mask, get_good_node_mask_tensors
 from .losses_ec import EdgeWeightBCELoss, falsify_low_pt_edges
+from .losses_ml import GraphConstructionHingeEmbeddingLoss
 from .losses_oc import CondensationLossRG, CondensationLossTiger, MultiLossFctReturn
 from .mlp import MLP
 from .precision import bf16_storage
@@ -28,4 +29,4 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "EdgeWeightBCELoss", "falsify_low_pt_edges", "MLGraphConstruction",
            "knn_with_max_radius", "get_good_node_mask", "get_good_node_mask_tensors",
            "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage", "GraphTCN", "ModularGraphTCN",
-           "PreTrainedECGraphTCN", "ResFCNN"]
+           "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss"]

@@ -55,6 +55,9 @@ from gnn_tracking.metrics.losses.oc import (  # noqa: E402
     CondensationLossRG,
     CondensationLossTiger,
 )
+from gnn_tracking.metrics.losses.metric_learning import (  # noqa: E402
+    GraphConstructionHingeEmbeddingLoss,
+)
 from gnn_tracking.models.edge_classifier import ECForGraphTCN  # noqa: E402
 from gnn_tracking.models.graph_construction import (  # noqa: E402
     MLGraphConstruction,
@@ -423,6 +426,61 @@ def g6_mlgc(test_graph):
     npz("g6_mlgc.npz", **arrs)
 
 
+PINNED_HINGE = {  # /root/reference/tests/test_losses.py:194-203 (td1)
+    "n_hits_oi": {"attractive": 0.7307405975481213, "repulsive": 11.076146539572338},
+    "n_rep_edges": {"attractive": 0.7307405975481213, "repulsive": 0.34612957938781874},
+}
+
+
+def g8_hinge():
+    """GraphConstructionHingeEmbeddingLoss: the reference's pinned float64 case td1, fp32
+    re-runs with gradients, and a two-event case (radius graph restricted by ``batch``)."""
+    from gnn_tracking.preprocessing.point_cloud_builder import get_truth_edge_index
+
+    print("G8 metric-learning hinge loss")
+    arrs = {}
+    cases = {"td1": _loss_testdata(50, 3, 0), "td4": _loss_testdata(1200, 150, 9, n_x=4)}
+    for cn, td in cases.items():
+        td["true_edge_index"] = torch.from_numpy(get_truth_edge_index(td["particle_id"].numpy()))
+        n = td["x"].shape[0]
+        td["batch"] = torch.zeros(n, dtype=torch.long) if cn == "td1" else (torch.arange(n) >= 700).long()
+        if cn == "td4":
+            td["x"] = td["x"] * 2.5
+            te = td["true_edge_index"]  # true edges never cross events
+            td["true_edge_index"] = te[:, td["batch"][te[0]] == td["batch"][te[1]]]
+        for norm in ("n_hits_oi", "n_rep_edges"):
+            for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+                t = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in td.items()}
+                x = t["x"].clone().requires_grad_(True)
+                ret = GraphConstructionHingeEmbeddingLoss(rep_normalization=norm, lw_repulsive=0.7)(
+                    x=x, particle_id=t["particle_id"], batch=t["batch"], true_edge_index=t["true_edge_index"],
+                    pt=t["pt"], eta=t["eta"], reconstructable=t["reconstructable"])
+                ld = ret.loss_dct
+                if cn == "td1" and dt is torch.float64:
+                    for k, v in PINNED_HINGE[norm].items():
+                        assert abs(ld[k].item() - v) <= 1e-9 * abs(v), (norm, k, ld[k].item())
+                ret.loss.backward()
+                mask = O.good_node_mask(t["pt"], t["particle_id"], t["reconstructable"], t["eta"])
+                xo = t["x"].clone().requires_grad_(True)
+                od = O.hinge_embedding_loss(x=xo, particle_id=t["particle_id"], batch=t["batch"],
+                                            true_edge_index=t["true_edge_index"], mask=mask, rep_normalization=norm)
+                tol = 1e-9 if dt is torch.float64 else 2e-5
+                for k in ("attractive", "repulsive"):
+                    close(od[k], ld[k], tol, f"{cn} {norm} {dt_name} {k}")
+                    arrs[f"{cn}/{dt_name}/{norm}/{k}"] = ld[k]
+                assert od["n_edges_rep"] == ret.extra_metrics["n_edges_rep"]
+                (od["attractive"] + 0.7 * od["repulsive"]).backward()
+                close(xo.grad, x.grad, 1e-8 if dt is torch.float64 else 2e-4, f"{cn} {norm} {dt_name} gx")
+                arrs[f"{cn}/{dt_name}/{norm}/grad_x"] = x.grad
+                arrs[f"{cn}/{dt_name}/{norm}/total"] = ret.loss
+                arrs[f"{cn}/{norm}/n_edges_rep"] = np.int64(od["n_edges_rep"])
+        for k, v in td.items():
+            arrs[f"{cn}/{k}"] = v
+        print(f"   {cn}: {od['n_edges_att']} attractive, {od['n_edges_rep']} repulsive edges, {od['n_hits_oi']} hits of interest")
+    print("  oracle == reference; reference == its own pinned values")
+    npz("g8_hinge.npz", **arrs)
+
+
 GTCN_VARIANTS = {
     # tests/test_tcn_training.py:109-117 builds GraphTCN(h_dim=2, hidden_dim=2, L_ec=2, L_hc=2)
     "test_cfg": dict(h_dim=2, hidden_dim=2, L_ec=2, L_hc=2),
@@ -502,4 +560,5 @@ if __name__ == "__main__":
     g5_oc()
     g6_mlgc(tg)
     g7_graph_tcn()
+    g8_hinge()
     print("all goldens written; oracle pinned against the reference.")

@@ -552,3 +552,33 @@ def graph_tcn(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *, L_ec
     hh = hh * p[f"{prefix}._latent_normalization"]
     return {"W": w.squeeze(1), "H": hh, "B": beta.squeeze(1), "ec_hit_mask": hit_mask,
             "ec_edge_mask": edge_mask}
+
+
+# ---------------------------------------------------------------------------------------
+# Metric-learning hinge loss
+def hinge_embedding_loss(*, x: Tensor, particle_id: Tensor, batch: Tensor | None, true_edge_index: Tensor,
+                         mask: Tensor, r_emb: float = 1.0, max_num_neighbors: int = 256,
+                         p_attr: float = 1.0, p_rep: float = 1.0, rep_normalization: str = "n_hits_oi",
+                         rep_oi_only: bool = True) -> dict:
+    """metrics/losses/metric_learning.py:14-55,94-178: attractive term over the true edges
+    that start at a hit of interest, repulsive hinge over the radius-graph edges (same event,
+    d < r_emb) that start at a hit of interest and join different particles."""
+    eps = 1e-9
+    near = radius_graph(x, r_emb, max_num_neighbors=max_num_neighbors, batch=batch)
+    rep = near[:, mask[near[0]]] if rep_oi_only else near
+    rep = rep[:, particle_id[rep[0]] != particle_id[rep[1]]]
+    att = true_edge_index[:, mask[true_edge_index[0]]]
+    d_att = torch.linalg.norm(x[att[0]] - x[att[1]], dim=-1)
+    v_att = torch.sum(torch.pow(d_att, p_attr)) / (att.shape[1] + eps)
+    d_rep = torch.linalg.norm(x[rep[0]] - x[rep[1]], dim=-1)
+    if rep_normalization == "n_rep_edges":
+        norm_rep = rep.shape[1] + eps
+    elif rep_normalization == "n_hits_oi":
+        norm_rep = mask.sum() + eps
+    elif rep_normalization == "n_att_edges":
+        norm_rep = att.shape[1] + eps
+    else:
+        raise ValueError(f"Normalization {rep_normalization} not recognized.")
+    v_rep = torch.sum(torch.relu(r_emb - torch.pow(d_rep, p_rep))) / norm_rep
+    return {"attractive": v_att, "repulsive": v_rep, "n_edges_att": att.shape[1],
+            "n_edges_rep": rep.shape[1], "n_hits_oi": int(mask.sum())}

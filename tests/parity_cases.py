@@ -717,3 +717,24 @@ def case_graph_tcn_bf16(device):
             gref = tt(z[f"{name}/grad/{k}"])
             if gref.abs().max() > 0:
                 assert v.grad is not None and v.grad.dtype == torch.float32 and torch.isfinite(v.grad).all(), k
+
+
+def case_hinge_loss(device, cases=("td1", "td4")):
+    """GraphConstructionHingeEmbeddingLoss vs the reference (G8: the reference's pinned td1
+    values re-run in fp32, and a two-event case), loss terms, edge counts and grad wrt x."""
+    z = load("g8_hinge.npz")
+    for cn in cases:
+        t = {k: tt(z[f"{cn}/{k}"]) for k in ("x", "particle_id", "pt", "eta", "reconstructable", "batch",
+                                              "true_edge_index")}
+        for norm in ("n_hits_oi", "n_rep_edges"):
+            x = t["x"].float().to(device).requires_grad_(True)
+            ret = G.GraphConstructionHingeEmbeddingLoss(rep_normalization=norm, lw_repulsive=0.7)(
+                x=x, particle_id=t["particle_id"].to(device), batch=t["batch"].to(device),
+                true_edge_index=t["true_edge_index"].to(device), pt=t["pt"].float().to(device),
+                eta=t["eta"].float().to(device), reconstructable=t["reconstructable"].float().to(device))
+            assert ret.extra_metrics["n_edges_rep"] == int(z[f"{cn}/{norm}/n_edges_rep"]), f"{cn} edge count"
+            for k in ("attractive", "repulsive"):
+                assert_close(ret.loss_dct[k], z[f"{cn}/f32/{norm}/{k}"], 2e-5, f"{cn} {norm} {k}")
+            assert_close(ret.loss, z[f"{cn}/f32/{norm}/total"], 2e-5, f"{cn} {norm} total")
+            ret.loss.backward()
+            assert_close(x.grad, z[f"{cn}/f32/{norm}/grad_x"], 2e-4, f"{cn} {norm} grad x")

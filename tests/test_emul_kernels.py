@@ -63,3 +63,8 @@ def test_condensation_losses_and_mask():
 def test_graph_tcn_emulated():
     with emulated():
         P.case_graph_tcn("cpu", names=("latent",))
+
+
+def test_hinge_loss_emulated():
+    with emulated():
+        P.case_hinge_loss("cpu", cases=("td1",))

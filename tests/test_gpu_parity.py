@@ -109,3 +109,7 @@ def test_graph_tcn(dev):
 
 def test_graph_tcn_bf16_storage(dev):
     P.case_graph_tcn_bf16(dev)
+
+
+def test_hinge_embedding_loss(dev):
+    P.case_hinge_loss(dev)

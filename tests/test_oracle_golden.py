@@ -116,3 +116,21 @@ def test_graph_tcn():
         for (k, v), g in zip(p0.items(), grads):
             g = g if g is not None else torch.zeros_like(v)
             assert_close(g, z[f"{name}/grad/{k}"], 1e-5, f"{name} grad {k}")
+
+
+def test_hinge_loss_pinned():
+    z = load("g8_hinge.npz")
+    pinned = {"n_hits_oi": (0.7307405975481213, 11.076146539572338),
+              "n_rep_edges": (0.7307405975481213, 0.34612957938781874)}  # reference tests/test_losses.py:194-203
+    for cn in ("td1", "td4"):
+        t = {k: tt(z[f"{cn}/{k}"]) for k in ("x", "particle_id", "pt", "eta", "reconstructable", "batch",
+                                              "true_edge_index")}
+        mask = O.good_node_mask(t["pt"], t["particle_id"], t["reconstructable"], t["eta"])
+        for norm in pinned:
+            od = O.hinge_embedding_loss(x=t["x"], particle_id=t["particle_id"], batch=t["batch"],
+                                        true_edge_index=t["true_edge_index"], mask=mask, rep_normalization=norm)
+            assert_close(od["attractive"], z[f"{cn}/f64/{norm}/attractive"], 1e-9, f"{cn} att")
+            assert_close(od["repulsive"], z[f"{cn}/f64/{norm}/repulsive"], 1e-9, f"{cn} rep")
+            if cn == "td1":
+                assert abs(float(od["attractive"]) - pinned[norm][0]) < 1e-9
+                assert abs(float(od["repulsive"]) - pinned[norm][1]) < 1e-8

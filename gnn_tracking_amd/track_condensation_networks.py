@@ -31,23 +31,28 @@ class ResFCNN(nn.Module):
     def __init__(self, *, in_dim: int, hidden_dim: int, out_dim: int, depth: int, alpha: float = 0.6,
                  bias: bool = True):
         """Fully connected network with residual connections (models/mlp.py:65-123):
-        L2-normalised input -> encoder -> ``depth-1`` residual hidden layers -> decoder.
+        L2-normalised input -> encoder -> ``depth-1`` residual hidden layers
+        ``x = sqrt(a) x + sqrt(1-a) W relu(x)`` -> decoder on ``relu(x)``.
 
-        Only ``depth == 1`` (normalise -> Linear -> ReLU -> Linear: the node encoder of
-        ``ModularGraphTCN``) runs on the fused kernels; deeper stacks raise
-        ``NotImplementedError`` (not on the reference's default path).
+        ``depth == 1`` with a hidden width the fused kernels cover (the node encoder of
+        ``ModularGraphTCN``) is ONE fused gather-MLP launch.  Deeper / wider stacks (the
+        metric-learning embedding network: hidden 256-512, depth 6) are plain GEMM-shaped
+        work on [N, hidden] x [hidden, hidden] and go to the library GEMM (hipBLASLt through
+        ``torch.nn.functional.linear``), with the residual mix as torch device ops.
         """
         super().__init__()
         if depth < 1:
             raise ValueError("Depth must be at least 1")
-        if depth != 1:
-            raise NotImplementedError("ResFCNN: only depth=1 is implemented on the fused kernels")
         self._encoder = nn.Linear(in_dim, hidden_dim, bias=bias)
         self._decoder = nn.Linear(hidden_dim, out_dim, bias=bias)
-        self._layers = nn.ModuleList([])
+        self._layers = nn.ModuleList([nn.Linear(hidden_dim, hidden_dim, bias=bias) for _ in range(depth - 1)])
         self._reset_layer_parameters(self._encoder, var=1 / in_dim)
+        for layer in self._layers:
+            self._reset_layer_parameters(layer, var=2 / hidden_dim)
         self._reset_layer_parameters(self._decoder, var=2 / hidden_dim)
         self._alpha = alpha
+        self._fusable = (depth == 1 and in_dim <= _capi.MAX_IN and hidden_dim <= 63
+                         and out_dim <= _capi.MAX_OUT)
 
     @staticmethod
     def _reset_layer_parameters(layer, var: float):
@@ -56,11 +61,33 @@ class ResFCNN(nn.Module):
             nn.init.normal_(p.data, mean=0, std=math.sqrt(var))
 
     def forward(self, x: Tensor, *, epilogue: int = _capi.EPI_NONE, **ignore) -> Tensor:
+        _capi.require_device(x)
         x = nn.functional.normalize(x.float(), p=2.0, dim=1, eps=1e-12)
-        if precision.use_bf16():  # bf16 storage: the normalised rows enter the kernels as bf16
-            x = x.to(torch.bfloat16)
-        return ops.fused_mlp([ops.Seg(x)], [self._encoder.weight, self._decoder.weight],
-                             [self._encoder.bias, self._decoder.bias], epilogue=epilogue)
+        if self._fusable:
+            if precision.use_bf16():  # bf16 storage: the normalised rows enter the kernels as bf16
+                x = x.to(torch.bfloat16)
+            return ops.fused_mlp([ops.Seg(x)], [self._encoder.weight, self._decoder.weight],
+                                 [self._encoder.bias, self._decoder.bias], epilogue=epilogue)
+        x = self._encoder(x)
+        for layer in self._layers:
+            x = math.sqrt(self._alpha) * x + math.sqrt(1 - self._alpha) * layer(torch.relu(x))
+        x = self._decoder(torch.relu(x))
+        return torch.relu(x) if epilogue == _capi.EPI_RELU else x
+
+
+class GraphConstructionFCNN(ResFCNN, HyperparametersMixin):
+    def __init__(self, *, in_dim: int, hidden_dim: int, out_dim: int, depth: int, alpha: float = 0.6):
+        """Embedding network of the metric-learning graph construction
+        (models/graph_construction.py:25-53): ``ResFCNN`` without biases plus a learnable
+        normalisation of the latent space; ``forward(data) -> {"H": ...}``."""
+        super().__init__(in_dim=in_dim, hidden_dim=hidden_dim, out_dim=out_dim, depth=depth, alpha=alpha,
+                         bias=False)
+        self._latent_normalization = nn.Parameter(torch.tensor([1.0]), requires_grad=True)
+        self.save_hyperparameters()
+
+    def forward(self, data) -> dict[str, Tensor]:
+        out = ResFCNN.forward(self, data.x).float() * self._latent_normalization
+        return {"H": out}
 
 
 class ModularGraphTCN(nn.Module, HyperparametersMixin):

@@ -60,6 +60,7 @@ from gnn_tracking.metrics.losses.metric_learning import (  # noqa: E402
 )
 from gnn_tracking.models.edge_classifier import ECForGraphTCN  # noqa: E402
 from gnn_tracking.models.graph_construction import (  # noqa: E402
+    GraphConstructionFCNN,
     MLGraphConstruction,
     knn_with_max_radius,
 )
@@ -426,6 +427,36 @@ def g6_mlgc(test_graph):
     npz("g6_mlgc.npz", **arrs)
 
 
+def g9_gc_fcnn():
+    """GraphConstructionFCNN (ResFCNN depth 1 and 4 + latent normalisation) on seeded hits:
+    H and the gradients of sum(H * r)."""
+    print("G9 GraphConstructionFCNN")
+    g = np.random.default_rng(12)
+    x = torch.from_numpy(g.normal(size=(700, 14))).float()
+    arrs = dict(x=x)
+    for name, kw in {"d1_h40": dict(hidden_dim=40, depth=1, out_dim=8), "d4_h96": dict(hidden_dim=96, depth=4, out_dim=8, alpha=0.6)}.items():
+        torch.manual_seed(5)
+        model = GraphConstructionFCNN(in_dim=14, **kw)
+        with torch.no_grad():
+            model._latent_normalization.fill_(1.7)
+        p0 = sd(model)
+        out = model(Data(x=x))["H"]
+        r = torch.from_numpy(g.normal(size=tuple(out.shape))).float()
+        (out * r).sum().backward()
+        po = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+        pp = {"." + k: v for k, v in po.items()}
+        oo = O.res_fcnn(x, pp, "", kw["depth"], kw.get("alpha", 0.6)) * po["_latent_normalization"]
+        close(oo, out, 1e-5, name + " H")
+        og = torch.autograd.grad((oo * r).sum(), list(po.values()))
+        for (k, v), gk in zip(model.named_parameters(), og):
+            close(gk, v.grad, 1e-4, f"{name} grad {k}")
+            arrs[f"{name}/p0/{k}"] = p0[k]
+            arrs[f"{name}/grad/{k}"] = v.grad
+        arrs[f"{name}/H"], arrs[f"{name}/r"] = out, r
+    print("  oracle == reference")
+    npz("g9_gc_fcnn.npz", **arrs)
+
+
 PINNED_HINGE = {  # /root/reference/tests/test_losses.py:194-203 (td1)
     "n_hits_oi": {"attractive": 0.7307405975481213, "repulsive": 11.076146539572338},
     "n_rep_edges": {"attractive": 0.7307405975481213, "repulsive": 0.34612957938781874},
@@ -561,4 +592,5 @@ if __name__ == "__main__":
     g6_mlgc(tg)
     g7_graph_tcn()
     g8_hinge()
+    g9_gc_fcnn()
     print("all goldens written; oracle pinned against the reference.")

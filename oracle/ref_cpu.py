@@ -582,3 +582,12 @@ def hinge_embedding_loss(*, x: Tensor, particle_id: Tensor, batch: Tensor | None
     v_rep = torch.sum(torch.relu(r_emb - torch.pow(d_rep, p_rep))) / norm_rep
     return {"attractive": v_att, "repulsive": v_rep, "n_edges_att": att.shape[1],
             "n_edges_rep": rep.shape[1], "n_hits_oi": int(mask.sum())}
+
+
+def res_fcnn(x: Tensor, p: dict, prefix: str, depth: int, alpha: float) -> Tensor:
+    """models/mlp.py:65-123, bias=False, any depth."""
+    x = torch.nn.functional.normalize(x, p=2.0, dim=1, eps=1e-12)
+    x = x @ p[f"{prefix}._encoder.weight"].t()
+    for i in range(depth - 1):
+        x = math.sqrt(alpha) * x + math.sqrt(1 - alpha) * (torch.clamp_min(x, 0.0) @ p[f"{prefix}._layers.{i}.weight"].t())
+    return torch.clamp_min(x, 0.0) @ p[f"{prefix}._decoder.weight"].t()

@@ -738,3 +738,22 @@ def case_hinge_loss(device, cases=("td1", "td4")):
             assert_close(ret.loss, z[f"{cn}/f32/{norm}/total"], 2e-5, f"{cn} {norm} total")
             ret.loss.backward()
             assert_close(x.grad, z[f"{cn}/f32/{norm}/grad_x"], 2e-4, f"{cn} {norm} grad x")
+
+
+def case_gc_fcnn(device, names=("d1_h40", "d4_h96")):
+    """GraphConstructionFCNN vs the reference (G9): depth 1 on the fused kernel, depth 4 /
+    hidden 96 on the library GEMM path."""
+    z = load("g9_gc_fcnn.npz")
+    x = tt(z["x"], device)
+    for name, kw in {"d1_h40": dict(hidden_dim=40, depth=1, out_dim=8),
+                     "d4_h96": dict(hidden_dim=96, depth=4, out_dim=8, alpha=0.6)}.items():
+        if name not in names:
+            continue
+        model = G.GraphConstructionFCNN(in_dim=14, **kw)
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        out = model(G.Data(x=x))["H"]
+        assert_close(out, z[f"{name}/H"], TOL_OUT, name + " H")
+        (out * tt(z[f"{name}/r"], device)).sum().backward()
+        for k, v in model.named_parameters():
+            assert_close(v.grad, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")

@@ -68,3 +68,8 @@ def test_graph_tcn_emulated():
 def test_hinge_loss_emulated():
     with emulated():
         P.case_hinge_loss("cpu", cases=("td1",))
+
+
+def test_gc_fcnn_emulated():
+    with emulated():
+        P.case_gc_fcnn("cpu")

@@ -113,3 +113,7 @@ def test_graph_tcn_bf16_storage(dev):
 
 def test_hinge_embedding_loss(dev):
     P.case_hinge_loss(dev)
+
+
+def test_graph_construction_fcnn(dev):
+    P.case_gc_fcnn(dev)

@@ -134,3 +134,11 @@ def test_hinge_loss_pinned():
             if cn == "td1":
                 assert abs(float(od["attractive"]) - pinned[norm][0]) < 1e-9
                 assert abs(float(od["repulsive"]) - pinned[norm][1]) < 1e-8
+
+
+def test_gc_fcnn():
+    z = load("g9_gc_fcnn.npz")
+    for name, depth in (("d1_h40", 1), ("d4_h96", 4)):
+        p0 = {"." + k: v for k, v in _params(z, f"{name}/p0/").items()}
+        out = O.res_fcnn(tt(z["x"]), p0, "", depth, 0.6) * p0["._latent_normalization"]
+        assert_close(out, z[f"{name}/H"], 1e-5, name)

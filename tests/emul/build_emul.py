@@ -37,13 +37,31 @@ def build(asan: bool = False, verbose: bool = False) -> pathlib.Path:
              f"-I{HERE / 'shim'}", f"-I{REPO / 'include'}", f"-I{CSRC}"]
     if asan:
         flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
-    cmd = ["g++", *flags]
-    for s in srcs:
-        cmd += ["-x", "c++", str(s)]
-    cmd += ["-x", "c++", str(HERE / "emul_runtime.cpp"), "-o", str(lib)]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    # one object per translation unit, compiled in parallel (the bf16 kernel headers make a
+    # single g++ invocation the longest step of a fresh CPU test run)
+    import concurrent.futures as cf
+    import os
+
+    cflags = [f for f in flags if f != "-shared"]
+    units = [(s, OUT / (s.stem + (".asan" if asan else "") + ".o")) for s in srcs]
+    units.append((HERE / "emul_runtime.cpp", OUT / ("emul_runtime" + (".asan" if asan else "") + ".o")))
+
+    def compile_one(unit):
+        src, obj = unit
+        cmd = ["g++", *cflags, "-c", "-x", "c++", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return subprocess.run(cmd, capture_output=True, text=True)
+
+    with cf.ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2)))) as ex:
+        results = list(ex.map(compile_one, units))
+    for r in results:
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("emulator build failed")
+    link = ["g++", "-shared", "-pthread", *(["-fsanitize=address,undefined"] if asan else []),
+            *[str(o) for _, o in units], "-o", str(lib)]
+    r = subprocess.run(link, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("emulator build failed")

@@ -11,6 +11,7 @@ no CPU fallback.
 """
 
 from .data import Data, collate
+from .io import GraphDataset, PrefetchLoader, load_graph
 from .edge_classifier import ECForGraphTCN
 from .interaction_network import InteractionNetwork
 from .graph_construction import MLGraphConstruction, knn_with_max_radius
@@ -30,4 +31,4 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "knn_with_max_radius", "get_good_node_mask", "get_good_node_mask_tensors",
            "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage", "GraphTCN", "ModularGraphTCN",
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
-           "GraphConstructionFCNN"]
+           "GraphConstructionFCNN", "load_graph", "GraphDataset", "PrefetchLoader"]

@@ -1,0 +1,182 @@
+"""Reading the reference's on-disk graphs without PyG.
+
+The reference stores one ``torch_geometric.data.Data`` per event with ``torch.save``
+(graph_construction/graph_builder.py:396-455: ``x`` f32[N,14], ``edge_index`` i64[2,E],
+``edge_attr`` f32[E,4], ``y``, ``pt``, ``particle_id`` i64, ``reconstructable``, ``sector``,
+``evtid``, ``s``, ``eta``, ``layer``) and reads them back in utils/loading.py:17-113.
+Such a file is a pickle that references PyG classes; here it is opened with a RESTRICTED
+unpickler: tensors and plain containers are rebuilt, the PyG container classes are mapped to
+inert stand-ins whose ``_store._mapping`` dict carries the fields, everything else is refused
+(no arbitrary code execution from a data file).
+
+``PrefetchLoader`` overlaps disk reads + host-to-device copies of the next graphs with the
+training step: a background thread fills pinned host buffers, the copy runs on a side stream.
+"""
+
+from __future__ import annotations
+
+import collections
+import io as _io
+import pathlib
+import pickle
+import queue
+import threading
+from typing import Iterable, Iterator, Sequence
+
+import torch
+
+from .data import Data, collate
+
+_PYG_CONTAINERS = {
+    ("torch_geometric.data.data", "Data"), ("torch_geometric.data.data", "DataEdgeAttr"),
+    ("torch_geometric.data.data", "DataTensorAttr"), ("torch_geometric.data.storage", "GlobalStorage"),
+    ("torch_geometric.data.storage", "BaseStorage"), ("torch_geometric.data.storage", "NodeStorage"),
+    ("torch_geometric.data.storage", "EdgeStorage"),
+}
+_ALLOWED = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"),
+    ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "int"),
+    ("builtins", "float"), ("builtins", "str"), ("builtins", "bool"), ("builtins", "slice"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+    ("torch._utils", "_rebuild_parameter"), ("torch", "Size"), ("torch", "device"),
+    ("torch.serialization", "_get_layout"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "scalar"), ("numpy", "dtype"),
+}
+
+
+class _Inert:
+    """Stand-in for a PyG container: keeps whatever state the pickle assigns."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, st):
+        self.__dict__.update(st if isinstance(st, dict) else {"_state": st})
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _PYG_CONTAINERS:
+            return type(name, (_Inert,), {})
+        if (module, name) in _ALLOWED:
+            return super().find_class(module, name)
+        if module == "torch" and (name.endswith("Storage") or name in (
+                "float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8",
+                "bool")):
+            return getattr(torch, name)
+        raise pickle.UnpicklingError(f"graph file references {module}.{name}: not a tensor container, refused")
+
+
+class _RestrictedPickle:
+    """Duck-typed ``pickle_module`` for ``torch.load``."""
+
+    __name__ = "gnn_tracking_amd.io.restricted_pickle"
+    Unpickler = _RestrictedUnpickler
+    UnpicklingError = pickle.UnpicklingError
+
+    @staticmethod
+    def load(f, **kw):
+        return _RestrictedUnpickler(f, **kw).load()
+
+
+def _fields(obj) -> dict:
+    if isinstance(obj, dict):
+        return obj
+    store = obj.__dict__.get("_store", None)
+    if store is not None:
+        mapping = store.__dict__.get("_mapping", None)
+        if isinstance(mapping, dict):
+            return mapping
+    return {k: v for k, v in obj.__dict__.items() if not k.startswith("_")}
+
+
+def load_graph(path, device=None) -> Data:
+    """Read one reference ``.pt`` graph into this package's ``Data`` (no PyG needed)."""
+    with open(path, "rb") as f:
+        payload = f.read()
+    obj = torch.load(_io.BytesIO(payload), map_location="cpu", pickle_module=_RestrictedPickle,
+                     weights_only=False)
+    fields = {k: v for k, v in _fields(obj).items() if v is not None}
+    if "x" not in fields or "edge_index" not in fields:
+        raise ValueError(f"{path}: not a graph file (fields: {sorted(fields)})")
+    d = Data(**fields)
+    return d if device is None else d.to(device)
+
+
+class GraphDataset:
+    """The ``*.pt`` files of one or several directories (utils/loading.py:17-113: sorted by
+    name, optional ``start``/``stop`` slice and sector filter)."""
+
+    def __init__(self, in_dirs: str | Sequence[str], *, start: int = 0, stop: int | None = None,
+                 sector: int | None = None):
+        dirs = [in_dirs] if isinstance(in_dirs, (str, pathlib.Path)) else list(in_dirs)
+        files: list[pathlib.Path] = []
+        for d in dirs:
+            files += sorted(pathlib.Path(d).glob("*.pt"))
+        if sector is not None:
+            files = [f for f in files if f.stem.endswith(f"_s{sector}")]
+        self.files = files[start:stop]
+
+    def __len__(self) -> int:
+        return len(self.files)
+
+    def __getitem__(self, i: int) -> Data:
+        return load_graph(self.files[i])
+
+
+class PrefetchLoader:
+    """Iterate over batches of ``batch_size`` collated graphs on ``device``.  A background
+    thread reads and collates the next ``depth`` batches into pinned memory; the
+    host-to-device copy is issued on a side stream and joined when the batch is handed out."""
+
+    def __init__(self, dataset, *, batch_size: int = 1, device=None, depth: int = 2, shuffle: bool = False,
+                 seed: int = 0):
+        self.dataset, self.batch_size, self.depth = dataset, int(batch_size), max(1, int(depth))
+        self.device = torch.device(device) if device is not None else None
+        self.shuffle, self.seed, self._epoch = shuffle, seed, 0
+
+    def __len__(self) -> int:
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def _order(self) -> list[int]:
+        idx = list(range(len(self.dataset)))
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self._epoch)
+            idx = torch.randperm(len(idx), generator=g).tolist()
+        return idx
+
+    def __iter__(self) -> Iterator[Data]:
+        order = self._order()
+        self._epoch += 1
+        q: queue.Queue = queue.Queue(maxsize=self.depth)
+        cuda = self.device is not None and self.device.type == "cuda"
+        side = torch.cuda.Stream(self.device) if cuda else None
+
+        def produce():
+            try:
+                for s in range(0, len(order), self.batch_size):
+                    batch = collate([self.dataset[i] for i in order[s:s + self.batch_size]])
+                    if cuda:
+                        batch = batch._map(lambda t: t.pin_memory())
+                        with torch.cuda.stream(side):
+                            dev_batch = batch.to(self.device, non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                        q.put((dev_batch, ev, batch))  # keep the pinned source alive until consumed
+                    else:
+                        q.put((batch if self.device is None else batch.to(self.device), None, None))
+                q.put(None)
+            except BaseException as e:  # surface loader errors in the consumer
+                q.put(e)
+
+        threading.Thread(target=produce, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            batch, ev, _pinned = item
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+            yield batch

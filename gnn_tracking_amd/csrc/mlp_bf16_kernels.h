@@ -529,7 +529,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
     gci_ptr gidx[GT];  // optional row permutation of the gradient slice (never NULL, see LaneChunks)
     int32_t gstride[GT], gin_off[GT];
     uint32_t gkeep[GT][2];
-    bool gon[GT], grelu[GT], gidx_on[GT];
+    uint32_t gmul_and[GT], gmul_or[GT];  // relu' multiplier (min(x, 1) & and) | or: branch-free "no ReLU" = 1
+    bool gon[GT], gidx_on[GT];
     gh_ptr my_trash = (gh_ptr) reinterpret_cast<uint16_t *>(trash + ((int64_t)(blockIdx.x * kWaves + wv) * 64 + lane) * 8);
 #pragma unroll
     for (int T = 0; T < GT; ++T) {
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         gidx_on[T] = false;
         gstride[T] = 0;
         gin_off[T] = 0;
-        grelu[T] = false;
+        bool relu_in = false;
         int d = 0;
         if (gon[T]) {
             const int p = s_plan.gchunk[q], j = s_plan.seg[p];
@@ -553,8 +554,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 gidx_on[T] = true;
             }
             gin_off[T] = 8 * p;  // byte offset of the chunk inside a row of the input image
-            grelu[T] = s_seg[j].relu != 0;
+            relu_in = s_seg[j].relu != 0;
         }
+        gmul_and[T] = relu_in ? 0xffffffffu : 0u;
+        gmul_or[T] = relu_in ? 0u : 0x00010001u;
         gkeep[T][0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
         gkeep[T][1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
     }
@@ -794,12 +797,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 const f32x4 acc = contract_hidden<HT>(wimg + I::kD1 + T * hid_k_dwords(HT), g1, lane, zero);
                 u32x2 gi = pack_tile(acc);
                 const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn + c * S::kInRow + (gin_off[T] ^ in_swz));
-                gi[0] = grelu[T] ? gate_bf16x2(gi[0], xin[0], k_one) : gi[0];
-                gi[1] = grelu[T] ? gate_bf16x2(gi[1], xin[1], k_one) : gi[1];
+                gi[0] = u16x2_mul(gi[0], (i16x2_min(xin[0], k_one) & gmul_and[T]) | gmul_or[T]);
+                gi[1] = u16x2_mul(gi[1], (i16x2_min(xin[1], k_one) & gmul_and[T]) | gmul_or[T]);
                 gi[0] &= gkeep[T][0];
                 gi[1] &= gkeep[T][1];
-                const bool st = gon[T] && valid;
-                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(st ? gptr[T] + (int64_t)srow[T] * gstride[T] : my_trash) = gi;
+                // (lanes without a chunk already point at their trash slot with stride 0)
+                const gh_ptr dst = gptr[T] + (int64_t)srow[T] * gstride[T];
+                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(valid ? dst : my_trash) = gi;
             }
             {
                 u32x2 bt[2 * KI];

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_ar
         stage_items<NI>(it, sc, part, c, pv);
         item_row_ids<NI>(it, clamp_row(tile + sch.step < sch.end ? tile + sch.step : tile), rid_n);
     }
-    for (; tile < sch.end; tile += sch.step) {
+    // counted loop on a scalar trip count: a plain do-while for the compiler (loop-carried
+    // MFMA accumulators are then updated in place instead of being copied every iteration)
+    const int n_iter = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tile < sch.end ? (sch.end - tile + sch.step - 1) / sch.step : 0));
+    for (int iter = 0; iter < n_iter; ++iter, tile += sch.step) {
         const int64_t row = tile * kTileRows + c;
         const bool valid = row < a.n_rows;
         item_values<NI>(it, rid_n, part, row_valid(tile + sch.step) && ld_on, pv);
@@ -418,7 +421,10 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
         item_row_ids<NI>(it, clamp_row(t1), rid_n);
         gout_rows(clamp_row(t1), gr0_n, gr1_n);
     }
-    for (; tile < sch.end; tile += sch.step) {
+    // counted loop on a scalar trip count: a plain do-while for the compiler (loop-carried
+    // MFMA accumulators are then updated in place instead of being copied every iteration)
+    const int n_iter = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tile < sch.end ? (sch.end - tile + sch.step - 1) / sch.step : 0));
+    for (int iter = 0; iter < n_iter; ++iter, tile += sch.step) {
         const int64_t row = tile * kTileRows + c;
         const bool valid = row < a.n_rows;
         item_values<NI>(it, rid_n, part, row_valid(tile + sch.step) && ld_on, pv);

@@ -365,7 +365,10 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
     ids_of(1);
     orows_of(1, orow_n);
 
-    for (int64_t grp = 0; tile_of(grp, 0) < sch.end; ++grp) {
+    // (counted loop on a scalar trip count, see mlp16_bwd_kernel)
+    const int64_t gstep = sch.step * D;
+    const int n_grp = (int)__builtin_amdgcn_readfirstlane((uint32_t)((sch.end - sch.cur + gstep - 1) / gstep));
+    for (int grp = 0; grp < n_grp; ++grp) {
 #pragma unroll
         for (int d = 0; d < D; ++d) raw_of(d, nxt[d]);
         ids_of(grp + 2);
@@ -664,7 +667,11 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         for (int d = 0; d < D; ++d) ids_of(1, d);
     }
 
-    for (int64_t grp = 0; tile_of(grp, 0) < sch.end; ++grp) {
+    // counted loop on a scalar trip count: a plain do-while for the compiler, so the
+    // loop-carried weight-gradient accumulators are updated in place
+    const int64_t span = sch.end - sch.cur, gstep = sch.step * D;
+    const int n_grp = (int)__builtin_amdgcn_readfirstlane((uint32_t)(span > 0 ? (span + gstep - 1) / gstep : 0));
+    for (int grp = 0; grp < n_grp; ++grp) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             load_raw<KI>(L, rid[d], nxt[d]);

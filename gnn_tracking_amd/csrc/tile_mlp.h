@@ -178,7 +178,11 @@ __device__ inline TileSched make_sched(int64_t n_tiles, int waves = kWaves) {
     const int x = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
     const int64_t t0 = n_tiles * x / nx, t1 = n_tiles * (x + 1) / nx;
     TileSched s;
-    s.cur = t0 + lb * waves + (threadIdx.x >> 6);
+    // the wave index is wave-uniform: taken through readfirstlane the whole schedule lives in
+    // SGPRs and the tile loop is a uniform (scalar-branch) loop.  As a divergent loop its
+    // loop-carried MFMA accumulators needed an exec-masked copy per register and iteration
+    // (an MFMA writes all lanes regardless of exec).
+    s.cur = t0 + lb * waves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     s.end = t1;
     s.step = (int64_t)bpx * waves;
     return s;

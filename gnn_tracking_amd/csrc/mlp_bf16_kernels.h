@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
     __shared__ SlotPlan s_plan;
     __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];
     __shared__ gnntrk_gseg s_gseg[GNNTRK_MAX_SEGS];
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15, wv = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
     stage_seg_args(s_seg, a.seg, tid);
 #pragma unroll
     for (int j = 0; j < GNNTRK_MAX_SEGS; ++j)

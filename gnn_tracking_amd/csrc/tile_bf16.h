@@ -93,11 +93,8 @@ __device__ __forceinline__ uint32_t opaque_u32(uint32_t v) {
     return v;
 }
 // acc += A * B (K = 16) for the weight-gradient accumulators that live across the whole
-// tile loop.  Known cost: the VGPR-destination MFMA form the compiler selects
-// is not tied to its SrcC; in the large backward loop the register allocator gives most
-// accumulators a second tuple and copies it back every iteration (v_mov per register per
-// tile).  Written as a separate add it is folded back into the same MFMA; inline-asm /
-// AGPR pinning either spills or halves the VGPR budget.
+// tile loop.  They are updated in place as long as the tile loop is a uniform counted loop
+// (DESIGN.md 4.3): in a divergent loop every accumulator is copied once per iteration.
 __device__ __forceinline__ void mfma_bf16_k16_acc(u32x2 a, u32x2 b, f32x4 &acc) {
     acc = mfma_bf16_k16(a, b, acc);
 }

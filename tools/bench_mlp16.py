@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--events", type=int, default=32)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--bwd", action="store_true")
+ap.add_argument("--head", action="store_true", help="also time the edge-weight head shape")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 events = [synthetic.make_event(100 + i, 150_000, 2_000_000, dev) for i in range(args.events)]
@@ -82,3 +83,38 @@ if args.bwd:
     tb = timeit(bwd16, args.iters)
     alg = E * (8 + 8 + 32 + 8 + 8 + 8 + 32)
     print(f"rel bwd  E={E}: bf16 {tb:.3f} ms ({E / tb / 1e6:.1f} G rows/s, alg {alg / tb / 1e9:.2f} TB/s)")
+
+
+if args.head:
+    # ECForGraphTCN.W: h[src], h[tgt], four edge tensors -> 40 -> 40 -> 1, sigmoid epilogue,
+    # W scattered back into edge_index order (out_idx = perm)
+    mh = G.MLP(26, 1, 40, L=3).to(dev)
+    Wh = [l.weight.detach().contiguous() for l in mh.linears()]
+    bh = [l.bias.detach().contiguous() for l in mh.linears()]
+    mlph = ops._fill_mlp(Wh, bh)
+    es = []
+    for i in range(4):
+        t = B.empty_rows(E, 4, dev, zero=True)
+        t.copy_(torch.randn(E, 4, device=dev))
+        es.append(t)
+
+    def head(out_idx):
+        return B.mlp_forward_raw([h16, h16] + es, [gi.src, gi.tgt, None, None, None, None], [False] * 6, Wh, bh,
+                                 n_rows=E, epilogue=_capi.EPI_SIGMOID, ca=0.001, cb=0.998, res=None,
+                                 out_idx=out_idx, out_rows=E, mlp=mlph)
+
+    t_sc = timeit(lambda: head(gi.perm), args.iters)
+    t_id = timeit(lambda: head(None), args.iters)
+    print(f"head fwd E={E}: scattered W {t_sc:.3f} ms | CSR-order W {t_id:.3f} ms")
+    if args.bwd:
+        gw = torch.randn(E, 1, device=dev)
+
+        def hbwd(gidx_on, spos):
+            return B.mlp_backward_raw([h16, h16] + es, [gi.src, gi.tgt, None, None, None, None], [False] * 6, Wh, bh,
+                                      n_rows=E, epilogue=_capi.EPI_SIGMOID, ca=0.001, cb=0.998,
+                                      gout=[(gw, gi.perm if gidx_on else None)], need_seg=[True] * 6, want_dw=True,
+                                      mlp=mlph, gidx=[gi.spos_inv if spos else None] + [None] * 5)
+
+        for a_, b_ in ((True, True), (False, True), (False, False)):
+            t = timeit(lambda: hbwd(a_, b_), args.iters)
+            print(f"head bwd: gathered g_W {a_}, source-sorted g_h[src] {b_}: {t:.3f} ms")

@@ -22,8 +22,10 @@ from .losses_oc import CondensationLossRG, CondensationLossTiger, MultiLossFctRe
 from .mlp import MLP
 from .precision import bf16_storage
 from .resin import ResIN
-from .track_condensation_networks import (GraphConstructionFCNN, GraphTCN, ModularGraphTCN,
-                                            PreTrainedECGraphTCN, ResFCNN)
+from .track_condensation_networks import (GraphConstructionFCNN, GraphConstructionHeteroEncResFCNN,
+                                            GraphConstructionHeteroResFCNN, GraphTCN,
+                                            HeterogeneousResFCNN, ModularGraphTCN, PreTrainedECGraphTCN,
+                                            ResFCNN)
 
 __version__ = "0.1.0"
 __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphTCN",
@@ -31,4 +33,5 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "knn_with_max_radius", "get_good_node_mask", "get_good_node_mask_tensors",
            "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage", "GraphTCN", "ModularGraphTCN",
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
-           "GraphConstructionFCNN", "load_graph", "GraphDataset", "PrefetchLoader"]
+           "GraphConstructionFCNN", "HeterogeneousResFCNN", "GraphConstructionHeteroResFCNN",
+           "GraphConstructionHeteroEncResFCNN", "load_graph", "GraphDataset", "PrefetchLoader"]

@@ -107,6 +107,9 @@ _SIGNATURES = {
     "gnntrk_knn_emit": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
     "gnntrk_edge_labels": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "gnntrk_edge_features": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),
+    "gnntrk_compact_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnntrk_threshold_compact": (C.c_int, [_P, C.c_int64, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
+    "gnntrk_connected_nodes": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_good_node_mask": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, _P, _P]),
     "gnntrk_oc_select_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnntrk_oc_select_cps": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P,

@@ -190,6 +190,19 @@ int gnntrk_edge_features(const float *x, int32_t dim, int32_t x_stride, const in
     return edge_features_launch(x, dim, x_stride, edge_index, n_edges, out, (hipStream_t)stream);
 }
 
+size_t gnntrk_compact_workspace_bytes(int64_t n) { return compact_ws_bytes(n); }
+int gnntrk_threshold_compact(const float *w, int64_t n, float threshold, uint8_t *mask, int32_t *idx,
+                             int64_t *n_out, void *workspace, size_t workspace_bytes, void *stream) {
+    return threshold_compact_launch(w, n, threshold, mask, idx, n_out, workspace, workspace_bytes,
+                                    (hipStream_t)stream);
+}
+int gnntrk_connected_nodes(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, uint8_t *hit,
+                           int32_t *node_idx, int32_t *newid, int64_t *n_out, int64_t *edge_index_out,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+    return connected_nodes_launch(edge_index, n_edges, n_nodes, hit, node_idx, newid, n_out, edge_index_out,
+                                  workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int gnntrk_good_node_mask(const float *pt, const int64_t *particle_id, const float *reconstructable,
                           const float *eta, int64_t n, float pt_thld, float max_eta, uint8_t *mask,
                           void *stream) {

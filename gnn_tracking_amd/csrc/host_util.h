@@ -47,6 +47,14 @@ size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m);
 int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes, hipStream_t stream);
 
 
+// compact.hip
+size_t compact_ws_bytes(int64_t n);
+int threshold_compact_launch(const float *w, int64_t n, float threshold, uint8_t *mask, int32_t *idx,
+                             int64_t *n_out, void *ws, size_t ws_bytes, hipStream_t stream);
+int connected_nodes_launch(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, uint8_t *hit,
+                           int32_t *node_idx, int32_t *newid, int64_t *n_out, int64_t *edge_index_out,
+                           void *ws, size_t ws_bytes, hipStream_t stream);
+
 // rows_bf16.hip
 int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
                         uint16_t *out, int out_stride, hipStream_t stream);

@@ -1,7 +1,8 @@
 """Graph track-condensation networks on the fused HIP kernels.
 
 Reference: models/track_condensation_networks.py:118-403 (``ModularGraphTCN``, ``GraphTCN``,
-``PreTrainedECGraphTCN``) and models/mlp.py:65-123 (``ResFCNN``).  Same constructor
+``PreTrainedECGraphTCN``), models/mlp.py:65-178 (``ResFCNN``, ``HeterogeneousResFCNN``) and
+models/graph_construction.py:25-132 (the ``GraphConstruction*FCNN`` embedding networks).  Same constructor
 keywords, ``hparams``, ``state_dict`` keys and output dict
 ``{"W", "H", "B", "ec_hit_mask", "ec_edge_mask"}``.
 
@@ -10,19 +11,21 @@ Data flow: edge classifier -> threshold cut on ``W`` (edge compaction,
 ``edge_index``) -> node / edge encoders -> track-condenser ``ResIN`` on the pruned graph
 -> beta head (clamped sigmoid, fused epilogue) and cluster-coordinate head.  The MLPs and
 interaction networks are the fused kernels of this package; the mask / compaction /
-relabel bookkeeping between them uses torch's device ops (boolean indexing, unique).
+relabel bookkeeping between them is two stream compactions (graph_cut.py, csrc/compact.hip)
+whose index lists gather the attributes.
 """
 
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import Tensor, nn
 
-from . import _capi, ops, precision
+from . import _capi, graph_cut, ops, precision
 from .edge_classifier import ECForGraphTCN
-from .hparams import HyperparametersMixin, obj_from_or_to_hparams
+from .hparams import HyperparametersMixin, assert_feat_dim, obj_from_or_to_hparams
 from .mlp import MLP
 from .resin import ResIN
 
@@ -51,8 +54,10 @@ class ResFCNN(nn.Module):
             self._reset_layer_parameters(layer, var=2 / hidden_dim)
         self._reset_layer_parameters(self._decoder, var=2 / hidden_dim)
         self._alpha = alpha
-        self._fusable = (depth == 1 and in_dim <= _capi.MAX_IN and hidden_dim <= 63
-                         and out_dim <= _capi.MAX_OUT)
+        # depth 1 = a two-layer MLP; depth 2 with alpha = 0 (the heterogeneous node encoder of
+        # ModularGraphTCN) = a three-layer MLP: both are one fused launch
+        self._fusable = ((depth == 1 or (depth == 2 and alpha == 0)) and in_dim <= _capi.MAX_IN
+                         and hidden_dim <= 63 and out_dim <= _capi.MAX_OUT)
 
     @staticmethod
     def _reset_layer_parameters(layer, var: float):
@@ -66,8 +71,9 @@ class ResFCNN(nn.Module):
         if self._fusable:
             if precision.use_bf16():  # bf16 storage: the normalised rows enter the kernels as bf16
                 x = x.to(torch.bfloat16)
-            return ops.fused_mlp([ops.Seg(x)], [self._encoder.weight, self._decoder.weight],
-                                 [self._encoder.bias, self._decoder.bias], epilogue=epilogue)
+            lin = [self._encoder, *self._layers, self._decoder]
+            return ops.fused_mlp([ops.Seg(x)], [l.weight for l in lin], [l.bias for l in lin],
+                                 epilogue=epilogue)
         x = self._encoder(x)
         for layer in self._layers:
             x = math.sqrt(self._alpha) * x + math.sqrt(1 - self._alpha) * layer(torch.relu(x))
@@ -90,6 +96,66 @@ class GraphConstructionFCNN(ResFCNN, HyperparametersMixin):
         return {"H": out}
 
 
+def get_pixel_mask(layer: Tensor) -> Tensor:
+    """models/mlp.py:123-124: hits on the 18 pixel layers."""
+    return torch.isin(layer, torch.arange(18, device=layer.device))
+
+
+class HeterogeneousResFCNN(nn.Module):
+    def __init__(self, *, in_dim: int, out_dim: int, hidden_dim: int, depth: int, alpha: float = 0.6,
+                 bias: bool = True):
+        """Separate ``ResFCNN`` s for pixel and strip hits (models/mlp.py:127-178).  As in the
+        reference the two embeddings are stacked, pixel rows first: the hits are expected
+        sorted by pixel, then strip."""
+        super().__init__()
+        kw = dict(in_dim=in_dim, hidden_dim=hidden_dim, out_dim=out_dim, depth=depth, alpha=alpha, bias=bias)
+        self.pixel_fcnn = ResFCNN(**kw)
+        self.strip_fcnn = ResFCNN(**kw)
+
+    def forward(self, x: Tensor, layer: Tensor, *, epilogue: int = _capi.EPI_NONE) -> Tensor:
+        pixel_mask = get_pixel_mask(layer)
+        if "PYTEST_CURRENT_TEST" not in os.environ and (pixel_mask.all() or not pixel_mask.any()):
+            raise ValueError("All or no pixel data found; this doesn't make sense with heterogeneous model")
+        embed_pixel = self.pixel_fcnn(x[pixel_mask], epilogue=epilogue)
+        embed_strip = self.strip_fcnn(x[~pixel_mask], epilogue=epilogue)
+        return torch.vstack([embed_pixel, embed_strip])
+
+
+class GraphConstructionHeteroResFCNN(HeterogeneousResFCNN, HyperparametersMixin):
+    def __init__(self, *, in_dim: int, hidden_dim: int, out_dim: int, depth: int, alpha: float = 0.6):
+        """Fully heterogeneous embedding network (models/graph_construction.py:56-87)."""
+        super().__init__(in_dim=in_dim, hidden_dim=hidden_dim, out_dim=out_dim, depth=depth, alpha=alpha,
+                         bias=False)
+        self._latent_normalization = nn.Parameter(torch.tensor([1.0]), requires_grad=True)
+        self.save_hyperparameters()
+
+    def forward(self, data) -> dict[str, Tensor]:
+        out = HeterogeneousResFCNN.forward(self, data.x, layer=data.layer).float() * self._latent_normalization
+        return {"H": out}
+
+
+class GraphConstructionHeteroEncResFCNN(nn.Module, HyperparametersMixin):
+    def __init__(self, *, in_dim: int, hidden_dim_enc: int, hidden_dim: int, out_dim: int, depth_enc: int,
+                 depth: int, alpha: float = 0.6):
+        """Heterogeneous encoding, shared ``ResFCNN`` behind it
+        (models/graph_construction.py:90-132)."""
+        super().__init__()
+        self.encoder = HeterogeneousResFCNN(in_dim=in_dim, hidden_dim=hidden_dim_enc, out_dim=hidden_dim,
+                                            depth=depth_enc, alpha=alpha, bias=False)
+        self.fcnn = ResFCNN(in_dim=hidden_dim, hidden_dim=hidden_dim, out_dim=out_dim, depth=depth,
+                            alpha=alpha, bias=False)
+        self._latent_normalization = nn.Parameter(torch.tensor([1.0]), requires_grad=True)
+        self.save_hyperparameters()
+
+    def forward(self, data) -> dict[str, Tensor]:
+        assert_feat_dim(data.x, self.hparams.in_dim)
+        enc = self.encoder(data.x, layer=data.layer, epilogue=_capi.EPI_RELU)
+        assert_feat_dim(enc, self.hparams.hidden_dim)
+        out = self.fcnn(enc).float()
+        assert_feat_dim(out, self.hparams.out_dim)
+        return {"H": out * self._latent_normalization}
+
+
 class ModularGraphTCN(nn.Module, HyperparametersMixin):
     def __init__(self, *, ec: nn.Module | None = None, hc_in: nn.Module, node_indim: int,
                  edge_indim: int, h_dim: int = 5, e_dim: int = 4, h_outdim: int = 2,
@@ -103,8 +169,6 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
         """
         super().__init__()
         self.save_hyperparameters(ignore=["ec", "hc_in"])
-        if heterogeneous_node_encoder:
-            raise NotImplementedError("heterogeneous_node_encoder=True is not implemented")
         self.relu = nn.ReLU()
         self.ec = obj_from_or_to_hparams(self, "ec", ec)
         self.hc_in = obj_from_or_to_hparams(self, "hc_in", hc_in)
@@ -115,8 +179,12 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
             edge_enc_indim += int(ec_edge_latent_dim)
         edge_enc_indim += int(feed_edge_weights)
         self.hc_edge_encoder = MLP(edge_enc_indim, e_dim, hidden_dim=hidden_dim, L=2, bias=False)
-        self.hc_node_encoder = ResFCNN(in_dim=node_enc_indim, out_dim=h_dim, hidden_dim=hidden_dim,
-                                       depth=1, bias=False, alpha=0)
+        if not heterogeneous_node_encoder:
+            self.hc_node_encoder = ResFCNN(in_dim=node_enc_indim, out_dim=h_dim, hidden_dim=hidden_dim,
+                                           depth=1, bias=False, alpha=0)
+        else:
+            self.hc_node_encoder = HeterogeneousResFCNN(in_dim=node_enc_indim, out_dim=h_dim,
+                                                        hidden_dim=hidden_dim, depth=2, bias=False, alpha=0)
         self.p_beta = MLP(h_dim, 1, hidden_dim, L=3)
         self.p_cluster = MLP(h_dim, h_outdim, hidden_dim, L=3)
         self._latent_normalization = nn.Parameter(torch.Tensor([1.0]), requires_grad=True)
@@ -129,13 +197,10 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
             data.ec_node_embedding = ec_result.get("node_embedding", None)
             data.ec_edge_embedding = ec_result.get("edge_embedding", None)
             edge_weights_unmasked = data.edge_weights.squeeze()
-            edge_mask = (data.edge_weights > self.hparams.ec_threshold).squeeze()
-            data = data.edge_subgraph(edge_mask)
+            # threshold cut and orphan masking: device stream compactions (graph_cut.py)
+            data, edge_mask = graph_cut.edge_cut(data, data.edge_weights, self.hparams.ec_threshold)
             if self.hparams.mask_orphan_nodes:
-                connected_nodes = data.edge_index.flatten().unique()
-                hit_mask = torch.zeros(data.num_nodes, dtype=torch.bool, device=data.x.device)
-                hit_mask[connected_nodes] = True
-                data = data.subgraph(connected_nodes)
+                data, hit_mask = graph_cut.drop_orphans(data)
             else:
                 hit_mask = torch.ones(data.num_nodes, dtype=torch.bool, device=data.x.device)
         if self.ec is None and self.hparams.feed_edge_weights:
@@ -155,7 +220,7 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
         edge_attrs = (torch.cat([t.to(cdt) for t in _edge_attrs], dim=1) if len(_edge_attrs) > 1
                       else _edge_attrs[0]).to(cdt)
         # relu(encoder(.)) with the ReLU fused as the kernels' epilogue
-        h_hc = self.hc_node_encoder(x, epilogue=_capi.EPI_RELU)
+        h_hc = self.hc_node_encoder(x, layer=getattr(data, "layer", None), epilogue=_capi.EPI_RELU)
         edge_attr_hc = self.hc_edge_encoder.fused([ops.Seg(edge_attrs)], epilogue=_capi.EPI_RELU)
 
         h_hc, _, _ = self.hc_in(h_hc, data.edge_index, edge_attr_hc)

@@ -326,6 +326,28 @@ int gnntrk_edge_labels(const int64_t *particle_id, const int64_t *edge_index, in
 int gnntrk_edge_features(const float *x, int32_t dim, int32_t x_stride, const int64_t *edge_index,
                          int64_t n_edges, float *out, void *stream);
 
+/* ------------------------------------------------------ ModularGraphTCN glue
+ * Threshold cut and orphan-node masking between the edge classifier and the track condenser
+ * (models/track_condensation_networks.py:251-262).  Deterministic three-pass stream
+ * compaction: outputs in ascending index order, exactly what boolean indexing /
+ * `unique` return.  Counts are written to device memory (`n_out`); the caller reads them
+ * back to size its tensors (the reference's `x[mask]` synchronises in the same place).
+ *
+ * threshold_compact  replaces `mask = W > ec_threshold; data.edge_subgraph(mask)`:
+ *   mask[i] = w[i] > threshold (NaN -> 0), idx[0..n_out[0]) = ascending i with mask[i].
+ *   Edge-level attributes are then gathered with idx.
+ * connected_nodes    replaces `edge_index.flatten().unique()`, `index_to_mask` and the
+ *   relabelling of `data.subgraph(connected)`:
+ *   hit[v] = 1 iff node v is an endpoint of an edge; node_idx[0..n_out[0]) = ascending
+ *   connected nodes; newid[v] = rank of v among them or -1; edge_index_out = newid[edge_index]
+ *   ([2, n_edges] int64); n_out[1] != 0 if an id was outside [0, n_nodes).              */
+size_t gnntrk_compact_workspace_bytes(int64_t n);
+int gnntrk_threshold_compact(const float *w, int64_t n, float threshold, uint8_t *mask, int32_t *idx,
+                             int64_t *n_out, void *workspace, size_t workspace_bytes, void *stream);
+int gnntrk_connected_nodes(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, uint8_t *hit,
+                           int32_t *node_idx, int32_t *newid, int64_t *n_out, int64_t *edge_index_out,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------ condensation losses
  * utils/graph_masks.py:19-28: mask = pt > thld && pid > 0 && reconstructable > 0 && |eta| < max_eta */
 int gnntrk_good_node_mask(const float *pt, const int64_t *particle_id, const float *reconstructable,

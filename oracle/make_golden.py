@@ -457,6 +457,51 @@ def g9_gc_fcnn():
     npz("g9_gc_fcnn.npz", **arrs)
 
 
+def g10_hetero_fcnn():
+    """GraphConstructionHeteroResFCNN / GraphConstructionHeteroEncResFCNN (pixel / strip
+    encoders, models/graph_construction.py:56-132) on seeded hits sorted pixel first."""
+    from gnn_tracking.models.graph_construction import (GraphConstructionHeteroEncResFCNN,
+                                                        GraphConstructionHeteroResFCNN)
+
+    print("G10 heterogeneous embedding networks")
+    g = np.random.default_rng(13)
+    x = torch.from_numpy(g.normal(size=(600, 14))).float()
+    layer = torch.from_numpy(np.sort(g.integers(0, 40, size=600))).long()
+    arrs = dict(x=x, layer=layer)
+    cases = {
+        "hetero_d2": (GraphConstructionHeteroResFCNN, dict(hidden_dim=40, depth=2, out_dim=8, alpha=0.0)),
+        "hetero_d3": (GraphConstructionHeteroResFCNN, dict(hidden_dim=48, depth=3, out_dim=6, alpha=0.6)),
+        "heteroenc": (GraphConstructionHeteroEncResFCNN,
+                      dict(hidden_dim_enc=24, hidden_dim=32, out_dim=8, depth_enc=2, depth=3, alpha=0.6)),
+    }
+    for name, (cls, kw) in cases.items():
+        torch.manual_seed(6)
+        model = cls(in_dim=14, **kw)
+        with torch.no_grad():
+            model._latent_normalization.fill_(0.8)
+        p0 = sd(model)
+        out = model(Data(x=x, layer=layer))["H"]
+        r = torch.from_numpy(g.normal(size=tuple(out.shape))).float()
+        (out * r).sum().backward()
+        po = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+        pp = {"." + k: v for k, v in po.items()}
+        if cls is GraphConstructionHeteroResFCNN:
+            oo = O.hetero_res_fcnn(x, layer, pp, "", kw["depth"], kw["alpha"])
+        else:
+            enc = torch.clamp_min(O.hetero_res_fcnn(x, layer, pp, ".encoder", kw["depth_enc"], kw["alpha"]), 0.0)
+            oo = O.res_fcnn(enc, pp, ".fcnn", kw["depth"], kw["alpha"])
+        oo = oo * po["_latent_normalization"]
+        close(oo, out, 1e-5, name + " H")
+        og = torch.autograd.grad((oo * r).sum(), list(po.values()))
+        for (k, v), gk in zip(model.named_parameters(), og):
+            close(gk, v.grad, 1e-4, f"{name} grad {k}")
+            arrs[f"{name}/p0/{k}"] = p0[k]
+            arrs[f"{name}/grad/{k}"] = v.grad
+        arrs[f"{name}/H"], arrs[f"{name}/r"] = out, r
+    print("  oracle == reference")
+    npz("g10_hetero_fcnn.npz", **arrs)
+
+
 PINNED_HINGE = {  # /root/reference/tests/test_losses.py:194-203 (td1)
     "n_hits_oi": {"attractive": 0.7307405975481213, "repulsive": 11.076146539572338},
     "n_rep_edges": {"attractive": 0.7307405975481213, "repulsive": 0.34612957938781874},
@@ -519,6 +564,8 @@ GTCN_VARIANTS = {
     "orphans_ecfeed": dict(L_ec=2, L_hc=2, hidden_dim=16, mask_orphan_nodes=True,
                            use_ec_embeddings_for_hc=True, feed_edge_weights=True),
     "latent": dict(L_ec=1, L_hc=2, hidden_dim=8, h_outdim=4, alpha_latent=0.4, n_embedding_coords=3),
+    # models/track_condensation_networks.py:209-217: pixel / strip node encoders (depth 2)
+    "hetero": dict(L_ec=1, L_hc=1, hidden_dim=12, mask_orphan_nodes=True, heterogeneous_node_encoder=True),
 }
 
 
@@ -529,7 +576,9 @@ def g7_graph_tcn():
     print("G7 GraphTCN variants")
     x, ei, ea, y, pt = synth_graph(2, 300, 2000, 14, 4)
     g = np.random.default_rng(77)
-    arrs = dict(x=x, edge_index=ei, edge_attr=ea, y=y)
+    # detector layer per hit, sorted pixel (0..17) then strip as the reference expects
+    layer = torch.from_numpy(np.sort(g.integers(0, 45, size=x.shape[0]))).long()
+    arrs = dict(x=x, edge_index=ei, edge_attr=ea, y=y, layer=layer)
     worst = 0.0
     for name, kw in GTCN_VARIANTS.items():
         # the cut must remove a real fraction of the edges: put the threshold at the 40 %
@@ -543,7 +592,7 @@ def g7_graph_tcn():
         torch.manual_seed(11)
         model = GraphTCN(14, 4, **kw)
         p0 = sd(model)
-        data = Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=torch.zeros(x.shape[0], dtype=torch.long))
+        data = Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=layer)
         out = model(data)
         thr = kw["ec_threshold"]
         arrs[f"{name}/ec_threshold"] = np.float64(thr)
@@ -555,9 +604,11 @@ def g7_graph_tcn():
         loss.backward()
         okw = dict(L_ec=kw.get("L_ec", 3), L_hc=kw.get("L_hc", 3))
         for k in ("ec_threshold", "mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc",
-                  "alpha_latent", "n_embedding_coords"):
+                  "alpha_latent", "n_embedding_coords", "heterogeneous_node_encoder"):
             if k in kw:
                 okw[k] = kw[k]
+        if kw.get("heterogeneous_node_encoder"):
+            okw["layer"] = layer
         po = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
         oo = O.graph_tcn(x, ei, ea, po, **okw)
         assert torch.equal(oo["ec_edge_mask"], out["ec_edge_mask"]) and torch.equal(oo["ec_hit_mask"], out["ec_hit_mask"])
@@ -583,14 +634,15 @@ def g7_graph_tcn():
 
 if __name__ == "__main__":
     assert REF.is_dir(), "needs /root/reference (build container only)"
-    tg = g1_ec_testgraph()
-    g2_ec_variants()
-    g3_in_layer()
-    g3b_resin()
-    g4_knn(tg)
-    g5_oc()
-    g6_mlgc(tg)
-    g7_graph_tcn()
-    g8_hinge()
-    g9_gc_fcnn()
-    print("all goldens written; oracle pinned against the reference.")
+    only = set(sys.argv[1:])  # e.g. "g7 g10": regenerate just these files
+
+    def want(tag):
+        return not only or tag in only
+
+    tg = g1_ec_testgraph() if (want("g1") or want("g4") or want("g6")) else None
+    for tag, fn in (("g2", g2_ec_variants), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
+                    ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g8", g8_hinge),
+                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn)):
+        if want(tag):
+            fn()
+    print("goldens written; oracle pinned against the reference.")

@@ -510,9 +510,10 @@ def graph_tcn(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *, L_ec
               alpha_ec: float = 0.5, alpha_hc: float = 0.5, ec_threshold: float = 0.5,
               mask_orphan_nodes: bool = False, feed_edge_weights: bool = False,
               use_ec_embeddings_for_hc: bool = False, alpha_latent: float = 0.0,
-              n_embedding_coords: int = 0, prefix: str = "_gtcn") -> dict:
+              n_embedding_coords: int = 0, prefix: str = "_gtcn", layer: Tensor | None = None,
+              heterogeneous_node_encoder: bool = False) -> dict:
     """models/track_condensation_networks.py:236-308 (``ModularGraphTCN.forward`` as built by
-    ``GraphTCN``, homogeneous node encoder)."""
+    ``GraphTCN``; node encoder homogeneous or, with ``layer``, heterogeneous :209-217)."""
     relu = lambda t: torch.clamp_min(t, 0.0)  # noqa: E731
     pe = {k[len(prefix) + 4:]: v for k, v in p.items() if k.startswith(prefix + ".ec.")}
     ec = ec_for_graph_tcn(x, edge_index, edge_attr, pe, L_ec=L_ec, alpha=alpha_ec)
@@ -532,6 +533,7 @@ def graph_tcn(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *, L_ec
         relabel[hit_mask] = torch.arange(int(hit_mask.sum()))
         ei = relabel[ei]
         xn, en = x[hit_mask], en[hit_mask]
+        layer = layer[hit_mask] if layer is not None else None
     else:
         hit_mask = torch.ones(n, dtype=torch.bool)
     xs, eas = [xn], [ea]
@@ -540,7 +542,10 @@ def graph_tcn(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *, L_ec
         eas.append(ee)
     if feed_edge_weights:
         eas.append(w_m)
-    h = relu(res_fcnn_depth1(torch.cat(xs, 1), p, f"{prefix}.hc_node_encoder"))
+    if heterogeneous_node_encoder:
+        h = relu(hetero_res_fcnn(torch.cat(xs, 1), layer, p, f"{prefix}.hc_node_encoder", 2, 0.0))
+    else:
+        h = relu(res_fcnn_depth1(torch.cat(xs, 1), p, f"{prefix}.hc_node_encoder"))
     e = relu(mlp(torch.cat(eas, 1), p, f"{prefix}.hc_edge_encoder", 2, bias=False))
     h, _, _ = resin(h, ei, e, p, f"{prefix}.hc_in", n_layers=L_hc, alpha=alpha_hc)
     eps = 1e-6
@@ -591,3 +596,30 @@ def res_fcnn(x: Tensor, p: dict, prefix: str, depth: int, alpha: float) -> Tenso
     for i in range(depth - 1):
         x = math.sqrt(alpha) * x + math.sqrt(1 - alpha) * (torch.clamp_min(x, 0.0) @ p[f"{prefix}._layers.{i}.weight"].t())
     return torch.clamp_min(x, 0.0) @ p[f"{prefix}._decoder.weight"].t()
+
+
+def hetero_res_fcnn(x: Tensor, layer: Tensor, p: dict, prefix: str, depth: int, alpha: float) -> Tensor:
+    """models/mlp.py:123-178: pixel hits (layer 0..17) and strip hits through separate
+    ``ResFCNN`` s, the two embeddings stacked pixel first."""
+    pm = (layer >= 0) & (layer < 18)
+    return torch.vstack([res_fcnn(x[pm], p, f"{prefix}.pixel_fcnn", depth, alpha),
+                         res_fcnn(x[~pm], p, f"{prefix}.strip_fcnn", depth, alpha)])
+
+
+# ---------------------------------------------------------------------------------------
+# ModularGraphTCN glue (models/track_condensation_networks.py:251-262)
+def threshold_compact(w: Tensor, threshold: float):
+    """``mask = w > threshold`` and the ascending positions boolean indexing keeps."""
+    mask = w.reshape(-1) > threshold
+    return mask, torch.nonzero(mask).reshape(-1)
+
+
+def connected_nodes(edge_index: Tensor, num_nodes: int):
+    """``connected = edge_index.flatten().unique()`` (ascending), ``index_to_mask`` and the
+    relabelling ``Data.subgraph(connected)`` applies to ``edge_index``."""
+    connected = edge_index.flatten().unique()
+    hit = torch.zeros(num_nodes, dtype=torch.bool)
+    hit[connected] = True
+    relabel = torch.full((num_nodes,), -1, dtype=torch.long)
+    relabel[connected] = torch.arange(connected.numel())
+    return hit, connected, relabel[edge_index]

@@ -651,13 +651,14 @@ GTCN_VARIANTS = {
     "orphans_ecfeed": dict(L_ec=2, L_hc=2, hidden_dim=16, mask_orphan_nodes=True,
                            use_ec_embeddings_for_hc=True, feed_edge_weights=True),
     "latent": dict(L_ec=1, L_hc=2, hidden_dim=8, h_outdim=4, alpha_latent=0.4, n_embedding_coords=3),
+    "hetero": dict(L_ec=1, L_hc=1, hidden_dim=12, mask_orphan_nodes=True, heterogeneous_node_encoder=True),
 }
 
 
 def gtcn_oracle_kwargs(kw, thr):
     okw = dict(L_ec=kw.get("L_ec", 3), L_hc=kw.get("L_hc", 3), ec_threshold=thr)
     for k in ("mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc", "alpha_latent",
-              "n_embedding_coords"):
+              "n_embedding_coords", "heterogeneous_node_encoder"):
         if k in kw:
             okw[k] = kw[k]
     return okw
@@ -677,7 +678,7 @@ def case_graph_tcn(device, names=None):
         model = G.GraphTCN(14, 4, ec_threshold=thr, **kw)
         load_params(model, z, f"{name}/p0/")
         model = model.to(device)
-        out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y))
+        out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=tt(z["layer"], device)))
         assert torch.equal(out["ec_edge_mask"].cpu(), tt(z[f"{name}/ec_edge_mask"])), name + " edge mask"
         assert torch.equal(out["ec_hit_mask"].cpu(), tt(z[f"{name}/ec_hit_mask"])), name + " hit mask"
         assert_close(out["W"], z[f"{name}/W"], TOL_OUT, name + " W")
@@ -704,7 +705,7 @@ def case_graph_tcn_bf16(device):
         load_params(model, z, f"{name}/p0/")
         model = model.to(device)
         with G.bf16_storage():
-            out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y))
+            out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=tt(z["layer"], device)))
             loss = out["H"].square().sum() + out["B"].sum() + G.EdgeWeightBCELoss()(w=out["W"], y=y.float())
             loss.backward()
         for k in ("W", "H", "B"):
@@ -757,3 +758,84 @@ def case_gc_fcnn(device, names=("d1_h40", "d4_h96")):
         (out * tt(z[f"{name}/r"], device)).sum().backward()
         for k, v in model.named_parameters():
             assert_close(v.grad, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
+
+
+HETERO_CASES = {
+    "hetero_d2": ("GraphConstructionHeteroResFCNN", dict(hidden_dim=40, depth=2, out_dim=8, alpha=0.0)),
+    "hetero_d3": ("GraphConstructionHeteroResFCNN", dict(hidden_dim=48, depth=3, out_dim=6, alpha=0.6)),
+    "heteroenc": ("GraphConstructionHeteroEncResFCNN",
+                  dict(hidden_dim_enc=24, hidden_dim=32, out_dim=8, depth_enc=2, depth=3, alpha=0.6)),
+}
+
+
+def case_hetero_fcnn(device, names=None):
+    """Pixel / strip embedding networks vs the reference (G10): depth 2 with alpha 0 is one
+    fused three-layer launch per detector part, the others run on the library GEMM path."""
+    z = load("g10_hetero_fcnn.npz")
+    x, layer = tt(z["x"], device), tt(z["layer"], device)
+    for name, (cls, kw) in HETERO_CASES.items():
+        if names is not None and name not in names:
+            continue
+        model = getattr(G, cls)(in_dim=14, **kw)
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        out = model(G.Data(x=x, layer=layer))["H"]
+        assert_close(out, z[f"{name}/H"], TOL_OUT, name + " H")
+        (out * tt(z[f"{name}/r"], device)).sum().backward()
+        for k, v in model.named_parameters():
+            assert_close(v.grad, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
+
+
+def case_graph_cut(device, sizes=(0, 1, 63, 2048, 2049, 5000), big=0):
+    """gnntrk_threshold_compact / gnntrk_connected_nodes vs the oracle (bit-exact): empty,
+    single, tile-boundary and ragged sizes, all / none kept, NaN weights, isolated nodes,
+    self loops and duplicate edges; ``big`` adds a size that needs a multi-chunk count scan."""
+    from gnn_tracking_amd import graph_cut
+
+    g = np.random.default_rng(21)
+    for n in tuple(sizes) + ((big,) if big else ()):
+        w = torch.from_numpy(g.random(n).astype(np.float32))
+        if n > 10:
+            w[3] = float("nan")
+            w[n - 1] = 0.5  # exactly the threshold: not kept (strict >)
+        for thr in (0.5, -1.0, 2.0):
+            mask, idx = graph_cut.threshold_compact(w.to(device), thr)
+            om, oi = O.threshold_compact(w, thr)
+            assert torch.equal(mask.cpu(), om), f"mask n={n} thr={thr}"
+            assert idx.dtype == torch.int32 and torch.equal(idx.cpu().long(), oi), f"idx n={n} thr={thr}"
+        if n > 1:  # a view that is not 16-byte aligned takes the item-by-item loads
+            mask, idx = graph_cut.threshold_compact(w.to(device)[1:], 0.5)
+            om, oi = O.threshold_compact(w[1:], 0.5)
+            assert torch.equal(mask.cpu(), om) and torch.equal(idx.cpu().long(), oi), f"unaligned view n={n}"
+    for n_nodes, n_edges in ((1, 0), (5, 3), (300, 150), (2049, 700), (6000, 9000)) + (((big, big // 3),) if big else ()):
+        ei = torch.from_numpy(g.integers(0, max(1, n_nodes // 2 * 2 - n_nodes // 3), size=(2, n_edges))).long()
+        if n_edges > 2:
+            ei[:, 1] = ei[:, 0]          # duplicate edge
+            ei[1, 2] = ei[0, 2]          # self loop
+        hit, node_idx, ei2 = graph_cut.connected_nodes(ei.to(device), n_nodes)
+        oh, oc, oe = O.connected_nodes(ei, n_nodes)
+        assert torch.equal(hit.cpu(), oh), f"hit mask N={n_nodes}"
+        assert torch.equal(node_idx.cpu().long(), oc), f"connected nodes N={n_nodes}"
+        assert ei2.dtype == torch.int64 and torch.equal(ei2.cpu(), oe), f"relabelled edge_index N={n_nodes}"
+    try:
+        graph_cut.connected_nodes(torch.tensor([[0, 7], [1, 2]], device=device), 5)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("out-of-range node id not reported")
+    # the container-level operations against Data.edge_subgraph / Data.subgraph
+    n_nodes, n_edges = 400, 1500
+    ei = torch.from_numpy(g.integers(0, 250, size=(2, n_edges))).long()
+    d = G.Data(x=torch.randn(n_nodes, 3), edge_index=ei, edge_attr=torch.randn(n_edges, 2),
+               y=torch.randint(0, 2, (n_edges,)), edge_weights=torch.rand(n_edges, 1),
+               particle_id=torch.arange(n_nodes)).to(device)
+    cut, mask = graph_cut.edge_cut(d, d.edge_weights, 0.6)
+    ref = d.edge_subgraph((d.edge_weights > 0.6).squeeze())
+    for k in ("edge_index", "edge_attr", "y", "edge_weights"):
+        assert torch.equal(getattr(cut, k), getattr(ref, k)), k
+    assert torch.equal(cut.x, d.x)
+    sub, hit = graph_cut.drop_orphans(cut)
+    ref2 = ref.subgraph(ref.edge_index.flatten().unique())
+    for k in ("edge_index", "edge_attr", "y", "x", "particle_id"):
+        assert torch.equal(getattr(sub, k), getattr(ref2, k)), k
+    assert int(hit.sum()) == sub.num_nodes

@@ -73,3 +73,14 @@ def test_hinge_loss_emulated():
 def test_gc_fcnn_emulated():
     with emulated():
         P.case_gc_fcnn("cpu")
+
+
+def test_hetero_fcnn_emulated():
+    with emulated():
+        P.case_hetero_fcnn("cpu", names=("hetero_d2", "heteroenc"))
+        P.case_graph_tcn("cpu", names=("hetero",))
+
+
+def test_graph_cut_emulated():
+    with emulated():
+        P.case_graph_cut("cpu")

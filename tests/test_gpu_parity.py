@@ -117,3 +117,11 @@ def test_hinge_embedding_loss(dev):
 
 def test_graph_construction_fcnn(dev):
     P.case_gc_fcnn(dev)
+
+
+def test_hetero_fcnn(dev):
+    P.case_hetero_fcnn(dev)
+
+
+def test_graph_cut(dev):
+    P.case_graph_cut(dev, big=3_000_000)

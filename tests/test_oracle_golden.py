@@ -105,7 +105,10 @@ def test_graph_tcn():
     x, ei, ea, y = (tt(z[k]) for k in ("x", "edge_index", "edge_attr", "y"))
     for name, kw in P.GTCN_VARIANTS.items():
         p0 = {k: v.clone().requires_grad_(True) for k, v in _params(z, f"{name}/p0/").items()}
-        out = O.graph_tcn(x, ei, ea, p0, **P.gtcn_oracle_kwargs(kw, float(z[f"{name}/ec_threshold"])))
+        okw = P.gtcn_oracle_kwargs(kw, float(z[f"{name}/ec_threshold"]))
+        if kw.get("heterogeneous_node_encoder"):
+            okw["layer"] = tt(z["layer"])
+        out = O.graph_tcn(x, ei, ea, p0, **okw)
         assert torch.equal(out["ec_edge_mask"], tt(z[f"{name}/ec_edge_mask"]))
         assert torch.equal(out["ec_hit_mask"], tt(z[f"{name}/ec_hit_mask"]))
         for k in ("W", "H", "B"):
@@ -142,3 +145,16 @@ def test_gc_fcnn():
         p0 = {"." + k: v for k, v in _params(z, f"{name}/p0/").items()}
         out = O.res_fcnn(tt(z["x"]), p0, "", depth, 0.6) * p0["._latent_normalization"]
         assert_close(out, z[f"{name}/H"], 1e-5, name)
+
+
+def test_hetero_fcnn():
+    z = load("g10_hetero_fcnn.npz")
+    x, layer = tt(z["x"]), tt(z["layer"])
+    for name, (cls, kw) in P.HETERO_CASES.items():
+        p0 = {"." + k: v for k, v in _params(z, f"{name}/p0/").items()}
+        if cls == "GraphConstructionHeteroResFCNN":
+            out = O.hetero_res_fcnn(x, layer, p0, "", kw["depth"], kw["alpha"])
+        else:
+            enc = torch.clamp_min(O.hetero_res_fcnn(x, layer, p0, ".encoder", kw["depth_enc"], kw["alpha"]), 0.0)
+            out = O.res_fcnn(enc, p0, ".fcnn", kw["depth"], kw["alpha"])
+        assert_close(out * p0["._latent_normalization"], z[f"{name}/H"], 1e-5, name)

@@ -105,6 +105,7 @@ _SIGNATURES = {
     "gnntrk_knn_search": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                     _P, _P, _P]),
     "gnntrk_knn_emit": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
+    "gnntrk_knn_emit_prefix": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "gnntrk_edge_labels": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "gnntrk_edge_features": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),
     "gnntrk_compact_workspace_bytes": (C.c_size_t, [C.c_int64]),

@@ -63,7 +63,7 @@ int graph_index_build(const int64_t *, const gnntrk_graph_index *, void *, size_
 // knn.hip
 int knn_search_launch(const float *, int64_t, int, int, int, float, int32_t *, int32_t *,
                       hipStream_t);
-int knn_emit_launch(const int32_t *, const int32_t *, int64_t, int, int64_t *, int64_t *, int64_t,
+int knn_emit_launch(const int32_t *, const int32_t *, int64_t, int, int, int64_t *, int64_t *, int64_t,
                     hipStream_t);
 int edge_features_launch(const float *, int, int, const int64_t *, int64_t, float *, hipStream_t);
 int edge_labels_launch(const int64_t *, const int64_t *, int64_t, int64_t *, hipStream_t);
@@ -179,7 +179,11 @@ int gnntrk_knn_search(const float *x, int64_t n, int32_t dim, int32_t x_stride, 
 }
 int gnntrk_knn_emit(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k, int64_t *offsets,
                     int64_t *edge_index, int64_t n_edges, void *stream) {
-    return knn_emit_launch(nbr, cnt, n, k, offsets, edge_index, n_edges, (hipStream_t)stream);
+    return knn_emit_launch(nbr, cnt, n, k, k, offsets, edge_index, n_edges, (hipStream_t)stream);
+}
+int gnntrk_knn_emit_prefix(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k_stride, int32_t k_take,
+                           int64_t *offsets, int64_t *edge_index, int64_t n_edges, void *stream) {
+    return knn_emit_launch(nbr, cnt, n, k_stride, k_take, offsets, edge_index, n_edges, (hipStream_t)stream);
 }
 int gnntrk_edge_labels(const int64_t *particle_id, const int64_t *edge_index, int64_t n_edges,
                        int64_t *y, void *stream) {

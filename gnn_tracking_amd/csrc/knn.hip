@@ -150,8 +150,9 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void knn_emit_kernel(const int32_t *__restrict__ nbr,
                                                        const int32_t *__restrict__ cnt,
                                                        const int64_t *__restrict__ off, int64_t n,
-                                                       int k, int64_t m_total,
+                                                       int k_stride, int k, int64_t m_total,
                                                        int64_t *__restrict__ ei) {
+    // the first min(cnt[q], k) neighbours of rows that are k_stride wide
     const int64_t total = n * k;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * 256) {
@@ -159,21 +160,22 @@ __global__ __launch_bounds__(256) void knn_emit_kernel(const int32_t *__restrict
         const int i = (int)(t - q * k);
         if (i < cnt[q]) {
             const int64_t o = off[q] + i;
-            ei[o] = nbr[t];
+            ei[o] = nbr[q * k_stride + i];
             ei[m_total + o] = q;
         }
     }
 }
 
 // serial-per-block inclusive scan is plenty for n <= a few million counts (HBM-trivial)
-__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t *__restrict__ cnt,
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t *__restrict__ cnt_raw, int k_take,
                                                            int64_t n, int64_t *__restrict__ off) {
+    auto cnt = [&](int64_t i) { const int32_t c = cnt_raw[i]; return c < k_take ? c : k_take; };
     __shared__ long long s_part[1024];
     const int t = threadIdx.x;
     const int64_t per = (n + 1023) / 1024;
     const int64_t b = t * per, e = (b + per < n) ? b + per : n;
     long long s = 0;
-    for (int64_t i = b; i < e; ++i) s += cnt[i];
+    for (int64_t i = b; i < e; ++i) s += cnt(i);
     s_part[t] = s;
     __syncthreads();
     if (t == 0) {
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t *__rest
     long long run = s_part[t];
     for (int64_t i = b; i < e; ++i) {
         off[i] = run;
-        run += cnt[i];
+        run += cnt(i);
     }
 }
 
@@ -254,17 +256,18 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
     return check_launch("knn_search");
 }
 
-int knn_emit_launch(const int32_t *nbr, const int32_t *cnt, int64_t n, int k, int64_t *offsets,
+int knn_emit_launch(const int32_t *nbr, const int32_t *cnt, int64_t n, int k_stride, int k, int64_t *offsets,
                     int64_t *edge_index, int64_t m_total, hipStream_t stream) {
-    if (!nbr || !cnt || !offsets || n < 0 || k < 1) return fail(GNNTRK_EINVAL, "knn_emit: bad argument");
+    if (!nbr || !cnt || !offsets || n < 0 || k < 1 || k > k_stride)
+        return fail(GNNTRK_EINVAL, "knn_emit: bad argument");
     if (n == 0) return GNNTRK_OK;
     if (!edge_index) {  // phase 1: offsets only (offsets[n] = total edge count)
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, cnt, n, offsets);
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, cnt, k, n, offsets);
         return check_launch("knn_emit(scan)");
     }
     if (m_total > 0)
         hipLaunchKernelGGL(knn_emit_kernel, dim3(stream_grid(n * k)), dim3(256), 0, stream, nbr, cnt,
-                           (const int64_t *)offsets, n, k, m_total, edge_index);
+                           (const int64_t *)offsets, n, k_stride, k, m_total, edge_index);
     return check_launch("knn_emit");
 }
 

@@ -23,6 +23,14 @@ def knn_with_max_radius(x: Tensor, k: int, max_radius: float | None = None) -> T
     return ops.knn_graph(x, k, max_radius)
 
 
+def knn_scan(x: Tensor, ks, max_radius: float | None = None) -> dict[int, Tensor]:
+    """Edge lists of ``knn_with_max_radius(x, k, max_radius)`` for every ``k`` in ``ks`` from
+    one neighbour search at ``max(ks)``: the device part of ``GraphConstructionKNNScanner``
+    (graph_construction/k_scanner.py:203-285, which searches once per k; its figures of
+    merit are CPU tracking metrics and stay with the caller)."""
+    return ops.knn_scan(x, ks, max_radius)
+
+
 def _freeze_if(module, freeze: bool):
     if module is not None and freeze:
         for p in module.parameters():

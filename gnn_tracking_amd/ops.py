@@ -545,6 +545,43 @@ def knn_graph(x: Tensor, k: int, max_radius: Optional[float] = None) -> Tensor:
     return ei
 
 
+def knn_scan(x: Tensor, ks: Sequence[int], max_radius: Optional[float] = None) -> dict:
+    """``{k: knn_with_max_radius(x, k, max_radius) for k in ks}`` from ONE neighbour search at
+    ``max(ks)`` (the k-scan of graph_construction/k_scanner.py:203-285 searches once per k):
+    the ``k`` nearest are a prefix of every query's sorted neighbour list."""
+    _capi.require_device(x)
+    lib = _capi.load()
+    if x.dim() != 2:
+        raise ValueError("knn_scan: x must be [N, D]")
+    ks = [int(k) for k in ks]
+    if not ks or min(ks) < 1:
+        raise ValueError("knn_scan: ks must be positive")
+    x = _as_rows(x.detach())
+    n, dim = int(x.shape[0]), int(x.shape[1])
+    dev = x.device
+    if n <= 1:
+        return {k: torch.empty(2, 0, dtype=torch.int64, device=dev) for k in ks}
+    kmax = min(max(ks), n - 1)
+    nbr = torch.empty(n * kmax, dtype=torch.int32, device=dev)
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    st = _stream(x)
+    r = float(max_radius) if max_radius is not None else -1.0
+    _capi.check(lib.gnntrk_knn_search(_p(x), n, dim, _row_stride(x), kmax, r, _p(nbr), _p(cnt), st), lib)
+    offs = {}
+    for k in ks:  # all offset scans first, then ONE host read of the edge counts
+        off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        _capi.check(lib.gnntrk_knn_emit_prefix(_p(nbr), _p(cnt), n, kmax, min(k, kmax), _p(off), None, 0, st), lib)
+        offs[k] = off
+    totals = torch.stack([offs[k][n] for k in ks]).tolist()
+    out = {}
+    for k, m in zip(ks, totals):
+        ei = torch.empty(2, int(m), dtype=torch.int64, device=dev)
+        _capi.check(lib.gnntrk_knn_emit_prefix(_p(nbr), _p(cnt), n, kmax, min(k, kmax), _p(offs[k]), _p(ei),
+                                               int(m), st), lib)
+        out[k] = ei
+    return out
+
+
 def edge_labels(particle_id: Tensor, edge_index: Tensor) -> Tensor:
     """``(pid[e0] == pid[e1]) & (pid[e0] > 0)`` as int64 (graph_construction.py:365-367)."""
     _capi.require_device(particle_id, edge_index)

@@ -316,6 +316,14 @@ int gnntrk_knn_search(const float *x, int64_t n, int32_t dim, int32_t x_stride, 
                       float max_radius, int32_t *nbr, int32_t *cnt, void *stream);
 int gnntrk_knn_emit(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k, int64_t *offsets,
                     int64_t *edge_index, int64_t n_edges, void *stream);
+/* The k_take <= k_stride nearest neighbours out of a search done with k = k_stride: the same
+ * edge list a search with k = k_take returns (neighbours are sorted by the key (d2, index) and
+ * the radius filter keeps a prefix).  GraphConstructionKNNScanner scans k = 1..9 with one
+ * search per k (graph_construction/k_scanner.py:203-285, :267-269); here ONE search at max(ks)
+ * feeds every k. */
+int gnntrk_knn_emit_prefix(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k_stride,
+                           int32_t k_take, int64_t *offsets, int64_t *edge_index, int64_t n_edges,
+                           void *stream);
 
 /* MLGraphConstruction.forward, models/graph_construction.py:365-367 and :386-393:
  *   y[e]        = (pid[e0] == pid[e1]) && pid[e0] > 0        (int64 compare, int64 0/1 out)

@@ -227,6 +227,12 @@ def case_knn_goldens(device, clouds=("tg3", "u2", "u8")):
                 ref = tt(z[f"{cn}/k{k}_r{r}"])
                 assert ei.dtype == torch.int64
                 assert torch.equal(ei.cpu(), ref), f"kNN {cn} k={k} r={r} differs from reference"
+        # the k-scan: ONE search at k = 9 reproduces the reference's per-k searches
+        from gnn_tracking_amd.graph_construction import knn_scan
+        for r in (None, 1.0, 0.3):
+            scan = knn_scan(x, (1, 2, 3, 9), max_radius=r)
+            for k in (1, 2, 3, 9):
+                assert torch.equal(scan[k].cpu(), tt(z[f"{cn}/k{k}_r{r}"])), f"k-scan {cn} k={k} r={r}"
 
 
 def case_knn_oracle(device, shapes=((300, 3, 4, None), (300, 8, 16, 0.9), (257, 2, 70, None),
@@ -239,6 +245,11 @@ def case_knn_oracle(device, shapes=((300, 3, 4, None), (300, 8, 16, 0.9), (257, 
         ei = ops.knn_graph(x.to(device), k, r)
         ref = O.knn_graph_c(x, k, r) if n > 1 else torch.empty(2, 0, dtype=torch.int64)
         assert torch.equal(ei.cpu(), ref), f"kNN n={n} d={d} k={k} r={r}"
+    x = tt(g.random((90, 4)).astype(np.float32))
+    scan = ops.knn_scan(x.to(device), (1, 5, 200), 0.6)  # 200 > n - 1: clipped like a plain search
+    for k in (1, 5, 200):
+        assert torch.equal(scan[k].cpu(), O.knn_graph_c(x, k, 0.6)), f"k-scan k={k}"
+    assert all(v.shape == (2, 0) for v in ops.knn_scan(x[:1].to(device), (1, 2)).values())
     x = torch.zeros(100, 3)
     x[50:] = 1.0  # massive ties: order must be by index
     assert torch.equal(ops.knn_graph(x.to(device), 5, None).cpu(), O.knn_graph_c(x, 5, None))

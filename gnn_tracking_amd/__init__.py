@@ -22,6 +22,7 @@ from .losses_oc import CondensationLossRG, CondensationLossTiger, MultiLossFctRe
 from .mlp import MLP
 from .precision import bf16_storage
 from .resin import ResIN
+from .postprocessing import DBSCANFastRescan, dbscan
 from .track_condensation_networks import (GraphConstructionFCNN, GraphConstructionHeteroEncResFCNN,
                                             GraphConstructionHeteroResFCNN, GraphTCN,
                                             HeterogeneousResFCNN, ModularGraphTCN, PreTrainedECGraphTCN,
@@ -34,4 +35,4 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage", "GraphTCN", "ModularGraphTCN",
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
            "GraphConstructionFCNN", "HeterogeneousResFCNN", "GraphConstructionHeteroResFCNN",
-           "GraphConstructionHeteroEncResFCNN", "load_graph", "GraphDataset", "PrefetchLoader"]
+           "GraphConstructionHeteroEncResFCNN", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]

@@ -111,6 +111,12 @@ _SIGNATURES = {
     "gnntrk_compact_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnntrk_threshold_compact": (C.c_int, [_P, C.c_int64, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_connected_nodes": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "gnntrk_radius_count": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_double, _P, _P, _P]),
+    "gnntrk_radius_fill": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P]),
+    "gnntrk_dbscan_init": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_int32, _P, _P, _P]),
+    "gnntrk_dbscan_propagate": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, _P, _P, C.c_int32, _P, _P]),
+    "gnntrk_dbscan_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnntrk_dbscan_labels": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_good_node_mask": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, _P, _P]),
     "gnntrk_oc_select_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnntrk_oc_select_cps": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P,

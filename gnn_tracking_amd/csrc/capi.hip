@@ -207,6 +207,30 @@ int gnntrk_connected_nodes(const int64_t *edge_index, int64_t n_edges, int64_t n
                                   workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int gnntrk_radius_count(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius, int32_t *cnt,
+                        int64_t *offsets, void *stream) {
+    return radius_count_launch(x, n, dim, x_stride, radius, cnt, offsets, (hipStream_t)stream);
+}
+int gnntrk_radius_fill(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius,
+                       const int64_t *offsets, int32_t *nbr, double *dist, void *stream) {
+    return radius_fill_launch(x, n, dim, x_stride, radius, offsets, nbr, dist, (hipStream_t)stream);
+}
+int gnntrk_dbscan_init(const int64_t *offsets, const double *dist, int64_t n, double eps, int32_t min_pts,
+                       uint8_t *core, int32_t *root, void *stream) {
+    return dbscan_init_launch(offsets, dist, n, eps, min_pts, core, root, (hipStream_t)stream);
+}
+int gnntrk_dbscan_propagate(const int64_t *offsets, const int32_t *nbr, const double *dist, int64_t n, double eps,
+                            const uint8_t *core, int32_t *root, int32_t rounds, int32_t *changed, void *stream) {
+    return dbscan_propagate_launch(offsets, nbr, dist, n, eps, core, root, rounds, changed, (hipStream_t)stream);
+}
+size_t gnntrk_dbscan_workspace_bytes(int64_t n) { return dbscan_ws_bytes(n); }
+int gnntrk_dbscan_labels(const int64_t *offsets, const int32_t *nbr, const double *dist, int64_t n, double eps,
+                         const uint8_t *core, const int32_t *root, int64_t *labels, int64_t *n_clusters,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    return dbscan_labels_launch(offsets, nbr, dist, n, eps, core, root, labels, n_clusters, workspace,
+                                workspace_bytes, (hipStream_t)stream);
+}
+
 int gnntrk_good_node_mask(const float *pt, const int64_t *particle_id, const float *reconstructable,
                           const float *eta, int64_t n, float pt_thld, float max_eta, uint8_t *mask,
                           void *stream) {

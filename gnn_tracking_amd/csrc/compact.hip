@@ -201,6 +201,14 @@ int threshold_compact_launch(const float *w, int64_t n, float threshold, uint8_t
                        "threshold_compact");
 }
 
+// idx = ascending positions of the non-zero bytes, newid = their ranks (or -1), n_out[0] = count
+int compact_bytes_launch(const uint8_t *flags, int64_t n, int32_t *idx, int32_t *newid, int64_t *n_out, void *ws,
+                         size_t ws_bytes, hipStream_t stream) {
+    if (n > 0 && !flags) return fail(GNNTRK_EINVAL, "compact_bytes: NULL flags");
+    return compact_run(FlagByte{flags, ((uintptr_t)flags & 7) == 0}, n, idx, nullptr, newid, n_out, ws, ws_bytes,
+                       stream, "compact_bytes");
+}
+
 int connected_nodes_launch(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, uint8_t *hit,
                            int32_t *node_idx, int32_t *newid, int64_t *n_out, int64_t *edge_index_out, void *ws,
                            size_t ws_bytes, hipStream_t stream) {

@@ -55,6 +55,23 @@ int connected_nodes_launch(const int64_t *edge_index, int64_t n_edges, int64_t n
                            int32_t *node_idx, int32_t *newid, int64_t *n_out, int64_t *edge_index_out,
                            void *ws, size_t ws_bytes, hipStream_t stream);
 
+int compact_bytes_launch(const uint8_t *flags, int64_t n, int32_t *idx, int32_t *newid, int64_t *n_out, void *ws,
+                         size_t ws_bytes, hipStream_t stream);
+
+// dbscan.hip
+int radius_count_launch(const float *x, int64_t n, int dim, int stride, double radius, int32_t *cnt,
+                        int64_t *offsets, hipStream_t stream);
+int radius_fill_launch(const float *x, int64_t n, int dim, int stride, double radius, const int64_t *off,
+                       int32_t *nbr, double *dist, hipStream_t stream);
+int dbscan_init_launch(const int64_t *off, const double *dist, int64_t n, double eps, int min_pts, uint8_t *core,
+                       int32_t *root, hipStream_t stream);
+int dbscan_propagate_launch(const int64_t *off, const int32_t *nbr, const double *dist, int64_t n, double eps,
+                            const uint8_t *core, int32_t *root, int rounds, int32_t *changed, hipStream_t stream);
+size_t dbscan_ws_bytes(int64_t n);
+int dbscan_labels_launch(const int64_t *off, const int32_t *nbr, const double *dist, int64_t n, double eps,
+                         const uint8_t *core, const int32_t *root, int64_t *labels, int64_t *n_clusters, void *ws,
+                         size_t ws_bytes, hipStream_t stream);
+
 // rows_bf16.hip
 int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
                         uint16_t *out, int out_stride, hipStream_t stream);

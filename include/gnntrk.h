@@ -356,6 +356,39 @@ int gnntrk_connected_nodes(const int64_t *edge_index, int64_t n_edges, int64_t n
                            int32_t *node_idx, int32_t *newid, int64_t *n_out, int64_t *edge_index_out,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------ DBSCAN post-processing
+ * postprocessing/fastrescanner.py:6-66 (`DBSCANFastRescan`): the radius-neighbourhood graph
+ * at max_eps (sklearn `NearestNeighbors.radius_neighbors`), then for any eps <= max_eps and
+ * min_pts the labels of sklearn's `dbscan_inner` on the edges with dist <= eps.
+ *
+ * Arithmetic = sklearn's kd-tree path (its choice for <= 15 features): fp64 coordinates,
+ * d2 = sequential sum of squared differences, member iff d2 <= radius*radius, dist = sqrt(d2);
+ * every point is its own neighbour (min_pts counts it).
+ *
+ *  radius_count : cnt[q] = neighbourhood size, offsets[0..n] = exclusive scan (offsets[n] = M:
+ *                 read it back to size nbr / dist).  dim <= 32.
+ *  radius_fill  : nbr / dist [M]: the neighbourhoods, CSR by query, ascending neighbour index.
+ *  dbscan_init  : core[i] = |{e: dist[e] <= eps}| >= min_pts; root[i] = i (core) or -1.
+ *  dbscan_propagate : `rounds` rounds of min-label propagation with pointer jumping over the
+ *                 core-core edges; changed[0] != 0 iff the last round still moved a label -
+ *                 call again until it is 0 (the fixpoint is unique: root = lowest core index
+ *                 of the component).
+ *  dbscan_labels: labels[i] (int64) = cluster number (clusters numbered by ascending lowest
+ *                 core index, as dbscan_inner discovers them); border points take the lowest
+ *                 cluster number among their core neighbours; noise = -1.  n_clusters[0].  */
+int gnntrk_radius_count(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius, int32_t *cnt,
+                        int64_t *offsets, void *stream);
+int gnntrk_radius_fill(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius,
+                       const int64_t *offsets, int32_t *nbr, double *dist, void *stream);
+int gnntrk_dbscan_init(const int64_t *offsets, const double *dist, int64_t n, double eps, int32_t min_pts,
+                       uint8_t *core, int32_t *root, void *stream);
+int gnntrk_dbscan_propagate(const int64_t *offsets, const int32_t *nbr, const double *dist, int64_t n, double eps,
+                            const uint8_t *core, int32_t *root, int32_t rounds, int32_t *changed, void *stream);
+size_t gnntrk_dbscan_workspace_bytes(int64_t n);
+int gnntrk_dbscan_labels(const int64_t *offsets, const int32_t *nbr, const double *dist, int64_t n, double eps,
+                         const uint8_t *core, const int32_t *root, int64_t *labels, int64_t *n_clusters,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------ condensation losses
  * utils/graph_masks.py:19-28: mask = pt > thld && pid > 0 && reconstructable > 0 && |eta| < max_eta */
 int gnntrk_good_node_mask(const float *pt, const int64_t *particle_id, const float *reconstructable,

@@ -502,6 +502,41 @@ def g10_hetero_fcnn():
     npz("g10_hetero_fcnn.npz", **arrs)
 
 
+DBSCAN_TRIALS = ((1.0, 1), (0.5, 2), (0.3, 3), (0.2, 5), (0.11, 4), (0.45, 6))
+
+
+def g11_dbscan():
+    """DBSCANFastRescan (postprocessing/fastrescanner.py): labels of the reference's own class
+    (sklearn radius_neighbors + dbscan_inner) for several (eps, min_pts) on blob clouds in
+    2, 3 and 8 dimensions, incl. trials with border points and noise."""
+    from gnn_tracking.postprocessing.fastrescanner import DBSCANFastRescan
+
+    print("G11 DBSCAN fast rescan")
+    g = np.random.default_rng(31)
+    arrs = {}
+    for name, (dim, n) in {"d2": (2, 700), "d3": (3, 500), "d8": (8, 600)}.items():
+        c = g.normal(size=(40, dim)) * 2
+        x = (c[g.integers(0, 40, n)] + 0.15 * g.normal(size=(n, dim))).astype(np.float32)
+        x[::50] = g.normal(size=(len(x[::50]), dim)).astype(np.float32) * 4  # stragglers
+        arrs[f"{name}/x"] = x
+        fr = DBSCANFastRescan(x, max_eps=1.0)
+        n_border = 0
+        for eps, mp in DBSCAN_TRIALS:
+            ref = fr.cluster(eps, mp)
+            mine = O.dbscan_labels(x, 1.0, eps, mp)
+            assert np.array_equal(ref, mine), f"{name} eps={eps} min_pts={mp}"
+            arrs[f"{name}/eps{eps}_mp{mp}"] = ref.astype(np.int64)
+            off, nbr, dist = O.radius_neighbors(x, 1.0)
+            cnt = np.array([(dist[off[i]:off[i + 1]] <= eps).sum() for i in range(n)])
+            n_border += int(((cnt < mp) & (ref >= 0)).sum())
+        # a rescan beyond max_eps rebuilds the graph (fastrescanner.py:48-49)
+        arrs[f"{name}/eps1.3_mp3"] = fr.cluster(1.3, 3).astype(np.int64)
+        assert np.array_equal(arrs[f"{name}/eps1.3_mp3"], O.dbscan_labels(x, 1.0, 1.3, 3))
+        print(f"   {name}: n={n}, border points over the trials: {n_border}")
+    print("  oracle == reference")
+    npz("g11_dbscan.npz", **arrs)
+
+
 PINNED_HINGE = {  # /root/reference/tests/test_losses.py:194-203 (td1)
     "n_hits_oi": {"attractive": 0.7307405975481213, "repulsive": 11.076146539572338},
     "n_rep_edges": {"attractive": 0.7307405975481213, "repulsive": 0.34612957938781874},
@@ -642,7 +677,7 @@ if __name__ == "__main__":
     tg = g1_ec_testgraph() if (want("g1") or want("g4") or want("g6")) else None
     for tag, fn in (("g2", g2_ec_variants), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
                     ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g8", g8_hinge),
-                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn)):
+                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan)):
         if want(tag):
             fn()
     print("goldens written; oracle pinned against the reference.")

@@ -623,3 +623,54 @@ def connected_nodes(edge_index: Tensor, num_nodes: int):
     relabel = torch.full((num_nodes,), -1, dtype=torch.long)
     relabel[connected] = torch.arange(connected.numel())
     return hit, connected, relabel[edge_index]
+
+
+# ---------------------------------------------------------------------------------------
+# DBSCAN post-processing
+def radius_neighbors(x, radius: float):
+    """sklearn ``NearestNeighbors(radius).radius_neighbors(x)`` on its kd-tree path
+    (postprocessing/fastrescanner.py:25-39): fp64, squared distance as a sequential sum over
+    the features, member iff d2 <= radius**2, self included; neighbours ascending.
+    Returns (offsets int64 [n+1], nbr int64 [M], dist float64 [M])."""
+    import numpy as np
+
+    x64 = np.asarray(x, dtype=np.float64)
+    n, dim = x64.shape
+    d2 = np.zeros((n, n))
+    for d in range(dim):
+        t = x64[:, None, d] - x64[None, :, d]
+        d2 = d2 + t * t
+    keep = d2 <= radius * radius
+    off = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int64)
+    src, nbr = np.nonzero(keep)
+    return off, nbr.astype(np.int64), np.sqrt(d2[src, nbr])
+
+
+def dbscan_labels(x, max_eps: float, eps: float, min_pts: int):
+    """postprocessing/fastrescanner.py:41-66 with sklearn's ``dbscan_inner`` restated: edges
+    with dist <= eps; core = at least ``min_pts`` neighbours (self included); depth-first
+    expansion from every unlabelled core point in index order; noise = -1."""
+    import numpy as np
+
+    off, nbr, dist = radius_neighbors(x, max(max_eps, eps))
+    n = len(off) - 1
+    lists = [nbr[off[i]:off[i + 1]][dist[off[i]:off[i + 1]] <= eps] for i in range(n)]
+    core = np.array([len(v) >= min_pts for v in lists], dtype=bool)
+    labels = np.full(n, -1, dtype=np.int64)
+    label_num = 0
+    for i0 in range(n):
+        if labels[i0] != -1 or not core[i0]:
+            continue
+        stack, i = [], i0
+        while True:
+            if labels[i] == -1:
+                labels[i] = label_num
+                if core[i]:
+                    for v in lists[i]:
+                        if labels[v] == -1:
+                            stack.append(v)
+            if not stack:
+                break
+            i = stack.pop()
+        label_num += 1
+    return labels

@@ -850,3 +850,33 @@ def case_graph_cut(device, sizes=(0, 1, 63, 2048, 2049, 5000), big=0):
     for k in ("edge_index", "edge_attr", "y", "x", "particle_id"):
         assert torch.equal(getattr(sub, k), getattr(ref2, k)), k
     assert int(hit.sum()) == sub.num_nodes
+
+
+DBSCAN_TRIALS = ((1.0, 1), (0.5, 2), (0.3, 3), (0.2, 5), (0.11, 4), (0.45, 6))
+
+
+def case_dbscan(device, clouds=("d2", "d3", "d8"), trials=DBSCAN_TRIALS):
+    """DBSCANFastRescan vs the labels of the reference's own class (G11, bit-exact) and the
+    neighbourhood graph vs the oracle (ids exact, fp64 distances exact); rescan beyond
+    max_eps; empty / single-point / all-noise inputs."""
+    from gnn_tracking_amd.postprocessing import DBSCANFastRescan, dbscan
+
+    z = load("g11_dbscan.npz")
+    for cn in clouds:
+        x = z[f"{cn}/x"]
+        fr = DBSCANFastRescan(tt(x, device), max_eps=1.0)
+        off, nbr, dist = O.radius_neighbors(x, 1.0)
+        assert np.array_equal(fr._off.cpu().numpy(), off), cn + " offsets"
+        assert np.array_equal(fr._nbr.cpu().numpy()[:len(nbr)].astype(np.int64), nbr), cn + " neighbours"
+        assert np.array_equal(fr._dist.cpu().numpy()[:len(dist)], dist), cn + " distances (fp64)"
+        for eps, mp in trials:
+            lab = fr.cluster(eps, mp)
+            assert lab.dtype == np.intp
+            assert np.array_equal(lab, z[f"{cn}/eps{eps}_mp{mp}"]), f"DBSCAN {cn} eps={eps} min_pts={mp}"
+        assert np.array_equal(fr.cluster(1.3, 3), z[f"{cn}/eps1.3_mp3"]), cn + " rescan beyond max_eps"
+    one = torch.zeros(1, 3)
+    assert dbscan(one.to(device), 0.5, 1).tolist() == [0] and dbscan(one.to(device), 0.5, 2).tolist() == [-1]
+    assert dbscan(torch.zeros(0, 3).to(device), 0.5, 1).shape == (0,)
+    # a long chain: the component's lowest index has to travel along every link
+    chain = torch.stack([torch.arange(300, dtype=torch.float32).flip(0) * 0.9, torch.zeros(300)], 1)
+    assert np.array_equal(dbscan(chain.to(device), 1.0, 2), O.dbscan_labels(chain.numpy(), 1.0, 1.0, 2))

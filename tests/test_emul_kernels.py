@@ -84,3 +84,8 @@ def test_hetero_fcnn_emulated():
 def test_graph_cut_emulated():
     with emulated():
         P.case_graph_cut("cpu")
+
+
+def test_dbscan_emulated():
+    with emulated():
+        P.case_dbscan("cpu", clouds=("d2", "d8"), trials=((0.5, 2), (0.2, 5), (0.45, 6)))

@@ -125,3 +125,7 @@ def test_hetero_fcnn(dev):
 
 def test_graph_cut(dev):
     P.case_graph_cut(dev, big=3_000_000)
+
+
+def test_dbscan(dev):
+    P.case_dbscan(dev)

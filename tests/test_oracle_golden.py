@@ -158,3 +158,10 @@ def test_hetero_fcnn():
             enc = torch.clamp_min(O.hetero_res_fcnn(x, layer, p0, ".encoder", kw["depth_enc"], kw["alpha"]), 0.0)
             out = O.res_fcnn(enc, p0, ".fcnn", kw["depth"], kw["alpha"])
         assert_close(out * p0["._latent_normalization"], z[f"{name}/H"], 1e-5, name)
+
+
+def test_dbscan_oracle_vs_reference_labels():
+    z = load("g11_dbscan.npz")
+    for cn in ("d2", "d3", "d8"):
+        for eps, mp in P.DBSCAN_TRIALS[:3] + ((1.3, 3),):
+            assert np.array_equal(O.dbscan_labels(z[f"{cn}/x"], 1.0, eps, mp), z[f"{cn}/eps{eps}_mp{mp}"])

@@ -39,7 +39,7 @@ from gnn_tracking_amd import ops, synthetic  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
 PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
-TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r01_hbm_traffic_bf16_v6.json"}
+TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r01_hbm_traffic_bf16_v8.json"}
 
 WORKLOADS = {
     # name: (events per GPU, hits per event, edges per event, model kwargs)

@@ -49,19 +49,20 @@ __device__ inline void wave_bitonic_sort(u64 *buf, int cap, int lane) {
     }
 }
 
-template <int DP>
+template <int DP, bool FULL>  // FULL: dim == DP (no per-feature guard on the scalar loads)
 __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict__ x, int64_t n,
                                                         int dim, int stride, int k, int cap,
                                                         int qw, float max_radius,
                                                         int32_t *__restrict__ nbr,
                                                         int32_t *__restrict__ cnt_out) {
     __shared__ __attribute__((aligned(16))) u64 s_keys[kKnnWaves][kKnnLdsPerWave / 8];
-    __shared__ __attribute__((aligned(16))) float s_xq[kKnnWaves][32 * DP];
     __shared__ u64 s_tau[kKnnWaves][32];
     __shared__ int s_cnt[kKnnWaves][32];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wave index through readfirstlane: q0 and everything derived from it are scalars, so
+    // the query coordinates below are SCALAR loads (constant cache) feeding the VALU as SGPR
+    // operands - no LDS traffic for them in the (query, chunk) step
+    const int lane = threadIdx.x & 63, wv = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u64 *keys = s_keys[wv];
-    float *xq = s_xq[wv];
     u64 *tau = s_tau[wv];
     int *cnt = s_cnt[wv];
     const int64_t q0 = ((int64_t)blockIdx.x * kKnnWaves + wv) * qw;
@@ -74,26 +75,33 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
         const float r2 = max_radius * max_radius * 1.000001f + 1e-30f;
         tau0 = ((u64)__float_as_uint(r2) << 32) | 0xffffffffull;
     }
-    for (int i = lane; i < nq * DP; i += 64) {
-        const int q = i / DP, d = i - q * DP;
-        xq[i] = (d < dim) ? x[(q0 + q) * stride + d] : 0.f;
-    }
     if (lane < 32) {
         tau[lane] = tau0;
         cnt[lane] = 0;
     }
     knn_wave_sync();
 
+    // candidate rows: every lane loads unconditionally (row index clamped, `d < dim` is a
+    // uniform condition) - a load inside a divergent branch forces s_waitcnt vmcnt(0) on each
+    // of them - and the NEXT chunk is fetched while the queries run over the current one
+    auto load_chunk = [&](int64_t c0, float (&v)[DP]) {
+        const int64_t j = c0 + lane;
+        const float *__restrict__ row = x + (j < n ? j : n - 1) * stride;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) v[d] = (FULL || d < dim) ? row[d] : 0.f;
+    };
+    float xc[DP], xn[DP];
+    load_chunk(0, xc);
     for (int64_t c0 = 0; c0 < n; c0 += 64) {
         const int64_t j = c0 + lane;
-        float xc[DP];
-#pragma unroll
-        for (int d = 0; d < DP; ++d) xc[d] = (j < n && d < dim) ? x[j * stride + d] : 0.f;
+        load_chunk(c0 + 64 < n ? c0 + 64 : c0, xn);
         for (int q = 0; q < nq; ++q) {
+            const float *__restrict__ xq = x + (q0 + q) * stride;  // wave-uniform address
             float d2 = 0.f;
 #pragma unroll
             for (int d = 0; d < DP; ++d) {
-                const float t = __fsub_rn(xq[q * DP + d], xc[d]);
+                const float qd = (FULL || d < dim) ? xq[d] : 0.f;
+                const float t = __fsub_rn(qd, xc[d]);
                 d2 = __fmaf_rn(t, t, d2);
             }
             u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)j;
@@ -117,6 +125,8 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
                 knn_wave_sync();
             }
         }
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xc[d] = xn[d];
     }
 
     // final: sort every buffer, apply the radius filter (a prefix: keys ascend), emit
@@ -240,9 +250,13 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
     int qw = kKnnLdsPerWave / (cap * 8);
     if (qw > 32) qw = 32;
     const int64_t grid = ceil_div(n, (int64_t)qw * kKnnWaves);
-#define KNN_CALL(DP)                                                                       \
-    hipLaunchKernelGGL(knn_kernel<DP>, dim3((unsigned)grid), dim3(kKnnBlock), 0, stream, x, n, \
-                       dim, stride, k, cap, qw, max_radius, nbr, cnt)
+#define KNN_CALL(DP)                                                                               \
+    if (dim == DP)                                                                                 \
+        hipLaunchKernelGGL((knn_kernel<DP, true>), dim3((unsigned)grid), dim3(kKnnBlock), 0, stream, x, n, \
+                           dim, stride, k, cap, qw, max_radius, nbr, cnt);                         \
+    else                                                                                           \
+        hipLaunchKernelGGL((knn_kernel<DP, false>), dim3((unsigned)grid), dim3(kKnnBlock), 0, stream, x, n, \
+                           dim, stride, k, cap, qw, max_radius, nbr, cnt)
     if (dim <= 4) {
         KNN_CALL(4);
     } else if (dim <= 8) {

@@ -23,6 +23,7 @@ constexpr int kKnnBlock = 256;
 constexpr int kKnnWaves = 4;
 constexpr int kKnnLdsPerWave = 16 * 1024;  // key buffers of one wave (bytes)
 constexpr u64 kKeyMax = ~0ull;
+constexpr int kKnnGroup = 4;  // queries per step (loads of a group overlap)
 
 __device__ __forceinline__ void knn_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -95,34 +96,49 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
     for (int64_t c0 = 0; c0 < n; c0 += 64) {
         const int64_t j = c0 + lane;
         load_chunk(c0 + 64 < n ? c0 + 64 : c0, xn);
-        for (int q = 0; q < nq; ++q) {
-            const float *__restrict__ xq = x + (q0 + q) * stride;  // wave-uniform address
-            float d2 = 0.f;
+        // queries in groups of kKnnGroup: the scalar loads of the coordinates and the LDS
+        // reads of the thresholds of the whole group are in flight together (a scalar load
+        // can only be waited for with lgkmcnt(0): one query per step means one full memory
+        // latency per step), then the distances, then the (rare) appends
+        for (int qb = 0; qb < nq; qb += kKnnGroup) {
+            u64 key[kKnnGroup], tq[kKnnGroup];
 #pragma unroll
-            for (int d = 0; d < DP; ++d) {
-                const float qd = (FULL || d < dim) ? xq[d] : 0.f;
-                const float t = __fsub_rn(qd, xc[d]);
-                d2 = __fmaf_rn(t, t, d2);
-            }
-            u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)j;
-            if (j >= n || j == q0 + q) key = kKeyMax;
-            const bool pass = key < tau[q];
-            const u64 mask = __ballot(pass);
-            if (mask != 0ull) {
-                const int base = cnt[q];
-                if (pass) keys[q * cap + base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
-                int nc = base + __popcll(mask);
-                knn_wave_sync();
-                if (nc > cap - 64) {  // no room for another full chunk: keep the k best
-                    u64 *b = keys + q * cap;
-                    for (int i = nc + lane; i < cap; i += 64) b[i] = kKeyMax;
-                    knn_wave_sync();
-                    wave_bitonic_sort(b, cap, lane);
-                    nc = k;
-                    if (lane == 0) tau[q] = b[k - 1];
+            for (int u = 0; u < kKnnGroup; ++u) tq[u] = tau[qb + u < nq ? qb + u : nq - 1];
+#pragma unroll
+            for (int u = 0; u < kKnnGroup; ++u) {
+                const int q = qb + u < nq ? qb + u : nq - 1;
+                const float *__restrict__ xq = x + (q0 + q) * stride;  // wave-uniform address
+                float d2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    const float qd = (FULL || d < dim) ? xq[d] : 0.f;
+                    const float t = __fsub_rn(qd, xc[d]);
+                    d2 = __fmaf_rn(t, t, d2);
                 }
-                if (lane == 0) cnt[q] = nc;
-                knn_wave_sync();
+                key[u] = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)j;
+                if (j >= n || j == q0 + q || qb + u >= nq) key[u] = kKeyMax;
+            }
+#pragma unroll
+            for (int u = 0; u < kKnnGroup; ++u) {
+                const bool pass = key[u] < tq[u];
+                const u64 mask = __ballot(pass);
+                if (mask != 0ull) {
+                    const int q = qb + u;
+                    const int base = cnt[q];
+                    if (pass) keys[q * cap + base + __popcll(mask & ((1ull << lane) - 1ull))] = key[u];
+                    int nc = base + __popcll(mask);
+                    knn_wave_sync();
+                    if (nc > cap - 64) {  // no room for another full chunk: keep the k best
+                        u64 *b = keys + q * cap;
+                        for (int i = nc + lane; i < cap; i += 64) b[i] = kKeyMax;
+                        knn_wave_sync();
+                        wave_bitonic_sort(b, cap, lane);
+                        nc = k;
+                        if (lane == 0) tau[q] = b[k - 1];
+                    }
+                    if (lane == 0) cnt[q] = nc;
+                    knn_wave_sync();
+                }
             }
         }
 #pragma unroll

@@ -21,7 +21,7 @@ namespace gnntrk {
 typedef unsigned long long u64;
 constexpr int kKnnBlock = 256;
 constexpr int kKnnWaves = 4;
-constexpr int kKnnLdsPerWave = 16 * 1024;  // key buffers of one wave (bytes)
+constexpr int kKnnLdsPerWave = 8 * 1024;  // key buffers of one wave (bytes): 20 waves per CU
 constexpr u64 kKeyMax = ~0ull;
 constexpr int kKnnGroup = 4;  // queries per step (loads of a group overlap)
 

@@ -25,9 +25,11 @@ def main():
     xd = x.cuda()
     for k in (16, 64):
         ops.knn_graph(xd[:4096], k, 1.0)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        ei = ops.knn_graph(xd, k, 1.0)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        dt = 1e9
+        for _ in range(3):  # best of three (the first full-size call also pays the allocations)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ei = ops.knn_graph(xd, k, 1.0)
+            torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
         print(f"GPU kNN n={n} k={k} r=1: {dt*1e3:.1f} ms, {ei.shape[1]} edges, "
               f"{n*n*8*2/dt/1e12:.2f} Tflop/s (N^2*D fma)")
         ns = 20000

@@ -92,6 +92,8 @@ def cpu_baseline(event, model, iters: int) -> dict:
         t0 = time.perf_counter()
         one(ei[:, sl], ea[sl], y[sl])
         probe[th] = time.perf_counter() - t0
+        if probe[th] > 1.4 * min(probe.values()):
+            break  # past the optimum: more threads only get slower (256 threads take 45 s here)
     threads = min(probe, key=probe.get)
     torch.set_num_threads(threads)
     one(ei, ea, y)  # warm-up (untimed)
@@ -103,7 +105,7 @@ def cpu_baseline(event, model, iters: int) -> dict:
             "sample": f"1 event ({x.shape[0]} hits, {E} edges) of the workload, "
                       f"{iters} timed fwd+BCE+bwd iterations after 1 warm-up, "
                       f"torch {torch.__version__} CPU, {threads} threads (fastest of "
-                      f"{sorted(probe)} probed on a 1/8-event slice; host has {ncpu} CPUs)",
+                      f"{sorted(probe)} probed on a 1/8-event slice, stopping once slower; host has {ncpu} CPUs)",
             "s_per_iter": dt, "thread_probe_s": probe}
 
 

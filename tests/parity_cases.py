@@ -880,3 +880,92 @@ def case_dbscan(device, clouds=("d2", "d3", "d8"), trials=DBSCAN_TRIALS):
     # a long chain: the component's lowest index has to travel along every link
     chain = torch.stack([torch.arange(300, dtype=torch.float32).flip(0) * 0.9, torch.zeros(300)], 1)
     assert np.array_equal(dbscan(chain.to(device), 1.0, 2), O.dbscan_labels(chain.numpy(), 1.0, 1.0, 2))
+
+
+def case_full_size_properties(device, n_events=32, n_nodes=150_000, n_edges=2_000_000, n_hits=200_000):
+    """BASELINE.json's full sizes (cfg3: 32 events x 150 k hits x 2 M edges collated; cfg5:
+    200 k hits), checked through properties that do not need an oracle run of that size:
+    sortedness / permutation / row-pointer consistency of the graph index, EVENT INDEPENDENCE
+    (an event's edge weights inside the collated batch are bit-identical to the event run
+    alone, fp32 and bf16 storage), the compaction invariants, the kNN ordering / prefix
+    properties and the DBSCAN label invariants."""
+    from gnn_tracking_amd import graph_cut, synthetic
+    from gnn_tracking_amd.postprocessing import DBSCANFastRescan
+
+    events = [synthetic.make_event(100 + i, n_nodes, n_edges, device) for i in range(n_events)]
+    batch = G.collate(events)
+    N, E = batch.num_nodes, batch.edge_index.shape[1]
+    gi = ops.graph_index(batch.edge_index, N, cache=False)
+    tgt, src, perm = gi.tgt.long(), gi.src.long(), gi.perm.long()
+    assert bool((tgt[1:] >= tgt[:-1]).all()), "CSR targets not sorted"
+    assert torch.equal(batch.edge_index[1][perm], tgt) and torch.equal(batch.edge_index[0][perm], src)
+    seen = torch.zeros(E, dtype=torch.bool, device=device)
+    seen[perm] = True
+    assert bool(seen.all()), "perm is not a permutation"
+    same_t = tgt[1:] == tgt[:-1]
+    assert bool((perm[1:][same_t] > perm[:-1][same_t]).all()), "target sort not stable"
+    assert int(gi.rowptr_t[-1]) == E and int(gi.rowptr_s[-1]) == E
+    assert torch.equal(gi.rowptr_t[1:].long() - gi.rowptr_t[:-1].long(), torch.bincount(tgt, minlength=N))
+    s_sorted = src[gi.spos.long()]
+    assert bool((s_sorted[1:] >= s_sorted[:-1]).all()), "source view not sorted"
+    assert torch.equal(gi.spos_inv.long()[gi.spos.long()], torch.arange(E, device=device))
+    del seen, same_t, s_sorted, tgt, src, perm, gi
+
+    torch.manual_seed(0)
+    model = G.ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=3, hidden_dim=40).to(device)
+    for mode in ("f32", "bf16"):
+        def run(d):
+            with torch.no_grad():
+                if mode == "bf16":
+                    with G.bf16_storage():
+                        return model(d)["W"]
+                return model(d)["W"]
+        w_batch = run(batch)
+        assert w_batch.shape == (E,) and bool(torch.isfinite(w_batch).all())
+        assert 0.001 <= float(w_batch.min()) and float(w_batch.max()) <= 0.999
+        for i in (0, n_events - 1):
+            w_one = run(events[i])
+            assert torch.equal(w_batch[i * n_edges:(i + 1) * n_edges], w_one), f"event {i} ({mode}) depends on its batch"
+        # the cut on the full edge list: ascending kept positions, count and threshold respected
+        mask, idx = graph_cut.threshold_compact(w_batch, 0.5)
+        assert idx.numel() == int(mask.sum()) and bool((idx[1:] > idx[:-1]).all())
+        assert bool((w_batch[idx.long()] > 0.5).all()) and bool((w_batch[~mask] <= 0.5).all())
+        del w_batch, mask, idx
+    del batch, events, model
+
+    # cfg5: kNN ordering / prefix properties and DBSCAN invariants on 200 k hits in 8 dimensions
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    centers = torch.randn(6000, 8, generator=g, device=device)
+    x = centers[torch.randint(0, 6000, (n_hits,), generator=g, device=device)] \
+        + 0.05 * torch.randn(n_hits, 8, generator=g, device=device)
+    scan = ops.knn_scan(x, (4, 16), 1.0)
+    ei = scan[16]
+    assert bool((ei[1][1:] >= ei[1][:-1]).all()), "edges not grouped by query"
+    assert bool((ei[0] != ei[1]).all()), "self loop"
+    d = (x[ei[0]] - x[ei[1]]).norm(dim=1)
+    assert float(d.max()) < 1.0
+    same_q = ei[1][1:] == ei[1][:-1]
+    assert bool((d[1:][same_q] >= d[:-1][same_q] - 1e-6).all()), "neighbours not in ascending distance"
+    assert int(torch.bincount(ei[1], minlength=n_hits).max()) <= 16
+    rank = torch.arange(ei.shape[1], device=device) - torch.searchsorted(ei[1], ei[1])  # position within the query
+    assert torch.equal(ei[:, rank < 4], scan[4]), "k = 4 is not the prefix of k = 16"
+    fr = DBSCANFastRescan(x, max_eps=0.3)
+    eps, mp = 0.2, 3
+    lab = fr.cluster_device(eps, mp)
+    off, nbr, dist = fr._off, fr._nbr.long()[:fr._n_edges], fr._dist[:fr._n_edges]
+    srcn = torch.repeat_interleave(torch.arange(n_hits, device=device), off[1:] - off[:-1])
+    keep = dist <= eps
+    deg = torch.bincount(srcn[keep], minlength=n_hits)
+    core = deg >= mp
+    assert bool((lab[core] >= 0).all()), "core point without a cluster"
+    cc = keep & core[srcn] & core[nbr]
+    assert torch.equal(lab[srcn[cc]], lab[nbr[cc]]), "core neighbours in different clusters"
+    reach = torch.zeros(n_hits, dtype=torch.bool, device=device)
+    reach[srcn[keep & core[nbr]]] = True
+    assert torch.equal(lab >= 0, core | reach), "noise / border assignment"
+    n_cl = int(lab.max()) + 1
+    assert torch.unique(lab[lab >= 0]).numel() == n_cl, "cluster numbers not dense"
+    first_core = torch.full((n_cl,), n_hits, dtype=torch.long, device=device)
+    first_core.scatter_reduce_(0, lab[core], torch.arange(n_hits, device=device)[core], reduce="amin")
+    assert bool((first_core[1:] > first_core[:-1]).all()), "clusters not numbered by their lowest core index"

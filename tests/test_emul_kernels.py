@@ -89,3 +89,9 @@ def test_graph_cut_emulated():
 def test_dbscan_emulated():
     with emulated():
         P.case_dbscan("cpu", clouds=("d2", "d8"), trials=((0.5, 2), (0.2, 5), (0.45, 6)))
+
+
+def test_full_size_properties_tiny_emulated():
+    # the property checks themselves, on a size the emulator finishes in seconds
+    with emulated():
+        P.case_full_size_properties("cpu", n_events=2, n_nodes=40, n_edges=96, n_hits=130)

@@ -129,3 +129,7 @@ def test_graph_cut(dev):
 
 def test_dbscan(dev):
     P.case_dbscan(dev)
+
+
+def test_full_size_properties(dev):
+    P.case_full_size_properties(dev)

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kTpb16) void rows_to_bf16_kernel(const float *__res
 // and stores.  Neighbouring lanes read neighbouring rows, so a CSR-ordered input streams
 // through full sectors; with `pos` (source-sorted folds) the rows are random 8/16-byte
 // gathers and the kernel is sector-bound.  The order of the fp32 additions is fixed.
-template <int NCH>
+template <int NCH, bool WIDE>  // WIDE: rows are 16-byte aligned -> one 16-byte load per chunk pair
 __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
     const uint16_t *__restrict__ rows, int dim, int row_stride, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ pos, int64_t n_seg, uint16_t *__restrict__ out, int out_stride) {
@@ -60,13 +60,25 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
         for (int32_t k = k0 + j; k < k1; k += 4) {
             const int64_t r = pos ? (int64_t)pos[k] : (int64_t)k;
             const uint16_t *p = rows + r * row_stride;
+            if (WIDE) {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const u32x2 v = *reinterpret_cast<const u32x2 *>(p + 4 * ch);
-                s[4 * ch + 0] += bf16_lo(v[0]);
-                s[4 * ch + 1] += bf16_hi(v[0]);
-                s[4 * ch + 2] += bf16_lo(v[1]);
-                s[4 * ch + 3] += bf16_hi(v[1]);
+                for (int ch = 0; ch < NCH; ch += 2) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(p + 4 * ch);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        s[4 * ch + 2 * w + 0] += bf16_lo(v[w]);
+                        s[4 * ch + 2 * w + 1] += bf16_hi(v[w]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const u32x2 v = *reinterpret_cast<const u32x2 *>(p + 4 * ch);
+                    s[4 * ch + 0] += bf16_lo(v[0]);
+                    s[4 * ch + 1] += bf16_hi(v[0]);
+                    s[4 * ch + 2] += bf16_lo(v[1]);
+                    s[4 * ch + 3] += bf16_hi(v[1]);
+                }
             }
         }
 #pragma unroll
@@ -130,10 +142,16 @@ int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const
     const int nch = (dim + 3) / 4;
     if (nch > 4) return fail(GNNTRK_EUNSUPPORTED, "segment_sum_bf16: dim > 16");
     const int grid = grid_for_threads(n_seg * 4);
-#define GNNTRK_SEGSUM16(N)                                                                          \
-    if (nch == N)                                                                                   \
-        hipLaunchKernelGGL(segment_sum_bf16_kernel<N>, dim3(grid), dim3(kTpb16), 0, stream, rows, dim, \
-                           row_stride, rowptr, pos, n_seg, out, out_stride);
+    const bool wide = nch % 2 == 0 && row_stride % 8 == 0 && ((uintptr_t)rows & 15) == 0;
+#define GNNTRK_SEGSUM16(N)                                                                              \
+    if (nch == N) {                                                                                     \
+        if (wide && N % 2 == 0)                                                                         \
+            hipLaunchKernelGGL((segment_sum_bf16_kernel<N, (N % 2 == 0)>), dim3(grid), dim3(kTpb16), 0, stream, \
+                               rows, dim, row_stride, rowptr, pos, n_seg, out, out_stride);            \
+        else                                                                                            \
+            hipLaunchKernelGGL((segment_sum_bf16_kernel<N, false>), dim3(grid), dim3(kTpb16), 0, stream, rows, dim, \
+                               row_stride, rowptr, pos, n_seg, out, out_stride);                       \
+    }
     GNNTRK_SEGSUM16(1) GNNTRK_SEGSUM16(2) GNNTRK_SEGSUM16(3) GNNTRK_SEGSUM16(4)
 #undef GNNTRK_SEGSUM16
     return check_launch("segment_sum_bf16");

@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "f32"),
                     help="storage / MFMA-input type of the activations (cfg3 names bf16 storage, "
                          "fp32 accumulate); parameters and their gradients are fp32 in both")
+    ap.add_argument("--index", default="inline", choices=("inline", "prefetch"),
+                    help="graph index built inline in the step (default), or for the next batch on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
     return ap.parse_args()
@@ -150,12 +152,33 @@ def main():
     yf = batch.y.float()
     E_local = batch.num_edges
 
+    # Every step pays one graph-index build.  --index inline (default): at the start of the forward.
+    # --index prefetch: the build for the NEXT batch runs on the loader's side stream
+    # while this step computes - the index depends on the input edge list only, and
+    # io.PrefetchLoader(build_index=True) does exactly this one batch ahead - so a step
+    # consumes the index the previous step built.  Two batch objects (own edge_index tensors,
+    # same content) alternate so that "next batch" is a different tensor, as with a loader.
+    side = torch.cuda.Stream(dev) if args.index == "prefetch" else None
+    batches = [batch]
+    if side is not None:
+        import copy
+        other = copy.copy(batch)
+        other.edge_index = batch.edge_index.clone()
+        batches.append(other)
+    counter = [0]
+
     def step():
-        ops.clear_graph_index_cache()          # every step pays the graph-index build
+        cur = batches[counter[0] % len(batches)]
+        nxt = batches[(counter[0] + 1) % len(batches)]
+        counter[0] += 1
+        if side is None:
+            ops.clear_graph_index_cache()
+        else:
+            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, side)
         flat.zero_grad()
         with G.bf16_storage(args.dtype == "bf16"):
-            out = model(batch)
-            loss = loss_fct(w=out["W"], y=yf, edge_index=batch.edge_index, pt=batch.pt)
+            out = model(cur)
+            loss = loss_fct(w=out["W"], y=yf, edge_index=cur.edge_index, pt=cur.pt)
             loss.backward()
         flat.all_reduce_grads()
         opt.step()
@@ -232,8 +255,11 @@ def main():
                 "workload": f"{args.workload}: per GPU {n_ev} events x {n_hits} hits x {n_edges} "
                             f"edges collated (N={batch.num_nodes}, E={E_local}); "
                             f"ECForGraphTCN(node_indim=14, edge_indim=4, L_ec={mkw['L_ec']}, "
-                            f"hidden_dim={mkw['hidden_dim']}); step = graph index + forward + "
-                            "BCE + backward + grad all-reduce + Adam",
+                            f"hidden_dim={mkw['hidden_dim']}); step = graph index "
+                            + ("(built for the next batch on the loader's side stream during the step) "
+                               if args.index == "prefetch" else "(inline) ")
+                            + "+ forward + BCE + backward + grad all-reduce + Adam",
+                "graph_index": args.index,
                 "global_edges_per_step": E_local * world,
                 "parallelism": f"dp{world} (events sharded, flat-gradient RCCL all-reduce)",
             },

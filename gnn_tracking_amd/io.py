@@ -130,7 +130,11 @@ class PrefetchLoader:
     host-to-device copy is issued on a side stream and joined when the batch is handed out."""
 
     def __init__(self, dataset, *, batch_size: int = 1, device=None, depth: int = 2, shuffle: bool = False,
-                 seed: int = 0):
+                 seed: int = 0, build_index: bool = False):
+        """``build_index``: also build the graph index of every staged batch on the side stream
+        (``ops.prefetch_graph_index``: it depends on ``edge_index`` only), so the step that
+        consumes the batch joins a finished index instead of building it."""
+        self.build_index = bool(build_index)
         self.dataset, self.batch_size, self.depth = dataset, int(batch_size), max(1, int(depth))
         self.device = torch.device(device) if device is not None else None
         self.shuffle, self.seed, self._epoch = shuffle, seed, 0
@@ -162,6 +166,9 @@ class PrefetchLoader:
                             dev_batch = batch.to(self.device, non_blocking=True)
                             ev = torch.cuda.Event()
                             ev.record(side)
+                        if self.build_index:
+                            from . import ops
+                            ops.prefetch_graph_index(dev_batch.edge_index, dev_batch.num_nodes, side)
                         q.put((dev_batch, ev, batch))  # keep the pinned source alive until consumed
                     else:
                         q.put((batch if self.device is None else batch.to(self.device), None, None))

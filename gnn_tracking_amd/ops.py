@@ -149,6 +149,7 @@ class GraphIndex:
     rowptr_s: Tensor  # [N+1] int32
     spos: Tensor      # [E] int32: source-sorted order -> CSR position
     spos_inv: Tensor  # [E] int32: CSR position -> position in the source-sorted order
+    ready: object = None  # event of a build on a side stream (prefetch_graph_index), joined on first use
 
 
 _GI_CACHE: dict[int, tuple] = {}
@@ -175,7 +176,7 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True) -> Grap
         if hit is not None:
             ref, ver, nn, gi = hit
             if ref() is edge_index and ver == edge_index._version and nn == n_nodes:
-                return gi
+                return _join(gi)
     lib = _capi.load()
     ei = edge_index.contiguous()
     E = int(ei.shape[1])
@@ -194,6 +195,31 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True) -> Grap
             while len(_GI_CACHE) > 16:
                 _GI_CACHE.pop(next(iter(_GI_CACHE)))
         _GI_CACHE[key] = (weakref.ref(edge_index), edge_index._version, n_nodes, gi)
+    return gi
+
+
+def _join(gi: GraphIndex) -> GraphIndex:
+    """First use of an index that was built on a side stream: the consumer's stream waits for
+    the build and the arrays are handed over to it (allocator bookkeeping)."""
+    if gi.ready is not None:
+        cur = torch.cuda.current_stream(gi.perm.device)
+        cur.wait_event(gi.ready)
+        for t in (gi.perm, gi.tgt, gi.src, gi.rowptr_t, gi.rowptr_s, gi.spos, gi.spos_inv):
+            t.record_stream(cur)
+        gi.ready = None
+    return gi
+
+
+def prefetch_graph_index(edge_index: Tensor, n_nodes: int, stream) -> GraphIndex:
+    """Build the index of ``edge_index`` on ``stream`` (a side stream: the loader's) while the
+    current stream computes, and register it in the cache; ``graph_index()`` for the same
+    tensor then joins it instead of building.  The index only depends on the input edge list,
+    so a loader can have it ready one batch ahead (io.PrefetchLoader(build_index=True))."""
+    with torch.cuda.stream(stream):
+        gi = graph_index(edge_index, n_nodes, cache=False)
+        gi.ready = torch.cuda.Event()
+        gi.ready.record(stream)
+    _GI_CACHE[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, n_nodes, gi)
     return gi
 
 

@@ -62,3 +62,14 @@ def test_prefetch_loader_to_device(tmp_path):
         assert b.x.is_cuda and torch.equal(b.x.cpu(), ref.x) and torch.equal(b.edge_index.cpu(), ref.edge_index)
         n += 1
     assert n == 4
+    # the loader can also build the graph index of a staged batch on its side stream
+    from gnn_tracking_amd import ops
+    for b in gio.PrefetchLoader(ds, batch_size=2, device="cuda:0", depth=2, build_index=True):
+        hit = ops._GI_CACHE.get(id(b.edge_index))
+        assert hit is not None and hit[3].ready is not None, "index was not prefetched"
+        gi = ops.graph_index(b.edge_index, b.num_nodes)
+        assert gi is hit[3] and gi.ready is None
+        ref_gi = ops.graph_index(b.edge_index, b.num_nodes, cache=False)
+        for k in ("perm", "tgt", "src", "rowptr_t", "rowptr_s", "spos", "spos_inv"):
+            assert torch.equal(getattr(gi, k), getattr(ref_gi, k)), k
+

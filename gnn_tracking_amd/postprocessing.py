@@ -72,12 +72,18 @@ class DBSCANFastRescan:
         args = (ops._p(self._off), ops._p(self._nbr), ops._p(self._dist), n, float(eps))
         _capi.check(lib.gnntrk_dbscan_init(args[0], args[2], n, float(eps), int(min_pts), ops._p(core),
                                            ops._p(root), st), lib)
-        for _ in range(64):  # a handful of rounds per host check; compact clusters need one or two
-            _capi.check(lib.gnntrk_dbscan_propagate(*args, ops._p(core), ops._p(root), 4, ops._p(changed), st), lib)
+        # a few rounds per host check (compact clusters need one or two), more per check for
+        # long chains; n rounds always suffice (the lowest index moves at least one hop per round)
+        rounds, done = 4, 0
+        while True:
+            _capi.check(lib.gnntrk_dbscan_propagate(*args, ops._p(core), ops._p(root), rounds, ops._p(changed), st),
+                        lib)
+            done += rounds
             if int(changed.item()) == 0:
                 break
-        else:
-            raise RuntimeError("DBSCAN label propagation did not converge")
+            if done > n + 8:
+                raise RuntimeError("DBSCAN label propagation did not converge")
+            rounds = min(2 * rounds, 64)
         ws = torch.empty(max(int(lib.gnntrk_dbscan_workspace_bytes(n)), 256), dtype=torch.uint8, device=dev)
         n_clusters = torch.empty(1, dtype=torch.int64, device=dev)
         _capi.check(lib.gnntrk_dbscan_labels(*args, ops._p(core), ops._p(root), ops._p(labels), ops._p(n_clusters),

@@ -24,7 +24,7 @@ from .precision import bf16_storage
 from .resin import ResIN
 from .postprocessing import DBSCANFastRescan, dbscan
 from .track_condensation_networks import (GraphConstructionFCNN, GraphConstructionHeteroEncResFCNN,
-                                            GraphConstructionHeteroResFCNN, GraphTCN,
+                                            GraphConstructionHeteroResFCNN, GraphConstructionResIN, GraphTCN,
                                             HeterogeneousResFCNN, ModularGraphTCN, PreTrainedECGraphTCN,
                                             ResFCNN)
 
@@ -35,4 +35,4 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage", "GraphTCN", "ModularGraphTCN",
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
            "GraphConstructionFCNN", "HeterogeneousResFCNN", "GraphConstructionHeteroResFCNN",
-           "GraphConstructionHeteroEncResFCNN", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]
+           "GraphConstructionHeteroEncResFCNN", "GraphConstructionResIN", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]

@@ -156,6 +156,38 @@ class GraphConstructionHeteroEncResFCNN(nn.Module, HyperparametersMixin):
         return {"H": out * self._latent_normalization}
 
 
+class GraphConstructionResIN(nn.Module, HyperparametersMixin):
+    def __init__(self, *, node_indim: int, edge_indim: int, h_outdim: int = 8, hidden_dim: int = 40,
+                 alpha: float = 0.5, n_layers: int = 1, alpha_fcnn: float = 0.5):
+        """Refinement of a metric-learning latent space with a residual stack of interaction
+        networks (models/graph_construction.py:136-219): encoders to ``hidden_dim``, ``ResIN``
+        with node and edge width ``hidden_dim``, decoder to ``h_outdim``, mixed with the first
+        ``h_outdim`` input features.  The interaction networks are the fused kernels, so
+        ``3 * hidden_dim`` has to fit their input width (48 features in fp32, 64 in bf16
+        storage); wider stacks raise ``NotImplementedError`` there."""
+        super().__init__()
+        self.save_hyperparameters()
+        self._node_encoder = MLP(node_indim, hidden_dim, hidden_dim=hidden_dim, L=2, bias=False)
+        self._edge_encoder = MLP(edge_indim, hidden_dim, hidden_dim=hidden_dim, L=2, bias=False)
+        self._resin = ResIN(node_dim=hidden_dim, edge_dim=hidden_dim, object_hidden_dim=hidden_dim,
+                            relational_hidden_dim=hidden_dim, n_layers=n_layers, alpha=alpha)
+        self._decoder = MLP(hidden_dim, h_outdim, hidden_dim=hidden_dim, L=2, bias=False)
+        self._latent_normalization = nn.Parameter(torch.tensor([1.0]), requires_grad=True)
+
+    def forward(self, data) -> dict[str, Tensor]:
+        x_fcnn = data.x[:, :self.hparams.h_outdim]
+        assert_feat_dim(data.x, self.hparams.node_indim)
+        assert_feat_dim(data.edge_attr, self.hparams.edge_indim)
+        x = self._node_encoder(data.x)
+        edge_attr = self._edge_encoder(data.edge_attr)
+        x, _, _ = self._resin(x, data.edge_index, edge_attr)
+        assert_feat_dim(x, self.hparams.hidden_dim)
+        delta = self._decoder(x).float()
+        assert_feat_dim(delta, self.hparams.h_outdim)
+        h = self.hparams.alpha_fcnn * x_fcnn + (1 - self.hparams.alpha_fcnn) * delta
+        return {"H": h * self._latent_normalization}
+
+
 class ModularGraphTCN(nn.Module, HyperparametersMixin):
     def __init__(self, *, ec: nn.Module | None = None, hc_in: nn.Module, node_indim: int,
                  edge_indim: int, h_dim: int = 5, e_dim: int = 4, h_outdim: int = 2,

@@ -502,6 +502,42 @@ def g10_hetero_fcnn():
     npz("g10_hetero_fcnn.npz", **arrs)
 
 
+GC_RESIN_CASES = {"h12_l2": dict(h_outdim=6, hidden_dim=12, n_layers=2, alpha=0.5, alpha_fcnn=0.5),
+                  "h16_l1": dict(h_outdim=8, hidden_dim=16, n_layers=1, alpha=0.3, alpha_fcnn=0.7)}
+
+
+def g12_gc_resin():
+    """GraphConstructionResIN (models/graph_construction.py:136-219) on the G2 graph: H and the
+    gradients of sum(H * r)."""
+    from gnn_tracking.models.graph_construction import GraphConstructionResIN
+
+    print("G12 GraphConstructionResIN")
+    x, ei, ea, y, pt = synth_graph(2, 300, 2000, 14, 4)
+    g = np.random.default_rng(41)
+    arrs = dict(x=x, edge_index=ei, edge_attr=ea)
+    for name, kw in GC_RESIN_CASES.items():
+        torch.manual_seed(8)
+        model = GraphConstructionResIN(node_indim=14, edge_indim=4, **kw)
+        with torch.no_grad():
+            model._latent_normalization.fill_(1.3)
+        p0 = sd(model)
+        out = model(Data(x=x, edge_index=ei, edge_attr=ea))["H"]
+        r = torch.from_numpy(g.normal(size=tuple(out.shape))).float()
+        (out * r).sum().backward()
+        po = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+        oo = O.graph_construction_resin(x, ei, ea, po, h_outdim=kw["h_outdim"], n_layers=kw["n_layers"],
+                                        alpha=kw["alpha"], alpha_fcnn=kw["alpha_fcnn"])
+        close(oo, out, 1e-5, name + " H")
+        og = torch.autograd.grad((oo * r).sum(), list(po.values()))
+        for (k, v), gk in zip(model.named_parameters(), og):
+            close(gk, v.grad, 1e-4, f"{name} grad {k}")
+            arrs[f"{name}/p0/{k}"] = p0[k]
+            arrs[f"{name}/grad/{k}"] = v.grad
+        arrs[f"{name}/H"], arrs[f"{name}/r"] = out, r
+    print("  oracle == reference")
+    npz("g12_gc_resin.npz", **arrs)
+
+
 DBSCAN_TRIALS = ((1.0, 1), (0.5, 2), (0.3, 3), (0.2, 5), (0.11, 4), (0.45, 6))
 
 
@@ -677,7 +713,7 @@ if __name__ == "__main__":
     tg = g1_ec_testgraph() if (want("g1") or want("g4") or want("g6")) else None
     for tag, fn in (("g2", g2_ec_variants), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
                     ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g8", g8_hinge),
-                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan)):
+                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan), ("g12", g12_gc_resin)):
         if want(tag):
             fn()
     print("goldens written; oracle pinned against the reference.")

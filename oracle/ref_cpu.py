@@ -674,3 +674,13 @@ def dbscan_labels(x, max_eps: float, eps: float, min_pts: int):
             i = stack.pop()
         label_num += 1
     return labels
+
+
+def graph_construction_resin(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *, h_outdim: int,
+                             n_layers: int, alpha: float = 0.5, alpha_fcnn: float = 0.5) -> Tensor:
+    """models/graph_construction.py:136-219 (``GraphConstructionResIN.forward``)."""
+    h = mlp(x, p, "_node_encoder", 2, bias=False)
+    e = mlp(edge_attr, p, "_edge_encoder", 2, bias=False)
+    h, _, _ = resin(h, edge_index, e, p, "_resin", n_layers=n_layers, alpha=alpha)
+    delta = mlp(h, p, "_decoder", 2, bias=False)
+    return (alpha_fcnn * x[:, :h_outdim] + (1 - alpha_fcnn) * delta) * p["_latent_normalization"]

@@ -969,3 +969,32 @@ def case_full_size_properties(device, n_events=32, n_nodes=150_000, n_edges=2_00
     first_core = torch.full((n_cl,), n_hits, dtype=torch.long, device=device)
     first_core.scatter_reduce_(0, lab[core], torch.arange(n_hits, device=device)[core], reduce="amin")
     assert bool((first_core[1:] > first_core[:-1]).all()), "clusters not numbered by their lowest core index"
+
+
+GC_RESIN_CASES = {"h12_l2": dict(h_outdim=6, hidden_dim=12, n_layers=2, alpha=0.5, alpha_fcnn=0.5),
+                  "h16_l1": dict(h_outdim=8, hidden_dim=16, n_layers=1, alpha=0.3, alpha_fcnn=0.7)}
+
+
+def case_gc_resin(device, names=None):
+    """GraphConstructionResIN vs the reference (G12): encoders, ResIN with node = edge width =
+    hidden_dim (relational input 3 x hidden_dim), decoder, latent mix."""
+    z = load("g12_gc_resin.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    for name, kw in GC_RESIN_CASES.items():
+        if names is not None and name not in names:
+            continue
+        model = G.GraphConstructionResIN(node_indim=14, edge_indim=4, **kw)
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        out = model(G.Data(x=x, edge_index=ei, edge_attr=ea))["H"]
+        assert_close(out, z[f"{name}/H"], TOL_OUT, name + " H")
+        (out * tt(z[f"{name}/r"], device)).sum().backward()
+        for k, v in model.named_parameters():
+            assert_close(v.grad, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
+    wide = G.GraphConstructionResIN(node_indim=14, edge_indim=4, hidden_dim=40).to(device)
+    try:
+        wide(G.Data(x=x, edge_index=ei, edge_attr=ea))
+    except NotImplementedError:
+        pass
+    else:
+        raise AssertionError("3 x 40 input features should exceed the fused kernel's width (no silent fallback)")

@@ -95,3 +95,8 @@ def test_full_size_properties_tiny_emulated():
     # the property checks themselves, on a size the emulator finishes in seconds
     with emulated():
         P.case_full_size_properties("cpu", n_events=2, n_nodes=40, n_edges=96, n_hits=130)
+
+
+def test_gc_resin_emulated():
+    with emulated():
+        P.case_gc_resin("cpu", names=("h16_l1",))

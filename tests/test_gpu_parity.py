@@ -133,3 +133,7 @@ def test_dbscan(dev):
 
 def test_full_size_properties(dev):
     P.case_full_size_properties(dev)
+
+
+def test_graph_construction_resin(dev):
+    P.case_gc_resin(dev)

@@ -165,3 +165,13 @@ def test_dbscan_oracle_vs_reference_labels():
     for cn in ("d2", "d3", "d8"):
         for eps, mp in P.DBSCAN_TRIALS[:3] + ((1.3, 3),):
             assert np.array_equal(O.dbscan_labels(z[f"{cn}/x"], 1.0, eps, mp), z[f"{cn}/eps{eps}_mp{mp}"])
+
+
+def test_gc_resin():
+    z = load("g12_gc_resin.npz")
+    x, ei, ea = tt(z["x"]), tt(z["edge_index"]), tt(z["edge_attr"])
+    for name, kw in P.GC_RESIN_CASES.items():
+        p0 = _params(z, f"{name}/p0/")
+        out = O.graph_construction_resin(x, ei, ea, p0, h_outdim=kw["h_outdim"], n_layers=kw["n_layers"],
+                                         alpha=kw["alpha"], alpha_fcnn=kw["alpha_fcnn"])
+        assert_close(out, z[f"{name}/H"], 1e-5, name)

@@ -12,7 +12,7 @@ no CPU fallback.
 
 from .data import Data, collate
 from .io import GraphDataset, PrefetchLoader, load_graph
-from .edge_classifier import ECForGraphTCN
+from .edge_classifier import ECForGraphTCN, PerfectEdgeClassification
 from .interaction_network import InteractionNetwork
 from .graph_construction import MLGraphConstruction, knn_with_max_radius
 from .graph_masks import get_good_node_mask, get_good_node_mask_tensors
@@ -25,6 +25,7 @@ from .resin import ResIN
 from .postprocessing import DBSCANFastRescan, dbscan
 from .track_condensation_networks import (GraphConstructionFCNN, GraphConstructionHeteroEncResFCNN,
                                             GraphConstructionHeteroResFCNN, GraphConstructionResIN, GraphTCN,
+                                            GraphTCNForMLGCPipeline, PerfectECGraphTCN,
                                             HeterogeneousResFCNN, ModularGraphTCN, PreTrainedECGraphTCN,
                                             ResFCNN)
 
@@ -35,4 +36,5 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage", "GraphTCN", "ModularGraphTCN",
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
            "GraphConstructionFCNN", "HeterogeneousResFCNN", "GraphConstructionHeteroResFCNN",
-           "GraphConstructionHeteroEncResFCNN", "GraphConstructionResIN", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]
+           "GraphConstructionHeteroEncResFCNN", "GraphConstructionResIN", "PerfectECGraphTCN",
+           "GraphTCNForMLGCPipeline", "PerfectEdgeClassification", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]

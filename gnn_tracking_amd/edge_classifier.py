@@ -13,6 +13,8 @@ caller's edge order while writing it.
 
 from __future__ import annotations
 
+import math
+
 import torch
 from torch import Tensor, nn
 
@@ -107,3 +109,27 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
             "node_embedding": h,
             "edge_embedding": ops.permute_rows(e, gi.perm, scatter=True),
         }
+
+
+class PerfectEdgeClassification(nn.Module, HyperparametersMixin):
+    def __init__(self, tpr=1.0, tnr=1.0, false_below_pt=0.0):
+        """Truth-based edge classifier (models/edge_classifier.py:124-163): ``W = y`` with an
+        optional rate of flipped true / false edges and a pt cut.  No kernel of its own - it
+        exists so that ``PerfectECGraphTCN`` configurations run unchanged."""
+        super().__init__()
+        self.save_hyperparameters()
+        assert 0.0 <= tpr <= 1.0
+        assert 0.0 <= tnr <= 1.0
+        self.tpr, self.tnr, self.false_below_pt = tpr, tnr, false_below_pt
+
+    def forward(self, data) -> dict[str, Tensor]:
+        r = data.y.bool()
+        if not math.isclose(self.tpr, 1.0, rel_tol=1e-5, abs_tol=1e-8):
+            true_mask = r.detach().clone()
+            r[true_mask] = torch.rand(int(true_mask.sum()), device=r.device) <= self.tpr
+        if not math.isclose(self.tnr, 1.0, rel_tol=1e-5, abs_tol=1e-8):
+            false_mask = (~r).detach().clone()
+            r[false_mask] = ~(torch.rand(int(false_mask.sum()), device=r.device) <= self.tnr)
+        if self.false_below_pt > 0.0:
+            r[data.pt < self.false_below_pt] = False
+        return {"W": r.float()}

@@ -24,7 +24,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _capi, graph_cut, ops, precision
-from .edge_classifier import ECForGraphTCN
+from .edge_classifier import ECForGraphTCN, PerfectEdgeClassification
 from .hparams import HyperparametersMixin, assert_feat_dim, obj_from_or_to_hparams
 from .mlp import MLP
 from .resin import ResIN
@@ -307,6 +307,40 @@ class PreTrainedECGraphTCN(nn.Module, HyperparametersMixin):
         self._gtcn = ModularGraphTCN(ec=ec, hc_in=hc_in, node_indim=node_indim,
                                      edge_indim=edge_indim, h_dim=h_dim, e_dim=e_dim,
                                      h_outdim=h_outdim, hidden_dim=hidden_dim, **kwargs)
+
+    def forward(self, data) -> dict[str, Tensor | None]:
+        return self._gtcn.forward(data=data)
+
+
+class PerfectECGraphTCN(nn.Module, HyperparametersMixin):
+    def __init__(self, *, node_indim: int, edge_indim: int, h_dim=5, e_dim=4, h_outdim=2, hidden_dim=40,
+                 L_hc=3, alpha_hc: float = 0.5, ec_tpr=1.0, ec_tnr=1.0, **kwargs):
+        """``GraphTCN`` with the truth-based edge classifier
+        (models/track_condensation_networks.py:389-454)."""
+        super().__init__()
+        self.save_hyperparameters()
+        ec = PerfectEdgeClassification(tpr=ec_tpr, tnr=ec_tnr)
+        hc_in = ResIN(node_dim=h_dim, edge_dim=e_dim, object_hidden_dim=hidden_dim,
+                      relational_hidden_dim=hidden_dim, alpha=alpha_hc, n_layers=L_hc)
+        self._gtcn = ModularGraphTCN(ec=ec, hc_in=hc_in, node_indim=node_indim, edge_indim=edge_indim,
+                                     h_dim=h_dim, e_dim=e_dim, h_outdim=h_outdim, hidden_dim=hidden_dim,
+                                     **kwargs)
+
+    def forward(self, data) -> dict[str, Tensor | None]:
+        return self._gtcn.forward(data=data)
+
+
+class GraphTCNForMLGCPipeline(nn.Module, HyperparametersMixin):
+    def __init__(self, *, node_indim: int, edge_indim: int, h_dim=5, e_dim=4, h_outdim=2, hidden_dim=40,
+                 L_hc=3, alpha_hc: float = 0.5, **kwargs):
+        """``GraphTCN`` without an edge classifier, behind a metric-learning graph construction
+        (models/track_condensation_networks.py:522-582)."""
+        super().__init__()
+        self.save_hyperparameters(ignore=["ec"])
+        hc_in = ResIN(node_dim=h_dim, edge_dim=e_dim, object_hidden_dim=hidden_dim,
+                      relational_hidden_dim=hidden_dim, alpha=alpha_hc, n_layers=L_hc)
+        self._gtcn = ModularGraphTCN(hc_in=hc_in, node_indim=node_indim, edge_indim=edge_indim, h_dim=h_dim,
+                                     e_dim=e_dim, h_outdim=h_outdim, hidden_dim=hidden_dim, **kwargs)
 
     def forward(self, data) -> dict[str, Tensor | None]:
         return self._gtcn.forward(data=data)

@@ -637,6 +637,9 @@ GTCN_VARIANTS = {
     "latent": dict(L_ec=1, L_hc=2, hidden_dim=8, h_outdim=4, alpha_latent=0.4, n_embedding_coords=3),
     # models/track_condensation_networks.py:209-217: pixel / strip node encoders (depth 2)
     "hetero": dict(L_ec=1, L_hc=1, hidden_dim=12, mask_orphan_nodes=True, heterogeneous_node_encoder=True),
+    # the wrappers around ModularGraphTCN with a truth-based / without an edge classifier (:389-454, :522-582)
+    "perfect_ec": dict(_cls="PerfectECGraphTCN", L_hc=2, hidden_dim=10, mask_orphan_nodes=True),
+    "mlgc": dict(_cls="GraphTCNForMLGCPipeline", L_hc=1, hidden_dim=10),
 }
 
 
@@ -654,26 +657,40 @@ def g7_graph_tcn():
     for name, kw in GTCN_VARIANTS.items():
         # the cut must remove a real fraction of the edges: put the threshold at the 40 %
         # quantile of this model's edge weights (they do not depend on it), away from any weight
-        torch.manual_seed(11)
-        probe = GraphTCN(14, 4, **kw)
-        wq = probe._gtcn.ec(Data(x=x, edge_index=ei, edge_attr=ea))["W"].detach().sort().values
-        gaps = wq[int(0.25 * len(wq)):int(0.55 * len(wq))].double()
-        j = int((gaps[1:] - gaps[:-1]).argmax())
-        kw = dict(kw, ec_threshold=float((gaps[j] + gaps[j + 1]) / 2))
-        torch.manual_seed(11)
-        model = GraphTCN(14, 4, **kw)
+        kw = dict(kw)
+        cls = kw.pop("_cls", "GraphTCN")
+        if cls == "GraphTCN":
+            torch.manual_seed(11)
+            probe = GraphTCN(14, 4, **kw)
+            wq = probe._gtcn.ec(Data(x=x, edge_index=ei, edge_attr=ea))["W"].detach().sort().values
+            gaps = wq[int(0.25 * len(wq)):int(0.55 * len(wq))].double()
+            j = int((gaps[1:] - gaps[:-1]).argmax())
+            kw = dict(kw, ec_threshold=float((gaps[j] + gaps[j + 1]) / 2))
+            torch.manual_seed(11)
+            model = GraphTCN(14, 4, **kw)
+        else:
+            import gnn_tracking.models.track_condensation_networks as tcn_mod
+            kw = dict(kw, ec_threshold=0.5)
+            torch.manual_seed(11)
+            model = getattr(tcn_mod, cls)(node_indim=14, edge_indim=4, **kw)
         p0 = sd(model)
         data = Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=layer)
         out = model(data)
         thr = kw["ec_threshold"]
         arrs[f"{name}/ec_threshold"] = np.float64(thr)
-        margin = (out["W"].detach() - thr).abs().min().item()
+        margin = (out["W"].detach() - thr).abs().min().item() if out["W"] is not None else 1.0
         assert margin > 1e-6, f"{name}: an edge weight sits {margin:.1e} from the threshold"
         rH = torch.from_numpy(g.normal(size=tuple(out["H"].shape))).float()
         rB = torch.from_numpy(g.normal(size=tuple(out["B"].shape))).float()
-        loss = (out["H"] * rH).sum() + (out["B"] * rB).sum() + EdgeWeightBCELoss()(w=out["W"], y=y.float())
+        loss = (out["H"] * rH).sum() + (out["B"] * rB).sum()
+        if cls == "GraphTCN":
+            loss = loss + EdgeWeightBCELoss()(w=out["W"], y=y.float())
         loss.backward()
         okw = dict(L_ec=kw.get("L_ec", 3), L_hc=kw.get("L_hc", 3))
+        if cls == "PerfectECGraphTCN":
+            okw.update(ec_kind="perfect", y=y)
+        elif cls == "GraphTCNForMLGCPipeline":
+            okw.update(ec_kind="none")
         for k in ("ec_threshold", "mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc",
                   "alpha_latent", "n_embedding_coords", "heterogeneous_node_encoder"):
             if k in kw:
@@ -682,10 +699,15 @@ def g7_graph_tcn():
             okw["layer"] = layer
         po = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
         oo = O.graph_tcn(x, ei, ea, po, **okw)
-        assert torch.equal(oo["ec_edge_mask"], out["ec_edge_mask"]) and torch.equal(oo["ec_hit_mask"], out["ec_hit_mask"])
-        worst = max(worst, close(oo["W"], out["W"], 1e-6, name + " W"), close(oo["H"], out["H"], 1e-5, name + " H"),
-                    close(oo["B"], out["B"], 1e-6, name + " B"))
-        ol = (oo["H"] * rH).sum() + (oo["B"] * rB).sum() + O.edge_weight_bce_loss(oo["W"], y.float())
+        if cls == "GraphTCNForMLGCPipeline":
+            assert out["W"] is None and out["ec_edge_mask"] is None and out["ec_hit_mask"] is None
+        else:
+            assert torch.equal(oo["ec_edge_mask"], out["ec_edge_mask"]) and torch.equal(oo["ec_hit_mask"], out["ec_hit_mask"])
+            worst = max(worst, close(oo["W"], out["W"], 1e-6, name + " W"))
+        worst = max(worst, close(oo["H"], out["H"], 1e-5, name + " H"), close(oo["B"], out["B"], 1e-6, name + " B"))
+        ol = (oo["H"] * rH).sum() + (oo["B"] * rB).sum()
+        if cls == "GraphTCN":
+            ol = ol + O.edge_weight_bce_loss(oo["W"], y.float())
         og = torch.autograd.grad(ol, list(po.values()), allow_unused=True)
         for (k, v), gk in zip(model.named_parameters(), og):
             gm = v.grad if v.grad is not None else torch.zeros_like(v)
@@ -694,11 +716,13 @@ def g7_graph_tcn():
             arrs[f"{name}/p0/{k}"] = p0[k]
             arrs[f"{name}/grad/{k}"] = gm
         for k in ("W", "H", "B", "ec_hit_mask", "ec_edge_mask"):
-            arrs[f"{name}/{k}"] = out[k]
+            if out[k] is not None:
+                arrs[f"{name}/{k}"] = out[k]
         arrs[f"{name}/rH"], arrs[f"{name}/rB"] = rH, rB
         arrs[f"{name}/loss"] = loss
-        print(f"   {name}: {int(out['ec_edge_mask'].sum())} of {ei.shape[1]} edges kept, "
-              f"{int(out['ec_hit_mask'].sum())} of {x.shape[0]} hits, threshold margin {margin:.1e}")
+        if out["ec_edge_mask"] is not None:
+            print(f"   {name}: {int(out['ec_edge_mask'].sum())} of {ei.shape[1]} edges kept, "
+                  f"{int(out['ec_hit_mask'].sum())} of {x.shape[0]} hits, threshold margin {margin:.1e}")
     print(f"  oracle == reference (max diff {worst:.2e})")
     npz("g7_graph_tcn.npz", **arrs)
 

@@ -511,18 +511,30 @@ def graph_tcn(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *, L_ec
               mask_orphan_nodes: bool = False, feed_edge_weights: bool = False,
               use_ec_embeddings_for_hc: bool = False, alpha_latent: float = 0.0,
               n_embedding_coords: int = 0, prefix: str = "_gtcn", layer: Tensor | None = None,
-              heterogeneous_node_encoder: bool = False) -> dict:
+              heterogeneous_node_encoder: bool = False, ec_kind: str = "model",
+              y: Tensor | None = None) -> dict:
     """models/track_condensation_networks.py:236-308 (``ModularGraphTCN.forward`` as built by
     ``GraphTCN``; node encoder homogeneous or, with ``layer``, heterogeneous :209-217)."""
     relu = lambda t: torch.clamp_min(t, 0.0)  # noqa: E731
-    pe = {k[len(prefix) + 4:]: v for k, v in p.items() if k.startswith(prefix + ".ec.")}
-    ec = ec_for_graph_tcn(x, edge_index, edge_attr, pe, L_ec=L_ec, alpha=alpha_ec)
+    if ec_kind == "none":  # GraphTCNForMLGCPipeline (:522-582): no edge classifier, no cut
+        h = relu(res_fcnn_depth1(x, p, f"{prefix}.hc_node_encoder"))
+        e = relu(mlp(edge_attr, p, f"{prefix}.hc_edge_encoder", 2, bias=False))
+        h, _, _ = resin(h, edge_index, e, p, f"{prefix}.hc_in", n_layers=L_hc, alpha=alpha_hc)
+        beta = 1e-6 + (1 - 2e-6) * torch.sigmoid(mlp(h, p, f"{prefix}.p_beta", 3))
+        hh = mlp(h, p, f"{prefix}.p_cluster", 3) * p[f"{prefix}._latent_normalization"]
+        return {"W": None, "H": hh, "B": beta.squeeze(1), "ec_hit_mask": None, "ec_edge_mask": None}
+    if ec_kind == "perfect":  # PerfectEdgeClassification with tpr = tnr = 1 (edge_classifier.py:147-163)
+        ec = {"W": y.bool().float(), "edge_embedding": None, "node_embedding": None}
+        assert not use_ec_embeddings_for_hc
+    else:
+        pe = {k[len(prefix) + 4:]: v for k, v in p.items() if k.startswith(prefix + ".ec.")}
+        ec = ec_for_graph_tcn(x, edge_index, edge_attr, pe, L_ec=L_ec, alpha=alpha_ec)
     w = ec["W"].reshape(-1, 1)
     edge_mask = (w > ec_threshold).squeeze(1)
     ei = edge_index[:, edge_mask]
     ea = edge_attr[edge_mask]
     w_m = w[edge_mask]
-    ee = ec["edge_embedding"][edge_mask]
+    ee = ec["edge_embedding"][edge_mask] if ec["edge_embedding"] is not None else None
     xn, en = x, ec["node_embedding"]
     n = x.shape[0]
     if mask_orphan_nodes:
@@ -532,7 +544,7 @@ def graph_tcn(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, *, L_ec
         relabel = torch.full((n,), -1, dtype=torch.long)
         relabel[hit_mask] = torch.arange(int(hit_mask.sum()))
         ei = relabel[ei]
-        xn, en = x[hit_mask], en[hit_mask]
+        xn, en = x[hit_mask], (en[hit_mask] if en is not None else None)
         layer = layer[hit_mask] if layer is not None else None
     else:
         hit_mask = torch.ones(n, dtype=torch.bool)

@@ -663,11 +663,26 @@ GTCN_VARIANTS = {
                            use_ec_embeddings_for_hc=True, feed_edge_weights=True),
     "latent": dict(L_ec=1, L_hc=2, hidden_dim=8, h_outdim=4, alpha_latent=0.4, n_embedding_coords=3),
     "hetero": dict(L_ec=1, L_hc=1, hidden_dim=12, mask_orphan_nodes=True, heterogeneous_node_encoder=True),
+    "perfect_ec": dict(_cls="PerfectECGraphTCN", L_hc=2, hidden_dim=10, mask_orphan_nodes=True),
+    "mlgc": dict(_cls="GraphTCNForMLGCPipeline", L_hc=1, hidden_dim=10),
 }
 
 
-def gtcn_oracle_kwargs(kw, thr):
+def make_gtcn(kw, thr):
+    """(model, class name) of a G7 variant."""
+    kw = dict(kw)
+    cls = kw.pop("_cls", "GraphTCN")
+    if cls == "GraphTCN":
+        return G.GraphTCN(14, 4, ec_threshold=thr, **kw), cls
+    return getattr(G, cls)(node_indim=14, edge_indim=4, ec_threshold=thr, **kw), cls
+
+
+def gtcn_oracle_kwargs(kw, thr, y=None):
     okw = dict(L_ec=kw.get("L_ec", 3), L_hc=kw.get("L_hc", 3), ec_threshold=thr)
+    if kw.get("_cls") == "PerfectECGraphTCN":
+        okw.update(ec_kind="perfect", y=y)
+    elif kw.get("_cls") == "GraphTCNForMLGCPipeline":
+        okw.update(ec_kind="none")
     for k in ("mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc", "alpha_latent",
               "n_embedding_coords", "heterogeneous_node_encoder"):
         if k in kw:
@@ -686,17 +701,21 @@ def case_graph_tcn(device, names=None):
         if names is not None and name not in names:
             continue
         thr = float(z[f"{name}/ec_threshold"])
-        model = G.GraphTCN(14, 4, ec_threshold=thr, **kw)
+        model, cls = make_gtcn(kw, thr)
         load_params(model, z, f"{name}/p0/")
         model = model.to(device)
         out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=tt(z["layer"], device)))
-        assert torch.equal(out["ec_edge_mask"].cpu(), tt(z[f"{name}/ec_edge_mask"])), name + " edge mask"
-        assert torch.equal(out["ec_hit_mask"].cpu(), tt(z[f"{name}/ec_hit_mask"])), name + " hit mask"
-        assert_close(out["W"], z[f"{name}/W"], TOL_OUT, name + " W")
+        if cls == "GraphTCNForMLGCPipeline":
+            assert out["W"] is None and out["ec_edge_mask"] is None and out["ec_hit_mask"] is None
+        else:
+            assert torch.equal(out["ec_edge_mask"].cpu(), tt(z[f"{name}/ec_edge_mask"])), name + " edge mask"
+            assert torch.equal(out["ec_hit_mask"].cpu(), tt(z[f"{name}/ec_hit_mask"])), name + " hit mask"
+            assert_close(out["W"], z[f"{name}/W"], TOL_OUT, name + " W")
         assert_close(out["H"], z[f"{name}/H"], TOL_OUT, name + " H")
         assert_close(out["B"], z[f"{name}/B"], TOL_OUT, name + " B")
-        loss = ((out["H"] * tt(z[f"{name}/rH"], device)).sum() + (out["B"] * tt(z[f"{name}/rB"], device)).sum()
-                + G.EdgeWeightBCELoss()(w=out["W"], y=y.float()))
+        loss = (out["H"] * tt(z[f"{name}/rH"], device)).sum() + (out["B"] * tt(z[f"{name}/rB"], device)).sum()
+        if cls == "GraphTCN":
+            loss = loss + G.EdgeWeightBCELoss()(w=out["W"], y=y.float())
         assert_close(loss, z[f"{name}/loss"], TOL_OUT, name + " loss")
         loss.backward()
         for k, v in model.named_parameters():
@@ -712,6 +731,8 @@ def case_graph_tcn_bf16(device):
     x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
     y = tt(z["y"], device)
     for name, kw in GTCN_VARIANTS.items():
+        if "_cls" in kw:
+            continue  # (the wrappers without a learned edge classifier add nothing in this mode)
         model = G.GraphTCN(14, 4, ec_threshold=float(z[f"{name}/ec_threshold"]), **kw)
         load_params(model, z, f"{name}/p0/")
         model = model.to(device)

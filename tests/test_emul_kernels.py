@@ -78,7 +78,7 @@ def test_gc_fcnn_emulated():
 def test_hetero_fcnn_emulated():
     with emulated():
         P.case_hetero_fcnn("cpu", names=("hetero_d2", "heteroenc"))
-        P.case_graph_tcn("cpu", names=("hetero",))
+        P.case_graph_tcn("cpu", names=("hetero", "perfect_ec"))
 
 
 def test_graph_cut_emulated():

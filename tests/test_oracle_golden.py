@@ -105,16 +105,19 @@ def test_graph_tcn():
     x, ei, ea, y = (tt(z[k]) for k in ("x", "edge_index", "edge_attr", "y"))
     for name, kw in P.GTCN_VARIANTS.items():
         p0 = {k: v.clone().requires_grad_(True) for k, v in _params(z, f"{name}/p0/").items()}
-        okw = P.gtcn_oracle_kwargs(kw, float(z[f"{name}/ec_threshold"]))
+        okw = P.gtcn_oracle_kwargs(kw, float(z[f"{name}/ec_threshold"]), y=y)
         if kw.get("heterogeneous_node_encoder"):
             okw["layer"] = tt(z["layer"])
         out = O.graph_tcn(x, ei, ea, p0, **okw)
-        assert torch.equal(out["ec_edge_mask"], tt(z[f"{name}/ec_edge_mask"]))
-        assert torch.equal(out["ec_hit_mask"], tt(z[f"{name}/ec_hit_mask"]))
+        if out["W"] is not None:
+            assert torch.equal(out["ec_edge_mask"], tt(z[f"{name}/ec_edge_mask"]))
+            assert torch.equal(out["ec_hit_mask"], tt(z[f"{name}/ec_hit_mask"]))
         for k in ("W", "H", "B"):
-            assert_close(out[k], z[f"{name}/{k}"], 1e-6 if k != "H" else 1e-5, f"{name} {k}")
-        loss = ((out["H"] * tt(z[f"{name}/rH"])).sum() + (out["B"] * tt(z[f"{name}/rB"])).sum()
-                + O.edge_weight_bce_loss(out["W"], y.float()))
+            if out[k] is not None:
+                assert_close(out[k], z[f"{name}/{k}"], 1e-6 if k != "H" else 1e-5, f"{name} {k}")
+        loss = (out["H"] * tt(z[f"{name}/rH"])).sum() + (out["B"] * tt(z[f"{name}/rB"])).sum()
+        if "_cls" not in kw:
+            loss = loss + O.edge_weight_bce_loss(out["W"], y.float())
         grads = torch.autograd.grad(loss, list(p0.values()), allow_unused=True)
         for (k, v), g in zip(p0.items(), grads):
             g = g if g is not None else torch.zeros_like(v)

@@ -16,7 +16,8 @@ from .edge_classifier import ECForGraphTCN, PerfectEdgeClassification
 from .interaction_network import InteractionNetwork
 from .graph_construction import MLGraphConstruction, knn_with_max_radius
 from .graph_masks import get_good_node_mask, get_good_node_mask_tensors
-from .losses_ec import EdgeWeightBCELoss, falsify_low_pt_edges
+from .losses_ec import (EdgeWeightBCELoss, EdgeWeightFocalLoss, HaughtyFocalLoss, binary_focal_loss,
+                        falsify_low_pt_edges)
 from .losses_ml import GraphConstructionHingeEmbeddingLoss
 from .losses_oc import CondensationLossRG, CondensationLossTiger, MultiLossFctReturn
 from .mlp import MLP
@@ -37,4 +38,4 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
            "GraphConstructionFCNN", "HeterogeneousResFCNN", "GraphConstructionHeteroResFCNN",
            "GraphConstructionHeteroEncResFCNN", "GraphConstructionResIN", "PerfectECGraphTCN",
-           "GraphTCNForMLGCPipeline", "PerfectEdgeClassification", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]
+           "GraphTCNForMLGCPipeline", "PerfectEdgeClassification", "EdgeWeightFocalLoss", "HaughtyFocalLoss", "binary_focal_loss", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]

@@ -56,6 +56,10 @@ int bce_forward_launch(const float *, const float *, const int64_t *, const floa
                        float *, void *, size_t, hipStream_t);
 int bce_backward_launch(const float *, const float *, const int64_t *, const float *, float,
                         int64_t, const float *, float *, hipStream_t);
+int focal_forward_launch(const float *, const float *, const int64_t *, const float *, float, float, float, float,
+                         int, int64_t, float *, void *, size_t, hipStream_t);
+int focal_backward_launch(const float *, const float *, const int64_t *, const float *, float, float, float, float,
+                          int, int64_t, const float *, float *, hipStream_t);
 // graph_index.hip
 size_t graph_index_ws_bytes(int64_t, int64_t);
 int graph_index_build(const int64_t *, const gnntrk_graph_index *, void *, size_t, hipStream_t);
@@ -173,6 +177,18 @@ int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
     return bce_backward_launch(w, y, src_node, pt, pt_thld, n, gscale, gw, (hipStream_t)stream);
 }
 
+int gnntrk_focal_forward(const float *w, const float *y, const int64_t *src_node, const float *pt, float pt_thld,
+                         float alpha, float gamma, float pos_weight, int32_t haughty, int64_t n, float *loss_out,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    return focal_forward_launch(w, y, src_node, pt, pt_thld, alpha, gamma, pos_weight, haughty, n, loss_out,
+                                workspace, workspace_bytes, (hipStream_t)stream);
+}
+int gnntrk_focal_backward(const float *w, const float *y, const int64_t *src_node, const float *pt, float pt_thld,
+                          float alpha, float gamma, float pos_weight, int32_t haughty, int64_t n,
+                          const float *gscale, float *gw, void *stream) {
+    return focal_backward_launch(w, y, src_node, pt, pt_thld, alpha, gamma, pos_weight, haughty, n, gscale, gw,
+                                 (hipStream_t)stream);
+}
 int gnntrk_knn_search(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k,
                       float max_radius, int32_t *nbr, int32_t *cnt, void *stream) {
     return knn_search_launch(x, n, dim, x_stride, k, max_radius, nbr, cnt, (hipStream_t)stream);

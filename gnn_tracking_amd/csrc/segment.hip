@@ -162,6 +162,68 @@ __global__ __launch_bounds__(kTpb) void bce_bwd_kernel(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------ focal loss
+// metrics/losses/ec.py:13-31: mean over edges of
+//   -alpha * pw * (1-w)^gamma * t * log(w)  -  (1-alpha) * w^gamma * (1-t) * log(1-w)
+// (no log clamp, as the reference).  haughty = 0 (EdgeWeightFocalLoss): t = falsified label,
+// pw = the scalar pos_weight; haughty = 1 (HaughtyFocalLoss :153-183): t = the label as given,
+// pw = the falsified label of the edge.
+__device__ __forceinline__ float focal_pow(float x, float gamma) {
+    if (gamma == 0.f) return 1.f;  // torch: pow(x, 0) = 1
+    if (gamma == 1.f) return x;
+    if (gamma == 2.f) return x * x;
+    return powf(x, gamma);
+}
+// d/dx x^gamma
+__device__ __forceinline__ float focal_dpow(float x, float gamma) {
+    if (gamma == 0.f) return 0.f;
+    if (gamma == 1.f) return 1.f;
+    if (gamma == 2.f) return 2.f * x;
+    return gamma * powf(x, gamma - 1.f);
+}
+__device__ __forceinline__ void focal_terms(const float *y, const int64_t *src_node, const float *pt, float thld,
+                                            float pos_weight, int haughty, int64_t e, float &t, float &pw) {
+    const float yf = bce_target(y, src_node, pt, thld, e);
+    t = haughty ? y[e] : yf;
+    pw = haughty ? yf : pos_weight;
+}
+
+__global__ __launch_bounds__(kTpb) void focal_partial_kernel(const float *__restrict__ w, const float *__restrict__ y,
+                                                             const int64_t *__restrict__ src_node,
+                                                             const float *__restrict__ pt, float thld, float alpha,
+                                                             float gamma, float pos_weight, int haughty, int64_t n,
+                                                             double *__restrict__ part) {
+    __shared__ double sh[kTpb / 64];
+    double acc = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * kTpb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kTpb) {
+        float t, pw;
+        focal_terms(y, src_node, pt, thld, pos_weight, haughty, e, t, pw);
+        const float p = w[e], q = 1.f - p;
+        const float pos = -alpha * pw * focal_pow(q, gamma) * t * logf(p);
+        const float neg = -(1.f - alpha) * focal_pow(p, gamma) * (1.f - t) * logf(q);
+        acc += (double)(pos + neg);
+    }
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kTpb) void focal_bwd_kernel(const float *__restrict__ w, const float *__restrict__ y,
+                                                         const int64_t *__restrict__ src_node,
+                                                         const float *__restrict__ pt, float thld, float alpha,
+                                                         float gamma, float pos_weight, int haughty, int64_t n,
+                                                         const float *__restrict__ gscale, float *__restrict__ gw) {
+    const float gs = gscale[0] / (float)n;
+    for (int64_t e = (int64_t)blockIdx.x * kTpb + threadIdx.x; e < n; e += (int64_t)gridDim.x * kTpb) {
+        float t, pw;
+        focal_terms(y, src_node, pt, thld, pos_weight, haughty, e, t, pw);
+        const float p = w[e], q = 1.f - p;
+        // d/dp [(1-p)^g log p] = -g (1-p)^(g-1) log p + (1-p)^g / p ;  d/dp [p^g log(1-p)] = g p^(g-1) log(1-p) - p^g / (1-p)
+        const float dpos = -focal_dpow(q, gamma) * logf(p) + focal_pow(q, gamma) / p;
+        const float dneg = focal_dpow(p, gamma) * logf(q) - focal_pow(p, gamma) / q;
+        gw[e] = gs * (-alpha * pw * t * dpos - (1.f - alpha) * (1.f - t) * dneg);
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 int segment_sum_launch(const float *rows, int dim, int row_stride, const int32_t *rowptr,
                        const int32_t *pos, int64_t n_seg, float *out, int out_stride,
@@ -232,6 +294,34 @@ int bce_backward_launch(const float *w, const float *y, const int64_t *src_node,
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(stream_grid(n)), dim3(kTpb), 0, stream, w, y, src_node,
                        pt, thld, n, gscale, gw);
     return check_launch("bce_backward");
+}
+
+int focal_forward_launch(const float *w, const float *y, const int64_t *src_node, const float *pt, float thld,
+                         float alpha, float gamma, float pos_weight, int haughty, int64_t n, float *loss, void *ws,
+                         size_t ws_bytes, hipStream_t stream) {
+    if (!w || !y || !loss || n < 1) return fail(GNNTRK_EINVAL, "focal_forward: bad argument");
+    if (!(gamma >= 0.f) || !(alpha >= 0.f && alpha <= 1.f)) return fail(GNNTRK_EINVAL, "focal_forward: bad alpha / gamma");
+    if (thld > 0.f && (!src_node || !pt))
+        return fail(GNNTRK_EINVAL, "focal_forward: pt threshold needs edge_index and pt");
+    if (!ws || ws_bytes < bce_ws_bytes(n)) return fail(GNNTRK_EINVAL, "focal_forward: workspace too small");
+    const int g = bce_grid(n);
+    double *part = reinterpret_cast<double *>(ws);
+    hipLaunchKernelGGL(focal_partial_kernel, dim3(g), dim3(kTpb), 0, stream, w, y, src_node, pt, thld, alpha, gamma,
+                       pos_weight, haughty, n, part);
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(kTpb), 0, stream, reinterpret_cast<const double *>(part), g, n,
+                       loss);
+    return check_launch("focal_forward");
+}
+
+int focal_backward_launch(const float *w, const float *y, const int64_t *src_node, const float *pt, float thld,
+                          float alpha, float gamma, float pos_weight, int haughty, int64_t n, const float *gscale,
+                          float *gw, hipStream_t stream) {
+    if (!w || !y || !gscale || !gw || n < 1) return fail(GNNTRK_EINVAL, "focal_backward: bad argument");
+    if (thld > 0.f && (!src_node || !pt))
+        return fail(GNNTRK_EINVAL, "focal_backward: pt threshold needs edge_index and pt");
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3(stream_grid(n)), dim3(kTpb), 0, stream, w, y, src_node, pt, thld, alpha,
+                       gamma, pos_weight, haughty, n, gscale, gw);
+    return check_launch("focal_backward");
 }
 
 }  // namespace gnntrk

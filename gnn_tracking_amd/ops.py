@@ -664,6 +664,58 @@ class _BCE(torch.autograd.Function):
         return gw, None, None, None, None
 
 
+class _Focal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, y, src_nodes, pt, pt_thld: float, alpha: float, gamma: float, pos_weight: float,
+                haughty: bool):
+        _capi.require_device(w, y)
+        lib = _capi.load()
+        w = w.contiguous().view(-1)
+        y = y.contiguous().view(-1)
+        n = w.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=w.device)
+        ws = _ws(lib.gnntrk_bce_workspace_bytes(n), w)
+        _capi.check(lib.gnntrk_focal_forward(_p(w), _p(y), _p(src_nodes), _p(pt), pt_thld, alpha, gamma, pos_weight,
+                                             int(haughty), n, _p(loss), _p(ws), ws.numel(), _stream(w)), lib)
+        ctx.save_for_backward(w, y)
+        ctx.aux = (src_nodes, pt, pt_thld, alpha, gamma, pos_weight, int(haughty))
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _capi.load()
+        w, y = ctx.saved_tensors
+        src_nodes, pt, thld, alpha, gamma, pos_weight, haughty = ctx.aux
+        g = g.contiguous().view(1).to(torch.float32)
+        gw = torch.empty_like(w)
+        _capi.check(lib.gnntrk_focal_backward(_p(w), _p(y), _p(src_nodes), _p(pt), thld, alpha, gamma, pos_weight,
+                                              haughty, w.numel(), _p(g), _p(gw), _stream(w)), lib)
+        return gw, None, None, None, None, None, None, None, None
+
+
+def focal_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None, pt: Optional[Tensor] = None,
+               pt_thld: float = 0.0, *, alpha: float = 0.25, gamma: float = 2.0, pos_weight: float = 1.0,
+               haughty: bool = False) -> Tensor:
+    """Binary focal loss of the edge weights (metrics/losses/ec.py:13-68) with the label
+    falsification of ``EdgeWeightFocalLoss`` (haughty=False) or ``HaughtyFocalLoss`` (True)."""
+    if w.numel() == 0:
+        raise ValueError("focal_loss: empty input")
+    if w.dtype != torch.float32:
+        raise TypeError("focal_loss: w must be fp32")
+    assert gamma >= 0.0
+    assert 0 <= alpha <= 1
+    y = y.to(torch.float32)
+    src_nodes = None
+    if pt_thld > 0.0:
+        assert edge_index is not None and pt is not None
+        src_nodes = edge_index[0].contiguous()
+        pt = pt.to(torch.float32).contiguous()
+    else:
+        pt = None
+    return _Focal.apply(w, y, src_nodes, pt, float(pt_thld), float(alpha), float(gamma), float(pos_weight),
+                        bool(haughty))
+
+
 def bce_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None,
              pt: Optional[Tensor] = None, pt_thld: float = 0.0) -> Tensor:
     """mean BCE(w, y') with y' = falsify_low_pt_edges(y) (metrics/losses/ec.py:71-121)."""

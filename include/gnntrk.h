@@ -298,6 +298,19 @@ int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
                         const float *pt, float pt_thld, int64_t n, const float *gscale,
                         float *gw, void *stream);
 
+/* ------------------------------------------------------------------ focal loss
+ * metrics/losses/ec.py:13-68 (binary_focal_loss), :124-150 (EdgeWeightFocalLoss), :153-183
+ * (HaughtyFocalLoss): mean over edges of
+ *   -alpha*pw*(1-w)^gamma*t*log(w) - (1-alpha)*w^gamma*(1-t)*log(1-w)        (no log clamp)
+ * haughty = 0: t = falsify_low_pt_edges(y), pw = pos_weight (scalar);
+ * haughty = 1: t = y, pw = falsify_low_pt_edges(y) per edge.  Workspace as for BCE.      */
+int gnntrk_focal_forward(const float *w, const float *y, const int64_t *src_node, const float *pt, float pt_thld,
+                         float alpha, float gamma, float pos_weight, int32_t haughty, int64_t n, float *loss_out,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int gnntrk_focal_backward(const float *w, const float *y, const int64_t *src_node, const float *pt, float pt_thld,
+                          float alpha, float gamma, float pos_weight, int32_t haughty, int64_t n,
+                          const float *gscale, float *gw, void *stream);
+
 /* ------------------------------------------------------------- kNN graph build
  * models/graph_construction.py:222-237 knn_with_max_radius(x, k, max_radius) =
  * torch_cluster.knn_graph(x, k) (no batch, loop=False, flow source_to_target) followed by

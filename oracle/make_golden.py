@@ -538,6 +538,44 @@ def g12_gc_resin():
     npz("g12_gc_resin.npz", **arrs)
 
 
+FOCAL_CASES = {"ew_default": ("EdgeWeightFocalLoss", dict()),
+               "ew_pt": ("EdgeWeightFocalLoss", dict(alpha=0.4, gamma=1.5, pos_weight=2.0, pt_thld=0.9)),
+               "ew_g0": ("EdgeWeightFocalLoss", dict(alpha=0.5, gamma=0.0)),
+               "haughty": ("HaughtyFocalLoss", dict(alpha=0.3, gamma=2.0, pt_thld=0.9)),
+               "haughty0": ("HaughtyFocalLoss", dict(alpha=0.25, gamma=3.0))}
+
+
+def g13_focal():
+    """EdgeWeightFocalLoss / HaughtyFocalLoss (metrics/losses/ec.py:124-183) on seeded edge
+    weights: loss and the gradient wrt w; the reference's own check focal(alpha=.5, gamma=0) =
+    BCE / 2 (tests/test_losses.py:152-157)."""
+    import gnn_tracking.metrics.losses.ec as ecl
+
+    print("G13 focal losses")
+    g = np.random.default_rng(51)
+    n_nodes, n = 400, 5000
+    w0 = torch.from_numpy(g.uniform(0.001, 0.999, size=n)).float()
+    y = torch.from_numpy((g.random(n) < 0.3)).float()
+    ei = torch.from_numpy(g.integers(0, n_nodes, size=(2, n))).long()
+    pt = torch.from_numpy(np.exp(g.normal(0, 0.8, size=n_nodes))).float()
+    arrs = dict(w=w0, y=y, edge_index=ei, pt=pt)
+    for name, (cls, kw) in FOCAL_CASES.items():
+        w = w0.clone().requires_grad_(True)
+        rkw = {k: (torch.tensor([v]) if k == "pos_weight" else v) for k, v in kw.items()}  # (a tensor there)
+        loss = getattr(ecl, cls)(**rkw)(w=w, y=y, edge_index=ei, pt=pt)
+        loss.backward()
+        wo = w0.clone().requires_grad_(True)
+        okw = {k: v for k, v in kw.items() if k in ("alpha", "gamma", "pos_weight", "pt_thld")}
+        lo = O.focal_loss(wo, y, edge_index=ei, pt=pt, haughty=cls == "HaughtyFocalLoss", **okw)
+        close(lo, loss, 1e-6, name + " loss")
+        close(torch.autograd.grad(lo, wo)[0], w.grad, 1e-6, name + " grad")
+        arrs[f"{name}/loss"], arrs[f"{name}/grad_w"] = loss.detach(), w.grad
+    bce = torch.nn.functional.binary_cross_entropy(w0, y)
+    assert abs(float(arrs["ew_g0/loss"]) - 0.5 * float(bce)) < 1e-6
+    print("  oracle == reference")
+    npz("g13_focal.npz", **arrs)
+
+
 DBSCAN_TRIALS = ((1.0, 1), (0.5, 2), (0.3, 3), (0.2, 5), (0.11, 4), (0.45, 6))
 
 
@@ -737,7 +775,7 @@ if __name__ == "__main__":
     tg = g1_ec_testgraph() if (want("g1") or want("g4") or want("g6")) else None
     for tag, fn in (("g2", g2_ec_variants), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
                     ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g8", g8_hinge),
-                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan), ("g12", g12_gc_resin)):
+                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan), ("g12", g12_gc_resin), ("g13", g13_focal)):
         if want(tag):
             fn()
     print("goldens written; oracle pinned against the reference.")

@@ -696,3 +696,18 @@ def graph_construction_resin(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p
     h, _, _ = resin(h, edge_index, e, p, "_resin", n_layers=n_layers, alpha=alpha)
     delta = mlp(h, p, "_decoder", 2, bias=False)
     return (alpha_fcnn * x[:, :h_outdim] + (1 - alpha_fcnn) * delta) * p["_latent_normalization"]
+
+
+def focal_loss(w: Tensor, y: Tensor, *, alpha: float = 0.25, gamma: float = 2.0, pos_weight=1.0,
+               edge_index: Tensor | None = None, pt: Tensor | None = None, pt_thld: float = 0.0,
+               haughty: bool = False) -> Tensor:
+    """metrics/losses/ec.py:13-31 with the label handling of ``EdgeWeightFocalLoss`` (:124-150:
+    falsified target, scalar pos_weight) or ``HaughtyFocalLoss`` (:153-183: the target as given,
+    pos_weight = the falsified label per edge)."""
+    yf = y.float()
+    if pt_thld > 0.0:
+        yf = (y.bool() & (pt[edge_index[0]] > pt_thld)).float()
+    t, pw = (y.float(), yf) if haughty else (yf, pos_weight)
+    pos = -alpha * pw * (1 - w).pow(gamma) * t * w.log()
+    neg = -(1.0 - alpha) * w.pow(gamma) * (1.0 - t) * (1 - w).log()
+    return torch.mean(pos + neg)

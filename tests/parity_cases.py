@@ -1019,3 +1019,26 @@ def case_gc_resin(device, names=None):
         pass
     else:
         raise AssertionError("3 x 40 input features should exceed the fused kernel's width (no silent fallback)")
+
+
+FOCAL_CASES = {"ew_default": ("EdgeWeightFocalLoss", dict()),
+               "ew_pt": ("EdgeWeightFocalLoss", dict(alpha=0.4, gamma=1.5, pos_weight=2.0, pt_thld=0.9)),
+               "ew_g0": ("EdgeWeightFocalLoss", dict(alpha=0.5, gamma=0.0)),
+               "haughty": ("HaughtyFocalLoss", dict(alpha=0.3, gamma=2.0, pt_thld=0.9)),
+               "haughty0": ("HaughtyFocalLoss", dict(alpha=0.25, gamma=3.0))}
+
+
+def case_focal_losses(device):
+    """EdgeWeightFocalLoss / HaughtyFocalLoss vs the reference (G13): loss 1e-6, gradient wrt w
+    1e-6 relative; the reference's own check focal(alpha=.5, gamma=0) = BCE / 2."""
+    z = load("g13_focal.npz")
+    y, ei, pt = tt(z["y"], device), tt(z["edge_index"], device), tt(z["pt"], device)
+    for name, (cls, kw) in FOCAL_CASES.items():
+        w = tt(z["w"], device).requires_grad_(True)
+        loss = getattr(G, cls)(**kw)(w=w, y=y, edge_index=ei, pt=pt)
+        assert_close(loss, z[f"{name}/loss"], 1e-6, name + " loss")
+        loss.backward()
+        assert_close(w.grad, z[f"{name}/grad_w"], 1e-5, name + " grad")
+    w = tt(z["w"], device)
+    half = G.binary_focal_loss(inpt=w, target=y, alpha=0.5, gamma=0.0)
+    assert_close(half, 0.5 * float(G.EdgeWeightBCELoss()(w=w, y=y)), 1e-6, "focal(.5, 0) = BCE / 2")

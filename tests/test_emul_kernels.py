@@ -100,3 +100,8 @@ def test_full_size_properties_tiny_emulated():
 def test_gc_resin_emulated():
     with emulated():
         P.case_gc_resin("cpu", names=("h16_l1",))
+
+
+def test_focal_losses_emulated():
+    with emulated():
+        P.case_focal_losses("cpu")

@@ -137,3 +137,7 @@ def test_full_size_properties(dev):
 
 def test_graph_construction_resin(dev):
     P.case_gc_resin(dev)
+
+
+def test_focal_losses(dev):
+    P.case_focal_losses(dev)

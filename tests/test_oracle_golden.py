@@ -178,3 +178,11 @@ def test_gc_resin():
         out = O.graph_construction_resin(x, ei, ea, p0, h_outdim=kw["h_outdim"], n_layers=kw["n_layers"],
                                          alpha=kw["alpha"], alpha_fcnn=kw["alpha_fcnn"])
         assert_close(out, z[f"{name}/H"], 1e-5, name)
+
+
+def test_focal_losses():
+    z = load("g13_focal.npz")
+    w, y, ei, pt = tt(z["w"]), tt(z["y"]), tt(z["edge_index"]), tt(z["pt"])
+    for name, (cls, kw) in P.FOCAL_CASES.items():
+        loss = O.focal_loss(w, y, edge_index=ei, pt=pt, haughty=cls == "HaughtyFocalLoss", **kw)
+        assert_close(loss, z[f"{name}/loss"], 1e-6, name)

@@ -77,8 +77,8 @@ def test_gc_fcnn_emulated():
 
 def test_hetero_fcnn_emulated():
     with emulated():
-        P.case_hetero_fcnn("cpu", names=("hetero_d2", "heteroenc"))
-        P.case_graph_tcn("cpu", names=("hetero", "perfect_ec"))
+        P.case_hetero_fcnn("cpu", names=("hetero_d2",))
+        P.case_graph_tcn("cpu", names=("hetero",))
 
 
 def test_graph_cut_emulated():

@@ -14,7 +14,7 @@ from .data import Data, collate
 from .io import GraphDataset, PrefetchLoader, load_graph
 from .edge_classifier import ECForGraphTCN, PerfectEdgeClassification
 from .interaction_network import InteractionNetwork
-from .graph_construction import MLGraphConstruction, knn_with_max_radius
+from .graph_construction import MLGraphConstruction, MLPCTransformer, knn_scan, knn_with_max_radius
 from .graph_masks import get_good_node_mask, get_good_node_mask_tensors
 from .losses_ec import (EdgeWeightBCELoss, EdgeWeightFocalLoss, HaughtyFocalLoss, binary_focal_loss,
                         falsify_low_pt_edges)
@@ -38,4 +38,4 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
            "GraphConstructionFCNN", "HeterogeneousResFCNN", "GraphConstructionHeteroResFCNN",
            "GraphConstructionHeteroEncResFCNN", "GraphConstructionResIN", "PerfectECGraphTCN",
-           "GraphTCNForMLGCPipeline", "PerfectEdgeClassification", "EdgeWeightFocalLoss", "HaughtyFocalLoss", "binary_focal_loss", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]
+           "GraphTCNForMLGCPipeline", "PerfectEdgeClassification", "MLPCTransformer", "knn_scan", "EdgeWeightFocalLoss", "HaughtyFocalLoss", "binary_focal_loss", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader"]

@@ -116,3 +116,22 @@ class MLGraphConstruction(nn.Module, HyperparametersMixin):
                     sector=getattr(data, "sector", None),
                     reconstructable=data.reconstructable, edge_attr=edge_attr, eta=data.eta,
                     layer=getattr(data, "layer", None))
+
+
+class MLPCTransformer(nn.Module, HyperparametersMixin):
+    def __init__(self, model: nn.Module, *, original_features: bool = False, freeze: bool = True):
+        """Transform a point cloud with a metric-learning model (models/graph_construction.py:
+        422-481): ``data.x`` becomes the latent space ``H`` (optionally followed by the original
+        features).  As in the reference the ``Data`` object is modified in place.  (The
+        ``from_ml_chkpt`` constructors read Lightning checkpoints: control plane, not here.)"""
+        super().__init__()
+        self._ml = _freeze_if(obj_from_or_to_hparams(self, "ml", model), freeze)
+        self.save_hyperparameters(ignore=["model"])
+
+    def forward(self, data) -> Data:
+        out = self._ml(data)
+        if self.hparams.original_features:
+            data.x = torch.cat((out["H"], data.x), dim=1)
+        else:
+            data.x = out["H"]
+        return data

@@ -800,6 +800,23 @@ HETERO_CASES = {
 }
 
 
+def case_pc_transformer(device):
+    """MLPCTransformer(GraphConstructionFCNN): data.x becomes the reference's latent space H
+    (G9), optionally followed by the original features; the model is frozen."""
+    z = load("g9_gc_fcnn.npz")
+    x = tt(z["x"], device)
+    ml = G.GraphConstructionFCNN(in_dim=14, hidden_dim=40, depth=1, out_dim=8)
+    load_params(ml, z, "d1_h40/p0/")
+    for orig in (False, True):
+        tr = G.MLPCTransformer(ml.to(device), original_features=orig)
+        assert all(not p.requires_grad for p in tr.parameters())
+        d = tr(G.Data(x=x.clone()))
+        assert d.x.shape[1] == (8 + 14 if orig else 8)
+        assert_close(d.x[:, :8], z["d1_h40/H"], TOL_OUT, "latent space")
+        if orig:
+            assert torch.equal(d.x[:, 8:], x)
+
+
 def case_hetero_fcnn(device, names=None):
     """Pixel / strip embedding networks vs the reference (G10): depth 2 with alpha 0 is one
     fused three-layer launch per detector part, the others run on the library GEMM path."""

@@ -73,6 +73,7 @@ def test_hinge_loss_emulated():
 def test_gc_fcnn_emulated():
     with emulated():
         P.case_gc_fcnn("cpu")
+        P.case_pc_transformer("cpu")
 
 
 def test_hetero_fcnn_emulated():

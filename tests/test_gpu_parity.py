@@ -141,3 +141,7 @@ def test_graph_construction_resin(dev):
 
 def test_focal_losses(dev):
     P.case_focal_losses(dev)
+
+
+def test_pc_transformer(dev):
+    P.case_pc_transformer(dev)

@@ -30,7 +30,9 @@ FLAGS = [
 
 # per-file additions: the bf16 kernels convert every MFMA result straight away (pack to
 # bf16), so results should land in VGPRs instead of AGPRs + v_accvgpr_read copies
-EXTRA_FLAGS = {"mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"mlp_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "mlp_bf16_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm",
+                                    "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _hipcc() -> str:

@@ -1,6 +1,7 @@
-// Launchers of the bf16-storage fused MLP kernels (mlp_bf16_kernels.h).  The backward
+// Backward launchers of the bf16-storage fused MLP kernels (mlp_bf16_kernels.h).  The
 // instantiations with an fp32 upstream gradient (EPI_SIGMOID: the edge-weight head) are
-// compiled in mlp_bf16_g32.hip so the two halves build in parallel.
+// compiled in mlp_bf16_g32.hip, the forward kernels in mlp_bf16_fwd.hip (own scheduling
+// strategy, see _build.py), so the three parts also build in parallel.
 #include "mlp_bf16_kernels.h"
 
 namespace gnntrk {
@@ -8,29 +9,6 @@ namespace gnntrk {
 int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, int KI, int HT, int GT, int grid, float *part,
                      uint8_t *trash, hipStream_t stream);  // mlp_bf16_g32.hip
 
-
-#define GNNTRK_FWD16_LAUNCH(KI_, HT_, T_, S_, R_)                                       \
-    {                                                                                   \
-        if (wide) {                                                                     \
-            auto kfn = mlp16_fwd_kernel<KI_, HT_, T_, S_, R_, true>;                    \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);           \
-        } else {                                                                        \
-            auto kfn = mlp16_fwd_kernel<KI_, HT_, T_, S_, R_, false>;                   \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);           \
-        }                                                                               \
-    }
-#define GNNTRK_FWD16_CASE(KI_, HT_)                                                     \
-    if (P.KI == KI_ && P.HT == HT_) {                                                   \
-        if (three && sig && share) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, true, 4)         \
-        else if (three && sig) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, true, 1)             \
-        else if (three && share) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, false, 4)          \
-        else if (three) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, false, 1)                   \
-        else if (sig && share) GNNTRK_FWD16_LAUNCH(KI_, HT_, false, true, 4)            \
-        else if (sig) GNNTRK_FWD16_LAUNCH(KI_, HT_, false, true, 1)                     \
-        else if (share) GNNTRK_FWD16_LAUNCH(KI_, HT_, false, false, 4)                  \
-        else GNNTRK_FWD16_LAUNCH(KI_, HT_, false, false, 1)                             \
-        launched = true;                                                                \
-    }
 
 int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int backward, char *buf,
                       size_t len) {
@@ -44,17 +22,6 @@ int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int
     return GNNTRK_OK;
 }
 
-// exact forward instantiation
-int mlp16_fwd_kernel_name(const gnntrk_mlp_fwd_args *a, char *buf, size_t len) {
-    if (!a || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
-    SlotPlan P;
-    make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
-    snprintf(buf, len, "mlp16_fwd_kernel<%d, %d, %s, %s, %d, %s>", P.KI, P.HT, a->mlp.n_layers == 3 ? "true" : "false",
-             a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false", a->mlp.out_dim <= 4 ? 4 : 1,
-             wide_ok(P, a->seg, a->n_rows) ? "true" : "false");
-    return GNNTRK_OK;
-}
-
 // exact backward instantiation (needs the gradient slices and the epilogue)
 int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     if (!a || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
@@ -64,47 +31,6 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s>", P.KI, P.HT, GT,
              a->mlp.n_layers == 3 ? "true" : "false", a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false");
     return GNNTRK_OK;
-}
-
-int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
-    if (!a) return fail(GNNTRK_EINVAL, "mlp_forward_bf16: NULL args");
-    int rc = check_bf16_mlp(a->mlp, a->n_seg, a->seg, "mlp_forward_bf16");
-    if (rc) return rc;
-    if (a->epilogue < 0 || a->epilogue > 3) return fail(GNNTRK_EINVAL, "mlp_forward_bf16: bad epilogue");
-    const int out_pad = (a->mlp.out_dim + 3) / 4 * 4;
-    if (a->epilogue == GNNTRK_EPI_SIGMOID) {
-        if (!a->out || a->out_stride < a->mlp.out_dim)
-            return fail(GNNTRK_EINVAL, "mlp_forward_bf16: bad (fp32) output");
-    } else if (!a->out || a->out_stride < out_pad || a->out_stride % 4 != 0 || ((uintptr_t)a->out & 7) != 0) {
-        return fail(GNNTRK_EINVAL,
-                    "mlp_forward_bf16: output rows must be 8-byte aligned bf16, stride a multiple of 4 >= "
-                    "out_dim rounded up to 4");
-    }
-    if (a->epilogue == GNNTRK_EPI_RESIDUAL &&
-        (!a->res || a->res_stride < out_pad || a->res_stride % 4 != 0 || ((uintptr_t)a->res & 7) != 0))
-        return fail(GNNTRK_EINVAL, "mlp_forward_bf16: residual epilogue needs padded bf16 res rows");
-    if (a->n_rows < 0 || a->n_rows > 0x7fffffff) return fail(GNNTRK_EINVAL, "mlp_forward_bf16: bad n_rows");
-    if (a->n_rows == 0) return GNNTRK_OK;
-    SlotPlan P;
-    make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
-    if (!P.ok || P.KI > 2)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: more than 16 input chunks / 4 hidden tiles");
-    const bool three = a->mlp.n_layers == 3, sig = a->epilogue == GNNTRK_EPI_SIGMOID;
-    const bool share = a->mlp.out_dim <= 4;  // four tiles share one output tile and one store
-    const bool wide = wide_ok(P, a->seg, a->n_rows);  // one 16-byte load per lane and k-step
-    int grid = grid16(a->n_rows, kFwd16BlocksPerCu, kWaves);
-    if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
-    bool launched = false;
-    GNNTRK_FWD16_CASE(1, 1)
-    GNNTRK_FWD16_CASE(1, 2)
-    GNNTRK_FWD16_CASE(1, 3)
-    GNNTRK_FWD16_CASE(1, 4)
-    GNNTRK_FWD16_CASE(2, 1)
-    GNNTRK_FWD16_CASE(2, 2)
-    GNNTRK_FWD16_CASE(2, 3)
-    GNNTRK_FWD16_CASE(2, 4)
-    if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: no instantiation");
-    return check_launch("mlp_forward_bf16");
 }
 
 // workspace = one partial block per wave | one 8-byte trash slot per lane

@@ -216,6 +216,11 @@ def main():
             kernels[k] = {"launches": d["launches"], "avg_ms": d["ms"] / d["launches"],
                           "tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12,
                           "alg_GBps": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
+            # HBM bytes actually moved (committed PMC passes) over THIS run's launch time
+            tr = measured_traffic(k, d["rows"] / d["launches"], args.dtype)
+            if tr is not None:
+                gbps = tr / (d["ms"] / d["launches"] * 1e-3) / 1e9
+                kernels[k].update({"traffic": tr, "hbm_GBps": gbps, "hbm_frac": gbps / (PEAK_HBM_TBPS * 1e3)})
         if dom:
             d = ks[dom]
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12

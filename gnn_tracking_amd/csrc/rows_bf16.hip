@@ -40,6 +40,25 @@ __global__ __launch_bounds__(kTpb16) void rows_to_bf16_kernel(const float *__res
     }
 }
 
+// dim == 4 with 16-byte aligned fp32 rows (the edge features: edge_classifier.py:97 reads
+// `edge_attr[E, 4]`, gathered here into target-sorted order): ONE 16-byte load and one 8-byte
+// store per row.  The general kernel above issues four predicated dword loads per row, which
+// for a random gather quadruples the request count of a sector-bound kernel.
+__global__ __launch_bounds__(kTpb16) void rows4_to_bf16_kernel(const float *__restrict__ in, int in_stride,
+                                                                const int32_t *__restrict__ idx,
+                                                                int64_t n_rows, uint16_t *__restrict__ out,
+                                                                int out_stride) {
+    for (int64_t m = (int64_t)blockIdx.x * kTpb16 + threadIdx.x; m < n_rows;
+         m += (int64_t)gridDim.x * kTpb16) {
+        const int64_t r = idx ? (int64_t)idx[m] : m;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + r * in_stride);
+        u32x2 o;
+        o[0] = bf16x2_pack(v[0], v[1]);
+        o[1] = bf16x2_pack(v[2], v[3]);
+        *reinterpret_cast<u32x2 *>(out + m * out_stride) = o;
+    }
+}
+
 // Four lanes per segment: lane j of the group sums rows k0 + j, k0 + j + 4, ... (whole
 // rows: 8 or 16 bytes per load), the group combines with two xor-shuffles, lane 0 rounds
 // and stores.  Neighbouring lanes read neighbouring rows, so a CSR-ordered input streams
@@ -127,8 +146,12 @@ int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *
     if (!in || dim < 1 || in_stride < dim || n_rows < 0 || !rows_ok(out, dim, out_stride))
         return fail(GNNTRK_EINVAL, "rows_to_bf16: bad argument");
     const int nch = (dim + 3) / 4;
-    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3(grid_for_threads(n_rows * nch)), dim3(kTpb16), 0, stream, in,
-                       dim, in_stride, idx, n_rows, out, out_stride);
+    if (dim == 4 && in_stride % 4 == 0 && ((uintptr_t)in & 15) == 0)
+        hipLaunchKernelGGL(rows4_to_bf16_kernel, dim3(grid_for_threads(n_rows)), dim3(kTpb16), 0, stream, in,
+                           in_stride, idx, n_rows, out, out_stride);
+    else
+        hipLaunchKernelGGL(rows_to_bf16_kernel, dim3(grid_for_threads(n_rows * nch)), dim3(kTpb16), 0, stream,
+                           in, dim, in_stride, idx, n_rows, out, out_stride);
     return check_launch("rows_to_bf16");
 }
 

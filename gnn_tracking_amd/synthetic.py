@@ -64,3 +64,43 @@ def make_event(seed: int, n_nodes: int, n_edges: int, device="cpu", *, node_dim:
     pt = torch.exp(0.7 * torch.randn(N, generator=g, device=dev))
     return Data(x=x, edge_index=edge_index, edge_attr=edge_attr, y=y, pt=pt, particle_id=pid,
                 eta=x[:, 3].clone(), reconstructable=torch.ones(N, device=dev))
+
+
+def make_pileup_cloud(seed: int, n_hits: int, dim: int = 8, *, n_clusters: int = 6000,
+                      sigma: float = 0.05, noise_frac: float = 0.1) -> torch.Tensor:
+    """Latent-space hits of a pile-up-like event: Gaussian
+    clusters (sigma) around centres uniform in a radius-3 ball plus uniform noise hits, in
+    shuffled order.  numpy generator: the same cloud on every host."""
+    import numpy as np
+
+    g = np.random.default_rng(seed)
+
+    def ball(m):
+        v = g.normal(size=(m, dim))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return v * (3.0 * g.random((m, 1)) ** (1.0 / dim))
+
+    centers = ball(n_clusters)
+    n_noise = int(noise_frac * n_hits)
+    which = g.integers(0, n_clusters, size=n_hits - n_noise)
+    pts = centers[which] + sigma * g.normal(size=(n_hits - n_noise, dim))
+    x = np.concatenate([pts, ball(n_noise)]).astype(np.float32)
+    return torch.from_numpy(x[g.permutation(n_hits)])
+
+
+def make_pileup_event(seed: int, n_hits: int, dim: int = 8, *, n_particles: int = 14000) -> dict:
+    """Config-5 inputs of the condensation losses on the cloud above: int64 particle ids
+    (10 % noise hits with id 0), per-particle pt (log-normal: roughly a seventh of the
+    particles pass the 0.9 GeV cut, K of a few thousand at 200 k hits), eta, beta ~ U(0.01, 0.99).
+    Returns CPU tensors keyed like the loss's keyword arguments."""
+    import numpy as np
+
+    g = np.random.default_rng(seed)
+    x = make_pileup_cloud(seed, n_hits, dim)
+    pid = torch.from_numpy(g.integers(1, n_particles + 1, size=n_hits)).long() * (2 ** 40)
+    pid[torch.from_numpy(g.random(n_hits) < 0.1)] = 0
+    pt_of = torch.from_numpy(np.exp(g.normal(-0.5, 0.9, size=n_particles + 1))).float()
+    pt = pt_of[pid // 2 ** 40]
+    eta = torch.from_numpy(g.normal(0, 2, size=n_hits)).float().clamp(-4.6, 4.6)
+    beta = torch.from_numpy(g.uniform(0.01, 0.99, size=n_hits)).float()
+    return dict(beta=beta, x=x, particle_id=pid, pt=pt, eta=eta, reconstructable=torch.ones(n_hits))

@@ -348,6 +348,70 @@ def condensation_loss_tiger(*, beta, x, particle_id, mask, q_min=0.01) -> dict:
     }
 
 
+def condensation_loss_chunked(*, beta, x, particle_id, mask, mode: str, q_min=0.01, radius=1.0,
+                              weights=(1.0, 1.0, 0.0, 0.0), chunk: int = 4096) -> dict:
+    """The two functions above in float64 with O(chunk x K) memory: the same sums taken
+    over blocks of hits, loss terms and the gradient of ``att + w_rep rep + w_coward coward
+    + w_noise noise`` w.r.t. (x, beta) accumulated block by block.  It exists so that the
+    200 k-hit event of BASELINE config 5 (K of several thousand: the dense formulation
+    needs 7 GB per temporary) has an oracle; tests/test_oracle_golden.py checks it against
+    the dense restatements (and through them the reference's pinned values) on the small
+    cases.  ``mode``: "rg" (oc.py:87-161; condensation points from the masked hits,
+    attraction of masked non-CP hits, repulsion 1 - sqrt(1e-9 + d2) inside the unit ball) or
+    "tiger" (oc.py:251-347; condensation points = arg-max charge over ALL hits of a
+    particle of interest, attraction of all its hits, repulsion 1 - d)."""
+    assert mode in ("rg", "tiger")
+    w_att, w_rep, w_cow, w_noise = weights
+    N = int(mask.shape[0])
+    if mode == "rg":
+        alphas, is_cp = _condensation_points(beta, particle_id, mask)
+        att_rows = mask & ~is_cp
+    else:
+        uniq = torch.unique(particle_id[mask])
+        assert uniq.numel() > 0, "No particles of interest found, cannot evaluate loss"
+        q32 = torch.arctanh(beta) ** 2 + q_min
+        idx = torch.nonzero(torch.isin(particle_id, uniq)).view(-1)
+        inv = torch.searchsorted(uniq, particle_id[idx])
+        order = torch.argsort(q32[idx], descending=True, stable=True)   # ties -> lowest index (argmax)
+        grouped = order[torch.argsort(inv[order], stable=True)]
+        counts = torch.bincount(inv, minlength=uniq.numel())
+        alphas = idx[grouped[torch.cumsum(counts, 0) - counts]]
+        att_rows = torch.ones(N, dtype=torch.bool)
+    K = int(alphas.shape[0])
+    pid_k = particle_id[alphas]
+    norm_att = float(1e-9 + mask.sum() - K)   # as the reference: float + int64 tensor promotes to fp32
+    norm_rep = 1e-9 + (K - 1) * N
+    b = beta.detach().double().requires_grad_(True)
+    xx = x.detach().double().requires_grad_(True)
+    v_att = v_rep = 0.0
+    n_rep = 0
+    for s in range(0, N, chunk):
+        sl = slice(s, min(s + chunk, N))
+        q = torch.arctanh(b) ** 2 + q_min
+        xj, xk, qj, qk = xx[sl], xx[alphas], q[sl], q[alphas]
+        d2 = ((xj ** 2).sum(1).view(-1, 1) + (xk ** 2).sum(1).view(1, -1) - 2.0 * xj @ xk.T).clamp_min(0.0)
+        same = particle_id[sl].view(-1, 1) == pid_k.view(1, -1)
+        qq = qj.view(-1, 1) * qk.view(1, -1)
+        a_sel = same & att_rows[sl].view(-1, 1)
+        att = (qq[a_sel] * d2[a_sel]).sum()
+        r_sel = ~same & (d2 < radius * radius)
+        dr = torch.sqrt(1e-9 + d2[r_sel]) if mode == "rg" else torch.sqrt(d2[r_sel])
+        rep = (qq[r_sel] * (radius - dr)).sum()
+        (w_att * att / norm_att + w_rep * rep / norm_rep).backward()
+        v_att += float(att.detach())
+        v_rep += float(rep.detach())
+        n_rep += int(r_sel.sum())
+    coward = (1 - b[alphas]).mean()
+    noise_sel = (particle_id == 0) if mode == "rg" else ~(particle_id > 0)
+    noise = b[noise_sel].mean()
+    (w_cow * coward + w_noise * noise).backward()
+    out = {"attractive": v_att / norm_att, "repulsive": v_rep / norm_rep, "coward": float(coward.detach()),
+           "noise": float(noise.detach()), "n_rep": n_rep, "K": K, "grad_x": xx.grad, "grad_beta": b.grad}
+    out["total"] = (w_att * out["attractive"] + w_rep * out["repulsive"] + w_cow * out["coward"]
+                    + w_noise * out["noise"])
+    return out
+
+
 # ------------------------------------------------------------- training step (H)
 def ec_training_step(x, edge_index, edge_attr, y, params: dict, *, model_kwargs: dict,
                      lr=1e-4, weight_decay=1e-4, pt=None, pt_thld=0.0):

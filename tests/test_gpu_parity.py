@@ -145,3 +145,16 @@ def test_focal_losses(dev):
 
 def test_pc_transformer(dev):
     P.case_pc_transformer(dev)
+
+
+# ---- BASELINE.json configs on their own workloads ---------------------------------------
+def test_cfg1_cfg2_event_vs_oracle(dev):
+    P.case_cfg12_event(dev)
+
+
+def test_cfg5_condensation_losses_200k(dev):
+    print(P.case_cfg5_condensation(dev))
+
+
+def test_cfg5_knn_200k(dev):
+    P.case_cfg5_knn(dev)

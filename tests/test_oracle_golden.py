@@ -88,6 +88,24 @@ def test_condensation_losses_pinned():
                     assert abs(float(od[k]) - pinned) <= 1e-6 * abs(pinned), (cn, strat, k)
 
 
+def test_condensation_losses_chunked_oracle():
+    """The blocked float64 oracle used at the 200 k-hit size of config 5 reproduces the
+    reference's float64 loss terms, total and gradients (G5) whatever the block size."""
+    z = load("g5_oc.npz")
+    for cn in ("td1", "td2", "td3"):
+        t = {k: tt(z[f"{cn}/{k}"]) for k in ("beta", "x", "particle_id", "pt", "eta",
+                                              "reconstructable")}
+        mask = O.good_node_mask(t["pt"], t["particle_id"], t["reconstructable"], t["eta"])
+        for strat in ("tiger", "rg"):
+            for chunk in (7, 4096):
+                od = O.condensation_loss_chunked(beta=t["beta"], x=t["x"], particle_id=t["particle_id"],
+                                                 mask=mask, mode=strat, weights=(1.0, 2.0, 0.25, 0.5),
+                                                 chunk=chunk)
+                for k in ("attractive", "repulsive", "coward", "noise", "total", "grad_x", "grad_beta"):
+                    assert_close(torch.as_tensor(od[k], dtype=torch.float64), z[f"{cn}/f64/{strat}/{k}"], 1e-9,
+                                 f"{cn} {strat} chunk={chunk} {k}")
+
+
 def test_ml_graph_construction_edges():
     z = load("g6_mlgc.npz")
     g1 = load("g1_ec_testgraph.npz")

@@ -7,17 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from gnn_tracking_amd import ops
 import ref_cpu as O
 
-def cloud(seed, n, d=8, n_clusters=6000, sigma=0.05, noise=0.1):
-    g = np.random.default_rng(seed)
-    def ball(m):
-        v = g.normal(size=(m, d)); v /= np.linalg.norm(v, axis=1, keepdims=True)
-        return v * (3.0 * g.random((m, 1)) ** (1.0 / d))
-    centers = ball(n_clusters)
-    n_noise = int(noise * n)
-    which = g.integers(0, n_clusters, size=n - n_noise)
-    pts = centers[which] + sigma * g.normal(size=(n - n_noise, d))
-    x = np.concatenate([pts, ball(n_noise)]).astype(np.float32)
-    return torch.from_numpy(x[g.permutation(n)])
+from gnn_tracking_amd.synthetic import make_pileup_cloud as cloud  # noqa: E402
+
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000

@@ -7,18 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gnn_tracking_amd as G
 import ref_cpu as O
-from bench_knn import cloud  # noqa
 
-def event(seed, n, n_part=14000):
-    g = np.random.default_rng(seed)
-    x = cloud(seed, n)
-    pid = torch.from_numpy(g.integers(1, n_part + 1, size=n)).long() * (2**40)
-    pid[torch.from_numpy(g.random(n) < 0.1)] = 0
-    pt_of = torch.from_numpy(np.exp(g.normal(-0.5, 0.9, size=n_part + 1))).float()
-    pt = pt_of[(pid // 2**40)]
-    eta = torch.from_numpy(g.normal(0, 2, size=n)).float().clamp(-4.6, 4.6)
-    beta = torch.from_numpy(g.uniform(0.01, 0.99, size=n)).float()
-    return dict(beta=beta, x=x, particle_id=pid, pt=pt, eta=eta, reconstructable=torch.ones(n))
+from gnn_tracking_amd.synthetic import make_pileup_event as event  # noqa: E402
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000

@@ -42,6 +42,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: cannot build libgnntrk.so (ROCm toolchain required)")
 
 
+def have_hipcc() -> bool:
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
 def _stamp(src: pathlib.Path) -> str:
     h = hashlib.sha256()
     h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src.name, [])).encode())

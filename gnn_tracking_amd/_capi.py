@@ -155,10 +155,17 @@ def load() -> C.CDLL:
         if _lib is not None:
             return _lib
         path = pathlib.Path(os.environ.get("GNNTRK_LIB", LIB_PATH))
-        if not path.exists():
+        if "GNNTRK_LIB" not in os.environ:
             from . import _build
 
-            _build.build_lib()
+            # stamp-based and cheap when nothing changed: a library older than its sources
+            # (edited csrc/, include/ or flags) is rebuilt instead of being loaded stale.
+            # Without a compiler an existing library is used as it is.
+            if _build.have_hipcc():
+                _build.build_lib()
+            elif not path.exists():
+                raise RuntimeError(f"gnn_tracking_amd: {path} is missing and hipcc was not found; "
+                                   "the package has no CPU fallback")
         try:
             lib = C.CDLL(str(path))
         except OSError as e:

@@ -23,12 +23,15 @@ __global__ __launch_bounds__(kTpb) void gi_keys_kernel(const int64_t *__restrict
 // src_sorted[k] = src[perm[k]]; also emits the keys/vals of the second (by-source) sort
 __global__ __launch_bounds__(kTpb) void gi_gather_src_kernel(const int64_t *__restrict__ src,
                                                              const uint32_t *__restrict__ perm,
-                                                             int64_t E, int32_t *__restrict__ src_s,
+                                                             int64_t E, int64_t N, int32_t *__restrict__ src_s,
                                                              uint32_t *__restrict__ keys,
-                                                             uint32_t *__restrict__ vals) {
+                                                             uint32_t *__restrict__ vals,
+                                                             int *__restrict__ bad) {
     for (int64_t k = (int64_t)blockIdx.x * kTpb + threadIdx.x; k < E;
          k += (int64_t)gridDim.x * kTpb) {
-        const uint32_t s = (uint32_t)src[perm[k]];
+        const int64_t v = src[perm[k]];
+        if (v < 0 || v >= N) atomicAdd(bad, 1);
+        const uint32_t s = (uint32_t)v;
         src_s[k] = (int32_t)s;
         keys[k] = s;
         vals[k] = (uint32_t)k;
@@ -114,7 +117,7 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, vo
         hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt_sorted, E, N,
                            o->rowptr_t);
         hipLaunchKernelGGL(gi_gather_src_kernel, dim3(grid), dim3(kTpb), 0, stream, src,
-                           reinterpret_cast<const uint32_t *>(o->perm), E, o->src, keys_a, vals_a);
+                           reinterpret_cast<const uint32_t *>(o->perm), E, N, o->src, keys_a, vals_a, bad);
         rc = sort_pairs_u32(keys_a, keys_b, vals_a, reinterpret_cast<uint32_t *>(o->spos), E, bits,
                             temp, temp_bytes, stream);
         if (rc) return rc;

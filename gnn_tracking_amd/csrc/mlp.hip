@@ -717,7 +717,8 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float *__
 }
 
 // ------------------------------------------------------------------ launchers
-static int check_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg) {
+// n_rows == 0 is a valid no-op: row pointers may then be NULL (what an empty tensor hands over)
+static int check_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, int64_t n_rows) {
     if (m.n_layers != 2 && m.n_layers != 3) return fail(GNNTRK_EUNSUPPORTED, "mlp: n_layers must be 2 or 3");
     if (m.in_dim < 1 || m.in_dim > GNNTRK_MAX_IN) return fail(GNNTRK_EUNSUPPORTED, "mlp: in_dim out of range [1,48]");
     if (m.hidden < 1 || m.hidden > GNNTRK_MAX_HIDDEN) return fail(GNNTRK_EUNSUPPORTED, "mlp: hidden out of range [1,64]");
@@ -725,7 +726,7 @@ static int check_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg) {
     if (n_seg < 1 || n_seg > GNNTRK_MAX_SEGS) return fail(GNNTRK_EINVAL, "mlp: bad segment count");
     int tot = 0;
     for (int j = 0; j < n_seg; ++j) {
-        if (!seg[j].ptr || seg[j].dim < 1 || seg[j].stride < seg[j].dim)
+        if ((!seg[j].ptr && n_rows != 0) || seg[j].dim < 1 || seg[j].stride < seg[j].dim)
             return fail(GNNTRK_EINVAL, "mlp: bad segment descriptor");
         tot += seg[j].dim;
     }
@@ -820,8 +821,9 @@ int mlp_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int b
 
 int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     if (!a) return fail(GNNTRK_EINVAL, "mlp_forward: NULL args");
-    int rc = check_mlp(a->mlp, a->n_seg, a->seg);
+    int rc = check_mlp(a->mlp, a->n_seg, a->seg, a->n_rows);
     if (rc) return rc;
+    if (a->n_rows == 0) return GNNTRK_OK;  // nothing to write: NULL row pointers are fine
     if (!a->out || a->out_stride < a->mlp.out_dim) return fail(GNNTRK_EINVAL, "mlp_forward: bad output");
     if (a->epilogue < 0 || a->epilogue > 3) return fail(GNNTRK_EINVAL, "mlp_forward: bad epilogue");
     if (a->epilogue == GNNTRK_EPI_RESIDUAL && (!a->res || a->res_stride < a->mlp.out_dim))
@@ -864,9 +866,10 @@ size_t mlp_backward_ws_bytes(const gnntrk_mlp *m) {
 int mlp_backward_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes,
                         hipStream_t stream) {
     if (!a) return fail(GNNTRK_EINVAL, "mlp_backward: NULL args");
-    int rc = check_mlp(a->mlp, a->n_seg, a->seg);
+    int rc = check_mlp(a->mlp, a->n_seg, a->seg, a->n_rows);
     if (rc) return rc;
-    if (a->n_gout < 1 || a->n_gout > 2 || !a->gout[0].ptr || (a->n_gout == 2 && !a->gout[1].ptr))
+    const bool empty = a->n_rows == 0;  // no rows: only the parameter gradients are written (zeros)
+    if (a->n_gout < 1 || a->n_gout > 2 || (!empty && (!a->gout[0].ptr || (a->n_gout == 2 && !a->gout[1].ptr))))
         return fail(GNNTRK_EINVAL, "mlp_backward: bad upstream gradient terms");
     if (a->epilogue < 0 || a->epilogue > 3) return fail(GNNTRK_EINVAL, "mlp_backward: bad epilogue");
     if (a->n_rows < 0) return fail(GNNTRK_EINVAL, "mlp_backward: negative n_rows");

@@ -44,10 +44,11 @@ size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m) {
 
 int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes, hipStream_t stream) {
     if (!a) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: NULL args");
-    int rc = check_bf16_mlp(a->mlp, a->n_seg, a->seg, "mlp_backward_bf16");
+    int rc = check_bf16_mlp(a->mlp, a->n_seg, a->seg, "mlp_backward_bf16", a->n_rows);
     if (rc) return rc;
     if (a->epilogue < 0 || a->epilogue > 3) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad epilogue");
-    if (a->n_gout < 1 || a->n_gout > 2 || !a->gout[0].ptr || (a->n_gout == 2 && !a->gout[1].ptr))
+    const bool empty = a->n_rows == 0;  // no rows: only the parameter gradients are written (zeros)
+    if (a->n_gout < 1 || a->n_gout > 2 || (!empty && (!a->gout[0].ptr || (a->n_gout == 2 && !a->gout[1].ptr))))
         return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad upstream gradient terms");
     const int out_pad = (a->mlp.out_dim + 3) / 4 * 4;
     if (a->epilogue == GNNTRK_EPI_SIGMOID) {

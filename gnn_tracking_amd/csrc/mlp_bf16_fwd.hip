@@ -41,9 +41,10 @@ int mlp16_fwd_kernel_name(const gnntrk_mlp_fwd_args *a, char *buf, size_t len) {
 
 int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     if (!a) return fail(GNNTRK_EINVAL, "mlp_forward_bf16: NULL args");
-    int rc = check_bf16_mlp(a->mlp, a->n_seg, a->seg, "mlp_forward_bf16");
+    int rc = check_bf16_mlp(a->mlp, a->n_seg, a->seg, "mlp_forward_bf16", a->n_rows);
     if (rc) return rc;
     if (a->epilogue < 0 || a->epilogue > 3) return fail(GNNTRK_EINVAL, "mlp_forward_bf16: bad epilogue");
+    if (a->n_rows == 0) return GNNTRK_OK;  // nothing to write: NULL row pointers are fine
     const int out_pad = (a->mlp.out_dim + 3) / 4 * 4;
     if (a->epilogue == GNNTRK_EPI_SIGMOID) {
         if (!a->out || a->out_stride < a->mlp.out_dim)

@@ -922,7 +922,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 }
 
 // ------------------------------------------------------------------ launchers
-int check_bf16_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, const char *who) {
+// n_rows == 0 is a valid no-op: row pointers may then be NULL (what an empty tensor hands over)
+int check_bf16_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, const char *who, int64_t n_rows) {
     if (m.n_layers != 2 && m.n_layers != 3) return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): n_layers must be 2 or 3");
     if (m.in_dim < 1 || m.hidden < 1 || m.hidden > 63 || m.out_dim < 1 || m.out_dim > 16)
         return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): hidden must be in [1,63], out in [1,16]");
@@ -930,7 +931,7 @@ int check_bf16_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, const 
     int tot = 0;
     for (int j = 0; j < n_seg; ++j) {
         const int padded = (seg[j].dim + 3) / 4 * 4;
-        if (!seg[j].ptr || seg[j].dim < 1 || seg[j].stride < padded || seg[j].stride % 4 != 0 ||
+        if ((!seg[j].ptr && n_rows != 0) || seg[j].dim < 1 || seg[j].stride < padded || seg[j].stride % 4 != 0 ||
             ((uintptr_t)seg[j].ptr & 7) != 0)
             return fail(GNNTRK_EINVAL,
                         "mlp(bf16): segment rows must be 8-byte aligned bf16 with stride a multiple of 4 "

@@ -228,10 +228,11 @@ __global__ __launch_bounds__(kTpb) void focal_bwd_kernel(const float *__restrict
 int segment_sum_launch(const float *rows, int dim, int row_stride, const int32_t *rowptr,
                        const int32_t *pos, int64_t n_seg, float *out, int out_stride,
                        int accumulate, hipStream_t stream) {
-    if (!rows || !rowptr || !out || dim < 1 || row_stride < dim || out_stride < dim || n_seg < 0)
-        return fail(GNNTRK_EINVAL, "segment_sum: bad argument");
     if (n_seg == 0) return GNNTRK_OK;
-    if (dim == 4 && row_stride == 4 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) {
+    // rows may be NULL when there are no rows at all (every segment empty: zeros are written)
+    if (!rowptr || !out || dim < 1 || row_stride < dim || out_stride < dim || n_seg < 0)
+        return fail(GNNTRK_EINVAL, "segment_sum: bad argument");
+    if (rows && dim == 4 && row_stride == 4 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) {
         hipLaunchKernelGGL(segment_sum4_kernel, dim3(stream_grid(n_seg)), dim3(kTpb), 0, stream, rows,
                            rowptr, pos, n_seg, out, out_stride, accumulate);
         return check_launch("segment_sum");
@@ -243,9 +244,9 @@ int segment_sum_launch(const float *rows, int dim, int row_stride, const int32_t
 
 int permute_rows_launch(const float *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
                         float *out, int out_stride, int scatter, hipStream_t stream) {
+    if (n_rows == 0) return GNNTRK_OK;  // empty tensors may carry NULL pointers
     if (!in || !idx || !out || dim < 1 || in_stride < dim || out_stride < dim || n_rows < 0)
         return fail(GNNTRK_EINVAL, "permute_rows: bad argument");
-    if (n_rows == 0) return GNNTRK_OK;
     hipLaunchKernelGGL(permute_rows_kernel, dim3(stream_grid(n_rows * dim)), dim3(kTpb), 0, stream,
                        in, dim, in_stride, idx, n_rows, out, out_stride, scatter);
     return check_launch("permute_rows");
@@ -253,8 +254,8 @@ int permute_rows_launch(const float *in, int dim, int in_stride, const int32_t *
 
 int axpby_launch(float a, const float *x, float b, const float *y, const float *mask, float *out,
                  int64_t n, hipStream_t stream) {
-    if (!x || !out || n < 0) return fail(GNNTRK_EINVAL, "axpby: bad argument");
     if (n == 0) return GNNTRK_OK;
+    if (!x || !out || n < 0) return fail(GNNTRK_EINVAL, "axpby: bad argument");
     hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(n)), dim3(kTpb), 0, stream, a, x, b, y, mask,
                        out, n);
     return check_launch("axpby");

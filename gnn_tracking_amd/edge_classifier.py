@@ -123,13 +123,19 @@ class PerfectEdgeClassification(nn.Module, HyperparametersMixin):
         self.tpr, self.tnr, self.false_below_pt = tpr, tnr, false_below_pt
 
     def forward(self, data) -> dict[str, Tensor]:
-        r = data.y.bool()
-        if not math.isclose(self.tpr, 1.0, rel_tol=1e-5, abs_tol=1e-8):
-            true_mask = r.detach().clone()
-            r[true_mask] = torch.rand(int(true_mask.sum()), device=r.device) <= self.tpr
-        if not math.isclose(self.tnr, 1.0, rel_tol=1e-5, abs_tol=1e-8):
-            false_mask = (~r).detach().clone()
-            r[false_mask] = ~(torch.rand(int(false_mask.sum()), device=r.device) <= self.tnr)
+        """Same random draws in the same order as the reference (one uniform per true edge,
+        then one per edge that is false after the first step), written as mask algebra."""
+        truth = data.y.bool()
+        w = truth
+        exact = lambda p: math.isclose(p, 1.0, rel_tol=1e-5, abs_tol=1e-8)  # noqa: E731
+        none = torch.zeros_like(truth)
+        if not exact(self.tpr):
+            kept = torch.rand(int(truth.sum()), device=truth.device) <= self.tpr
+            w = none.masked_scatter(truth, kept)
+        if not exact(self.tnr):
+            negative = ~w
+            promoted = torch.rand(int(negative.sum()), device=truth.device) > self.tnr
+            w = w | none.masked_scatter(negative, promoted)
         if self.false_below_pt > 0.0:
-            r[data.pt < self.false_below_pt] = False
-        return {"W": r.float()}
+            w = w.masked_fill(data.pt < self.false_below_pt, False)
+        return {"W": w.to(torch.float32)}

@@ -104,7 +104,7 @@ class MLGraphConstruction(nn.Module, HyperparametersMixin):
                            torch.ones(true_edges.shape[1], dtype=y.dtype, device=y.device)))
         edge_attr = None
         if self.hparams.build_edge_features:
-            edge_attr = ops.edge_features(x.detach(), edge_index)
+            edge_attr = ops.edge_features(x, edge_index)
         if self._ef is not None:
             w = self._ef(Data(x=x, edge_index=edge_index, edge_attr=edge_attr))["W"]
             mask = w > self.hparams.ec_threshold

@@ -15,6 +15,12 @@ def get_good_node_mask_tensors(*, pt: Tensor, particle_id: Tensor, reconstructab
     _capi.require_device(pt, particle_id, reconstructable, eta)
     lib = _capi.load()
     n = int(pt.shape[0])
+    for name, t in (("particle_id", particle_id), ("reconstructable", reconstructable), ("eta", eta)):
+        # (the reference's elementwise & raises on a mismatch too, e.g. an eta that was not
+        # sliced by ec_hit_mask, oc.py:207-213)
+        if t.dim() != 1 or int(t.shape[0]) != n or pt.dim() != 1:
+            raise RuntimeError(f"get_good_node_mask_tensors: {name} has shape {tuple(t.shape)}, "
+                               f"pt has shape {tuple(pt.shape)}: the node attributes must be 1-D of one length")
     pt32 = pt.to(torch.float32).contiguous()
     pid = particle_id.to(torch.int64).contiguous()
     reco = reconstructable.to(torch.float32).contiguous()

@@ -185,5 +185,10 @@ class PrefetchLoader:
                 raise item
             batch, ev, _pinned = item
             if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                # the device tensors were allocated on the side stream: tell the caching
+                # allocator that the consumer's stream uses them, or the producer's next
+                # copy could be handed the same blocks while kernels queued here still read them
+                batch._map(lambda t: (t.record_stream(cur), t)[1])
             yield batch

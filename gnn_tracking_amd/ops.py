@@ -22,6 +22,8 @@ Operators
 
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import dataclasses
 import weakref
@@ -159,11 +161,20 @@ def clear_graph_index_cache() -> None:
     _GI_CACHE.clear()
 
 
-def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True) -> GraphIndex:
+_VALIDATE = bool(os.environ.get("GNNTRK_VALIDATE"))
+
+
+def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
+                validate: Optional[bool] = None) -> GraphIndex:
     """Build (or fetch) the index of ``edge_index`` ([2,E] int64, unsorted COO).
 
     Cached per tensor OBJECT (weakref + version counter), so the L layers of a
     ResIN stack and the forward/backward of one step share one build.
+
+    ``validate`` (default: the environment variable ``GNNTRK_VALIDATE``): read back the
+    build's count of node ids outside ``[0, n_nodes)`` (sources and targets) and raise
+    ``IndexError`` as torch's ``index_select`` would.  It costs a host synchronisation, so it
+    is off by default; ids out of range then give undefined results.
     """
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
@@ -188,14 +199,26 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True) -> Grap
     ws = _ws(lib.gnntrk_graph_index_workspace_bytes(n_nodes, E), ei)
     _capi.check(lib.gnntrk_graph_index_build(_p(ei), C.byref(d), _p(ws), ws.numel(),
                                              _stream(ei)), lib)
+    if _VALIDATE if validate is None else validate:
+        bad = int(ws[:4].view(torch.int32).item())  # first workspace word: ids out of range
+        if bad:
+            raise IndexError(f"edge_index: {bad} node ids out of range [0, {n_nodes})")
     if cache:
-        if len(_GI_CACHE) > 16:
-            for k in [k for k, v in _GI_CACHE.items() if v[0]() is None]:
-                _GI_CACHE.pop(k, None)
-            while len(_GI_CACHE) > 16:
-                _GI_CACHE.pop(next(iter(_GI_CACHE)))
-        _GI_CACHE[key] = (weakref.ref(edge_index), edge_index._version, n_nodes, gi)
+        _cache_put(edge_index, n_nodes, gi)
     return gi
+
+
+_GI_CACHE_MAX = 4   # live entries: the EC graph, the cut graph and a prefetched batch or two
+
+
+def _cache_put(edge_index: Tensor, n_nodes: int, gi: GraphIndex) -> None:
+    """An index is 28 B/edge (1.8 GB at 64 M edges): entries whose edge list is gone are
+    dropped on every insertion, and at most ``_GI_CACHE_MAX`` live ones are kept (oldest out)."""
+    for k in [k for k, v in _GI_CACHE.items() if v[0]() is None]:
+        _GI_CACHE.pop(k, None)
+    while len(_GI_CACHE) >= _GI_CACHE_MAX:
+        _GI_CACHE.pop(next(iter(_GI_CACHE)))
+    _GI_CACHE[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, n_nodes, gi)
 
 
 def _join(gi: GraphIndex) -> GraphIndex:
@@ -219,7 +242,7 @@ def prefetch_graph_index(edge_index: Tensor, n_nodes: int, stream) -> GraphIndex
         gi = graph_index(edge_index, n_nodes, cache=False)
         gi.ready = torch.cuda.Event()
         gi.ready.record(stream)
-    _GI_CACHE[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, n_nodes, gi)
+    _cache_put(edge_index, n_nodes, gi)
     return gi
 
 
@@ -620,19 +643,40 @@ def edge_labels(particle_id: Tensor, edge_index: Tensor) -> Tensor:
     return y
 
 
+class _EdgeFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, edge_index):
+        lib = _capi.load()
+        x2 = _as_rows(x.detach())
+        ei = edge_index.contiguous()
+        m, f = int(ei.shape[1]), int(x2.shape[1])
+        out = torch.empty(m, 2 * f, dtype=torch.float32, device=x2.device)
+        _capi.check(lib.gnntrk_edge_features(_p(x2), f, _row_stride(x2), _p(ei), m, _p(out),
+                                             _stream(x2)), lib)
+        ctx.ei, ctx.n, ctx.f = edge_index, int(x2.shape[0]), f
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        # d/dx[n] = sum over edges with e0 = n of (g_diff + g_sum) + over edges with e1 = n of
+        # (g_sum - g_diff): two deterministic segment sums over the graph index of the edge list
+        f, n = ctx.f, ctx.n
+        gi = graph_index(ctx.ei, n)
+        g0 = _permute_raw((g[:, :f] + g[:, f:]).contiguous(), gi.perm, scatter=False)
+        g1 = _permute_raw((g[:, f:] - g[:, :f]).contiguous(), gi.perm, scatter=False)
+        gx = _segment_sum_raw(g1, gi.rowptr_t, None, n)
+        _segment_sum_raw(g0, gi.rowptr_s, gi.spos, n, out=gx, accumulate=True)
+        return gx, None
+
+
 def edge_features(x: Tensor, edge_index: Tensor) -> Tensor:
-    """``cat[x[e0] - x[e1], x[e0] + x[e1]]`` -> ``[M, 2F]`` (graph_construction.py:386-393)."""
+    """``cat[x[e0] - x[e1], x[e0] + x[e1]]`` -> ``[M, 2F]`` (graph_construction.py:386-393);
+    differentiable w.r.t. ``x`` (the reference back-propagates through it into the embedding
+    network when ``use_embedding_features`` is set and the network is not frozen)."""
     _capi.require_device(x, edge_index)
-    lib = _capi.load()
-    if x.requires_grad:
-        raise NotImplementedError("edge_features: inputs that require grad are not supported")
-    x = _as_rows(x)
-    ei = edge_index.contiguous()
-    m, f = int(ei.shape[1]), int(x.shape[1])
-    out = torch.empty(m, 2 * f, dtype=torch.float32, device=x.device)
-    _capi.check(lib.gnntrk_edge_features(_p(x), f, _row_stride(x), _p(ei), m, _p(out),
-                                         _stream(x)), lib)
-    return out
+    if x.dtype != torch.float32:
+        x = x.float()
+    return _EdgeFeatures.apply(x, edge_index)
 
 
 # -------------------------------------------------------------------------- BCE
@@ -699,7 +743,7 @@ def focal_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None, pt: Op
     """Binary focal loss of the edge weights (metrics/losses/ec.py:13-68) with the label
     falsification of ``EdgeWeightFocalLoss`` (haughty=False) or ``HaughtyFocalLoss`` (True)."""
     if w.numel() == 0:
-        raise ValueError("focal_loss: empty input")
+        return w.sum() * float("nan")  # the reference's mean over no edges
     if w.dtype != torch.float32:
         raise TypeError("focal_loss: w must be fp32")
     assert gamma >= 0.0
@@ -720,7 +764,7 @@ def bce_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None,
              pt: Optional[Tensor] = None, pt_thld: float = 0.0) -> Tensor:
     """mean BCE(w, y') with y' = falsify_low_pt_edges(y) (metrics/losses/ec.py:71-121)."""
     if w.numel() == 0:
-        raise ValueError("bce_loss: empty input")
+        return w.sum() * float("nan")  # the reference's mean over no edges
     if w.dtype != torch.float32:
         raise TypeError("bce_loss: w must be fp32")
     y = y.to(torch.float32)

@@ -678,6 +678,9 @@ GTCN_VARIANTS = {
     # the wrappers around ModularGraphTCN with a truth-based / without an edge classifier (:389-454, :522-582)
     "perfect_ec": dict(_cls="PerfectECGraphTCN", L_hc=2, hidden_dim=10, mask_orphan_nodes=True),
     "mlgc": dict(_cls="GraphTCNForMLGCPipeline", L_hc=1, hidden_dim=10),
+    # a threshold above every weight (W <= 0.999): the cut leaves NO edge, the track condenser
+    # runs on an edgeless graph (the reference does not special-case it)
+    "all_cut": dict(L_ec=1, L_hc=2, hidden_dim=8, _thr=0.9995),
 }
 
 
@@ -697,7 +700,12 @@ def g7_graph_tcn():
         # quantile of this model's edge weights (they do not depend on it), away from any weight
         kw = dict(kw)
         cls = kw.pop("_cls", "GraphTCN")
-        if cls == "GraphTCN":
+        fixed_thr = kw.pop("_thr", None)
+        if fixed_thr is not None:
+            kw = dict(kw, ec_threshold=fixed_thr)
+            torch.manual_seed(11)
+            model = GraphTCN(14, 4, **kw)
+        elif cls == "GraphTCN":
             torch.manual_seed(11)
             probe = GraphTCN(14, 4, **kw)
             wq = probe._gtcn.ec(Data(x=x, edge_index=ei, edge_attr=ea))["W"].detach().sort().values

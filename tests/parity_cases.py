@@ -194,23 +194,48 @@ def case_ec_variants(device, names=None):
             assert_close(gk, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
 
 
-def case_edge_cases(device):
-    """Empty / ragged inputs: zero edges, one edge, isolated nodes only, a tile-size
-    multiple and +-1 row around it."""
+def case_edge_cases(device, modes=("f32",)):
+    """Empty / ragged inputs: ZERO edges (an ``ec_threshold`` cut or a radius cut can leave
+    none; the reference runs through), one edge, isolated nodes only, a tile-size multiple and
+    +-1 row around it; forward and all parameter gradients."""
     torch.manual_seed(3)
     model = G.ECForGraphTCN(node_indim=6, edge_indim=3, L_ec=2, hidden_dim=8)
     p = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(device)
     g = np.random.default_rng(9)
-    for N, E in ((7, 1), (7, 2), (40, 15), (40, 16), (40, 17), (3, 64), (100, 63)):
+    for N, E in ((7, 0), (7, 1), (7, 2), (40, 15), (40, 16), (40, 17), (3, 64), (100, 63)):
         x = tt(g.normal(size=(N, 6)).astype(np.float32))
         ea = tt(g.normal(size=(E, 3)).astype(np.float32))
         ei = tt(g.integers(0, N, size=(2, E))).long()
-        ref = O.ec_for_graph_tcn(x, ei, ea, p, L_ec=2)
-        out = model(G.Data(x=x.to(device), edge_index=ei.to(device), edge_attr=ea.to(device)))
-        assert_close(out["W"].reshape(-1), ref["W"].reshape(-1), TOL_OUT, f"N={N} E={E} W")
-        assert_close(out["node_embedding"], ref["node_embedding"], TOL_OUT, f"N={N} E={E} node")
-        assert_close(out["edge_embedding"], ref["edge_embedding"], TOL_OUT, f"N={N} E={E} edge")
+        rn, rw = tt(g.normal(size=(N, 5)).astype(np.float32)), tt(g.normal(size=(E,)).astype(np.float32))
+        ps = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ref = O.ec_for_graph_tcn(x, ei, ea, ps, L_ec=2)
+        rl = (ref["node_embedding"] * rn).sum() + (ref["W"].reshape(-1) * rw).sum()
+        rg = torch.autograd.grad(rl, list(ps.values()), allow_unused=True)
+        for mode in modes:
+            model.zero_grad()
+            d = G.Data(x=x.to(device), edge_index=ei.to(device), edge_attr=ea.to(device))
+            if mode == "bf16":
+                with G.bf16_storage():
+                    out = model(d)
+            else:
+                out = model(d)
+            tol_o, tol_g = (TOL_OUT, TOL_GRAD) if mode == "f32" else (0.05, 0.1)
+            tag = f"N={N} E={E} {mode}"
+            assert out["W"].reshape(-1).shape == (E,) and out["edge_embedding"].shape == (E, 4)
+            assert_close(out["W"].reshape(-1), ref["W"].reshape(-1), tol_o, tag + " W")
+            assert_close(out["node_embedding"].float(), ref["node_embedding"], tol_o, tag + " node")
+            assert_close(out["edge_embedding"].float(), ref["edge_embedding"], tol_o, tag + " edge")
+            loss = (out["node_embedding"].float() * rn.to(device)).sum() + (out["W"].reshape(-1) * rw.to(device)).sum()
+            loss.backward()
+            for (k, v), gk in zip(model.named_parameters(), rg):
+                got = v.grad if v.grad is not None else torch.zeros_like(v)
+                want = gk if gk is not None else torch.zeros_like(v)
+                assert torch.isfinite(got).all(), f"{tag} grad {k} not finite"
+                if mode == "f32":
+                    assert_close(got, want, tol_g, f"{tag} grad {k}")
+                elif E == 0:
+                    assert_close(got, want, tol_g, f"{tag} grad {k}")
 
 
 # ----------------------------------------------------------------- kNN / graphs
@@ -270,6 +295,18 @@ def case_ml_graph_construction(device):
         assert torch.equal(out.edge_index.cpu(), tt(z[f"k{k}_r{r}/edge_index"]))
         assert torch.equal(out.y.cpu(), tt(z[f"k{k}_r{r}/y"]))
         assert torch.equal(out.edge_attr.cpu(), tt(z[f"k{k}_r{r}/edge_attr"])), "edge features"
+    # the edge features are differentiable w.r.t. the node features (graph_construction.py:386-393
+    # is plain indexing + cat in the reference): gradient against torch autograd of that expression
+    g = np.random.default_rng(4)
+    x = tt(g.normal(size=(40, 5)).astype(np.float32))
+    ei = tt(g.integers(0, 40, size=(2, 300))).long()
+    r = tt(g.normal(size=(300, 10)).astype(np.float32))
+    xo = x.clone().requires_grad_(True)
+    (torch.cat([xo[ei[0]] - xo[ei[1]], xo[ei[0]] + xo[ei[1]]], dim=1) * r).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    f = ops.edge_features(xd, ei.to(device))
+    (f * r.to(device)).sum().backward()
+    assert_close(xd.grad, xo.grad, TOL_GRAD, "edge_features grad x")
 
 
 # ------------------------------------------------------------ condensation losses
@@ -665,6 +702,7 @@ GTCN_VARIANTS = {
     "hetero": dict(L_ec=1, L_hc=1, hidden_dim=12, mask_orphan_nodes=True, heterogeneous_node_encoder=True),
     "perfect_ec": dict(_cls="PerfectECGraphTCN", L_hc=2, hidden_dim=10, mask_orphan_nodes=True),
     "mlgc": dict(_cls="GraphTCNForMLGCPipeline", L_hc=1, hidden_dim=10),
+    "all_cut": dict(L_ec=1, L_hc=2, hidden_dim=8, _thr=0.9995),  # threshold above every weight: no edge left
 }
 
 
@@ -672,6 +710,7 @@ def make_gtcn(kw, thr):
     """(model, class name) of a G7 variant."""
     kw = dict(kw)
     cls = kw.pop("_cls", "GraphTCN")
+    kw.pop("_thr", None)
     if cls == "GraphTCN":
         return G.GraphTCN(14, 4, ec_threshold=thr, **kw), cls
     return getattr(G, cls)(node_indim=14, edge_indim=4, ec_threshold=thr, **kw), cls

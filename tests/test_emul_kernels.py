@@ -62,7 +62,7 @@ def test_condensation_losses_and_mask():
 
 def test_graph_tcn_emulated():
     with emulated():
-        P.case_graph_tcn("cpu", names=("latent",))
+        P.case_graph_tcn("cpu", names=("latent", "all_cut"))
 
 
 def test_hinge_loss_emulated():

@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: edges/s (forward + BCE + backward + grad all-reduce + Adam) of the
+"""Headline benchmark: edges/s (forward + loss + backward + grad all-reduce + Adam) of the
 ECForGraphTCN edge classifier on synthetic TrackML-shaped hit graphs.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2]/[3]): per GPU a batch of 32
-events x (150 000 hits, 2 000 000 edges) collated into one disjoint graph (N = 4.8 M,
-E = 64 M), model ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=3, hidden_dim=40), fp32.
-Weak scaling: every rank owns its own 32 events; the only collective is one RCCL
-all-reduce of the flat gradient buffer per step.  A step does everything a training
-step does, including rebuilding the graph index from the raw COO edge_index (the cache
-is cleared every step: a new batch would arrive every step in real training).
+Without torchrun's environment ``--gpus N`` (N > 1) makes this script launch its own N ranks
+(one process per GPU, RCCL); either way the line is only printed when the process group
+really has N ranks (``rccl_ranks``).
 
-Prints ONE JSON line (rank 0).  ``roofline`` describes the dominant kernel (the fused
-gather-MLP backward, fp32 MFMA bound at hidden width 40) from HIP-event timings taken
-inside the timed region; ``cpu_baseline`` is the CPU oracle (oracle/ref_cpu.py, a
-restatement of the reference pinned against it) timed on this box's host cores on one
-event of the same workload.
+Workloads (BASELINE.json ``configs``):
+
+* ``cfg3`` (default; configs[2]): per GPU a batch of 32 events x (150 000 hits, 2 000 000
+  edges) collated into one disjoint graph (N = 4.8 M, E = 64 M), ``ECForGraphTCN(14, 4,
+  L_ec=3, hidden_dim=40)``, bf16 storage / fp32 accumulate (``--dtype f32``: reference
+  precision).  Weak scaling: every rank owns its own 32 events.
+* ``cfg4`` (configs[3]): 256 events with N ~ U(100 k, 200 k) hits (E = 40/3 N), greedy
+  size-balanced into 8 shards of 32 events; the SAME 256 events at every rank count (strong
+  scaling): a rank owns 8/N shards and runs them as micro-batches of one optimisation step.
+* ``cfg2`` (configs[1]): one 10 000-hit / 100 000-edge event (cache resident, launch bound).
+* ``cfg5`` (configs[4]): the object-condensation step on a 200 000-hit pile-up event: kNN
+  graph build (MLGraphConstruction) -> GraphTCN -> CondensationLossRG -> backward -> Adam.
+
+A step does everything a training step does, including rebuilding the graph index from the
+raw COO edge_index (the cache is cleared every step: a new batch would arrive every step).
+The only collective is one RCCL all-reduce of the flat gradient buffer per step.
+
+Prints ONE JSON line (rank 0).  ``roofline`` describes the dominant fused gather-MLP kernel
+from HIP-event timings taken inside the timed region; ``cpu_baseline`` is the CPU oracle
+(oracle/ref_cpu.py, a restatement of the reference pinned against it) timed on this box's
+host cores on one event of the same workload; ``extra`` (N = 1 default run) holds short
+driver-timed runs of the other configurations.
 """
 
 from __future__ import annotations
@@ -25,6 +38,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,36 +50,79 @@ sys.path.insert(0, ROOT)
 
 import gnn_tracking_amd as G  # noqa: E402
 from gnn_tracking_amd import dist as gdist  # noqa: E402
-from gnn_tracking_amd import ops, synthetic  # noqa: E402
+from gnn_tracking_amd import ops, synthetic, training  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
 PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
-TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r01_hbm_traffic_bf16_v8.json"}
+TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r02_hbm_traffic_bf16.json"}
+TRAFFIC_FALLBACK = {"bf16": "r01_hbm_traffic_bf16_v8.json"}
 
-WORKLOADS = {
-    # name: (events per GPU, hits per event, edges per event, model kwargs)
-    "cfg3": (32, 150_000, 2_000_000, dict(L_ec=3, hidden_dim=40)),
-    "cfg2": (1, 10_000, 100_000, dict(L_ec=3, hidden_dim=40)),
-}
+EC_MODEL = dict(L_ec=3, hidden_dim=40)
+CFG4_EVENTS, CFG4_SHARDS = 256, 8
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--events", type=int, default=None, help="override events per GPU")
+    ap.add_argument("--workload", default="cfg3", choices=("cfg2", "cfg3", "cfg4", "cfg5"))
+    ap.add_argument("--events", type=int, default=None, help="override the event count (cfg3: per GPU; cfg4: total)")
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "f32"),
                     help="storage / MFMA-input type of the activations (cfg3 names bf16 storage, "
                          "fp32 accumulate); parameters and their gradients are fp32 in both")
     ap.add_argument("--index", default="inline", choices=("inline", "prefetch"),
                     help="graph index built inline in the step (default), or for the next batch on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configurations")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST ONLY: replace the HIP workload by a CPU toy model (gloo) to exercise the "
+                         "launcher / barrier / reduction control flow; the line is marked as a stub")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------- launcher
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """``python bench.py --gpus N`` without torchrun: start N copies of this script, one per
+    GPU, with torchrun's environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    Rank 0 inherits stdout (it prints the line).  Returns the worst exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   GNNTRK_BENCH_SELF_LAUNCHED="1")
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=out))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:       # one rank failed: the others would wait in a collective
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# --------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(event, model, iters: int) -> dict:
     """Oracle fwd+BCE+bwd on ONE event on the host cores (rank 0, N=1 only).
 
@@ -99,182 +157,404 @@ def cpu_baseline(event, model, iters: int) -> dict:
     threads = min(probe, key=probe.get)
     torch.set_num_threads(threads)
     one(ei, ea, y)  # warm-up (untimed)
-    t0 = time.perf_counter()
+    times = []
     for _ in range(iters):
+        t0 = time.perf_counter()
         one(ei, ea, y)
-    dt = (time.perf_counter() - t0) / iters
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     return {"value": E / dt, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"1 event ({x.shape[0]} hits, {E} edges) of the workload, "
+            "sample": f"1 event ({x.shape[0]} hits, {E} edges) of the workload, median of "
                       f"{iters} timed fwd+BCE+bwd iterations after 1 warm-up, "
                       f"torch {torch.__version__} CPU, {threads} threads (fastest of "
                       f"{sorted(probe)} probed on a 1/8-event slice, stopping once slower; host has {ncpu} CPUs)",
-            "s_per_iter": dt, "thread_probe_s": probe}
+            "s_per_iter": dt, "s_all_iters": times, "thread_probe_s": probe}
 
 
 def measured_traffic(kernel: str, rows_per_launch: float, dtype: str):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and
     WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; see the JSON's _about),
     scaled by rows when this run's launch size differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILES[dtype])
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rec = json.load(f)["kernels"].get(kernel)
-    if rec is None:
-        return None
-    return rec["hbm_bytes_per_launch"] * rows_per_launch / rec["rows_per_launch"]
+    for name in (TRAFFIC_PROFILES.get(dtype), TRAFFIC_FALLBACK.get(dtype)):
+        if not name:
+            continue
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+        if rec is not None:
+            return rec["hbm_bytes_per_launch"] * rows_per_launch / rec["rows_per_launch"]
+    return None
 
 
-def main():
-    args = parse()
-    rank, local, world = gdist.init_process_group_from_env()
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the package has no CPU path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+# ------------------------------------------------------------------------------ workloads
+class Workload:
+    """What a rank runs per step.  ``step()`` returns the loss tensor of the last micro-batch."""
 
-    n_ev, n_hits, n_edges, mkw = WORKLOADS[args.workload]
-    if args.events:
-        n_ev = args.events
-    torch.manual_seed(0)  # identical initial weights on every rank
-    model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **mkw).to(dev)
-    flat = gdist.FlatParameters(model)
-    opt = torch.optim.Adam([flat.flat_param], lr=1e-4, weight_decay=1e-4)
-    loss_fct = G.EdgeWeightBCELoss()
+    name = ""
+    scaling = "weak"
+    edges_per_step_global = 0      # edges ALL ranks process in one step
+    describe = ""
+    info: dict = {}
 
-    events = [synthetic.make_event(100 + rank * n_ev + i, n_hits, n_edges, dev)
-              for i in range(n_ev)]
-    batch = G.collate(events)
-    first_event_cpu = events[0].cpu() if (rank == 0 and world == 1) else None
-    del events
-    yf = batch.y.float()
-    E_local = batch.num_edges
+    def step(self):
+        raise NotImplementedError
 
-    # Every step pays one graph-index build.  --index inline (default): at the start of the forward.
-    # --index prefetch: the build for the NEXT batch runs on the loader's side stream
-    # while this step computes - the index depends on the input edge list only, and
-    # io.PrefetchLoader(build_index=True) does exactly this one batch ahead - so a step
-    # consumes the index the previous step built.  Two batch objects (own edge_index tensors,
-    # same content) alternate so that "next batch" is a different tensor, as with a loader.
-    side = torch.cuda.Stream(dev) if args.index == "prefetch" else None
-    batches = [batch]
-    if side is not None:
-        import copy
-        other = copy.copy(batch)
-        other.edge_index = batch.edge_index.clone()
-        batches.append(other)
-    counter = [0]
 
-    def step():
-        cur = batches[counter[0] % len(batches)]
-        nxt = batches[(counter[0] + 1) % len(batches)]
-        counter[0] += 1
-        if side is None:
-            ops.clear_graph_index_cache()
+def cfg4_event_sizes(n_events: int) -> list[tuple[int, int]]:
+    """(hits, edges) of the cfg4 events: N ~ U(100 k, 200 k), E/N = 40/3 as cfg3 (numpy
+    generator: the same list on every rank and host)."""
+    import numpy as np
+
+    g = np.random.default_rng(4)
+    hits = g.integers(100_000, 200_001, size=n_events)
+    return [(int(h), int(h * 40 // 3) // 2 * 2) for h in hits]
+
+
+class ECWorkload(Workload):
+    """cfg2 / cfg3 / cfg4: ECForGraphTCN training step(s) on collated events."""
+
+    def __init__(self, args, rank: int, world: int, dev, *, workload: str, dtype: str, index: str = "inline"):
+        self.name, self.dtype = workload, dtype
+        torch.manual_seed(0)  # identical initial weights on every rank
+        self.model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_MODEL).to(dev)
+        self.flat = gdist.FlatParameters(self.model)
+        self.module = training.ECModule(
+            self.model, loss_fct=G.EdgeWeightBCELoss(), flat=self.flat, bf16=dtype == "bf16",
+            optimizer=lambda p: torch.optim.Adam(p, lr=1e-4, weight_decay=1e-4))
+        self.first_event_cpu = None
+        if workload == "cfg4":
+            n_events = args.events or CFG4_EVENTS
+            if CFG4_SHARDS % world:
+                raise SystemExit(f"cfg4 has {CFG4_SHARDS} shards: --gpus must divide it, got {world}")
+            sizes = cfg4_event_sizes(n_events)
+            shards = gdist.shard_events([e for _, e in sizes], CFG4_SHARDS)
+            loads = [sum(sizes[i][1] for i in s) for s in shards]
+            mine = [s for j, s in enumerate(shards) if j % world == rank]
+            self.batches = [G.collate([synthetic.make_event(1000 + i, *sizes[i], dev) for i in s]) for s in mine]
+            self.scaling = "strong"
+            self.edges_per_step_global = sum(loads)
+            rank_loads = [sum(loads[j] for j in range(CFG4_SHARDS) if j % world == r) for r in range(world)]
+            self.info = {"events": n_events, "shards": CFG4_SHARDS, "micro_batches_per_rank": len(mine),
+                         "shard_edges_max_over_mean": max(loads) / (sum(loads) / len(loads)),
+                         "rank_edges_max_over_mean": max(rank_loads) / (sum(rank_loads) / world),
+                         "rank_edges": rank_loads}
+            self.describe = (f"cfg4: {n_events} events, hits ~ U(100k, 200k), E = 40/3 N, greedy size-balanced into "
+                             f"{CFG4_SHARDS} shards; the same events at every rank count, {len(mine)} "
+                             f"micro-batch(es) of ~32 events per rank and step (total E = {sum(loads)})")
         else:
-            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, side)
-        flat.zero_grad()
-        with G.bf16_storage(args.dtype == "bf16"):
-            out = model(cur)
-            loss = loss_fct(w=out["W"], y=yf, edge_index=cur.edge_index, pt=cur.pt)
-            loss.backward()
-        flat.all_reduce_grads()
+            n_ev, n_hits, n_edges = {"cfg3": (32, 150_000, 2_000_000), "cfg2": (1, 10_000, 100_000)}[workload]
+            if args.events:
+                n_ev = args.events
+            seed0 = 1 if workload == "cfg2" else 100 + rank * n_ev
+            events = [synthetic.make_event(seed0 + i, n_hits, n_edges, dev) for i in range(n_ev)]
+            if rank == 0 and world == 1:
+                self.first_event_cpu = events[0].cpu()
+            self.batches = [G.collate(events)]
+            del events
+            b = self.batches[0]
+            self.edges_per_step_global = b.num_edges * world
+            self.describe = (f"{workload}: per GPU {n_ev} events x {n_hits} hits x {n_edges} edges collated "
+                             f"(N={b.num_nodes}, E={b.num_edges})")
+        self.describe += (f"; ECForGraphTCN(node_indim=14, edge_indim=4, L_ec={EC_MODEL['L_ec']}, "
+                          f"hidden_dim={EC_MODEL['hidden_dim']}); step = graph index "
+                          + ("(built for the next batch on the loader's side stream during the step) "
+                             if index == "prefetch" else "(inline) ")
+                          + "+ forward + BCE + backward + grad all-reduce + Adam")
+        for b in self.batches:
+            b.y = b.y.float()
+        # --index prefetch: the build for the NEXT batch runs on the loader's side stream while
+        # this step computes (io.PrefetchLoader(build_index=True) does exactly this one batch
+        # ahead).  Two batch objects (own edge_index tensors, same content) alternate so that
+        # "next batch" is a different tensor, as with a loader.
+        self.side = torch.cuda.Stream(dev) if index == "prefetch" else None
+        if self.side is not None:
+            if len(self.batches) != 1:
+                raise SystemExit("--index prefetch is wired for the single-batch workloads")
+            import copy
+            other = copy.copy(self.batches[0])
+            other.edge_index = self.batches[0].edge_index.clone()
+            self.batches.append(other)
+        self.counter = 0
+
+    def step(self):
+        opt = self.module.configure_optimizers()
+        self.module.zero_grad()
+        if self.side is not None:
+            cur = self.batches[self.counter % 2]
+            nxt = self.batches[(self.counter + 1) % 2]
+            self.counter += 1
+            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, self.side)
+            loss = self.module.backward_step(cur)
+        else:
+            n = len(self.batches)
+            for b in self.batches:
+                ops.clear_graph_index_cache()   # a new batch every step: every step pays its index
+                loss = self.module.backward_step(b, scale=1.0 / n)
+        self.flat.all_reduce_grads()
         opt.step()
         return loss
 
-    def barrier():
+
+class StubWorkload(Workload):
+    """TEST ONLY (``--stub``): a CPU toy model so that tests can drive the launcher, barrier,
+    max-over-ranks timing and the all-reduce through this file's real control flow."""
+
+    name, scaling = "stub", "weak"
+
+    def __init__(self, args, rank: int, world: int, dev):
+        torch.manual_seed(0)
+        self.model = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.ReLU(), torch.nn.Linear(4, 1))
+        self.flat = gdist.FlatParameters(self.model)
+        self.opt = torch.optim.Adam([self.flat.flat_param], lr=1e-2)
+        g = torch.Generator().manual_seed(100 + rank)   # per-rank data
+        self.x = torch.randn(64, 3, generator=g)
+        self.edges_per_step_global = 64 * world
+        self.describe = "stub: CPU toy model (launcher / collective control-flow test), not a measurement"
+        self.info = {"rank_seed": 100 + rank}
+
+    def step(self):
+        self.flat.zero_grad()
+        loss = self.model(self.x).pow(2).mean()
+        loss.backward()
+        self.flat.all_reduce_grads()
+        self.opt.step()
+        return loss.detach()
+
+
+# ------------------------------------------------------------------------------ timing
+def barrier(world: int) -> None:
+    if torch.cuda.is_available():
         torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
+    if world > 1:
+        torch.distributed.barrier()
+    if torch.cuda.is_available():
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    timer = ops.KernelTimer()
+
+def timed_steps(wl: Workload, world: int, dev, steps: int, warmup: int, *, kernel_timer: bool):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides;
+    returns (seconds = max over ranks, last loss, kernel summary)."""
+    for _ in range(warmup):
+        wl.step()
+    timer = ops.KernelTimer() if kernel_timer else None
     ops.set_kernel_timer(timer)
-    barrier()
+    barrier(world)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
+    for _ in range(steps):
+        loss = wl.step()
+    barrier(world)
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(loss.item())
+    return dt, float(loss.item()), (timer.summary() if timer else {})
+
+
+def roofline_of(ks: dict, dtype: str):
+    """Per-instantiation table and the roofline block of the dominant fused-MLP kernel."""
+    kernels = {}
+    for k, d in ks.items():
+        kernels[k] = {"launches": d["launches"], "avg_ms": d["ms"] / d["launches"],
+                      "tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12,
+                      "alg_GBps": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
+        # HBM bytes actually moved (committed PMC passes) over THIS run's launch time
+        tr = measured_traffic(k, d["rows"] / d["launches"], dtype)
+        if tr is not None:
+            gbps = tr / (d["ms"] / d["launches"] * 1e-3) / 1e9
+            kernels[k].update({"traffic": tr, "hbm_GBps": gbps, "hbm_frac": gbps / (PEAK_HBM_TBPS * 1e3)})
+    if not ks:
+        return None, kernels
+    dom = max(ks, key=lambda k: ks[k]["ms"])
+    d = ks[dom]
+    tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    gbps = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    common = {"kernel": dom, "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
+              "alg_flops_per_launch": d["flops"] / d["launches"],
+              "alg_bytes_per_launch": d["bytes"] / d["launches"],
+              "traffic": measured_traffic(dom, d["rows"] / d["launches"], dtype)}
+    if dtype == "bf16":
+        # bf16 MFMA (2.5 PFLOP/s) leaves the fused kernels HBM / issue bound: the
+        # roofline that bounds them is HBM bandwidth (SURVEY.md section 8d)
+        roof = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_TBPS * 1e3, "unit": "GB/s",
+                "frac": gbps / (PEAK_HBM_TBPS * 1e3), **common, "mfma_tflops_algorithmic": tf}
+    else:
+        roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / PEAK_F32_MFMA_TFLOPS, **common, "hbm_frac_algorithmic": gbps / (PEAK_HBM_TBPS * 1e3)}
+    return roof, kernels
+
+
+def hipgraph_cfg2(dev, dtype: str, steps: int) -> dict:
+    """cfg2 (launch bound: ~100 kernels of a few microseconds) eager and as ONE captured HIP
+    graph: every gnntrk_* entry point is stream ordered, allocation- and sync-free."""
+    torch.manual_seed(0)
+    model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_MODEL).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
+    mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), bf16=dtype == "bf16", optimizer=lambda p: opt)
+    batch = G.collate([synthetic.make_event(1, 10_000, 100_000, dev)])
+    batch.y = batch.y.float()
+
+    def step():
+        ops.clear_graph_index_cache()
+        return mod.optimisation_step(batch)
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    for _ in range(5):
+        step()
+    eager = timed(step, steps)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    g.replay()
+    graph = timed(g.replay, steps)
+    E = batch.num_edges
+    return {"workload": "cfg2: 1 event x 10000 hits x 100000 edges, whole step as one hipGraph replay",
+            "dtype": dtype, "steps": steps, "eager_ms_per_step": eager, "ms_per_step": graph,
+            "value": E / graph * 1e3, "unit": "edges/s", "roofline": "n/a (cache resident, launch bound)"}
+
+
+def cfg4_short(args, rank: int, world: int, dev) -> dict:
+    """BASELINE config 4 (strong scaling over the same 256 events) as a short run; collective:
+    every rank calls it."""
+    wl = ECWorkload(args, rank, world, dev, workload="cfg4", dtype="bf16")
+    dt, loss, _ = timed_steps(wl, world, dev, 3, 1, kernel_timer=False)
+    return {"workload": wl.describe, "n_gpus": world, "steps": 3, "warmup": 1, "ms_per_step": dt / 3 * 1e3,
+            "value": wl.edges_per_step_global * 3 / dt, "unit": "edges/s", "scaling": "strong",
+            "final_loss": loss, **wl.info}
+
+
+def extras(args, rank: int, world: int, dev) -> dict:
+    """Short driver-timed runs of the configurations the headline does not cover: cfg4 at
+    every rank count; at N = 1 also cfg3 in fp32 and cfg2 as a HIP graph."""
+    out = {}
+    try:
+        ops.clear_graph_index_cache()
+        torch.cuda.empty_cache()
+        out["cfg4_strong_bf16"] = cfg4_short(args, rank, world, dev)
+        ops.clear_graph_index_cache()
+        torch.cuda.empty_cache()
+        if world > 1:
+            return out
+        wl = ECWorkload(args, 0, 1, dev, workload="cfg3", dtype="f32")
+        dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
+        roof, _ = roofline_of(ks, "f32")
+        out["cfg3_f32"] = {"workload": "cfg3 in the reference's precision (fp32 storage, fp32 MFMA)", "steps": 5,
+                           "warmup": 2, "ms_per_step": dt / 5 * 1e3, "value": wl.edges_per_step_global * 5 / dt,
+                           "unit": "edges/s", "final_loss": loss, "roofline": roof}
+        del wl
+        ops.clear_graph_index_cache()
+        torch.cuda.empty_cache()
+        out["cfg2_hipgraph_bf16"] = hipgraph_cfg2(dev, "bf16", 100)
+        out["cfg2_hipgraph_f32"] = hipgraph_cfg2(dev, "f32", 100)
+    except Exception as e:  # the headline line must survive a failing extra
+        if world > 1:
+            raise   # (a rank that drops out of a collective would hang the others)
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+# ----------------------------------------------------------------------------------- main
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))
+
+    backend = "gloo" if args.stub else None
+    rank, local, world = gdist.init_process_group_from_env(backend=backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has WORLD_SIZE={world}")
+    if world > 1:
+        assert torch.distributed.is_initialized() and torch.distributed.get_world_size() == args.gpus
+    if args.stub:
+        dev = torch.device("cpu")
+        wl: Workload = StubWorkload(args, rank, world, dev)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (the package has no CPU path)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if args.workload == "cfg5":
+            from gnn_tracking_amd import bench_cfg5
+            wl = bench_cfg5.TCWorkload(args, rank, world, dev)
+        else:
+            wl = ECWorkload(args, rank, world, dev, workload=args.workload, dtype=args.dtype, index=args.index)
+
+    dt, final_loss, ks = timed_steps(wl, world, dev, args.steps, args.warmup, kernel_timer=not args.stub)
+    want_extra = not args.no_extra and not args.stub and args.workload == "cfg3" and args.dtype == "bf16"
+    model_for_cpu = (getattr(wl, "first_event_cpu", None), getattr(wl, "model", None))
+    describe, info, scaling, wdtype = wl.describe, wl.info, wl.scaling, getattr(wl, "dtype", args.dtype)
+    edges_per_step = wl.edges_per_step_global
+    roof_fn = getattr(wl, "roofline", None)
+    cpu_fn = getattr(wl, "cpu_baseline", None)
+    stages = wl.stages() if hasattr(wl, "stages") else None
+    extra = None
+    if want_extra:
+        del wl
+        extra = extras(args, rank, world, dev)
 
     if rank == 0:
-        ks = timer.summary()
-        dom = max(ks, key=lambda k: ks[k]["ms"]) if ks else None
-        roof = None
-        kernels = {}
-        for k, d in ks.items():
-            kernels[k] = {"launches": d["launches"], "avg_ms": d["ms"] / d["launches"],
-                          "tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12,
-                          "alg_GBps": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
-            # HBM bytes actually moved (committed PMC passes) over THIS run's launch time
-            tr = measured_traffic(k, d["rows"] / d["launches"], args.dtype)
-            if tr is not None:
-                gbps = tr / (d["ms"] / d["launches"] * 1e-3) / 1e9
-                kernels[k].update({"traffic": tr, "hbm_GBps": gbps, "hbm_frac": gbps / (PEAK_HBM_TBPS * 1e3)})
-        if dom:
-            d = ks[dom]
-            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            gbps = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            common = {"kernel": dom, "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
-                      "alg_flops_per_launch": d["flops"] / d["launches"],
-                      "alg_bytes_per_launch": d["bytes"] / d["launches"],
-                      "traffic": measured_traffic(dom, d["rows"] / d["launches"], args.dtype)}
-            if args.dtype == "bf16":
-                # bf16 MFMA (2.5 PFLOP/s) leaves the fused kernels HBM / issue bound: the
-                # roofline that bounds them is HBM bandwidth (SURVEY.md section 8d)
-                roof = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_TBPS * 1e3, "unit": "GB/s",
-                        "frac": gbps / (PEAK_HBM_TBPS * 1e3), **common,
-                        "mfma_tflops_algorithmic": tf}
-            else:
-                roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf / PEAK_F32_MFMA_TFLOPS, **common,
-                        "hbm_frac_algorithmic": gbps / (PEAK_HBM_TBPS * 1e3)}
+        if roof_fn is not None:
+            roof, kernels = roof_fn(ks)
+        else:
+            roof, kernels = roofline_of(ks, args.dtype)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and first_event_cpu is not None:
-            cpu = cpu_baseline(first_event_cpu, model, args.cpu_iters)
-        total_edges = E_local * world * args.steps
+        if world == 1 and not args.no_cpu_baseline and not args.stub:
+            if cpu_fn is not None:
+                cpu = cpu_fn(args.cpu_iters)
+            elif model_for_cpu[0] is not None:
+                cpu = cpu_baseline(model_for_cpu[0], model_for_cpu[1], args.cpu_iters)
+        total = edges_per_step * args.steps
         line = {
-            "metric": "edges_per_sec_fwd_bwd",
-            "value": total_edges / dt,
+            "metric": "edges_per_sec_fwd_bwd" if not args.stub else "stub_not_a_measurement",
+            "value": total / dt,
             "unit": "edges/s",
             "n_gpus": world,
+            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "self_launched": bool(os.environ.get("GNNTRK_BENCH_SELF_LAUNCHED")),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
+            "dtype": wdtype,
+            "data": "synthetic" if not args.stub else "stub",
             "config": {
-                "workload": f"{args.workload}: per GPU {n_ev} events x {n_hits} hits x {n_edges} "
-                            f"edges collated (N={batch.num_nodes}, E={E_local}); "
-                            f"ECForGraphTCN(node_indim=14, edge_indim=4, L_ec={mkw['L_ec']}, "
-                            f"hidden_dim={mkw['hidden_dim']}); step = graph index "
-                            + ("(built for the next batch on the loader's side stream during the step) "
-                               if args.index == "prefetch" else "(inline) ")
-                            + "+ forward + BCE + backward + grad all-reduce + Adam",
+                "workload": describe,
                 "graph_index": args.index,
-                "global_edges_per_step": E_local * world,
+                "global_edges_per_step": edges_per_step,
                 "parallelism": f"dp{world} (events sharded, flat-gradient RCCL all-reduce)",
+                **info,
             },
-            "edge_layers_per_sec": total_edges * mkw["L_ec"] / dt,
+            "edge_layers_per_sec": total * EC_MODEL["L_ec"] / dt,
             "final_loss": final_loss,
             "roofline": roof,
             "kernels": kernels,
             "cpu_baseline": cpu,
         }
+        if stages is not None:
+            line["stages"] = stages
+        if extra is not None:
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
+    barrier(world)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -1,0 +1,76 @@
+"""bench.py's multi-rank control flow on CPU (gloo, world size 2) through the SAME code path
+a GPU run takes: self-launch of N ranks when torchrun's environment is absent, torchrun's
+environment contract, the rank-count check, barrier + max-over-ranks timing, the flat-gradient
+all-reduce.  ``--stub`` swaps the HIP workload for a CPU toy model (the line says so)."""
+
+import json
+import os
+import pathlib
+import socket
+import subprocess
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def _line(out: str) -> dict:
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}:\n{out}"
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--stub", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["self_launched"] is True
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["data"] == "stub"
+    assert d["config"]["global_edges_per_step"] == 128          # both ranks' work is counted
+    assert abs(d["value"] - 128 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_under_torchrun_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+                        "--gpus", "2", "--stub", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["self_launched"] is False
+
+
+def test_rank_count_mismatch_is_refused():
+    env = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--stub", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no line may be printed"
+
+
+def test_cfg4_shards_are_balanced_and_rank_count_independent():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from gnn_tracking_amd import dist as gdist
+
+    sizes = bench.cfg4_event_sizes(256)
+    assert sizes == bench.cfg4_event_sizes(256), "the event list must be the same on every rank"
+    assert all(100_000 <= h <= 200_000 and e % 2 == 0 and abs(e - h * 40 / 3) <= 2 for h, e in sizes)
+    shards = gdist.shard_events([e for _, e in sizes], 8)
+    assert sorted(i for s in shards for i in s) == list(range(256))
+    loads = [sum(sizes[i][1] for i in s) for s in shards]
+    assert max(loads) / (sum(loads) / 8) < 1.01, "greedy assignment leaves > 1 % imbalance"
+    # a rank of an N-rank job owns shards r, r + N, ...: every shard is owned exactly once
+    for world in (1, 2, 4, 8):
+        owned = [j for r in range(world) for j in range(8) if j % world == r]
+        assert sorted(owned) == list(range(8))

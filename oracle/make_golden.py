@@ -242,6 +242,44 @@ def g2_ec_variants():
     npz("g2_ec_variants.npz", **arrs)
 
 
+def g2b_ec_autocast():
+    """The bf16 pin: the reference's OWN ECForGraphTCN variants of G2 (same inputs, same initial
+    parameters) run under ``torch.autocast("cpu", dtype=torch.bfloat16)`` - what Lightning's
+    ``precision="bf16-mixed"`` does to these modules: every Linear takes bf16 inputs / weights
+    and returns bf16, the scatter-add of the messages accumulates in bf16, W comes back as
+    bf16.  Outputs (as fp32), the fp32 BCE of W and the fp32 parameter gradients.  The tests
+    state how far the bf16-storage kernels (fp32 accumulation everywhere, one rounding per
+    stored tensor) and oracle/ref_cpu.py's restatement of their rounding contract are from it."""
+    print("G2b ECForGraphTCN variants under CPU bf16 autocast")
+    x, ei, ea, y, pt = synth_graph(2, 300, 2000, 14, 4)
+    z = np.load(OUT / "g2_ec_variants.npz")
+    arrs = {}
+    for name, kw in EC_VARIANTS.items():
+        torch.manual_seed(7)
+        model = ECForGraphTCN(node_indim=14, edge_indim=4, **kw)
+        for k, v in sd(model).items():
+            assert np.array_equal(v.numpy(), z[f"{name}/p0/{k}"]), "G2b must start from G2's parameters"
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = model(Data(x=x, edge_index=ei, edge_attr=ea))
+        assert out["W"].dtype == torch.bfloat16, "autocast did not reach the edge-weight head"
+        loss = EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"].float(), y=y.float(), pt=pt, edge_index=ei)
+        loss.backward()
+        for k in ("W", "node_embedding", "edge_embedding"):
+            arrs[f"{name}/{k}"] = out[k].detach().float()
+        arrs[f"{name}/loss"] = loss.detach()
+        for k, v in model.named_parameters():
+            arrs[f"{name}/grad/{k}"] = v.grad if v.grad is not None else torch.zeros_like(v)
+        df = (torch.from_numpy(z[f"{name}/W"]) - out["W"].float()).abs().max().item()
+        msg = f"   {name}: |W_autocast - W_fp32| {df:.2e}"
+        plain = (kw.get("residual_type", "skip1") == "skip1" and kw.get("use_node_embedding", True)
+                 and kw.get("use_intermediate_edge_embeddings", True))
+        if plain:  # the restatement of the kernels' rounding contract covers the default wiring
+            o16 = O.ec_for_graph_tcn_bf16(x, ei, ea, sd(model), L_ec=kw["L_ec"], alpha=kw.get("alpha", 0.5))
+            msg += f"   |W_contract - W_autocast| {(o16['W'].float() - out['W'].float()).abs().max().item():.2e}"
+        print(msg)
+    npz("g2b_ec_bf16_autocast.npz", **arrs)
+
+
 def g3_in_layer():
     """One InteractionNetwork(5,4 -> 5,4; H=40/40) and one with odd sizes, on a seeded
     N=1000, E=10000 graph: outputs and grads wrt x, edge_attr and all parameters of
@@ -781,7 +819,7 @@ if __name__ == "__main__":
         return not only or tag in only
 
     tg = g1_ec_testgraph() if (want("g1") or want("g4") or want("g6")) else None
-    for tag, fn in (("g2", g2_ec_variants), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
+    for tag, fn in (("g2", g2_ec_variants), ("g2b", g2b_ec_autocast), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
                     ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g8", g8_hinge),
                     ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan), ("g12", g12_gc_resin), ("g13", g13_focal)):
         if want(tag):

@@ -568,6 +568,8 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):
     against the reference-pinned fp32 goldens with a bf16-sized tolerance; loss and
     parameter gradients against the fp32 goldens (bf16 noise bound)."""
     z = load("g2_ec_variants.npz")
+    za = load("g2b_ec_bf16_autocast.npz")   # the reference's own modules under CPU bf16 autocast
+    report = {}
     x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
     y, pt = tt(z["y"], device), tt(z["pt"], device)
     for name in names:
@@ -600,6 +602,31 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):
             assert v.grad.dtype == torch.float32
             err = (v.grad.detach().cpu().double() - gref).norm() / max(gref.norm().item(), 1e-6)
             assert err < 0.1, f"{name} grad {k}: relative L2 error {err:.3f} vs fp32 golden"
+        # THE PIN AGAINST THE REFERENCE IN ITS OWN MIXED PRECISION (golden G2b): W within one
+        # bf16 ulp of the reference's bf16-rounded W (2^-8 on [0.5, 1)), embeddings within
+        # BF16_PIN_EMB of the largest reference entry, loss 5e-3 (the reference rounds W itself to bf16), parameter gradients 6 %
+        # relative L2 (measured: W <= 2.9e-3, embeddings <= 3.1e-3, gradients <= 2.9 %; the reference's own scatter-add accumulates in bf16; ours in fp32).
+        rep = report.setdefault(name, {})
+        rep["W"] = (out["W"].detach().cpu() - tt(za[f"{name}/W"])).abs().max().item()
+        for k in ("node_embedding", "edge_embedding"):
+            ref_k = tt(za[f"{name}/{k}"])
+            rep[k] = ((out[k].detach().float().cpu() - ref_k).abs().max() / max(1.0, ref_k.abs().max().item())).item()
+        rep["loss"] = abs(float(loss) - float(za[f"{name}/loss"]))
+        worst = 0.0
+        for k, v in model.named_parameters():
+            gref = tt(za[f"{name}/grad/{k}"]).double()
+            if v.grad is None or gref.norm().item() < 1e-6:
+                continue
+            worst = max(worst, ((v.grad.detach().cpu().double() - gref).norm() / gref.norm()).item())
+        rep["grad_rel_l2"] = worst
+        assert rep["W"] <= BF16_PIN_W, f"{name}: |W - W_autocast| {rep['W']:.2e}"
+        assert rep["node_embedding"] <= BF16_PIN_EMB and rep["edge_embedding"] <= BF16_PIN_EMB, (name, rep)
+        assert rep["loss"] <= 5e-3 and rep["grad_rel_l2"] <= 0.06, (name, rep)
+    return report
+
+
+BF16_PIN_W = 2.0 ** -8       # one ulp of the reference's bf16 W on [0.5, 1)
+BF16_PIN_EMB = 2.0 ** -6     # four bf16 ulps relative to the largest entry
 
 
 def case_bf16_reproducible(device):
@@ -772,7 +799,8 @@ def case_graph_tcn_bf16(device):
     for name, kw in GTCN_VARIANTS.items():
         if "_cls" in kw:
             continue  # (the wrappers without a learned edge classifier add nothing in this mode)
-        model = G.GraphTCN(14, 4, ec_threshold=float(z[f"{name}/ec_threshold"]), **kw)
+        all_cut = "_thr" in kw
+        model, _ = make_gtcn(kw, float(z[f"{name}/ec_threshold"]))
         load_params(model, z, f"{name}/p0/")
         model = model.to(device)
         with G.bf16_storage():
@@ -784,7 +812,7 @@ def case_graph_tcn_bf16(device):
         # (the golden thresholds sit inside a dense cluster of weights, so the kept fraction
         # itself moves with bf16 noise; it only has to stay a genuine cut)
         kept = out["ec_edge_mask"].float().mean().item()
-        assert 0.02 < kept < 0.98, f"{name}: cut keeps {kept:.2f} of the edges"
+        assert (kept == 0.0) if all_cut else (0.02 < kept < 0.98), f"{name}: cut keeps {kept:.2f} of the edges"
         for k, v in model.named_parameters():
             gref = tt(z[f"{name}/grad/{k}"])
             if gref.abs().max() > 0:

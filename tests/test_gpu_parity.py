@@ -87,7 +87,10 @@ def test_bf16_mlp_backward(dev):
 
 
 def test_bf16_edge_classifier(dev):
-    P.case_ec_bf16(dev, names=tuple(P.EC_VARIANTS))  # all residual layouts / head inputs
+    # all residual layouts / head inputs; includes the pin against the reference's own modules
+    # under bf16 autocast (golden G2b) - the report holds the measured distances
+    for name, rep in P.case_ec_bf16(dev, names=tuple(P.EC_VARIANTS)).items():
+        print("bf16 vs reference autocast:", name, {k: float(f"{v:.3g}") for k, v in rep.items()})
 
 
 def test_bf16_backward_is_reproducible(dev):

@@ -204,3 +204,25 @@ def test_focal_losses():
     for name, (cls, kw) in P.FOCAL_CASES.items():
         loss = O.focal_loss(w, y, edge_index=ei, pt=pt, haughty=cls == "HaughtyFocalLoss", **kw)
         assert_close(loss, z[f"{name}/loss"], 1e-6, name)
+
+
+def test_bf16_contract_vs_reference_autocast():
+    """oracle/ref_cpu.py's restatement of the kernels' bf16 rounding contract against the
+    reference's OWN modules under ``torch.autocast("cpu", bfloat16)`` (golden G2b): W within
+    one bf16 ulp of the reference's bf16-rounded W, embeddings within four ulps of the largest
+    entry.  (The contract accumulates in fp32 where autocast accumulates in bf16, so it sits
+    closer to the fp32 reference than autocast itself does.)"""
+    z, za = load("g2_ec_variants.npz"), load("g2b_ec_bf16_autocast.npz")
+    x, ei, ea = tt(z["x"]), tt(z["edge_index"]), tt(z["edge_attr"])
+    for name in ("skip1_L3_h40", "skip1_L2_h2", "alpha0"):
+        kw = P.EC_VARIANTS[name]
+        out = O.ec_for_graph_tcn_bf16(x, ei, ea, _params(z, f"{name}/p0/"), L_ec=kw["L_ec"],
+                                      alpha=kw.get("alpha", 0.5))
+        assert (out["W"] - tt(za[f"{name}/W"])).abs().max().item() <= P.BF16_PIN_W, name
+        for k in ("node_embedding", "edge_embedding"):
+            ref = tt(za[f"{name}/{k}"])
+            assert (out[k] - ref).abs().max().item() <= P.BF16_PIN_EMB * max(1.0, ref.abs().max().item()), (name, k)
+        # and the contract is the better approximation of the fp32 reference
+        d_contract = (out["W"] - tt(z[f"{name}/W"])).abs().max().item()
+        d_autocast = (tt(za[f"{name}/W"]) - tt(z[f"{name}/W"])).abs().max().item()
+        assert d_contract < d_autocast, (name, d_contract, d_autocast)

@@ -7,8 +7,9 @@ YAML ``class_path`` swap is the whole integration.
 
 The whole stack runs with edges in target-sorted order: the edge encoder gathers
 ``edge_attr`` through the CSR permutation while reading it, every intermediate edge
-embedding stays in CSR order, and the classification head scatters ``W`` back to the
-caller's edge order while writing it.
+embedding stays in CSR order, and ``W`` / ``edge_embedding`` are handed out as
+``edge_order.EdgeOrdered``: tensors that behave as if they were in the caller's edge order
+and pay for the scatter only when something other than this package's losses reads them.
 """
 
 from __future__ import annotations
@@ -19,6 +20,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _capi, ops, ops_bf16, precision
+from .edge_order import EdgeOrdered
 from .hparams import HyperparametersMixin, assert_feat_dim
 from .mlp import MLP
 from .resin import ResIN
@@ -102,12 +104,14 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         else:
             segs.append(ops.Seg(e))
         eps = 0.001
-        w = self.W.fused(segs, n_rows=E, epilogue=_capi.EPI_SIGMOID, ca=eps, cb=1 - 2 * eps,
-                         out_idx=gi.perm)
+        # W and the edge embedding stay in CSR order; they present themselves in edge_index
+        # order (edge_order.EdgeOrdered: the scatter happens only if something other than
+        # this package's losses looks at the values)
+        w = self.W.fused(segs, n_rows=E, epilogue=_capi.EPI_SIGMOID, ca=eps, cb=1 - 2 * eps)
         return {
-            "W": w.squeeze(),
+            "W": EdgeOrdered(w.squeeze(), gi),
             "node_embedding": h,
-            "edge_embedding": ops.permute_rows(e, gi.perm, scatter=True),
+            "edge_embedding": EdgeOrdered(e, gi),
         }
 
 

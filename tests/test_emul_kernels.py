@@ -106,3 +106,8 @@ def test_gc_resin_emulated():
 def test_focal_losses_emulated():
     with emulated():
         P.case_focal_losses("cpu")
+
+
+def test_edge_ordered_outputs_emulated():
+    with emulated():
+        P.case_edge_ordered("cpu")

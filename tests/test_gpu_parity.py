@@ -150,6 +150,10 @@ def test_pc_transformer(dev):
     P.case_pc_transformer(dev)
 
 
+def test_edge_ordered_outputs(dev):
+    P.case_edge_ordered(dev)
+
+
 # ---- BASELINE.json configs on their own workloads ---------------------------------------
 def test_cfg1_cfg2_event_vs_oracle(dev):
     P.case_cfg12_event(dev)

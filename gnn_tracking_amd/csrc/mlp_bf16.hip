@@ -28,8 +28,9 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
     const int GT = (P.GT <= 1) ? 1 : 2 * P.KI;
-    snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s>", P.KI, P.HT, GT,
-             a->mlp.n_layers == 3 ? "true" : "false", a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false");
+    const int D = (P.KI == 1 && P.HT <= 3 && !(a->debug_flags & 64)) ? 2 : 1;  // as launch_bwd16 dispatches
+    snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s, %d>", P.KI, P.HT, GT,
+             a->mlp.n_layers == 3 ? "true" : "false", a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false", D);
     return GNNTRK_OK;
 }
 

@@ -26,7 +26,6 @@ namespace {
 
 constexpr uint32_t kBf16One = 0x3f80u;
 constexpr int kFwdDepth = 4;  // tiles per wave and pipeline stage (forward)
-constexpr int kBwdDepth = 1;  // (backward: the dW accumulators take the registers)
 
 // floats of one partial block = all parameters in order W1, b1, [W2, b2,] W3, b3 (the layout
 // of part_layout() in mlp.hip: bias slots exist whether or not the layer has a bias)
@@ -498,14 +497,14 @@ struct RawGout {
     u32x4 v;
 };
 
-template <int KI, int HT, int GT, bool THREE, bool G32>
+template <int KI, int HT, int GT, bool THREE, bool G32, int D>
 __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                               uint8_t *trash) {
     using I = BwdImg<KI, HT, GT, THREE>;
     using F = FwdImg<KI, HT>;
     using S = BwdStage<KI, HT>;
     __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves * S::kWave];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves * D * S::kWave];
     __shared__ SlotPlan s_plan;
     __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];
     __shared__ gnntrk_gseg s_gseg[GNNTRK_MAX_SEGS];
@@ -597,7 +596,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 #pragma unroll
     for (int r = 0; r < 4; ++r) gcol[r] = (4 * gq + r < out_dim) ? 4 * gq + r : out_dim - 1;
 
-    uint8_t *stIn = s_stage + wv * S::kWave, *stX = stIn + S::kIn, *stG = stX + S::kX;
+    uint8_t *stIn[D], *stX[D], *stG[D];  // one set of staging images per 16-row half
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        stIn[d] = s_stage + (wv * D + d) * S::kWave;
+        stX[d] = stIn[d] + S::kIn;
+        stG[d] = stX[d] + S::kX;
+    }
     // byte offsets inside the staging images
     const int wr_tile = c * 32 + 8 * (g ^ ((c >> 2) & 3));                  // write [row c][4g..4g+3]
     const int rd_tile = (4 * g + (c >> 2)) * 32 + 8 * ((c & 3) ^ g);        // transpose read (row >> 2 = g)
@@ -618,19 +623,22 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         for (int j = 0; j < HT; ++j) dW2[i][j] = zero;
 
     const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
-    const TileSched sch = make_sched(n_tiles);
+    const TileSched sch = make_sched((n_tiles + D - 1) / D);   // in units of D tiles
     const int32_t last_row = (int32_t)(a.n_rows - 1);
     auto clamp_row = [&](int64_t t) {
         const int64_t r = t * kTileRows + c;
         return (int32_t)(r < last_row ? r : last_row);
     };
 
-    constexpr int D = kBwdDepth;
     RowIds<KI> rid[D];
     int32_t grow[D][2];
     RawTile<KI> cur[D], nxt[D];
     RawGout gcur[D], gnxt[D];
-    auto tile_of = [&](int64_t grp, int d) { return sch.cur + (grp * D + d) * sch.step; };
+    // D = 1: one 16-row tile per iteration.  D = 2: a wave owns SUPER tiles of 32 consecutive rows
+    // and walks the two 16-row halves stage by stage (two independent dependency chains in one
+    // instruction stream: the LDS round trips and MFMA latencies of one half hide behind the
+    // other), and the weight-gradient contractions run over all 32 rows with K = 32 MFMAs.
+    auto tile_of = [&](int64_t grp, int d) { return (sch.cur + grp * sch.step) * D + d; };
     auto ids_of = [&](int64_t grp, int d) {
         const int32_t row = clamp_row(tile_of(grp, d));
         load_row_ids<KI>(L, row, rid[d]);
@@ -667,9 +675,20 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         for (int d = 0; d < D; ++d) ids_of(1, d);
     }
 
+    // transposed reads of the staging images as MFMA operands over the rows: one K = 16
+    // operand per half; for D = 2 the halves are joined into one K = 32 operand (k-slot
+    // (g, e): e < 4 -> row 4g + e of half 0, e >= 4 -> row 4g + e - 4 of half 1, the same on
+    // both operands)
+    auto dw_acc = [&](const u32x2 (&at)[D], const u32x2 (&bt)[D], f32x4 &acc) {
+        if constexpr (D == 2)
+            acc = mfma_bf16_k32(join(at[0], at[1]), join(bt[0], bt[1]), acc);
+        else
+            mfma_bf16_k16_acc(at[0], bt[0], acc);
+    };
+
     // counted loop on a scalar trip count: a plain do-while for the compiler, so the
     // loop-carried weight-gradient accumulators are updated in place
-    const int64_t span = sch.end - sch.cur, gstep = sch.step * D;
+    const int64_t span = sch.end - sch.cur, gstep = sch.step;
     const int n_grp = (int)__builtin_amdgcn_readfirstlane((uint32_t)(span > 0 ? (span + gstep - 1) / gstep : 0));
     for (int grp = 0; grp < n_grp; ++grp) {
 #pragma unroll
@@ -680,35 +699,40 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 #pragma unroll
         for (int d = 0; d < D; ++d) ids_of(grp + 2, d);
 
+        // (tiles past the end run as all-invalid rows: zero upstream gradient, stores
+        // redirected - no second loop exit for the accumulators)
+        bool valid[D];
+        int32_t srow[D][GT];  // destination rows of the input-gradient slices
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            // (tiles past the end of the schedule run as all-invalid rows: zero upstream
-            // gradient, stores redirected - no second loop exit for the accumulators)
             const int64_t tile = tile_of(grp, d);
-            const int64_t row = tile * kTileRows + c;
-            const bool valid = tile < sch.end && row < a.n_rows;
-
-            // destination rows of the input-gradient slices (used at the end of the tile)
-            int32_t srow[GT];
+            valid[d] = tile < n_tiles && tile * kTileRows + c < a.n_rows;
+            const int32_t rc = clamp_row(tile);
 #pragma unroll
             for (int T = 0; T < GT; ++T) {
-                const int32_t rc = clamp_row(tile < sch.end ? tile : sch.cur);
                 const int32_t v = gidx[T][rc];
-                srow[T] = gidx_on[T] ? v : rc;
+                srow[d][T] = gidx_on[T] ? v : rc;
             }
+        }
 
-            // ---- S0: recompute ------------------------------------------------------
-            const uint32_t *wimg = s_img + opaque_zero();
+        // ---- S0: recompute ----------------------------------------------------------
+        const uint32_t *wimg = s_img + opaque_zero();
+        u32x2 P1[D][HT], P2[D][HT];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
             u32x4 B[KI];
             finish_inputs<KI>(L, cur[d], B);
-            u32x2 P1[HT], P2[HT];
-            hidden_chain<KI, HT, THREE>(wimg, B, lane, P1, P2);
-            const u32x2(&PL)[HT] = THREE ? P2 : P1;  // input of the last layer
+            hidden_chain<KI, HT, THREE>(wimg, B, lane, P1[d], P2[d]);
 #pragma unroll
             for (int kk = 0; kk < KI; ++kk)
-                *reinterpret_cast<u32x4 *>(stIn + c * S::kInRow + ((64 * kk + 16 * g) ^ in_swz)) = B[kk];
+                *reinterpret_cast<u32x4 *>(stIn[d] + c * S::kInRow + ((64 * kk + 16 * g) ^ in_swz)) = B[kk];
+        }
+        auto PL = [&](int d) -> const u32x2(&)[HT] { return THREE ? P2[d] : P1[d]; };  // input of the last layer
 
-            // ---- S1: upstream gradient ---------------------------------------------
+        // ---- S1: upstream gradient --------------------------------------------------
+        u32x2 g3[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
             f32x4 gy;
             if (G32) {
 #pragma unroll
@@ -719,9 +743,9 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 gy[2] = bf16_lo(gcur[d].v[1]) + bf16_lo(gcur[d].v[3]);
                 gy[3] = bf16_hi(gcur[d].v[1]) + bf16_hi(gcur[d].v[3]);
             }
-            if (!(out_lane && valid)) gy = zero;
+            if (!(out_lane && valid[d])) gy = zero;
             if (need_y) {
-                const f32x4 y = contract_hidden<HT>(wimg + F::kA3, PL, lane, zero);
+                const f32x4 y = contract_hidden<HT>(wimg + F::kA3, PL(d), lane, zero);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (epi == GNNTRK_EPI_RELU) {
@@ -735,98 +759,127 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gy[r] *= a.cb;
             }
-            u32x2 g3 = pack_tile(gy);
-            g3[0] &= okeep[0];
-            g3[1] &= okeep[1];
+            g3[d] = pack_tile(gy);
+            g3[d][0] &= okeep[0];
+            g3[d][1] &= okeep[1];
+        }
 
-            // ---- S2 / S3 interleaved: every dW stage reuses the two staging images ------
-            // last layer
-            u32x2 gh[HT];  // gradient at the input of the last layer (hidden, after relu')
+        // ---- S2 / S3 interleaved: every dW stage reuses the staging images --------------
+        // last layer: gradient at its input (hidden, after relu')
+        u32x2 gh[D][HT];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
-                const f32x4 acc = mfma_bf16_k16(frag_k16(wimg + I::kD3 + t * 128, lane), g3, zero);
-                gh[t] = pack_tile(acc);
-                gh[t][0] = gate_bf16x2(gh[t][0], PL[t][0], k_one);
-                gh[t][1] = gate_bf16x2(gh[t][1], PL[t][1], k_one);
+                const f32x4 acc = mfma_bf16_k16(frag_k16(wimg + I::kD3 + t * 128, lane), g3[d], zero);
+                gh[d][t] = pack_tile(acc);
+                gh[d][t][0] = gate_bf16x2(gh[d][t][0], PL(d)[t][0], k_one);
+                gh[d][t][1] = gate_bf16x2(gh[d][t][1], PL(d)[t][1], k_one);
             }
-            {   // weight gradients are always accumulated (a branch here would turn the
-                // loop-carried accumulators into phi copies); only the final write is optional
+        {   // weight gradients are always accumulated (a branch here would turn the
+            // loop-carried accumulators into phi copies); only the final write is optional
 #pragma unroll
-                for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stX + t * 512 + wr_tile) = PL[t];
-                *reinterpret_cast<u32x2 *>(stG + wr_tile) = g3;
-                lds_wave_sync();
-                const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + rd_tile));
+            for (int d = 0; d < D; ++d) {
 #pragma unroll
-                for (int t = 0; t < HT; ++t)
-                    mfma_bf16_k16_acc(
-                        at, lds_read_tr16(reinterpret_cast<const uint16_t *>(stX + t * 512 + rd_tile)), dW3[t]);
+                for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stX[d] + t * 512 + wr_tile) = PL(d)[t];
+                *reinterpret_cast<u32x2 *>(stG[d] + wr_tile) = g3[d];
             }
-            // middle layer
-            u32x2 g1[HT];
-            if (THREE) {
+            lds_wave_sync();
+            u32x2 at[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) at[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG[d] + rd_tile));
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                u32x2 bt[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    bt[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stX[d] + t * 512 + rd_tile));
+                dw_acc(at, bt, dW3[t]);
+            }
+        }
+        // middle layer
+        u32x2 g1[D][HT];
+        if (THREE) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
 #pragma unroll
                 for (int t = 0; t < HT; ++t) {
-                    const f32x4 acc = contract_hidden<HT>(wimg + I::kD2 + t * hid_k_dwords(HT), gh, lane, zero);
-                    g1[t] = pack_tile(acc);
-                    g1[t][0] = gate_bf16x2(g1[t][0], P1[t][0], k_one);
-                    g1[t][1] = gate_bf16x2(g1[t][1], P1[t][1], k_one);
+                    const f32x4 acc = contract_hidden<HT>(wimg + I::kD2 + t * hid_k_dwords(HT), gh[d], lane, zero);
+                    g1[d][t] = pack_tile(acc);
+                    g1[d][t][0] = gate_bf16x2(g1[d][t][0], P1[d][t][0], k_one);
+                    g1[d][t][1] = gate_bf16x2(g1[d][t][1], P1[d][t][1], k_one);
                 }
-                {
-                    lds_wave_sync();
+            lds_wave_sync();
 #pragma unroll
-                    for (int t = 0; t < HT; ++t) {
-                        *reinterpret_cast<u32x2 *>(stX + t * 512 + wr_tile) = P1[t];
-                        *reinterpret_cast<u32x2 *>(stG + t * 512 + wr_tile) = gh[t];
-                    }
-                    lds_wave_sync();
-                    u32x2 bt[HT];
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-                    for (int t = 0; t < HT; ++t)
-                        bt[t] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stX + t * 512 + rd_tile));
-#pragma unroll
-                    for (int to = 0; to < HT; ++to) {
-                        const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + to * 512 + rd_tile));
-#pragma unroll
-                        for (int t = 0; t < HT; ++t) mfma_bf16_k16_acc(at, bt[t], dW2[to][t]);
-                    }
+                for (int t = 0; t < HT; ++t) {
+                    *reinterpret_cast<u32x2 *>(stX[d] + t * 512 + wr_tile) = P1[d][t];
+                    *reinterpret_cast<u32x2 *>(stG[d] + t * 512 + wr_tile) = gh[d][t];
                 }
-            } else {
+            lds_wave_sync();
+            u32x2 bt[HT][D];
 #pragma unroll
-                for (int t = 0; t < HT; ++t) g1[t] = gh[t];
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    bt[t][d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stX[d] + t * 512 + rd_tile));
+#pragma unroll
+            for (int to = 0; to < HT; ++to) {
+                u32x2 at[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    at[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG[d] + to * 512 + rd_tile));
+#pragma unroll
+                for (int t = 0; t < HT; ++t) dw_acc(at, bt[t], dW2[to][t]);
             }
-            // first layer: stage g1, input gradients, dW1
-            lds_wave_sync();
+        } else {
 #pragma unroll
-            for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stG + t * 512 + wr_tile) = g1[t];
-            lds_wave_sync();
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int t = 0; t < HT; ++t) g1[d][t] = gh[d][t];
+        }
+        // first layer: stage g1, input gradients, dW1
+        lds_wave_sync();
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stG[d] + t * 512 + wr_tile) = g1[d][t];
+        lds_wave_sync();
+#pragma unroll
+        for (int d = 0; d < D; ++d)
 #pragma unroll
             for (int T = 0; T < GT; ++T) {
-                const f32x4 acc = contract_hidden<HT>(wimg + I::kD1 + T * hid_k_dwords(HT), g1, lane, zero);
+                const f32x4 acc = contract_hidden<HT>(wimg + I::kD1 + T * hid_k_dwords(HT), g1[d], lane, zero);
                 u32x2 gi = pack_tile(acc);
-                const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn + c * S::kInRow + (gin_off[T] ^ in_swz));
+                const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn[d] + c * S::kInRow + (gin_off[T] ^ in_swz));
                 gi[0] = u16x2_mul(gi[0], (i16x2_min(xin[0], k_one) & gmul_and[T]) | gmul_or[T]);
                 gi[1] = u16x2_mul(gi[1], (i16x2_min(xin[1], k_one) & gmul_and[T]) | gmul_or[T]);
                 gi[0] &= gkeep[T][0];
                 gi[1] &= gkeep[T][1];
                 // (lanes without a chunk already point at their trash slot with stride 0)
-                const gh_ptr dst = gptr[T] + (int64_t)srow[T] * gstride[T];
-                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(valid ? dst : my_trash) = gi;
+                const gh_ptr dst = gptr[T] + (int64_t)srow[d][T] * gstride[T];
+                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(valid[d] ? dst : my_trash) = gi;
             }
-            {
-                u32x2 bt[2 * KI];
+        {
+            u32x2 bt[2 * KI][D];
 #pragma unroll
-                for (int ts = 0; ts < 2 * KI; ++ts)
-                    bt[ts] = lds_read_tr16(reinterpret_cast<const uint16_t *>(
-                        stIn + rd_row * S::kInRow + ((32 * ts + 8 * (c & 3)) ^ (16 * (g >> 1)))));
+            for (int ts = 0; ts < 2 * KI; ++ts)
 #pragma unroll
-                for (int to = 0; to < HT; ++to) {
-                    const u32x2 at = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG + to * 512 + rd_tile));
+                for (int d = 0; d < D; ++d)
+                    bt[ts][d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(
+                        stIn[d] + rd_row * S::kInRow + ((32 * ts + 8 * (c & 3)) ^ (16 * (g >> 1)))));
 #pragma unroll
-                    for (int ts = 0; ts < 2 * KI; ++ts) mfma_bf16_k16_acc(at, bt[ts], dW1[to][ts]);
-                }
+            for (int to = 0; to < HT; ++to) {
+                u32x2 at[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    at[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG[d] + to * 512 + rd_tile));
+#pragma unroll
+                for (int ts = 0; ts < 2 * KI; ++ts) dw_acc(at, bt[ts], dW1[to][ts]);
             }
-            lds_wave_sync();  // the next tile overwrites the images
         }
+        lds_wave_sync();  // the next tile overwrites the images
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             cur[d] = nxt[d];
@@ -965,14 +1018,23 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
                  uint8_t *trash, hipStream_t stream) {
     const bool three = a->mlp.n_layers == 3;
     bool launched = false;
+// D = 2 (two 16-row halves per iteration, K = 32 weight-gradient contractions) wherever the
+// doubled staging images fit the workgroup's LDS budget: one k-step, up to three hidden tiles -
+// every shape of the reference's default models.  debug_flags & 64 forces D = 1 (A/B timing).
+#define GNNTRK_BWD16_LAUNCH(KI_, HT_, GT_, T_, D_)                                             \
+    {                                                                                          \
+        auto kfn = mlp16_bwd_kernel<KI_, HT_, GT_, T_, G32, D_>;                               \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash);         \
+    }
 #define GNNTRK_BWD16_CASE(KI_, HT_, GT_)                                                       \
     if (P.KI == KI_ && P.HT == HT_ && GT == GT_) {                                             \
-        if (three) {                                                                           \
-            auto kfn = mlp16_bwd_kernel<KI_, HT_, GT_, true, G32>;                             \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash);     \
+        constexpr bool kTwo = (KI_ == 1 && HT_ <= 3);                                          \
+        if (kTwo && !(a->debug_flags & 64)) {                                                  \
+            if (three) GNNTRK_BWD16_LAUNCH(KI_, HT_, GT_, true, (kTwo ? 2 : 1))                \
+            else GNNTRK_BWD16_LAUNCH(KI_, HT_, GT_, false, (kTwo ? 2 : 1))                     \
         } else {                                                                               \
-            auto kfn = mlp16_bwd_kernel<KI_, HT_, GT_, false, G32>;                            \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash);     \
+            if (three) GNNTRK_BWD16_LAUNCH(KI_, HT_, GT_, true, 1)                             \
+            else GNNTRK_BWD16_LAUNCH(KI_, HT_, GT_, false, 1)                                  \
         }                                                                                      \
         launched = true;                                                                       \
     }
@@ -985,6 +1047,7 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     GNNTRK_BWD16_HT(2, 4)
 #undef GNNTRK_BWD16_HT
 #undef GNNTRK_BWD16_CASE
+#undef GNNTRK_BWD16_LAUNCH
     if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: no instantiation");
     return check_launch("mlp_backward_bf16");
 }

@@ -22,6 +22,9 @@ from . import _capi
 BF16 = torch.bfloat16
 
 
+_DEBUG_FLAGS = int(__import__("os").environ.get("GNNTRK_DEBUG_FLAGS", "0"))
+
+
 def pad4(d: int) -> int:
     return (int(d) + 3) // 4 * 4
 
@@ -142,6 +145,7 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
     # always needed: per-wave partial blocks + the store-redirect slots of masked lanes
     ws = ops._ws(lib.gnntrk_mlp_backward_bf16_workspace_bytes(C.byref(a.mlp)), segs[0])
     a.accumulate_params = 0
+    a.debug_flags = _DEBUG_FLAGS   # (64: one 16-row tile per iteration instead of two, for A/B timing)
     M = n_rows
     nbytes = M * (sum(2 * s.shape[1] + (4 if idx[j] is not None else 0)
                       + (2 * s.shape[1] if need_seg[j] else 0) for j, s in enumerate(segs))

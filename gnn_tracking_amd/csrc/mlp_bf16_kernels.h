@@ -259,6 +259,56 @@ __device__ __forceinline__ void hidden_chain(const uint32_t *img, const u32x4 (&
     }
 }
 
+// The same for D independent tiles with ONE LDS read of every weight fragment (backward kernel:
+// the fragments cannot stay in registers next to the weight-gradient accumulators).
+template <int HT, int D>
+__device__ __forceinline__ void contract_hidden_d(const uint32_t *img, const u32x2 (&P)[D][HT], int lane,
+                                                  f32x4 (&acc)[D]) {
+#pragma unroll
+    for (int u = 0; u < HT / 2; ++u) {
+        const u32x4 fr = frag_k32(img + 256 * u, lane);
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = mfma_bf16_k32(fr, join(P[d][2 * u], P[d][2 * u + 1]), acc[d]);
+    }
+    if (HT % 2) {
+        const u32x2 zero = {0u, 0u};
+        const u32x4 fr = frag_k32(img + 256 * (HT / 2), lane);
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = mfma_bf16_k32(fr, join(P[d][HT - 1], zero), acc[d]);
+    }
+}
+template <int KI, int HT, bool THREE, int D>
+__device__ __forceinline__ void hidden_chain_d(const uint32_t *img, const u32x4 (&B)[D][KI], int lane,
+                                               u32x2 (&P1)[D][HT], u32x2 (&P2)[D][HT]) {
+    using I = FwdImg<KI, HT>;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        f32x4 acc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = zero;
+#pragma unroll
+        for (int kk = 0; kk < KI; ++kk) {
+            const u32x4 fr = frag_k32(img + I::kA1 + (t * KI + kk) * 256, lane);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] = mfma_bf16_k32(fr, B[d][kk], acc[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) P1[d][t] = pack_tile_relu(acc[d]);
+    }
+    if (THREE) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            f32x4 acc[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] = zero;
+            contract_hidden_d<HT, D>(img + I::kA2 + t * hid_k_dwords(HT), P1, lane, acc);
+#pragma unroll
+            for (int d = 0; d < D; ++d) P2[d][t] = pack_tile_relu(acc[d]);
+        }
+    }
+}
+
 // Store-redirect slots of the forward kernel (16 bytes per lane of the largest grid): the
 // forward C ABI has no workspace argument.  Contents are never read.
 constexpr int kFwdMaxBlocks = 2048;
@@ -718,16 +768,19 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         // ---- S0: recompute ----------------------------------------------------------
         const uint32_t *wimg = s_img + opaque_zero();
         u32x2 P1[D][HT], P2[D][HT];
+        {
+            u32x4 B[D][KI];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            u32x4 B[KI];
-            finish_inputs<KI>(L, cur[d], B);
-            hidden_chain<KI, HT, THREE>(wimg, B, lane, P1[d], P2[d]);
+            for (int d = 0; d < D; ++d) {
+                finish_inputs<KI>(L, cur[d], B[d]);
 #pragma unroll
-            for (int kk = 0; kk < KI; ++kk)
-                *reinterpret_cast<u32x4 *>(stIn[d] + c * S::kInRow + ((64 * kk + 16 * g) ^ in_swz)) = B[kk];
+                for (int kk = 0; kk < KI; ++kk)
+                    *reinterpret_cast<u32x4 *>(stIn[d] + c * S::kInRow + ((64 * kk + 16 * g) ^ in_swz)) = B[d][kk];
+            }
+            hidden_chain_d<KI, HT, THREE, D>(wimg, B, lane, P1, P2);
         }
-        auto PL = [&](int d) -> const u32x2(&)[HT] { return THREE ? P2[d] : P1[d]; };  // input of the last layer
+        const u32x2(&PLs)[D][HT] = THREE ? P2 : P1;  // input of the last layer
+        auto PL = [&](int d) -> const u32x2(&)[HT] { return PLs[d]; };
 
         // ---- S1: upstream gradient --------------------------------------------------
         u32x2 g3[D];
@@ -768,14 +821,16 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         // last layer: gradient at its input (hidden, after relu')
         u32x2 gh[D][HT];
 #pragma unroll
-        for (int d = 0; d < D; ++d)
+        for (int t = 0; t < HT; ++t) {
+            const u32x2 fr = frag_k16(wimg + I::kD3 + t * 128, lane);
 #pragma unroll
-            for (int t = 0; t < HT; ++t) {
-                const f32x4 acc = mfma_bf16_k16(frag_k16(wimg + I::kD3 + t * 128, lane), g3[d], zero);
+            for (int d = 0; d < D; ++d) {
+                const f32x4 acc = mfma_bf16_k16(fr, g3[d], zero);
                 gh[d][t] = pack_tile(acc);
                 gh[d][t][0] = gate_bf16x2(gh[d][t][0], PL(d)[t][0], k_one);
                 gh[d][t][1] = gate_bf16x2(gh[d][t][1], PL(d)[t][1], k_one);
             }
+        }
         {   // weight gradients are always accumulated (a branch here would turn the
             // loop-carried accumulators into phi copies); only the final write is optional
 #pragma unroll
@@ -801,14 +856,18 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         u32x2 g1[D][HT];
         if (THREE) {
 #pragma unroll
-            for (int d = 0; d < D; ++d)
+            for (int t = 0; t < HT; ++t) {
+                f32x4 acc[D];
 #pragma unroll
-                for (int t = 0; t < HT; ++t) {
-                    const f32x4 acc = contract_hidden<HT>(wimg + I::kD2 + t * hid_k_dwords(HT), gh[d], lane, zero);
-                    g1[d][t] = pack_tile(acc);
+                for (int d = 0; d < D; ++d) acc[d] = zero;
+                contract_hidden_d<HT, D>(wimg + I::kD2 + t * hid_k_dwords(HT), gh, lane, acc);
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    g1[d][t] = pack_tile(acc[d]);
                     g1[d][t][0] = gate_bf16x2(g1[d][t][0], P1[d][t][0], k_one);
                     g1[d][t][1] = gate_bf16x2(g1[d][t][1], P1[d][t][1], k_one);
                 }
+            }
             lds_wave_sync();
 #pragma unroll
             for (int d = 0; d < D; ++d)
@@ -847,11 +906,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stG[d] + t * 512 + wr_tile) = g1[d][t];
         lds_wave_sync();
 #pragma unroll
-        for (int d = 0; d < D; ++d)
+        for (int T = 0; T < GT; ++T) {
+            f32x4 accs[D];
 #pragma unroll
-            for (int T = 0; T < GT; ++T) {
-                const f32x4 acc = contract_hidden<HT>(wimg + I::kD1 + T * hid_k_dwords(HT), g1[d], lane, zero);
-                u32x2 gi = pack_tile(acc);
+            for (int d = 0; d < D; ++d) accs[d] = zero;
+            contract_hidden_d<HT, D>(wimg + I::kD1 + T * hid_k_dwords(HT), g1, lane, accs);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                u32x2 gi = pack_tile(accs[d]);
                 const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn[d] + c * S::kInRow + (gin_off[T] ^ in_swz));
                 gi[0] = u16x2_mul(gi[0], (i16x2_min(xin[0], k_one) & gmul_and[T]) | gmul_or[T]);
                 gi[1] = u16x2_mul(gi[1], (i16x2_min(xin[1], k_one) & gmul_and[T]) | gmul_or[T]);
@@ -861,6 +923,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 const gh_ptr dst = gptr[T] + (int64_t)srow[d][T] * gstride[T];
                 *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(valid[d] ? dst : my_trash) = gi;
             }
+        }
         {
             u32x2 bt[2 * KI][D];
 #pragma unroll

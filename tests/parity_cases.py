@@ -408,6 +408,10 @@ def case_mlp_stress(device, rounds=3, seed=5, cases_per_round=12, row_choices=(1
 # differ by fp32 summation order only, which can move a value across a bf16 rounding
 # boundary (1 ulp = 2^-8 relative).  TOL16 bounds that; fp32 outputs (sigmoid) are tight.
 TOL16 = 2.0 ** -7
+# fp32 sigmoid output: agreement is ~1e-6 unless ONE hidden activation lands on the other side of
+# a bf16 rounding boundary (kernel and oracle sum in different orders): that moves the
+# pre-activation by 2^-9 |h| |w| ~ 2e-4 and the weight by a quarter of it
+TOL16_SIG = 1e-4
 
 
 def _rand_rows16(rows, dim, device, gen):
@@ -424,6 +428,7 @@ def _rand_rows16(rows, dim, device, gen):
 def case_mlp_bf16_forward(device, rows=75):
     from gnn_tracking_amd import _capi, ops_bf16 as B
     gen = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)  # (the layer initialisations use the global generator)
     cases = [
         # (segment dims, gathered?, relu?, hidden, out, L, bias, epilogue)
         ((5, 5, 4), (True, True, False), (True, True, True), 40, 4, 3, True, "none"),
@@ -473,7 +478,7 @@ def case_mlp_bf16_forward(device, rows=75):
                               epilogue=epi_code[epi], ca=ca, cb=cb, res=res, out_idx=out_idx,
                               out_rows=rows, mlp=mlp)
         tag = f"bf16 MLP {dims}->{hid}->{out} L={L} bias={bias} {epi}"
-        assert_close(y.float(), yo, 1e-5 if epi == "sigmoid" else TOL16, tag)
+        assert_close(y.float(), yo, TOL16_SIG if epi == "sigmoid" else TOL16, tag)
         if epi != "sigmoid" and B.pad4(out) > out:  # padding written as zeros
             buf = y.as_strided((rows, B.pad4(out)), (B.pad4(out), 1))
             assert (buf[:, out:] == 0).all(), tag + " padding"

@@ -41,6 +41,21 @@ def assert_close(a, b, tol, what):
     assert err <= tol * scale, f"{what}: max|diff| {err:.3e} > {tol:.0e} * {scale:.3g}"
 
 
+def assert_rows_close(a, b, tol, what, flips_per_rows=20000):
+    """``assert_close`` for row-wise gradients of bf16 MLPs at large row counts: a ReLU whose
+    pre-activation lies within fp32 summation noise of zero is gated differently by kernel and
+    oracle (they sum in different orders), which changes ONE row's gradient by a whole term.
+    At most one such row per ``flips_per_rows`` rows may exceed the tolerance (none below that
+    size); everything must be finite."""
+    a = a.detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape and torch.isfinite(a).all(), what
+    bad = ((a - b).abs() > tol * max(1.0, b.abs().max().item())).reshape(a.shape[0], -1).any(dim=1)
+    allowed = a.shape[0] // flips_per_rows
+    assert int(bad.sum()) <= allowed, (f"{what}: {int(bad.sum())} rows beyond {tol:.0e} (allowed {allowed}), "
+                                       f"max|diff| {(a - b).abs().max().item():.3e}")
+
+
 def load_params(module, z, prefix):
     sd = {k[len(prefix):]: tt(z[k]) for k in z.files if k.startswith(prefix)}
     missing = module.load_state_dict(sd, strict=True)
@@ -487,6 +502,7 @@ def case_mlp_bf16_forward(device, rows=75):
 def case_mlp_bf16_backward(device, rows=75, full=True):
     from gnn_tracking_amd import _capi, ops_bf16 as B
     gen = torch.Generator().manual_seed(1)
+    torch.manual_seed(1)  # (the layer initialisations use the global generator)
     cases = [
         # (segment dims, gathered?, relu?, need grad?, hidden, out, L, bias, epilogue, n_gout)
         ((5, 5, 4), (True, True, False), (True, True, True), (True, True, True), 40, 4, 3, True, "none", 2),
@@ -557,7 +573,7 @@ def case_mlp_bf16_backward(device, rows=75, full=True):
         for j, d in enumerate(dims):
             if need[j]:
                 want = gin[:, col:col + d] * ((raw[j] > 0) if relu[j] else 1.0)
-                assert_close(slices[j].float(), want, TOL16, f"{tag} gseg{j}")
+                assert_rows_close(slices[j].float(), want, TOL16, f"{tag} gseg{j}")
             else:
                 assert slices[j] is None
             col += d

@@ -262,8 +262,6 @@ class ECWorkload(Workload):
                           + ("(built for the next batch on the loader's side stream during the step) "
                              if index == "prefetch" else "(inline) ")
                           + "+ forward + BCE + backward + grad all-reduce + Adam")
-        for b in self.batches:
-            b.y = b.y.float()
         # --index prefetch: the build for the NEXT batch runs on the loader's side stream while
         # this step computes (io.PrefetchLoader(build_index=True) does exactly this one batch
         # ahead).  Two batch objects (own edge_index tensors, same content) alternate so that
@@ -395,7 +393,6 @@ def hipgraph_cfg2(dev, dtype: str, steps: int) -> dict:
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
     mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), bf16=dtype == "bf16", optimizer=lambda p: opt)
     batch = G.collate([synthetic.make_event(1, 10_000, 100_000, dev)])
-    batch.y = batch.y.float()
 
     def step():
         ops.clear_graph_index_cache()

@@ -102,7 +102,7 @@ _SIGNATURES = {
     "gnntrk_bce_forward": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P, _P, C.c_size_t,
                                      _P]),
     "gnntrk_bce_backward": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P, _P, _P]),
-    "gnntrk_edge_targets_csr": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P, _P]),
+    "gnntrk_edge_targets_csr": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_float, C.c_int64, _P, _P]),
     "gnntrk_focal_forward": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                        C.c_int64, _P, _P, C.c_size_t, _P]),
     "gnntrk_focal_backward": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,

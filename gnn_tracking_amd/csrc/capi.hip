@@ -56,7 +56,7 @@ int bce_forward_launch(const float *, const float *, const int64_t *, const floa
                        float *, void *, size_t, hipStream_t);
 int bce_backward_launch(const float *, const float *, const int64_t *, const float *, float,
                         int64_t, const float *, float *, hipStream_t);
-int edge_targets_csr_launch(const float *, const int32_t *, const int32_t *, const float *, float, int64_t, float *,
+int edge_targets_csr_launch(const void *, int, const int32_t *, const int32_t *, const float *, float, int64_t, float *,
                             hipStream_t);
 int focal_forward_launch(const float *, const float *, const int64_t *, const float *, float, float, float, float,
                          int, int64_t, float *, void *, size_t, hipStream_t);
@@ -179,9 +179,9 @@ int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
     return bce_backward_launch(w, y, src_node, pt, pt_thld, n, gscale, gw, (hipStream_t)stream);
 }
 
-int gnntrk_edge_targets_csr(const float *y, const int32_t *perm, const int32_t *src_csr, const float *pt,
-                            float pt_thld, int64_t n, float *out, void *stream) {
-    return edge_targets_csr_launch(y, perm, src_csr, pt, pt_thld, n, out, (hipStream_t)stream);
+int gnntrk_edge_targets_csr(const void *y, int32_t y_is_u8, const int32_t *perm, const int32_t *src_csr,
+                            const float *pt, float pt_thld, int64_t n, float *out, void *stream) {
+    return edge_targets_csr_launch(y, y_is_u8, perm, src_csr, pt, pt_thld, n, out, (hipStream_t)stream);
 }
 
 int gnntrk_focal_forward(const float *w, const float *y, const int64_t *src_node, const float *pt, float pt_thld,

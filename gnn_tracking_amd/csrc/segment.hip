@@ -166,13 +166,14 @@ __global__ __launch_bounds__(kTpb) void bce_bwd_kernel(const float *__restrict__
 // lets the loss run on the CSR-ordered edge weights the classification head produces.
 //   out[k] = y[perm[k]]                                          (thld <= 0)
 //   out[k] = y[perm[k]] != 0 && pt[src_csr[k]] > thld ? 1 : 0    (falsify_low_pt_edges, ec.py:71-92)
-__global__ __launch_bounds__(kTpb) void edge_targets_csr_kernel(const float *__restrict__ y,
+template <class Y>  // float labels (what the losses take) or the dataset's 1-byte bool labels
+__global__ __launch_bounds__(kTpb) void edge_targets_csr_kernel(const Y *__restrict__ y,
                                                                 const int32_t *__restrict__ perm,
                                                                 const int32_t *__restrict__ src_csr,
                                                                 const float *__restrict__ pt, float thld, int64_t n,
                                                                 float *__restrict__ out) {
     for (int64_t k = (int64_t)blockIdx.x * kTpb + threadIdx.x; k < n; k += (int64_t)gridDim.x * kTpb) {
-        float t = y[perm[k]];
+        float t = (float)y[perm[k]];
         if (thld > 0.f) t = (t != 0.f && pt[src_csr[k]] > thld) ? 1.f : 0.f;
         out[k] = t;
     }
@@ -313,14 +314,18 @@ int bce_backward_launch(const float *w, const float *y, const int64_t *src_node,
     return check_launch("bce_backward");
 }
 
-int edge_targets_csr_launch(const float *y, const int32_t *perm, const int32_t *src_csr, const float *pt, float thld,
-                            int64_t n, float *out, hipStream_t stream) {
+int edge_targets_csr_launch(const void *y, int y_is_u8, const int32_t *perm, const int32_t *src_csr, const float *pt,
+                            float thld, int64_t n, float *out, hipStream_t stream) {
     if (n == 0) return GNNTRK_OK;
     if (!y || !perm || !out || n < 0) return fail(GNNTRK_EINVAL, "edge_targets_csr: bad argument");
     if (thld > 0.f && (!src_csr || !pt))
         return fail(GNNTRK_EINVAL, "edge_targets_csr: pt threshold needs the CSR source ids and pt");
-    hipLaunchKernelGGL(edge_targets_csr_kernel, dim3(stream_grid(n)), dim3(kTpb), 0, stream, y, perm, src_csr, pt,
-                       thld, n, out);
+    if (y_is_u8)
+        hipLaunchKernelGGL(edge_targets_csr_kernel<uint8_t>, dim3(stream_grid(n)), dim3(kTpb), 0, stream,
+                           reinterpret_cast<const uint8_t *>(y), perm, src_csr, pt, thld, n, out);
+    else
+        hipLaunchKernelGGL(edge_targets_csr_kernel<float>, dim3(stream_grid(n)), dim3(kTpb), 0, stream,
+                           reinterpret_cast<const float *>(y), perm, src_csr, pt, thld, n, out);
     return check_launch("edge_targets_csr");
 }
 

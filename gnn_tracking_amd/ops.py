@@ -747,7 +747,9 @@ def edge_targets_csr(y: Tensor, gi: GraphIndex, pt: Optional[Tensor] = None, pt_
         return hit[2]
     _capi.require_device(y)
     lib = _capi.load()
-    yf = y.detach().to(torch.float32).contiguous().view(-1)
+    # 1-byte labels (the dataset's bool y) are gathered as they are; anything else as float
+    u8 = y.dtype in (torch.bool, torch.uint8)
+    yf = (y.detach().view(torch.uint8) if u8 else y.detach().to(torch.float32)).contiguous().view(-1)
     if yf.numel() != gi.n_edges:
         raise ValueError(f"labels have {yf.numel()} entries, the graph has {gi.n_edges} edges")
     ptf = None
@@ -755,7 +757,7 @@ def edge_targets_csr(y: Tensor, gi: GraphIndex, pt: Optional[Tensor] = None, pt_
         assert pt is not None
         ptf = pt.detach().to(torch.float32).contiguous()
     out = torch.empty(gi.n_edges, dtype=torch.float32, device=yf.device)
-    _capi.check(lib.gnntrk_edge_targets_csr(_p(yf), _p(gi.perm), _p(gi.src), _p(ptf), float(pt_thld),
+    _capi.check(lib.gnntrk_edge_targets_csr(_p(yf), int(u8), _p(gi.perm), _p(gi.src), _p(ptf), float(pt_thld),
                                             gi.n_edges, _p(out), _stream(yf)), lib)
     gi._targets = (key, weakref.ref(y), out)
     return out

@@ -113,7 +113,10 @@ class ECModule(TrackingModule):
         self.loss_fct = loss_fct
 
     def get_losses(self, out: dict[str, Any], data) -> Tensor:
-        return self.loss_fct(w=out["W"], y=data.y.float(), pt=data.pt, edge_index=data.edge_index)
+        # (the reference passes ``data.y.float()``; this package's losses also take the dataset's
+        # 1-byte bool labels as they are and skip the conversion pass)
+        y = data.y if data.y.dtype in (torch.bool, torch.uint8) else data.y.float()
+        return self.loss_fct(w=out["W"], y=y, pt=data.pt, edge_index=data.edge_index)
 
     def training_step(self, batch, batch_idx: int = 0) -> Tensor:
         batch = self.data_preproc(batch)

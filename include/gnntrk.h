@@ -301,10 +301,12 @@ int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
 /* Edge labels in the CSR order of a graph index, pt-falsified (metrics/losses/ec.py:71-92):
  *   out[k] = y[perm[k]]                                           pt_thld <= 0
  *   out[k] = (y[perm[k]] != 0 && pt[src_csr[k]] > pt_thld) ? 1:0  otherwise
- * perm / src_csr: gnntrk_graph_index.perm / .src.  One gather per batch; the losses then run
+ * y: float labels, or (y_is_u8) the dataset's 1-byte bool labels: a quarter of the array, so
+ * the random gather mostly hits the Infinity Cache.  perm / src_csr: gnntrk_graph_index.perm /
+ * .src.  One gather per batch; the losses then run
  * with src_node = NULL, pt_thld = 0 on the CSR-ordered edge weights the classification head
  * writes (models/edge_classifier.py:108-116 without the scatter back to edge_index order). */
-int gnntrk_edge_targets_csr(const float *y, const int32_t *perm, const int32_t *src_csr,
+int gnntrk_edge_targets_csr(const void *y, int32_t y_is_u8, const int32_t *perm, const int32_t *src_csr,
                             const float *pt, float pt_thld, int64_t n, float *out, void *stream);
 
 /* ------------------------------------------------------------------ focal loss

@@ -674,7 +674,7 @@ def case_rows_bf16(device):
     not multiples of 4), row permutations - against torch on the same bf16 values."""
     from gnn_tracking_amd import ops_bf16 as B
     g = np.random.default_rng(4)
-    for N, E, D in ((1, 0, 4), (7, 20, 5), (300, 4000, 4), (1000, 9000, 9)):
+    for N, E, D in ((1, 0, 4), (7, 20, 5), (300, 4000, 4), (1000, 9000, 9), (50, 333, 4), (5, 1, 3), (9, 2, 2)):
         ei = tt(g.integers(0, N, size=(2, E)), device).long()
         gi = ops.graph_index(ei, N, cache=False)
         x32 = tt(g.normal(size=(E, D)).astype(np.float32), device)

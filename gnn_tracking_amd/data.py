@@ -35,6 +35,13 @@ class Data:
     def __contains__(self, k) -> bool:
         return k in self.__dict__
 
+    def __getattr__(self, k):
+        # PyG declares these as properties that are None when the attribute was never set
+        # (training/tc.py:61 reads ``data.batch`` of a graph built by MLGraphConstruction)
+        if k in ("batch", "pos", "edge_weight", "edge_attr", "y", "x", "edge_index"):
+            return None
+        raise AttributeError(k)
+
     @property
     def num_nodes(self) -> int:
         return int(self.x.shape[0])

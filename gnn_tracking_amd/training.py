@@ -29,12 +29,17 @@ class TrackingModule:
     """``training/base.py:72-116`` without the Lightning base class."""
 
     def __init__(self, model: nn.Module, *, optimizer: Callable[..., torch.optim.Optimizer] = torch.optim.Adam,
+                 scheduler: Optional[Callable[..., Any]] = torch.optim.lr_scheduler.ConstantLR,
                  preproc: Optional[nn.Module] = None, flat=None, bf16: bool = False):
         """
         Args:
             model: the network (``forward(data) -> dict``)
             optimizer: called with the parameters, as Lightning calls ``OptimizerCallable``
                 (default Adam, base.py:77); built on first use
+            scheduler: called with the optimizer (default ``ConstantLR``, base.py:78 - note that
+                its default factor 1/3 applies from construction on, i.e. the reference's first
+                five epochs run at a third of the learning rate); ``None`` for none.  Stepping
+                it (once per epoch in Lightning) is the caller's business: ``self.scheduler``
             preproc: optional module applied to every batch first (``MLGraphConstruction``)
             flat: ``dist.FlatParameters`` of ``model`` (+ ``preproc`` parameters if trained): one
                 gradient bucket, all-reduced before the optimizer step
@@ -42,6 +47,7 @@ class TrackingModule:
         """
         self.model, self.preproc, self.flat, self.bf16 = model, preproc, flat, bool(bf16)
         self._optimizer_fn, self._optimizer = optimizer, None
+        self._scheduler_fn, self.scheduler = scheduler, None
 
     # -- base.py:94-104
     def forward(self, data, _preprocessed: bool = False):
@@ -71,6 +77,8 @@ class TrackingModule:
         if self._optimizer is None:
             params = [self.flat.flat_param] if self.flat is not None else list(self.parameters())
             self._optimizer = self._optimizer_fn(params)
+            if self._scheduler_fn is not None:
+                self.scheduler = self._scheduler_fn(self._optimizer)
         return self._optimizer
 
     def get_losses(self, out: dict[str, Any], data):

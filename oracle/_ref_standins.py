@@ -93,6 +93,14 @@ class Data:
     def __contains__(self, k):
         return k in self.__dict__
 
+    def __getattr__(self, k):
+        # PyG ``Data`` declares x / edge_index / edge_attr / y / pos / batch ... as properties that
+        # return None when the attribute was never set (training/tc.py:61 reads ``data.batch`` of a
+        # graph built by MLGraphConstruction, which has none)
+        if k in ("batch", "pos", "edge_weight", "edge_attr", "y", "x", "edge_index"):
+            return None
+        raise AttributeError(k)
+
     @property
     def num_nodes(self):
         return self.x.shape[0]

@@ -811,6 +811,93 @@ def g7_graph_tcn():
     npz("g7_graph_tcn.npz", **arrs)
 
 
+TC_STEP_CASES = {
+    # RG loss: its forward does not slice eta by the post-EC hit mask (oc.py:207-213), so it only
+    # runs without orphan masking - as in the reference
+    "rg_feedw": dict(loss="rg", gtcn=dict(L_ec=2, L_hc=2, hidden_dim=16, h_outdim=3, feed_edge_weights=True)),
+    "tiger_orphans": dict(loss="tiger", gtcn=dict(L_ec=1, L_hc=2, hidden_dim=12, h_outdim=2, mask_orphan_nodes=True,
+                                                   use_ec_embeddings_for_hc=True)),
+}
+TC_MLGC = dict(embedding_slice=(0, 3), max_radius=1.0, max_num_neighbors=6)
+TC_LOSS_W = (2.0, 0.25, 0.5)   # lw_repulsive, lw_coward, lw_noise
+
+
+def g14_tc_step():
+    """Row H, second half: ONE optimisation step of the object-condensation training exactly as
+    the reference's ``TCModule`` runs it (training/tc.py:50-84, training/base.py:94-116):
+    ``preproc = MLGraphConstruction(ml=None)`` -> ``GraphTCN`` -> condensation loss with the
+    post-EC hit mask -> backward -> the module's own optimizer (Adam, default arguments), on the
+    reference's test graph.  Built graph, outputs, loss terms, all gradients, parameters after."""
+    from gnn_tracking.training.tc import TCModule
+
+    print("G14 TC training step")
+    tg = load_reference_graph(REF / "tests/test_data/graphs/test_graph.pt")
+    # the test graph has no noise hits (particle id 0): the noise term would be the mean of an
+    # empty tensor.  Every ninth hit is declared noise, as real events always contain some.
+    tg.particle_id = tg.particle_id.clone()
+    tg.particle_id[::9] = 0
+    arrs = {k: getattr(tg, k) for k in ("x", "particle_id", "pt", "eta", "reconstructable", "layer", "sector")}
+    arrs["edge_index_in"] = tg.edge_index
+    for name, cfg in TC_STEP_CASES.items():
+        def fresh():
+            return Data(**{a: getattr(tg, a) for a in tg.keys()})
+        torch.manual_seed(21)
+        probe = GraphTCN(14, 28, **cfg["gtcn"])
+        pre = MLGraphConstruction(ml=None, **TC_MLGC)
+        wq = probe._gtcn.ec(pre(fresh()))["W"].detach().sort().values
+        gaps = wq[int(0.25 * len(wq)):int(0.6 * len(wq))].double()
+        j = int((gaps[1:] - gaps[:-1]).argmax())
+        thr = float((gaps[j] + gaps[j + 1]) / 2)
+        torch.manual_seed(21)
+        model = GraphTCN(14, 28, ec_threshold=thr, **cfg["gtcn"])
+        lw_rep, lw_cow, lw_noise = TC_LOSS_W
+        loss_cls = CondensationLossTiger if cfg["loss"] == "tiger" else CondensationLossRG
+        mod = TCModule(model=model, loss_fct=loss_cls(lw_repulsive=lw_rep, lw_coward=lw_cow, lw_noise=lw_noise),
+                       preproc=MLGraphConstruction(ml=None, **TC_MLGC))
+        p0 = sd(model)
+        data = mod.data_preproc(fresh())
+        out = mod(data, _preprocessed=True)
+        margin = (out["W"].detach() - thr).abs().min().item()
+        assert margin > 1e-6, f"{name}: an edge weight sits {margin:.1e} from the threshold"
+        loss, metrics = mod.get_losses(out, data)
+        loss.backward()
+        grads = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v))
+                 for k, v in model.named_parameters()}
+        opt = mod.configure_optimizers()["optimizer"]
+        opt.step()
+        p1 = sd(model)
+        # the restatement
+        gk = dict(cfg["gtcn"])
+        okw = dict(L_ec=gk.pop("L_ec"), L_hc=gk.pop("L_hc"), ec_threshold=thr)
+        for k in ("mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc"):
+            if k in gk:
+                okw[k] = gk[k]
+        raw = {k: getattr(tg, k) for k in ("x", "particle_id", "pt", "eta", "reconstructable")}
+        graph, oo, terms, total, og, op = O.tc_training_step(raw, p0, mlgc=TC_MLGC, gtcn=okw, loss_kind=cfg["loss"],
+                                                            loss_weights=TC_LOSS_W)
+        assert torch.equal(graph["edge_index"], data.edge_index) and torch.equal(graph["y"], data.y)
+        worst = max(close(graph["edge_attr"], data.edge_attr, 0.0, "edge_attr"),
+                    close(oo["W"], out["W"], 1e-6, "W"), close(oo["H"], out["H"], 1e-5, "H"),
+                    close(oo["B"], out["B"], 1e-6, "B"), close(total, loss, 1e-6, "loss"))
+        assert torch.equal(oo["ec_hit_mask"], out["ec_hit_mask"]) and torch.equal(oo["ec_edge_mask"], out["ec_edge_mask"])
+        for k in ("attractive", "repulsive", "coward", "noise"):
+            worst = max(worst, close(terms[k], metrics[k], 1e-6, name + " " + k))
+            arrs[f"{name}/{k}"] = metrics[k]
+        for k in grads:
+            worst = max(worst, close(og[k], grads[k], 1e-5, f"{name} grad {k}"),
+                        close(op[k], p1[k], 1e-6, f"{name} adam {k}"))
+            arrs[f"{name}/p0/{k}"], arrs[f"{name}/p1/{k}"], arrs[f"{name}/grad/{k}"] = p0[k], p1[k], grads[k]
+        arrs[f"{name}/ec_threshold"] = np.float64(thr)
+        arrs[f"{name}/edge_index"], arrs[f"{name}/y"], arrs[f"{name}/edge_attr"] = data.edge_index, data.y, data.edge_attr
+        for k in ("W", "H", "B", "ec_hit_mask", "ec_edge_mask"):
+            arrs[f"{name}/{k}"] = out[k]
+        arrs[f"{name}/loss"] = loss
+        print(f"   {name}: {int(out['ec_edge_mask'].sum())} of {data.edge_index.shape[1]} edges kept, "
+              f"{int(out['ec_hit_mask'].sum())} of {tg.x.shape[0]} hits, loss {loss.item():.6f}, oracle == reference "
+              f"(max diff {worst:.2e})")
+    npz("g14_tc_step.npz", **arrs)
+
+
 if __name__ == "__main__":
     assert REF.is_dir(), "needs /root/reference (build container only)"
     only = set(sys.argv[1:])  # e.g. "g7 g10": regenerate just these files
@@ -821,7 +908,8 @@ if __name__ == "__main__":
     tg = g1_ec_testgraph() if (want("g1") or want("g4") or want("g6")) else None
     for tag, fn in (("g2", g2_ec_variants), ("g2b", g2b_ec_autocast), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
                     ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g8", g8_hinge),
-                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan), ("g12", g12_gc_resin), ("g13", g13_focal)):
+                    ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan), ("g12", g12_gc_resin), ("g13", g13_focal),
+                    ("g14", g14_tc_step)):
         if want(tag):
             fn()
     print("goldens written; oracle pinned against the reference.")

@@ -429,6 +429,42 @@ def ec_training_step(x, edge_index, edge_attr, y, params: dict, *, model_kwargs:
     return out, loss, {n: ps[n].grad for n in names}, {n: ps[n].detach() for n in names}
 
 
+def tc_training_step(data: dict, params: dict, *, mlgc: dict, gtcn: dict, loss_kind: str, loss_weights: tuple,
+                     lr: float = 1e-3):
+    """training/tc.py:50-84 + training/base.py:94-116: ``data_preproc`` = ``MLGraphConstruction(ml=None)``
+    (kNN on a slice of the node features, labels, edge features), ``GraphTCN`` forward,
+    ``CondensationLossRG`` / ``CondensationLossTiger`` with the post-EC hit mask, backward, one
+    Adam step (Lightning's default optimizer call ``torch.optim.Adam(parameters)``).  ``data``:
+    x, particle_id, pt, eta, reconstructable.  Returns (built graph, model outputs, loss terms,
+    total, grads, params after the step)."""
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    x, pid = data["x"], data["particle_id"]
+    s0, s1 = mlgc["embedding_slice"]
+    ei = knn_with_max_radius(x[:, s0:s1], mlgc["max_num_neighbors"], mlgc["max_radius"])
+    y, edge_attr = ml_graph_construction_edges(x, pid, ei)
+    out = graph_tcn(x, ei, edge_attr, ps, **gtcn)
+    hm = out["ec_hit_mask"]
+    pt, reco, eta = data["pt"][hm], data["reconstructable"][hm], data["eta"]
+    if loss_kind == "tiger":  # (oc.py:207-213 vs :394-401: only the Tiger variant slices eta)
+        eta = eta[hm]
+    mask = good_node_mask(pt, pid[hm], reco, eta)
+    fn = condensation_loss_tiger if loss_kind == "tiger" else condensation_loss_rg
+    terms = fn(beta=out["B"], x=out["H"], particle_id=pid[hm], mask=mask)
+    w_rep, w_cow, w_noise = loss_weights
+    total = terms["attractive"] + w_rep * terms["repulsive"] + w_noise * terms["noise"] + w_cow * terms["coward"]
+    names = list(ps)
+    grads = torch.autograd.grad(total, [ps[n] for n in names], allow_unused=True)
+    for n, g in zip(names, grads):
+        ps[n].grad = g if g is not None else torch.zeros_like(ps[n])
+    # base.py:106-112: the default scheduler ConstantLR(optimizer) scales the learning rate by its
+    # default factor 1/3 from construction on (for the first five epochs)
+    opt = torch.optim.Adam([ps[n] for n in names], lr=lr)
+    torch.optim.lr_scheduler.ConstantLR(opt)
+    opt.step()
+    graph = {"edge_index": ei, "y": y, "edge_attr": edge_attr}
+    return graph, out, terms, total, {n: ps[n].grad for n in names}, {n: ps[n].detach() for n in names}
+
+
 # ------------------------------------------------------------- compiled kNN oracle
 def knn_graph_c(x: Tensor, k: int, max_radius: float | None = None) -> Tensor:
     """Bit-exact kNN(+radius) edge list from the C oracle (oracle/knn_ref.c): the

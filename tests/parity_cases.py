@@ -1300,3 +1300,76 @@ def case_edge_ordered(device):
     hl = G.HaughtyFocalLoss(pt_thld=0.9)(w=model(G.Data(x=x, edge_index=ei, edge_attr=ea))["W"], y=y, pt=pt,
                                           edge_index=ei)
     assert torch.isfinite(hl)
+
+
+# ------------------------------------------------------------- TC training step (row H)
+TC_STEP_CASES = {
+    "rg_feedw": dict(loss="rg", gtcn=dict(L_ec=2, L_hc=2, hidden_dim=16, h_outdim=3, feed_edge_weights=True)),
+    "tiger_orphans": dict(loss="tiger", gtcn=dict(L_ec=1, L_hc=2, hidden_dim=12, h_outdim=2, mask_orphan_nodes=True,
+                                                   use_ec_embeddings_for_hc=True)),
+}
+TC_MLGC = dict(embedding_slice=(0, 3), max_radius=1.0, max_num_neighbors=6)
+TC_LOSS_W = (2.0, 0.25, 0.5)   # lw_repulsive, lw_coward, lw_noise
+
+
+def case_tc_step(device, names=None):
+    """SURVEY.md section 8a row H, object-condensation half: one optimisation step as the
+    reference's ``TCModule`` runs it (training/tc.py:50-84; golden G14 from the reference's own
+    module): ``MLGraphConstruction(ml=None)`` -> ``GraphTCN`` -> condensation loss with the
+    post-EC hit mask -> backward -> Adam under the default ConstantLR scheduler.  Built graph and
+    masks bit-exact, W / H / B and the loss terms 1e-5, gradients 1e-4, parameters after the
+    step 1e-6."""
+    from gnn_tracking_amd import training
+    from gnn_tracking_amd.losses_oc import CondensationLossRG, CondensationLossTiger
+
+    z = load("g14_tc_step.npz")
+    for name, cfg in TC_STEP_CASES.items():
+        if names is not None and name not in names:
+            continue
+        model = G.GraphTCN(14, 28, ec_threshold=float(z[f"{name}/ec_threshold"]), **cfg["gtcn"])
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        lw_rep, lw_cow, lw_noise = TC_LOSS_W
+        loss_cls = CondensationLossTiger if cfg["loss"] == "tiger" else CondensationLossRG
+        mod = training.TCModule(model, loss_fct=loss_cls(lw_repulsive=lw_rep, lw_coward=lw_cow, lw_noise=lw_noise),
+                                preproc=G.MLGraphConstruction(ml=None, **TC_MLGC))
+        data = G.Data(x=tt(z["x"], device), edge_index=tt(z["edge_index_in"], device),
+                      particle_id=tt(z["particle_id"], device), pt=tt(z["pt"], device), eta=tt(z["eta"], device),
+                      reconstructable=tt(z["reconstructable"], device), layer=tt(z["layer"], device),
+                      sector=tt(z["sector"], device))
+        data = mod.data_preproc(data)
+        assert torch.equal(data.edge_index.cpu(), tt(z[f"{name}/edge_index"])), name + " built edge_index"
+        assert torch.equal(data.y.cpu(), tt(z[f"{name}/y"])), name + " edge labels"
+        assert torch.equal(data.edge_attr.cpu(), tt(z[f"{name}/edge_attr"])), name + " edge features"
+        out = mod(data, _preprocessed=True)
+        assert torch.equal(out["ec_edge_mask"].cpu(), tt(z[f"{name}/ec_edge_mask"])), name + " edge mask"
+        assert torch.equal(out["ec_hit_mask"].cpu(), tt(z[f"{name}/ec_hit_mask"])), name + " hit mask"
+        for k in ("W", "H", "B"):
+            assert_close(out[k], z[f"{name}/{k}"], TOL_OUT, f"{name} {k}")
+        loss, metrics = mod.get_losses(out, data)
+        for k in ("attractive", "repulsive", "coward", "noise"):
+            assert_close(metrics[k], z[f"{name}/{k}"], 2e-5, f"{name} {k}")
+        assert_close(loss, z[f"{name}/loss"], 2e-5, name + " loss")
+        mod.zero_grad()
+        loss.backward()
+        for k, v in model.named_parameters():
+            gk = v.grad if v.grad is not None else torch.zeros_like(v)
+            assert_close(gk, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
+        mod.configure_optimizers().step()
+        for k, v in model.state_dict().items():
+            # Adam's first step is lr * g / (|g| + 1e-8): where a gradient ELEMENT vanishes (dead
+            # ReLU units; the bias of the last cluster layer - the potentials are translation
+            # invariant) rounding noise of 1e-9 becomes a step of a tenth of lr.  Those elements
+            # are only required to stay within one step (lr / 3 under the default ConstantLR).
+            ref1 = tt(z[f"{name}/p1/{k}"]).double()
+            got = v.detach().cpu().double()
+            tol = torch.full_like(ref1, 1e-6)
+            if f"{name}/grad/{k}" in z.files:
+                tol[tt(z[f"{name}/grad/{k}"]).abs() < 1e-6] = 3.4e-4
+            bad = (got - ref1).abs() > tol * torch.clamp_min(ref1.abs(), 1.0)
+            assert not bool(bad.any()), f"{name} after Adam {k}: max|diff| {(got - ref1).abs().max().item():.3e}"
+        # and the same through the one-call form (a second step from the updated parameters)
+        assert torch.isfinite(mod.optimisation_step(G.Data(
+            x=tt(z["x"], device), edge_index=tt(z["edge_index_in"], device), particle_id=tt(z["particle_id"], device),
+            pt=tt(z["pt"], device), eta=tt(z["eta"], device), reconstructable=tt(z["reconstructable"], device),
+            layer=tt(z["layer"], device), sector=tt(z["sector"], device))))

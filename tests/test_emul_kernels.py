@@ -111,3 +111,8 @@ def test_focal_losses_emulated():
 def test_edge_ordered_outputs_emulated():
     with emulated():
         P.case_edge_ordered("cpu")
+
+
+def test_tc_training_step_emulated():
+    with emulated():
+        P.case_tc_step("cpu")

@@ -154,6 +154,10 @@ def test_edge_ordered_outputs(dev):
     P.case_edge_ordered(dev)
 
 
+def test_tc_training_step(dev):
+    P.case_tc_step(dev)
+
+
 # ---- BASELINE.json configs on their own workloads ---------------------------------------
 def test_cfg1_cfg2_event_vs_oracle(dev):
     P.case_cfg12_event(dev)

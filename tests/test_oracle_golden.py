@@ -226,3 +226,22 @@ def test_bf16_contract_vs_reference_autocast():
         d_contract = (out["W"] - tt(z[f"{name}/W"])).abs().max().item()
         d_autocast = (tt(za[f"{name}/W"]) - tt(z[f"{name}/W"])).abs().max().item()
         assert d_contract < d_autocast, (name, d_contract, d_autocast)
+
+
+def test_tc_training_step_oracle():
+    """oracle.tc_training_step against the reference's own TCModule step (golden G14)."""
+    z = load("g14_tc_step.npz")
+    raw = {k: tt(z[k]) for k in ("x", "particle_id", "pt", "eta", "reconstructable")}
+    for name, cfg in P.TC_STEP_CASES.items():
+        gk = dict(cfg["gtcn"])
+        okw = dict(L_ec=gk.pop("L_ec"), L_hc=gk.pop("L_hc"), ec_threshold=float(z[f"{name}/ec_threshold"]))
+        for k in ("mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc"):
+            if k in gk:
+                okw[k] = gk[k]
+        graph, out, terms, total, grads, after = O.tc_training_step(
+            raw, _params(z, f"{name}/p0/"), mlgc=P.TC_MLGC, gtcn=okw, loss_kind=cfg["loss"], loss_weights=P.TC_LOSS_W)
+        assert torch.equal(graph["edge_index"], tt(z[f"{name}/edge_index"]))
+        assert_close(total, z[f"{name}/loss"], 1e-6, name + " loss")
+        for k, v in grads.items():
+            assert_close(v, z[f"{name}/grad/{k}"], 1e-5, f"{name} grad {k}")
+            assert_close(after[k], z[f"{name}/p1/{k}"], 1e-6, f"{name} adam {k}")

@@ -221,7 +221,7 @@ class ECWorkload(Workload):
         self.model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_MODEL).to(dev)
         self.flat = gdist.FlatParameters(self.model)
         self.module = training.ECModule(
-            self.model, loss_fct=G.EdgeWeightBCELoss(), flat=self.flat, bf16=dtype == "bf16",
+            self.model, loss_fct=G.EdgeWeightBCELoss(), flat=self.flat, bf16=dtype == "bf16", scheduler=None,
             optimizer=lambda p: torch.optim.Adam(p, lr=1e-4, weight_decay=1e-4))
         self.first_event_cpu = None
         if workload == "cfg4":
@@ -295,6 +295,156 @@ class ECWorkload(Workload):
         return loss
 
 
+class _StageTimer:
+    """HIP-event brackets around the stages of a step (events on the launch stream; read after
+    the timed region)."""
+
+    def __init__(self):
+        self.rec, self.on = [], False
+
+    def __call__(self, name):
+        timer = self
+
+        class _Ctx:
+            def __enter__(self):
+                if timer.on:
+                    self.e0 = torch.cuda.Event(enable_timing=True)
+                    self.e1 = torch.cuda.Event(enable_timing=True)
+                    self.e0.record()
+
+            def __exit__(self, *exc):
+                if timer.on:
+                    self.e1.record()
+                    timer.rec.append((name, self.e0, self.e1))
+        return _Ctx()
+
+    def summary(self) -> dict:
+        out: dict = {}
+        for name, e0, e1 in self.rec:
+            d = out.setdefault(name, [0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+        return {k: {"calls": n, "avg_ms": ms / n} for k, (n, ms) in out.items()}
+
+
+class TCWorkload(Workload):
+    """cfg5 (BASELINE.json configs[4]): the object-condensation training step of the reference's
+    ``TCModule`` (training/tc.py:50-84) on one 200 000-hit pile-up-like event per GPU:
+    ``MLGraphConstruction`` (HIP kNN in the 8-d latent slice, k = 16, r = 1; labels; edge
+    features) -> ``GraphTCN`` -> ``CondensationLossRG`` -> backward -> Adam."""
+
+    name, scaling, dtype = "cfg5", "weak", "f32"
+    K_NN, DIM = 16, 8
+
+    def __init__(self, args, rank: int, world: int, dev):
+        import numpy as np
+
+        n = args.events or 200_000     # --events overrides the hit count here
+        ev = synthetic.make_pileup_event(500 + rank, n, self.DIM)
+        g = np.random.default_rng(500 + rank)
+        extra = torch.from_numpy(g.uniform(0, 1.5, size=(n, 6)).astype(np.float32))
+        x = torch.cat([ev["x"], extra], dim=1)   # 14 node features; the first 8 are the latent coordinates
+        self.data = G.Data(x=x.to(dev), edge_index=torch.zeros(2, 0, dtype=torch.long, device=dev),
+                           particle_id=ev["particle_id"].to(dev), pt=ev["pt"].to(dev), eta=ev["eta"].to(dev),
+                           reconstructable=ev["reconstructable"].to(dev))
+        self.cpu_event = {k: v for k, v in ev.items()} | {"x14": x}
+        torch.manual_seed(0)
+        self.model = G.GraphTCN(14, 28, h_outdim=self.DIM, hidden_dim=40, L_ec=3, L_hc=3, alpha_latent=0.9,
+                                n_embedding_coords=self.DIM).to(dev)
+        self.preproc = G.MLGraphConstruction(ml=None, embedding_slice=(0, self.DIM), max_radius=1.0,
+                                              max_num_neighbors=self.K_NN)
+        self.flat = gdist.FlatParameters(self.model)
+        self.module = training.TCModule(
+            self.model, loss_fct=G.CondensationLossRG(lw_repulsive=1.0, lw_noise=0.1, lw_coward=0.1),
+            preproc=self.preproc, flat=self.flat, scheduler=None,
+            optimizer=lambda p: torch.optim.Adam(p, lr=1e-4))
+        self.stage = _StageTimer()
+        self.n_hits = n
+        built = self.preproc(self._fresh())
+        self.n_edges = int(built.edge_index.shape[1])
+        self.edges_per_step_global = self.n_edges * world
+        mask = G.get_good_node_mask_tensors(pt=self.data.pt, particle_id=self.data.particle_id,
+                                            reconstructable=self.data.reconstructable, eta=self.data.eta)
+        self.n_cp = int(torch.unique(self.data.particle_id[mask]).numel())
+        self.info = {"hits": n, "knn_k": self.K_NN, "edges_built": self.n_edges, "condensation_points": self.n_cp}
+        self.describe = (f"cfg5: per GPU one pile-up-like event of {n} hits (14 node features, 8-d latent slice: 6000 "
+                         f"Gaussian clusters + 10 % noise); step = MLGraphConstruction (kNN k={self.K_NN}, r=1 -> "
+                         f"{self.n_edges} edges, labels, 28 edge features) + GraphTCN(14, 28, h_outdim=8, hidden 40, "
+                         f"L_ec=3, L_hc=3, alpha_latent=0.9) forward + CondensationLossRG (K={self.n_cp}) + backward + Adam")
+
+    def _fresh(self):
+        import copy
+        return copy.copy(self.data)
+
+    def step(self):
+        m, st = self.module, self.stage
+        opt = m.configure_optimizers()
+        m.zero_grad()
+        ops.clear_graph_index_cache()
+        with st("graph_build"):
+            data = m.data_preproc(self._fresh())
+        with st("model_forward"):
+            out = m(data, _preprocessed=True)
+        with st("oc_loss_forward"):
+            loss, _ = m.get_losses(out, data, metrics=False)
+        with st("backward"):
+            loss.backward()
+        with st("allreduce_adam"):
+            self.flat.all_reduce_grads()
+            opt.step()
+        return loss.detach()
+
+    def stages(self) -> dict:
+        s = self.stage.summary()
+        n, d, k = self.n_hits, self.DIM, self.n_cp
+        if "graph_build" in s:   # brute-force search: N^2 D multiply-adds on the fp32 vector pipe
+            t = s["graph_build"]["avg_ms"] * 1e-3
+            s["graph_build"]["roofline"] = {"bound": "valu_f32", "achieved": 2.0 * n * n * d / t / 1e12,
+                                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": 2.0 * n * n * d / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                            "note": "includes labels + edge features (HBM-bound tails)"}
+        if "oc_loss_forward" in s:  # N x K pair pass: 3 D flops for the distance + ~12 for the potentials
+            t = s["oc_loss_forward"]["avg_ms"] * 1e-3
+            fl = float(n) * k * (3 * d + 12)
+            s["oc_loss_forward"]["roofline"] = {"bound": "valu_f32", "achieved": fl / t / 1e12,
+                                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                                "note": "includes the condensation-point selection (sort + scans)"}
+        return s
+
+    def roofline(self, ks):
+        roof, kernels = roofline_of(ks, "f32")
+        return roof, kernels
+
+    def cpu_baseline(self, iters: int) -> dict:
+        """The oracle's TC step on the first 20 000 hits of the event (the reference's kNN is
+        O(N^2) on the CPU as well: the full event would take minutes)."""
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ref_cpu as O
+
+        ns = min(20_000, self.n_hits)
+        ev = self.cpu_event
+        raw = {"x": ev["x14"][:ns], "particle_id": ev["particle_id"][:ns], "pt": ev["pt"][:ns],
+               "eta": ev["eta"][:ns], "reconstructable": ev["reconstructable"][:ns]}
+        p = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        threads = min(32, os.cpu_count() or 1)
+        torch.set_num_threads(threads)
+        kw = dict(mlgc=dict(embedding_slice=(0, self.DIM), max_radius=1.0, max_num_neighbors=self.K_NN),
+                  gtcn=dict(L_ec=3, L_hc=3, alpha_latent=0.9, n_embedding_coords=self.DIM), loss_kind="rg",
+                  loss_weights=(1.0, 0.1, 0.1))
+        times, edges = [], 0
+        for _ in range(max(1, min(iters, 2))):
+            t0 = time.perf_counter()
+            graph, *_ = O.tc_training_step(raw, p, **kw)
+            times.append(time.perf_counter() - t0)
+            edges = int(graph["edge_index"].shape[1])
+        dt = min(times)
+        return {"value": edges / dt, "unit": "edges/s", "cores": threads, "kind": "port",
+                "sample": f"oracle TC step (kNN + GraphTCN + CondensationLossRG + backward + Adam) on the first {ns} "
+                          f"hits of the event ({edges} edges), best of {len(times)}, {threads} threads",
+                "s_per_iter": dt, "hits_per_s": ns / dt}
+
+
 class StubWorkload(Workload):
     """TEST ONLY (``--stub``): a CPU toy model so that tests can drive the launcher, barrier,
     max-over-ranks timing and the all-reduce through this file's real control flow."""
@@ -338,6 +488,8 @@ def timed_steps(wl: Workload, world: int, dev, steps: int, warmup: int, *, kerne
         wl.step()
     timer = ops.KernelTimer() if kernel_timer else None
     ops.set_kernel_timer(timer)
+    if hasattr(wl, "stage"):
+        wl.stage.on = True
     barrier(world)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -345,6 +497,8 @@ def timed_steps(wl: Workload, world: int, dev, steps: int, warmup: int, *, kerne
     barrier(world)
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    if hasattr(wl, "stage"):
+        wl.stage.on = False
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -391,7 +545,8 @@ def hipgraph_cfg2(dev, dtype: str, steps: int) -> dict:
     torch.manual_seed(0)
     model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_MODEL).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
-    mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), bf16=dtype == "bf16", optimizer=lambda p: opt)
+    mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), bf16=dtype == "bf16", optimizer=lambda p: opt,
+                            scheduler=None)
     batch = G.collate([synthetic.make_event(1, 10_000, 100_000, dev)])
 
     def step():
@@ -488,8 +643,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         if args.workload == "cfg5":
-            from gnn_tracking_amd import bench_cfg5
-            wl = bench_cfg5.TCWorkload(args, rank, world, dev)
+            wl = TCWorkload(args, rank, world, dev)
         else:
             wl = ECWorkload(args, rank, world, dev, workload=args.workload, dtype=args.dtype, index=args.index)
 

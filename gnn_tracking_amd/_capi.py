@@ -128,7 +128,8 @@ _SIGNATURES = {
                                        C.c_size_t, _P]),
     "gnntrk_oc_forward_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnntrk_oc_forward": (C.c_int, [C.POINTER(OcArgs), _P, _P, C.c_size_t, _P]),
-    "gnntrk_oc_backward": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P]),
+    "gnntrk_oc_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "gnntrk_oc_backward": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

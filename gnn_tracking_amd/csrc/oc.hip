@@ -105,9 +105,13 @@ __global__ __launch_bounds__(kOcTpb) void oc_assign_kernel(
     if (s == 0) n_cp[0] = (int32_t)seg_off[n];
     if (s == 0 || keys[s] != keys[s - 1]) {
         const u64 key = keys[s];
+        // gid is preset to -1: only particles of interest walk their (short) segment - the noise
+        // "particle" (id 0) has a tenth of all hits and would keep one thread busy for milliseconds
         const int32_t k = seg_flag[s] ? (int32_t)seg_off[s] : -1;
-        if (k >= 0) alphas[k] = seg_best[s];
-        for (int64_t t = s; t < n && keys[t] == key; ++t) gid[order[t]] = k;
+        if (k >= 0) {
+            alphas[k] = seg_best[s];
+            for (int64_t t = s; t < n && keys[t] == key; ++t) gid[order[t]] = k;
+        }
     }
 }
 
@@ -357,41 +361,52 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_hits_kernel(const OcParams
     }
 }
 
-// backward, condensation-point side: thread = CP k, hits streamed; adds into gx[alpha_k],
-// gbeta[alpha_k] (alpha_k are distinct hits: no conflicts).  Runs after the hit pass.
+// backward, condensation-point side: thread = CP k (of the batch [k_base, k_base + kOcCpBatch)),
+// the hits are cut into gridDim.y slices streamed through LDS; every (slice, CP) writes its
+// partial (d/dx_k [DP], d/dq_k) and oc_backward_cps_reduce_kernel adds the slices in slice order
+// into gx[alpha_k], gbeta[alpha_k] (alpha_k are distinct hits: no conflicts).  Thread = CP alone
+// would leave the chip idle: K is a few thousand (19 workgroups at K = 4625) while each of them
+// walks all N hits.  Runs after the hit pass.
+constexpr int kOcCpBatch = 16384;  // condensation points per launch (bounds the partial buffer)
+constexpr int kOcSlices = 32;      // hit slices
+
 template <int DP>
 __global__ __launch_bounds__(kOcTpb) void oc_backward_cps_kernel(const OcParams p,
                                                                  const float *__restrict__ g,
                                                                  const float *__restrict__ fwd,
-                                                                 float *__restrict__ gx,
-                                                                 float *__restrict__ gbeta) {
+                                                                 int k_base, float *__restrict__ part) {
     __shared__ float s_x[kOcChunk][DP];
     __shared__ float s_q[kOcChunk];
     __shared__ long long s_pid[kOcChunk];
     __shared__ int s_att[kOcChunk];  // gid if the hit takes part in the attractive sum, else -2
     const int K = p.n_cp[0];
-    const int k = blockIdx.x * kOcTpb + threadIdx.x;
+    if (k_base + (int)blockIdx.x * kOcTpb >= K) return;  // (uniform: before any barrier)
+    const int kl = blockIdx.x * kOcTpb + threadIdx.x;    // CP inside the batch
+    const int k = k_base + kl;
     const bool live = k < K;
     const float ca = g[0] / fwd[4], cr = g[1] / fwd[5];
     float xk[DP], gxk[DP];
-    float qk = 0.f, gqk = 0.f, bk = 0.5f;
+    float qk = 0.f, gqk = 0.f;
     long long pk = -1;
-    int32_t ak = 0;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
         xk[d] = 0.f;
         gxk[d] = 0.f;
     }
     if (live) {
-        ak = p.alphas[k];
+        const int32_t ak = p.alphas[k];
 #pragma unroll
         for (int d = 0; d < DP; ++d) xk[d] = d < p.dim ? p.x[(int64_t)ak * p.stride + d] : 0.f;
-        bk = p.beta[ak];
-        qk = oc_q(bk, p.q_min);
+        qk = oc_q(p.beta[ak], p.q_min);
         pk = p.pid[ak];
     }
     const float r2 = p.radius * p.radius;
-    for (int64_t j0 = 0; j0 < p.n; j0 += kOcChunk) {
+    // slice of the hits (whole LDS chunks)
+    const int64_t n_chunks = (p.n + kOcChunk - 1) / kOcChunk;
+    const int64_t per = (n_chunks + gridDim.y - 1) / gridDim.y;
+    const int64_t j_begin = (int64_t)blockIdx.y * per * kOcChunk;
+    const int64_t j_stop = ((int64_t)(blockIdx.y + 1) * per * kOcChunk < p.n) ? (int64_t)(blockIdx.y + 1) * per * kOcChunk : p.n;
+    for (int64_t j0 = j_begin; j0 < j_stop; j0 += kOcChunk) {
         __syncthreads();
         for (int i = threadIdx.x; i < kOcChunk; i += kOcTpb) {
             const int64_t j = j0 + i;
@@ -434,10 +449,37 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_cps_kernel(const OcParams 
         }
     }
     if (live) {
-        for (int d = 0; d < p.dim; ++d) gx[(int64_t)ak * p.stride + d] += gxk[d];
-        const float a = atanhf(bk);
-        gbeta[ak] += gqk * 2.f * a / (1.f - bk * bk) - g[2] / fwd[6];  // coward: mean(1 - beta)
+        float *o = part + ((int64_t)blockIdx.y * kOcCpBatch + kl) * (DP + 1);
+#pragma unroll
+        for (int d = 0; d < DP; ++d) o[d] = gxk[d];
+        o[DP] = gqk;
     }
+}
+
+template <int DP>
+__global__ __launch_bounds__(kOcTpb) void oc_backward_cps_reduce_kernel(const OcParams p,
+                                                                        const float *__restrict__ g,
+                                                                        const float *__restrict__ fwd,
+                                                                        int k_base, int n_slices,
+                                                                        const float *__restrict__ part,
+                                                                        float *__restrict__ gx,
+                                                                        float *__restrict__ gbeta) {
+    const int K = p.n_cp[0];
+    const int kl = blockIdx.x * kOcTpb + threadIdx.x, k = k_base + kl;
+    if (k >= K) return;
+    float acc[DP + 1];
+#pragma unroll
+    for (int d = 0; d <= DP; ++d) acc[d] = 0.f;
+    for (int sl = 0; sl < n_slices; ++sl) {  // fixed order: bit-reproducible
+        const float *o = part + ((int64_t)sl * kOcCpBatch + kl) * (DP + 1);
+#pragma unroll
+        for (int d = 0; d <= DP; ++d) acc[d] += o[d];
+    }
+    const int32_t ak = p.alphas[k];
+    for (int d = 0; d < p.dim; ++d) gx[(int64_t)ak * p.stride + d] += acc[d];
+    const float bk = p.beta[ak];
+    const float a = atanhf(bk);
+    gbeta[ak] += acc[DP] * 2.f * a / (1.f - bk * bk) - g[2] / fwd[6];  // coward: mean(1 - beta)
 }
 
 // ---- launchers -----------------------------------------------------------------------
@@ -487,6 +529,8 @@ int oc_select_launch(const float *score, const int64_t *pid, const uint8_t *mask
     hipLaunchKernelGGL(oc_segment_best_kernel, dim3(grid), dim3(kOcTpb), 0, stream,
                        (const u64 *)keys_b, (const uint32_t *)vals_b, score, mask, n, mode, flag, best);
     hipLaunchKernelGGL(oc_scan_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t *)flag, n, off);
+    rc = check_hip(hipMemsetAsync(gid, 0xff, (size_t)n * sizeof(int32_t), stream), "oc_select_cps(memset)");
+    if (rc) return rc;
     hipLaunchKernelGGL(oc_assign_kernel, dim3(grid), dim3(kOcTpb), 0, stream, (const u64 *)keys_b,
                        (const uint32_t *)vals_b, (const int32_t *)flag, (const int32_t *)best,
                        (const int64_t *)off, n, alphas, gid, n_cp);
@@ -533,19 +577,40 @@ int oc_forward_launch(const gnntrk_oc_args *a, float *out, void *ws, size_t ws_b
     return check_launch("oc_forward");
 }
 
+// partial buffer of the condensation-point pass: [slices][kOcCpBatch][dim padded + 1] floats
+size_t oc_backward_ws_bytes(int64_t n, int dim) {
+    (void)n;
+    const int dp = dim <= 2 ? 2 : dim <= 4 ? 4 : dim <= 8 ? 8 : dim <= 16 ? 16 : 32;
+    return (size_t)kOcSlices * kOcCpBatch * (dp + 1) * sizeof(float);
+}
+
 int oc_backward_launch(const gnntrk_oc_args *a, const float *g, const float *fwd, float *gx, float *gbeta,
-                       int64_t max_cps, hipStream_t stream) {
+                       int64_t max_cps, void *ws, size_t ws_bytes, hipStream_t stream) {
     int rc = oc_check(a);
     if (rc) return rc;
     if (!g || !fwd || !gx || !gbeta || max_cps < 1) return fail(GNNTRK_EINVAL, "oc_backward: bad argument");
+    if (!ws || ws_bytes < oc_backward_ws_bytes(a->n, a->dim)) return fail(GNNTRK_EINVAL, "oc_backward: workspace too small");
     const OcParams p = oc_params(a);
-    const int grid = oc_grid(a->n), kgrid = oc_grid(max_cps);
+    const int grid = oc_grid(a->n);
 #define CALL_BH(DP) hipLaunchKernelGGL(oc_backward_hits_kernel<DP>, dim3(grid), dim3(kOcTpb), 0, stream, p, g, fwd, gx, gbeta)
     OC_DISPATCH(CALL_BH)
 #undef CALL_BH
-#define CALL_BC(DP) hipLaunchKernelGGL(oc_backward_cps_kernel<DP>, dim3(kgrid), dim3(kOcTpb), 0, stream, p, g, fwd, gx, gbeta)
-    OC_DISPATCH(CALL_BC)
+    // condensation-point side in batches of kOcCpBatch (the count K lives on the device: batches
+    // past it exit at once), each batch cut into hit slices
+    int64_t n_chunks = (a->n + kOcChunk - 1) / kOcChunk;
+    const int slices = (int)(n_chunks < kOcSlices ? n_chunks : kOcSlices);
+    float *part = reinterpret_cast<float *>(ws);
+    for (int64_t kb = 0; kb < max_cps; kb += kOcCpBatch) {
+        const int64_t in_batch = (max_cps - kb < kOcCpBatch) ? (max_cps - kb) : kOcCpBatch;
+        const int kgrid = oc_grid(in_batch);
+#define CALL_BC(DP)                                                                                          \
+    hipLaunchKernelGGL(oc_backward_cps_kernel<DP>, dim3(kgrid, slices), dim3(kOcTpb), 0, stream, p, g, fwd,    \
+                       (int)kb, part);                                                                        \
+    hipLaunchKernelGGL(oc_backward_cps_reduce_kernel<DP>, dim3(kgrid), dim3(kOcTpb), 0, stream, p, g, fwd,     \
+                       (int)kb, slices, (const float *)part, gx, gbeta)
+        OC_DISPATCH(CALL_BC)
 #undef CALL_BC
+    }
     return check_launch("oc_backward");
 }
 

@@ -99,8 +99,9 @@ class _CondensationPotentials(torch.autograd.Function):
                          ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode)
         gx = torch.empty_like(x_c)
         gbeta = torch.empty_like(beta_c)
+        ws = ops._ws(lib.gnntrk_oc_backward_workspace_bytes(n, dim), x_c)
         _capi.check(lib.gnntrk_oc_backward(C.byref(a), ops._p(g), ops._p(out), ops._p(gx),
-                                           ops._p(gbeta), n, ops._stream(x_c)), lib)
+                                           ops._p(gbeta), n, ops._p(ws), ws.numel(), ops._stream(x_c)), lib)
         return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None
 
 

@@ -454,8 +454,13 @@ typedef struct gnntrk_oc_args {
 size_t gnntrk_oc_forward_workspace_bytes(int64_t n);
 int gnntrk_oc_forward(const gnntrk_oc_args *args, float *out /*[9]*/, void *workspace,
                       size_t workspace_bytes, void *stream);
+/* backward: hit pass (thread = hit) + condensation-point pass (thread = CP, the hits cut into
+ * slices whose partials - the workspace - are added in slice order: deterministic).  max_cps:
+ * host-side upper bound of the condensation-point count (n always works). */
+size_t gnntrk_oc_backward_workspace_bytes(int64_t n, int32_t dim);
 int gnntrk_oc_backward(const gnntrk_oc_args *args, const float *g /*[4]*/, const float *fwd /*[9]*/,
-                       float *gx, float *gbeta, int64_t max_cps, void *stream);
+                       float *gx, float *gbeta, int64_t max_cps, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -151,10 +151,11 @@ inline int lane() { return threadIdx.x & 63; }
 
 template <class F>
 void launch(dim3 grid, dim3 block, F fn) {
-    if (block.x % 64 != 0 || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) {
+    if (block.x % 64 != 0 || block.y != 1 || block.z != 1 || grid.z != 1) {
         fprintf(stderr, "hipemul: unsupported launch geometry\n");
         abort();
     }
+    for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned b = 0; b < grid.x; ++b) {
         Block blk;
         blk.bar.init(block.x);
@@ -163,11 +164,11 @@ void launch(dim3 grid, dim3 block, F fn) {
         std::vector<std::thread> th;
         th.reserve(block.x);
         for (unsigned t = 0; t < block.x; ++t) {
-            th.emplace_back([&, t, b]() {
+            th.emplace_back([&, t, b, by]() {
                 threadIdx = {t, 0, 0};
-                blockIdx = {b, 0, 0};
+                blockIdx = {b, by, 0};
                 blockDim = {block.x, 1, 1};
-                gridDim = {grid.x, 1, 1};
+                gridDim = {grid.x, grid.y, 1};
                 cur_block = &blk;
                 fn();
             });

@@ -58,10 +58,11 @@ class InteractionNetwork(nn.Module, HyperparametersMixin):
             ops.Seg(x, gi.src, relu_in, ("src", gi)),
             ops.Seg(e_csr, None, relu_in),
         ]
-        if x.dtype == torch.bfloat16:
+        lin = self.relational_model.linears()
+        if x.dtype == torch.bfloat16 and ops._fused_supported(rel_segs, [m.weight for m in lin],
+                                                              [m.bias for m in lin], True):
             # bf16 storage: relational model + aggregation as one autograd node, so that the
             # backward kernel takes "direct" and "through aggr" gradients as two terms
-            lin = self.relational_model.linears()
             e_tilde, aggr = ops_bf16.in_edge(rel_segs, [m.weight for m in lin], [m.bias for m in lin],
                                              gi, gi.n_edges)
         else:

@@ -309,6 +309,8 @@ def segment_sum(rows: Tensor, gi: GraphIndex, by: str = "tgt") -> Tensor:
     """``out[n] = sum of rows[k] over CSR positions k whose target (source) is n``.
     ``rows`` must be in CSR order.  PyG ``aggr="add"`` (interaction_network.py:36)."""
     if rows.dtype == torch.bfloat16:
+        if rows.dim() == 2 and rows.shape[1] > 16:  # wider than the bf16 kernel's four chunks: fp32 kernel
+            return _SegmentSum.apply(rows.float(), gi, by).to(torch.bfloat16)
         from . import ops_bf16
         return ops_bf16.SegmentSum16.apply(rows, gi, by)
     return _SegmentSum.apply(rows, gi, by)
@@ -555,14 +557,116 @@ def fused_mlp(segs: Sequence[Seg], weights: Sequence[Tensor],
     for s in segs:
         if s.t.dim() == 1:
             raise ValueError("fused_mlp segments must be 2-D [rows, dim]")
+    bf16 = segs[0].t.dtype == torch.bfloat16
+    if not _fused_supported(segs, weights, biases, bf16):
+        return _wide_mlp(segs, weights, biases, n_rows=int(n_rows), epilogue=epilogue, ca=float(ca), cb=float(cb),
+                         res=res, out_idx=out_idx, out_rows=int(out_rows if out_rows is not None else n_rows))
     spec = _MlpSpec(len(segs), len(weights), any(b is not None for b in biases),
                     [s.idx for s in segs], [s.relu for s in segs], [s.reduce for s in segs],
                     epilogue, float(ca), float(cb), out_idx,
                     int(out_rows if out_rows is not None else n_rows), int(n_rows))
-    if segs[0].t.dtype == torch.bfloat16:  # bf16-storage path (ops_bf16.py)
+    if bf16:  # bf16-storage path (ops_bf16.py)
         from . import ops_bf16
         return ops_bf16.FusedMLP16.apply(spec, *[s.t for s in segs], *weights, *biases, res)
     return _FusedMLP.apply(spec, *[s.t for s in segs], *weights, *biases, res)
+
+
+# ------------------------------------------------ MLPs beyond the fused kernels' shapes
+def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf16: bool) -> bool:
+    """The shapes the register-resident fused kernels hold (include/gnntrk.h: L in {2, 3}; at
+    most sixteen 4-feature input chunks; fp32: in <= 48, hidden <= 64, out <= 16; bf16 storage:
+    hidden (+ the bias row) <= 64, out <= 16)."""
+    L = len(weights)
+    if L not in (2, 3):
+        return False
+    hidden, out_dim = int(weights[0].shape[0]), int(weights[-1].shape[0])
+    in_dim = sum(int(s.t.shape[1]) if s.t.dim() == 2 else 1 for s in segs)
+    chunks = sum((int(s.t.shape[1]) + 3) // 4 for s in segs if s.t.dim() == 2)
+    if out_dim > _capi.MAX_OUT:
+        return False
+    if bf16:
+        has_bias = any(b is not None for b in biases)
+        spare = any(int(s.t.shape[1]) % 4 for s in segs if s.t.dim() == 2)   # a pad slot carries the ones column
+        return chunks + (1 if has_bias and not spare else 0) <= 16 and hidden + (1 if has_bias else 0) <= 64
+    return in_dim <= _capi.MAX_IN and hidden <= _capi.MAX_HIDDEN and chunks <= 16
+
+
+class _GatherRows(torch.autograd.Function):
+    """``out[m] = t[idx[m]]``; the backward folds the row gradients onto the source rows with the
+    deterministic CSR segment sums of the graph index (``reduce`` as in ``Seg``)."""
+
+    @staticmethod
+    def forward(ctx, t, idx, reduce):
+        ctx.idx, ctx.reduce, ctx.n, ctx.dt = idx, reduce, int(t.shape[0]), t.dtype
+        return t.index_select(0, idx.long())
+
+    @staticmethod
+    def backward(ctx, g):
+        g32 = g.to(torch.float32).contiguous()
+        if ctx.reduce == "perm":
+            out = _permute_raw(g32, ctx.idx, scatter=True)
+        elif ctx.reduce is None:
+            raise RuntimeError("gathered segment requires a `reduce` rule for backward")
+        else:
+            by, gi = ctx.reduce
+            rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
+            out = _segment_sum_raw(g32, rowptr, pos, ctx.n)
+        return out.to(ctx.dt), None, None
+
+
+_WIDE_WARNED: set = set()
+
+
+def _wide_mlp(segs: Sequence[Seg], weights, biases, *, n_rows: int, epilogue: int, ca: float, cb: float,
+              res: Optional[Tensor], out_idx: Optional[Tensor], out_rows: int) -> Tensor:
+    """The same operator for shapes the fused kernels do not hold (e.g. ``GraphConstructionResIN``
+    at its default ``hidden_dim=40``: a 120-wide relational input; 128-wide models; L = 1 or
+    L > 3): row gathers, ``cat``, a chain of library GEMMs (hipBLASLt through
+    ``torch.nn.functional.linear``), the epilogue as torch ops.  Gathered node rows still get
+    their gradients through the deterministic segment sums.  Slower than the fused kernels (the
+    layer outputs travel through HBM) - a one-time notice says so."""
+    import torch.nn.functional as F
+
+    bf16 = segs[0].t.dtype == torch.bfloat16
+    shape = (sum(int(s.t.shape[1]) for s in segs), *[int(w.shape[0]) for w in weights])
+    if shape not in _WIDE_WARNED:
+        _WIDE_WARNED.add(shape)
+        import logging
+        logging.getLogger("gnn_tracking_amd").info(
+            "MLP %s is outside the fused kernels' shapes; running it as library GEMMs", "->".join(map(str, shape)))
+    _capi.require_device(*[s.t for s in segs])
+    cols = []
+    for s_ in segs:
+        t = s_.t
+        if s_.relu:
+            t = torch.relu(t)
+        if s_.idx is not None:
+            t = _GatherRows.apply(t, s_.idx, s_.reduce)
+        cols.append(t)
+    x = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
+    if x.shape[0] != n_rows:
+        raise ValueError(f"segments have {x.shape[0]} rows, expected {n_rows}")
+    dt = torch.bfloat16 if bf16 else torch.float32
+    L = len(weights)
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        x = F.linear(x.to(dt), w.to(dt), None if b is None else b.to(dt))
+        if i < L - 1:
+            x = torch.relu(x)
+    if epilogue == _capi.EPI_RELU:
+        x = torch.relu(x)
+    elif epilogue == _capi.EPI_RESIDUAL:
+        x = ca * res.to(x.dtype) + cb * x
+    elif epilogue == _capi.EPI_SIGMOID:
+        x = ca + cb * torch.sigmoid(x.float())   # fp32 in both storage modes
+    if out_idx is not None:
+        if out_rows != n_rows:
+            raise ValueError("out_idx must be a permutation of the rows")
+        x = permute_rows(x.contiguous(), out_idx, scatter=True)
+    if bf16 and x.dtype == torch.bfloat16:
+        # hand the rows on in the padded layout the bf16 kernels expect
+        d, pad = int(x.shape[1]), (-int(x.shape[1])) % 4
+        x = F.pad(x, (0, pad))[:, :d] if pad else x.contiguous()
+    return x
 
 
 # ------------------------------------------------------------------- kNN graphs

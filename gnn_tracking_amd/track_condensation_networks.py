@@ -162,9 +162,10 @@ class GraphConstructionResIN(nn.Module, HyperparametersMixin):
         """Refinement of a metric-learning latent space with a residual stack of interaction
         networks (models/graph_construction.py:136-219): encoders to ``hidden_dim``, ``ResIN``
         with node and edge width ``hidden_dim``, decoder to ``h_outdim``, mixed with the first
-        ``h_outdim`` input features.  The interaction networks are the fused kernels, so
-        ``3 * hidden_dim`` has to fit their input width (48 features in fp32, 64 in bf16
-        storage); wider stacks raise ``NotImplementedError`` there."""
+        ``h_outdim`` input features.  Where ``3 * hidden_dim`` fits the fused kernels' input width
+        (48 features in fp32, 64 in bf16 storage) the interaction networks are the fused kernels;
+        wider stacks - the reference's default ``hidden_dim=40`` included - run the same operator
+        as library GEMMs (``ops._wide_mlp``)."""
         super().__init__()
         self.save_hyperparameters()
         self._node_encoder = MLP(node_indim, hidden_dim, hidden_dim=hidden_dim, L=2, bias=False)

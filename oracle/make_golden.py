@@ -205,6 +205,8 @@ EC_VARIANTS = {
                              use_node_embedding=False),
     "no_node": dict(L_ec=2, hidden_dim=8, use_node_embedding=False),
     "alpha0": dict(L_ec=2, hidden_dim=None, alpha=0.0),
+    # widths beyond the fused kernels (hidden 128, 20-wide node / edge spaces): library-GEMM path
+    "wide_h128": dict(L_ec=1, hidden_dim=128, interaction_node_dim=20, interaction_edge_dim=20),
 }
 
 
@@ -222,7 +224,7 @@ def g2_ec_variants():
         out = model(Data(x=x, edge_index=ei, edge_attr=ea))
         loss = EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"], y=y.float(), pt=pt, edge_index=ei)
         loss.backward()
-        okw = {k: v for k, v in kw.items() if k != "hidden_dim"}
+        okw = {k: v for k, v in kw.items() if k not in ("hidden_dim", "interaction_node_dim", "interaction_edge_dim")}
         oo, ol, og, _ = O.ec_training_step(x, ei, ea, y, p0, model_kwargs=okw, pt=pt,
                                            pt_thld=0.9)
         worst = max(worst, close(oo["W"], out["W"], 1e-6, name + " W"),
@@ -541,7 +543,9 @@ def g10_hetero_fcnn():
 
 
 GC_RESIN_CASES = {"h12_l2": dict(h_outdim=6, hidden_dim=12, n_layers=2, alpha=0.5, alpha_fcnn=0.5),
-                  "h16_l1": dict(h_outdim=8, hidden_dim=16, n_layers=1, alpha=0.3, alpha_fcnn=0.7)}
+                  "h16_l1": dict(h_outdim=8, hidden_dim=16, n_layers=1, alpha=0.3, alpha_fcnn=0.7),
+                  # the reference's own defaults (models/graph_construction.py:140-148)
+                  "default_h40": dict(h_outdim=8, hidden_dim=40, n_layers=1, alpha=0.5, alpha_fcnn=0.5)}
 
 
 def g12_gc_resin():

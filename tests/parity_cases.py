@@ -184,6 +184,8 @@ EC_VARIANTS = {
                              use_node_embedding=False),
     "no_node": dict(L_ec=2, hidden_dim=8, use_node_embedding=False),
     "alpha0": dict(L_ec=2, hidden_dim=None, alpha=0.0),
+    # widths beyond the fused kernels (hidden 128, 20-wide node / edge spaces): library-GEMM path
+    "wide_h128": dict(L_ec=1, hidden_dim=128, interaction_node_dim=20, interaction_edge_dim=20),
 }
 
 
@@ -1098,7 +1100,9 @@ def case_full_size_properties(device, n_events=32, n_nodes=150_000, n_edges=2_00
 
 
 GC_RESIN_CASES = {"h12_l2": dict(h_outdim=6, hidden_dim=12, n_layers=2, alpha=0.5, alpha_fcnn=0.5),
-                  "h16_l1": dict(h_outdim=8, hidden_dim=16, n_layers=1, alpha=0.3, alpha_fcnn=0.7)}
+                  "h16_l1": dict(h_outdim=8, hidden_dim=16, n_layers=1, alpha=0.3, alpha_fcnn=0.7),
+                  # the reference's defaults: 120-wide relational input, 40-wide outputs -> library-GEMM path
+                  "default_h40": dict(h_outdim=8, hidden_dim=40, n_layers=1, alpha=0.5, alpha_fcnn=0.5)}
 
 
 def case_gc_resin(device, names=None):
@@ -1117,13 +1121,17 @@ def case_gc_resin(device, names=None):
         (out * tt(z[f"{name}/r"], device)).sum().backward()
         for k, v in model.named_parameters():
             assert_close(v.grad, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
-    wide = G.GraphConstructionResIN(node_indim=14, edge_indim=4, hidden_dim=40).to(device)
-    try:
-        wide(G.Data(x=x, edge_index=ei, edge_attr=ea))
-    except NotImplementedError:
-        pass
-    else:
-        raise AssertionError("3 x 40 input features should exceed the fused kernel's width (no silent fallback)")
+    # bf16 storage through the library-GEMM path (the default width): runs, finite, close to fp32
+    kw = GC_RESIN_CASES["default_h40"]
+    if names is None or "default_h40" in names:
+        model = G.GraphConstructionResIN(node_indim=14, edge_indim=4, **kw)
+        load_params(model, z, "default_h40/p0/")
+        model = model.to(device)
+        with G.bf16_storage():
+            out16 = model(G.Data(x=x, edge_index=ei, edge_attr=ea))["H"]
+            (out16.float() * tt(z["default_h40/r"], device)).sum().backward()
+        assert_close(out16.float(), z["default_h40/H"], 0.05, "default_h40 H (bf16 storage)")
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
 FOCAL_CASES = {"ew_default": ("EdgeWeightFocalLoss", dict()),

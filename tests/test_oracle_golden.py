@@ -34,7 +34,7 @@ def test_ec_variants():
     z = load("g2_ec_variants.npz")
     x, ei, ea, y, pt = (tt(z[k]) for k in ("x", "edge_index", "edge_attr", "y", "pt"))
     for name, kw in P.EC_VARIANTS.items():
-        okw = {k: v for k, v in kw.items() if k != "hidden_dim"}
+        okw = {k: v for k, v in kw.items() if k not in ("hidden_dim", "interaction_node_dim", "interaction_edge_dim")}
         p0 = _params(z, f"{name}/p0/")
         out, loss, grads, _ = O.ec_training_step(x, ei, ea, y, p0, model_kwargs=okw, pt=pt,
                                                  pt_thld=0.9)

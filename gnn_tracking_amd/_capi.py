@@ -67,7 +67,8 @@ class OcArgs(C.Structure):
                 ("mask", C.c_void_p), ("gid", C.c_void_p), ("alphas", C.c_void_p),
                 ("n_cp", C.c_void_p), ("n", C.c_int64), ("dim", C.c_int32), ("stride", C.c_int32),
                 ("q_min", C.c_float), ("radius", C.c_float), ("eps_sqrt", C.c_float),
-                ("mode", C.c_int32)]
+                ("mode", C.c_int32), ("rep_keep_prob", C.c_float), ("_pad", C.c_int32),
+                ("rep_seed", C.c_uint64)]
 
 
 _P = C.c_void_p
@@ -109,6 +110,8 @@ _SIGNATURES = {
                                         C.c_int64, _P, _P, _P]),
     "gnntrk_knn_search": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                     _P, _P, _P]),
+    "gnntrk_knn_search_batched": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                            _P, C.c_int32, _P, _P, _P]),
     "gnntrk_knn_emit": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
     "gnntrk_knn_emit_prefix": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "gnntrk_edge_labels": (C.c_int, [_P, _P, C.c_int64, _P, _P]),

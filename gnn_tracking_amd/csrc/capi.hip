@@ -67,7 +67,7 @@ size_t graph_index_ws_bytes(int64_t, int64_t);
 int graph_index_build(const int64_t *, const gnntrk_graph_index *, void *, size_t, hipStream_t);
 
 // knn.hip
-int knn_search_launch(const float *, int64_t, int, int, int, float, int32_t *, int32_t *,
+int knn_search_launch(const float *, int64_t, int, int, int, float, const int64_t *, int, int32_t *, int32_t *,
                       hipStream_t);
 int knn_emit_launch(const int32_t *, const int32_t *, int64_t, int, int, int64_t *, int64_t *, int64_t,
                     hipStream_t);
@@ -199,7 +199,12 @@ int gnntrk_focal_backward(const float *w, const float *y, const int64_t *src_nod
 }
 int gnntrk_knn_search(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k,
                       float max_radius, int32_t *nbr, int32_t *cnt, void *stream) {
-    return knn_search_launch(x, n, dim, x_stride, k, max_radius, nbr, cnt, (hipStream_t)stream);
+    return knn_search_launch(x, n, dim, x_stride, k, max_radius, nullptr, 0, nbr, cnt, (hipStream_t)stream);
+}
+int gnntrk_knn_search_batched(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k,
+                              float max_radius, const int64_t *seg_ptr, int32_t n_seg, int32_t *nbr,
+                              int32_t *cnt, void *stream) {
+    return knn_search_launch(x, n, dim, x_stride, k, max_radius, seg_ptr, n_seg, nbr, cnt, (hipStream_t)stream);
 }
 int gnntrk_knn_emit(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k, int64_t *offsets,
                     int64_t *edge_index, int64_t n_edges, void *stream) {

@@ -50,15 +50,30 @@ __device__ inline void wave_bitonic_sort(u64 *buf, int cap, int lane) {
     }
 }
 
-template <int DP, bool FULL>  // FULL: dim == DP (no per-feature guard on the scalar loads)
+// segment (event) of row q: the last s with seg_ptr[s] <= q (seg_ptr ascending, seg_ptr[0] = 0)
+__device__ __forceinline__ int knn_segment_of(const int64_t *__restrict__ seg_ptr, int n_seg, int64_t q) {
+    int lo = 0, hi = n_seg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_ptr[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// FULL: dim == DP (no per-feature guard on the scalar loads).  BATCH: rows are grouped into
+// segments (the events of a collated batch, `batch` of torch_cluster's knn_graph / radius_graph:
+// metrics/losses/metric_learning.py:97); a query only sees candidates of its own segment.
+template <int DP, bool FULL, bool BATCH>
 __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict__ x, int64_t n,
                                                         int dim, int stride, int k, int cap,
                                                         int qw, float max_radius,
+                                                        const int64_t *__restrict__ seg_ptr, int n_seg,
                                                         int32_t *__restrict__ nbr,
                                                         int32_t *__restrict__ cnt_out) {
     __shared__ __attribute__((aligned(16))) u64 s_keys[kKnnWaves][kKnnLdsPerWave / 8];
     __shared__ u64 s_tau[kKnnWaves][32];
     __shared__ int s_cnt[kKnnWaves][32];
+    __shared__ int s_lo[kKnnWaves][32], s_hi[kKnnWaves][32];  // candidate range of each query (BATCH)
     // the wave index through readfirstlane: q0 and everything derived from it are scalars, so
     // the query coordinates below are SCALAR loads (constant cache) feeding the VALU as SGPR
     // operands - no LDS traffic for them in the (query, chunk) step
@@ -80,6 +95,20 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
         tau[lane] = tau0;
         cnt[lane] = 0;
     }
+    // candidate range of the wave = the segments its queries live in
+    int64_t c_begin = 0, c_end = n;
+    int *qlo = s_lo[wv], *qhi = s_hi[wv];
+    if (BATCH) {
+        if (lane < 32) {
+            const int64_t q = q0 + (lane < nq ? lane : nq - 1);
+            const int sg = knn_segment_of(seg_ptr, n_seg, q);
+            qlo[lane] = (int)seg_ptr[sg];
+            qhi[lane] = (int)seg_ptr[sg + 1];
+        }
+        knn_wave_sync();
+        c_begin = qlo[0];
+        c_end = qhi[nq - 1];
+    }
     knn_wave_sync();
 
     // candidate rows: every lane loads unconditionally (row index clamped, `d < dim` is a
@@ -92,10 +121,10 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
         for (int d = 0; d < DP; ++d) v[d] = (FULL || d < dim) ? row[d] : 0.f;
     };
     float xc[DP], xn[DP];
-    load_chunk(0, xc);
-    for (int64_t c0 = 0; c0 < n; c0 += 64) {
+    load_chunk(c_begin, xc);
+    for (int64_t c0 = c_begin; c0 < c_end; c0 += 64) {
         const int64_t j = c0 + lane;
-        load_chunk(c0 + 64 < n ? c0 + 64 : c0, xn);
+        load_chunk(c0 + 64 < c_end ? c0 + 64 : c0, xn);
         // queries in groups of kKnnGroup: the scalar loads of the coordinates and the LDS
         // reads of the thresholds of the whole group are in flight together (a scalar load
         // can only be waited for with lgkmcnt(0): one query per step means one full memory
@@ -116,7 +145,8 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
                     d2 = __fmaf_rn(t, t, d2);
                 }
                 key[u] = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)j;
-                if (j >= n || j == q0 + q || qb + u >= nq) key[u] = kKeyMax;
+                if (j >= c_end || j == q0 + q || qb + u >= nq) key[u] = kKeyMax;
+                if (BATCH && (j < qlo[q] || j >= qhi[q])) key[u] = kKeyMax;  // another event's hit
             }
 #pragma unroll
             for (int u = 0; u < kKnnGroup; ++u) {
@@ -254,9 +284,10 @@ static int stream_grid(int64_t n) {
 }
 
 int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, float max_radius,
-                      int32_t *nbr, int32_t *cnt, hipStream_t stream) {
+                      const int64_t *seg_ptr, int n_seg, int32_t *nbr, int32_t *cnt, hipStream_t stream) {
     if (!x || !nbr || !cnt || n < 0 || dim < 1 || stride < dim || k < 1)
         return fail(GNNTRK_EINVAL, "knn_search: bad argument");
+    if (seg_ptr && n_seg < 1) return fail(GNNTRK_EINVAL, "knn_search: seg_ptr needs n_seg >= 1");
     if (dim > 32) return fail(GNNTRK_EUNSUPPORTED, "knn_search: dim > 32 not supported");
     if (k > 448) return fail(GNNTRK_EUNSUPPORTED, "knn_search: k > 448 not supported");
     if (n > 0x7fffffff) return fail(GNNTRK_EUNSUPPORTED, "knn_search: n must fit int32");
@@ -266,13 +297,15 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
     int qw = kKnnLdsPerWave / (cap * 8);
     if (qw > 32) qw = 32;
     const int64_t grid = ceil_div(n, (int64_t)qw * kKnnWaves);
+#define KNN_LAUNCH(DP, FULL_, BATCH_)                                                               \
+    hipLaunchKernelGGL((knn_kernel<DP, FULL_, BATCH_>), dim3((unsigned)grid), dim3(kKnnBlock), 0, stream, x, n, \
+                       dim, stride, k, cap, qw, max_radius, seg_ptr, n_seg, nbr, cnt)
 #define KNN_CALL(DP)                                                                               \
-    if (dim == DP)                                                                                 \
-        hipLaunchKernelGGL((knn_kernel<DP, true>), dim3((unsigned)grid), dim3(kKnnBlock), 0, stream, x, n, \
-                           dim, stride, k, cap, qw, max_radius, nbr, cnt);                         \
-    else                                                                                           \
-        hipLaunchKernelGGL((knn_kernel<DP, false>), dim3((unsigned)grid), dim3(kKnnBlock), 0, stream, x, n, \
-                           dim, stride, k, cap, qw, max_radius, nbr, cnt)
+    if (seg_ptr) {                                                                                 \
+        if (dim == DP) KNN_LAUNCH(DP, true, true); else KNN_LAUNCH(DP, false, true);               \
+    } else {                                                                                       \
+        if (dim == DP) KNN_LAUNCH(DP, true, false); else KNN_LAUNCH(DP, false, false);             \
+    }
     if (dim <= 4) {
         KNN_CALL(4);
     } else if (dim <= 8) {
@@ -283,6 +316,7 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
         KNN_CALL(32);
     }
 #undef KNN_CALL
+#undef KNN_LAUNCH
     return check_launch("knn_search");
 }
 

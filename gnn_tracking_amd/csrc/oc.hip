@@ -155,7 +155,19 @@ struct OcParams {
     int32_t dim, stride;
     float q_min, radius, eps_sqrt;
     int32_t mode;  // 0 RG, 1 Tiger
+    float keep;    // probability of keeping a repulsive pair (>= 1: all)
+    u64 seed;
 };
+
+// repulsive pair (hit j, condensation point k) kept?  splitmix64 of (seed, j, k) -> 24-bit uniform
+__device__ __forceinline__ bool oc_keep_pair(const OcParams &p, int64_t j, int k) {
+    if (p.keep >= 1.f) return true;
+    u64 z = p.seed + 0x9E3779B97F4A7C15ull * ((u64)j * 0x100000001B3ull + (u64)(uint32_t)k + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.f / 16777216.f) < p.keep;
+}
 
 __device__ __forceinline__ float oc_q(float beta, float q_min) {
     const float a = atanhf(beta);
@@ -216,8 +228,8 @@ __global__ __launch_bounds__(kOcTpb) void oc_forward_kernel(const OcParams p,
                 const bool att = (p.mode == 1) ? (gj == k0 + i) : (gj == k0 + i && mj && !is_cp);
                 if (att) va += (double)(qq * d2);
             } else if (d2 < r2) {
-                vr += (double)(qq * (p.radius - sqrtf(p.eps_sqrt + d2)));
-                nrep += 1.0;
+                nrep += 1.0;  // (counted before the sub-sampling, as the reference's n_rep)
+                if (oc_keep_pair(p, j, k0 + i)) vr += (double)(qq * (p.radius - sqrtf(p.eps_sqrt + d2)));
             }
         }
     }
@@ -262,7 +274,8 @@ __global__ __launch_bounds__(kOcTpb) void oc_finalize_kernel(const OcParams p,
     if (threadIdx.x == 0) {
         const double eps = 1e-9;
         const double norm_att = eps + n_oi - (double)K;
-        const double norm_rep = eps + ((double)K - 1.0) * (double)p.n;
+        double norm_rep = eps + ((double)K - 1.0) * (double)p.n;
+        if (p.keep < 1.f) norm_rep *= (double)p.keep;  // oc.py:328
         out[0] = (float)(va / norm_att);
         out[1] = (float)(vr / norm_rep);
         out[2] = (float)(cow / (double)K);
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_hits_kernel(const OcParams
                     cx = ca * 2.f * qj * s_q[i];
                     cq = ca * s_q[i] * d2;
                 }
-            } else if (d2 < r2) {
+            } else if (d2 < r2 && oc_keep_pair(p, j, k0 + i)) {
                 const float sd = sqrtf(p.eps_sqrt + d2);
                 cx = sd > 0.f ? -cr * qj * s_q[i] / sd : 0.f;
                 cq = cr * s_q[i] * (p.radius - sd);
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_cps_kernel(const OcParams 
                     cx = ca * 2.f * s_q[i] * qk;
                     cq = ca * s_q[i] * d2;
                 }
-            } else if (d2 < r2) {
+            } else if (d2 < r2 && oc_keep_pair(p, j0 + i, k)) {
                 const float sd = sqrtf(p.eps_sqrt + d2);
                 cx = sd > 0.f ? -cr * s_q[i] * qk / sd : 0.f;
                 cq = cr * s_q[i] * (p.radius - sd);
@@ -551,6 +564,8 @@ static OcParams oc_params(const gnntrk_oc_args *a) {
     p.x = a->x; p.beta = a->beta; p.pid = a->particle_id; p.mask = a->mask; p.gid = a->gid;
     p.alphas = a->alphas; p.n_cp = a->n_cp; p.n = a->n; p.dim = a->dim; p.stride = a->stride;
     p.q_min = a->q_min; p.radius = a->radius; p.eps_sqrt = a->eps_sqrt; p.mode = a->mode;
+    p.keep = a->rep_keep_prob > 0.f ? a->rep_keep_prob : 1.f;   // (0 = field left unset: all pairs)
+    p.seed = a->rep_seed;
     return p;
 }
 

@@ -30,17 +30,16 @@ def radius_graph(x: T, r: float, batch: T | None = None, max_num_neighbors: int 
     xd = x.detach()
     if batch is None:
         return ops.knn_graph(xd, max_num_neighbors, r)
-    counts = torch.bincount(batch.long())
-    if bool((batch[1:] < batch[:-1]).any()):
+    # all events of the collated batch in ONE search (gnntrk_knn_search_batched): row offsets of
+    # the events from `batch` (sorted, as PyG's collate produces it - checked on the device
+    # together with the one unavoidable read of the edge count)
+    b = batch.long()
+    counts = torch.bincount(b)
+    seg_ptr = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=x.device)
+    seg_ptr[1:] = torch.cumsum(counts, 0)
+    if b.numel() > 1 and bool((b[1:] < b[:-1]).any()):
         raise ValueError("radius_graph: `batch` must be sorted (PyG convention)")
-    out, off = [], 0
-    for n in counts.tolist():
-        if n > 1:
-            out.append(ops.knn_graph(xd[off:off + n], max_num_neighbors, r) + off)
-        off += n
-    if not out:
-        return torch.empty(2, 0, dtype=torch.int64, device=x.device)
-    return torch.cat(out, dim=1)
+    return ops.knn_graph(xd, max_num_neighbors, r, seg_ptr=seg_ptr)
 
 
 class GraphConstructionHingeEmbeddingLoss(nn.Module, HyperparametersMixin):

@@ -6,8 +6,9 @@ constructor keywords, ``hparams`` and return type.  Neither the N x K matrices o
 variant nor the radius graph of the RG variant are materialised: both are sums over
 (hit, condensation point) pairs evaluated by ``gnntrk_oc_forward/backward`` (csrc/oc.hip).
 
-Not implemented (raise): ``sample_pids < 1`` and Tiger's ``max_n_rep > 0`` - both are random
-sub-sampling switches for memory that the fused kernels make unnecessary.
+``sample_pids < 1`` and Tiger's ``max_n_rep > 0`` (random sub-sampling switches the reference
+has for memory) are honoured for parity of the training dynamics; the random draws differ from
+the reference's (as they do between its own CPU and GPU runs).
 """
 
 from __future__ import annotations
@@ -60,7 +61,7 @@ class _CondensationPotentials(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, beta, x, particle_id, mask, q_min: float, radius: float, eps_sqrt: float,
-                mode: int):
+                mode: int, keep: float = 1.0, seed: int = 0):
         _capi.require_device(beta, x, particle_id, mask)
         lib = _capi.load()
         dev = x.device
@@ -78,31 +79,33 @@ class _CondensationPotentials(torch.autograd.Function):
                                              ops._p(alphas), ops._p(gid), ops._p(n_cp), ops._p(ws),
                                              ws.numel(), st), lib)
         a = _capi.OcArgs(ops._p(x_c), ops._p(beta_c), ops._p(pid), ops._p(mask8), ops._p(gid),
-                         ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode)
+                         ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode,
+                         float(keep), 0, int(seed))
         out = torch.empty(9, dtype=torch.float32, device=dev)
         ws2 = ops._ws(lib.gnntrk_oc_forward_workspace_bytes(n), x_c)
         _capi.check(lib.gnntrk_oc_forward(C.byref(a), ops._p(out), ops._p(ws2), ws2.numel(), st), lib)
         ctx.save_for_backward(beta_c, x_c, pid, mask8, gid, alphas, n_cp, out)
-        ctx.cfg = (q_min, radius, eps_sqrt, mode, beta.dtype, x.dtype)
+        ctx.cfg = (q_min, radius, eps_sqrt, mode, beta.dtype, x.dtype, float(keep), int(seed))
         return out[0], out[1], out[2], out[3], out[7].detach()
 
     @staticmethod
     def backward(ctx, g_att, g_rep, g_cow, g_noise, _g_nrep):
         lib = _capi.load()
         beta_c, x_c, pid, mask8, gid, alphas, n_cp, out = ctx.saved_tensors
-        q_min, radius, eps_sqrt, mode, bdt, xdt = ctx.cfg
+        q_min, radius, eps_sqrt, mode, bdt, xdt, keep, seed = ctx.cfg
         n, dim = int(x_c.shape[0]), int(x_c.shape[1])
         g = torch.stack([t.to(torch.float32).reshape(()) if t is not None
                          else torch.zeros((), device=x_c.device)
                          for t in (g_att, g_rep, g_cow, g_noise)]).contiguous()
         a = _capi.OcArgs(ops._p(x_c), ops._p(beta_c), ops._p(pid), ops._p(mask8), ops._p(gid),
-                         ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode)
+                         ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode,
+                         keep, 0, seed)
         gx = torch.empty_like(x_c)
         gbeta = torch.empty_like(beta_c)
         ws = ops._ws(lib.gnntrk_oc_backward_workspace_bytes(n, dim), x_c)
         _capi.check(lib.gnntrk_oc_backward(C.byref(a), ops._p(g), ops._p(out), ops._p(gx),
                                            ops._p(gbeta), n, ops._p(ws), ws.numel(), ops._stream(x_c)), lib)
-        return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None
+        return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None, None, None
 
 
 class _CondensationLoss(MultiLossFct, HyperparametersMixin):
@@ -123,13 +126,22 @@ class _CondensationLoss(MultiLossFct, HyperparametersMixin):
                                           pt_thld=self.hparams.pt_thld,
                                           max_eta=self.hparams.max_eta)
         if self.hparams.sample_pids < 1:
-            raise NotImplementedError(
-                "sample_pids < 1 (random sub-sampling to save memory) is not implemented: the "
-                "fused kernels never materialise the N x K matrices it exists to shrink")
+            # oc.py:222-226 / :403-407: a random subset of the hits of interest (the reference does
+            # it to save memory; kept for parity of the training dynamics)
+            mask = mask & (torch.rand_like(beta, dtype=torch.float16) < self.hparams.sample_pids)
         # If there are no hits left after masking, then we get a NaN loss.
         assert bool(mask.any()), "No hits left after masking"
-        att, rep, cow, noise, n_rep = _CondensationPotentials.apply(
-            beta, x, particle_id, mask, float(self.hparams.q_min), 1.0, self._eps_sqrt, self._mode)
+        args = (beta, x, particle_id, mask, float(self.hparams.q_min), 1.0, self._eps_sqrt, self._mode)
+        att, rep, cow, noise, n_rep = _CondensationPotentials.apply(*args)
+        max_n_rep = int(getattr(self.hparams, "max_n_rep", 0) or 0)
+        if max_n_rep > 0 and int(n_rep) > max_n_rep:
+            # oc.py:322-328: keep repulsive pairs with probability max_n_rep / n_rep and scale the
+            # normalisation accordingly.  The pairs are chosen by a hash of (seed, hit, condensation
+            # point) inside the kernels (no N x K random matrix); the seed comes from torch's
+            # generator, so runs are reproducible under torch.manual_seed.  n_rep is reported
+            # before the sub-sampling, as the reference does.
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            att, rep, cow, noise, _ = _CondensationPotentials.apply(*args, max_n_rep / float(n_rep), seed)
         losses = {"attractive": att, "repulsive": rep, "coward": cow, "noise": noise}
         weights = {"attractive": 1.0, "repulsive": self.hparams.lw_repulsive,
                    "noise": self.hparams.lw_noise, "coward": self.hparams.lw_coward}
@@ -157,13 +169,23 @@ class CondensationLossRG(_CondensationLoss):
                 interface parity; the fused kernel sums over ALL hits within the unit radius
                 (the reference's result whenever the cap is not reached - with the cap reached
                 torch_cluster keeps an implementation-defined subset)
-            sample_pids: must be 1.0
+            sample_pids: fraction of the hits of interest that take part (random, per call)
         """
         super().__init__()
         self.save_hyperparameters()
 
+    _cap_notice_given = False
+
     def forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
                 ec_hit_mask: T | None = None, eta: T, **kwargs) -> MultiLossFctReturn:
+        if not CondensationLossRG._cap_notice_given:
+            CondensationLossRG._cap_notice_given = True
+            import logging
+            logging.getLogger("gnn_tracking_amd").warning(
+                "CondensationLossRG: max_num_neighbors=%s is not applied - every hit inside the unit radius of a "
+                "condensation point contributes.  This equals the reference whenever no hit has more than that many "
+                "neighbours inside the radius; beyond that torch_cluster.radius_graph keeps an implementation-defined "
+                "subset (the first ones found, differently on CPU and GPU).", self.hparams.max_num_neighbors)
         # NB: like the reference (oc.py:207-213) eta is NOT sliced by ec_hit_mask here
         return self._forward(beta=beta, x=x, particle_id=particle_id,
                              reconstructable=reconstructable, pt=pt, ec_hit_mask=ec_hit_mask,
@@ -179,13 +201,11 @@ class CondensationLossTiger(_CondensationLoss):
                  sample_pids: float = 1.0):
         """Condensation loss, dense formulation (oc.py:350-436) without the N x K matrices.
 
-        Args: as ``CondensationLossRG``; ``max_n_rep`` (random sub-sampling of repulsive
-            pairs) must be 0.
+        Args: as ``CondensationLossRG``; ``max_n_rep``: if more repulsive pairs than this are
+            inside the unit radius, a random subset of about that size is used (0: all).
         """
         super().__init__()
         self.save_hyperparameters()
-        if max_n_rep:
-            raise NotImplementedError("max_n_rep > 0 (random sub-sampling) is not implemented")
 
     def forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
                 ec_hit_mask: T | None = None, eta: T, **kwargs) -> MultiLossFctReturn:

@@ -670,10 +670,13 @@ def _wide_mlp(segs: Sequence[Seg], weights, biases, *, n_rows: int, epilogue: in
 
 
 # ------------------------------------------------------------------- kNN graphs
-def knn_graph(x: Tensor, k: int, max_radius: Optional[float] = None) -> Tensor:
+def knn_graph(x: Tensor, k: int, max_radius: Optional[float] = None, seg_ptr: Optional[Tensor] = None) -> Tensor:
     """``knn_with_max_radius`` (models/graph_construction.py:222-237): int64 ``[2, M]``
     edge index, row 0 = neighbour (source), row 1 = query (target), grouped by query,
-    ascending distance, self excluded; with ``max_radius`` only ``||x_j - x_i|| < r``."""
+    ascending distance, self excluded; with ``max_radius`` only ``||x_j - x_i|| < r``.
+    ``seg_ptr`` (int64 ``[S + 1]`` row offsets of the events of a collated batch): neighbours
+    are searched inside the query's own event - torch_cluster's ``batch`` argument, all events
+    in one launch."""
     _capi.require_device(x)
     lib = _capi.load()
     if x.dim() != 2:
@@ -688,8 +691,12 @@ def knn_graph(x: Tensor, k: int, max_radius: Optional[float] = None) -> Tensor:
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
     st = _stream(x)
     r = float(max_radius) if max_radius is not None else -1.0
-    _capi.check(lib.gnntrk_knn_search(_p(x), n, dim, _row_stride(x), kk, r, _p(nbr), _p(cnt), st),
-                lib)
+    if seg_ptr is not None:
+        sp = seg_ptr.to(device=dev, dtype=torch.int64).contiguous()
+        _capi.check(lib.gnntrk_knn_search_batched(_p(x), n, dim, _row_stride(x), kk, r, _p(sp), int(sp.numel()) - 1,
+                                                  _p(nbr), _p(cnt), st), lib)
+    else:
+        _capi.check(lib.gnntrk_knn_search(_p(x), n, dim, _row_stride(x), kk, r, _p(nbr), _p(cnt), st), lib)
     off = torch.empty(n + 1, dtype=torch.int64, device=dev)
     _capi.check(lib.gnntrk_knn_emit(_p(nbr), _p(cnt), n, kk, _p(off), None, 0, st), lib)
     m = int(off[n].item())  # the one host sync: the output size is data dependent

@@ -83,22 +83,34 @@ class Skip2ResidualNetwork(ResidualNetwork):
                  add_bn: bool = False, **kwargs):
         """Blocks of two layers joined by a residual (resin.py:117-175).  The reference
         walks ``pairwise(range(n))`` - overlapping pairs (0,1),(1,2),... - and so does
-        this.  ``add_bn=True`` (BatchNorm1d between layers) is not implemented: it is
-        off in every reference config and would couple events of a batch."""
+        this.  ``add_bn``: ``BatchNorm1d`` on the node and edge inputs of every layer
+        (resin.py:143-151; torch's own batch norm between the fused kernels - its statistics
+        are sums over rows, so the CSR edge order does not change them; note that it couples the
+        events of a collated batch, exactly as in the reference)."""
         if len(layers) % 2 != 0:
             raise ValueError("Only even number of layers allowed at the moment")
-        if add_bn:
-            raise NotImplementedError("skip2 with add_bn=True is not implemented")
         super().__init__(layers=layers, **kwargs)
+        self._add_bn = bool(add_bn)
+        self._node_batch_norms = nn.ModuleList(
+            [nn.BatchNorm1d(node_dim) if add_bn else nn.Identity() for _ in layers])
+        self._edge_batch_norms = nn.ModuleList(
+            [nn.BatchNorm1d(edge_dim) if add_bn else nn.Identity() for _ in layers])
+
+    def _bn(self, norms, i: int, t):
+        if not self._add_bn:
+            return t
+        return norms[i](t.float()).to(t.dtype)
 
     def forward_csr(self, gi, x, e):
         es = [e] if self._collect_hidden_edge_embeds else None
         n = len(self.layers)
         for i0 in range(n - 1):
-            hx, he = self.layers[i0].forward_csr(gi, x, e, relu_in=i0 > 0)
-            x, e = self.layers[i0 + 1].forward_csr(gi, hx, he, relu_in=True,
-                                                   residue=_res(x, self._alpha),
-                                                   alpha_residue=self._alpha)
+            i1 = i0 + 1
+            hx, he = self.layers[i0].forward_csr(gi, self._bn(self._node_batch_norms, i0, x),
+                                                 self._bn(self._edge_batch_norms, i0, e), relu_in=i0 > 0)
+            x, e = self.layers[i1].forward_csr(gi, self._bn(self._node_batch_norms, i1, hx),
+                                               self._bn(self._edge_batch_norms, i1, he), relu_in=True,
+                                               residue=_res(x, self._alpha), alpha_residue=self._alpha)
             if es is not None:
                 es.append(e)
         return x, e, es

@@ -338,6 +338,13 @@ int gnntrk_focal_backward(const float *w, const float *y, const int64_t *src_nod
  */
 int gnntrk_knn_search(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k,
                       float max_radius, int32_t *nbr, int32_t *cnt, void *stream);
+/* The `batch` argument of torch_cluster's knn_graph / radius_graph (metrics/losses/
+ * metric_learning.py:97, :232): rows [seg_ptr[s], seg_ptr[s+1]) are event s of a collated batch
+ * (seg_ptr: n_seg + 1 ascending int64 offsets on the device, seg_ptr[0] = 0, seg_ptr[n_seg] = n);
+ * neighbours are searched inside the query's own event only - all events in ONE launch. */
+int gnntrk_knn_search_batched(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k,
+                              float max_radius, const int64_t *seg_ptr, int32_t n_seg, int32_t *nbr,
+                              int32_t *cnt, void *stream);
 int gnntrk_knn_emit(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k, int64_t *offsets,
                     int64_t *edge_index, int64_t n_edges, void *stream);
 /* The k_take <= k_stride nearest neighbours out of a search done with k = k_stride: the same
@@ -449,6 +456,12 @@ typedef struct gnntrk_oc_args {
     int32_t dim, stride;
     float q_min, radius, eps_sqrt;
     int32_t mode;
+    /* condensation_loss_tiger's max_n_rep (oc.py:322-328): keep a repulsive pair (hit j, condensation
+     * point k) with probability rep_keep_prob, decided by a hash of (rep_seed, j, k) - the same
+     * pairs in the forward and both backward passes - and scale norm_rep by it.  >= 1: all pairs. */
+    float rep_keep_prob;
+    int32_t _pad;
+    uint64_t rep_seed;
 } gnntrk_oc_args;
 
 size_t gnntrk_oc_forward_workspace_bytes(int64_t n);

@@ -333,13 +333,22 @@ def g3b_resin():
         "skip1": dict(n_layers=3, residual_type="skip1", alpha=0.5),
         "skip2": dict(n_layers=2, residual_type="skip2", alpha=0.3),
         "skip_top": dict(n_layers=3, residual_type="skip_top", alpha=0.7),
+        # resin.py:143-151: BatchNorm1d on the inputs of every layer, training mode (batch statistics)
+        "skip2_bn": dict(n_layers=2, residual_type="skip2", alpha=0.3, add_bn=True),
     }.items():
+        kw = dict(kw)
+        add_bn = kw.pop("add_bn", False)
         torch.manual_seed(5)
         m = ResIN(node_dim=5, edge_dim=4, object_hidden_dim=12, relational_hidden_dim=20,
-                  residual_kwargs={"collect_hidden_edge_embeds": True}, **kw)
+                  residual_kwargs={"collect_hidden_edge_embeds": True, **({"add_bn": True} if add_bn else {})}, **kw)
+        if add_bn:
+            with torch.no_grad():   # non-trivial affine parameters
+                for bn in list(m.network._node_batch_norms) + list(m.network._edge_batch_norms):
+                    bn.weight.uniform_(0.5, 1.5)
+                    bn.bias.uniform_(-0.3, 0.3)
         p0 = {"r." + k: v for k, v in sd(m).items()}
         xo, eo, es = m(x, ei, ea)
-        ox, oe, oes = O.resin(x, ei, ea, p0, "r", collect_hidden_edge_embeds=True, **kw)
+        ox, oe, oes = O.resin(x, ei, ea, p0, "r", collect_hidden_edge_embeds=True, add_bn=add_bn, **kw)
         worst = max(worst, close(ox, xo, 1e-6, name), close(oe, eo, 1e-6, name),
                     close(torch.cat(oes, 1), torch.cat(es, 1), 1e-6, name))
         arrs[f"{name}/x_out"] = xo

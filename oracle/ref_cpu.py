@@ -92,8 +92,9 @@ def _sqconvex(delta: Tensor, residue: Tensor | None, alpha: float) -> Tensor:
 
 def resin(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, prefix: str, *,
           n_layers: int, alpha: float = 0.5, residual_type: str = "skip1",
-          collect_hidden_edge_embeds: bool = False, connect_to: int = 1):
-    """models/resin.py:99-114 (skip1), :153-175 (skip2, no BN), :197-216 (skip_top).
+          collect_hidden_edge_embeds: bool = False, connect_to: int = 1, add_bn: bool = False):
+    """models/resin.py:99-114 (skip1), :153-175 (skip2; ``add_bn``: BatchNorm1d in training
+    mode on the inputs of every layer, :143-151), :197-216 (skip_top).
 
     Returns ``(x, edge_attr, edge_attrs or None)``.
     """
@@ -113,11 +114,17 @@ def resin(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: dict, prefix: str
             raise ValueError("Only even number of layers allowed at the moment")
         # NB: the reference iterates ``pairwise(range(n))`` = (0,1),(1,2),...,(n-2,n-1)
         # (resin.py:157), i.e. overlapping pairs: n-1 blocks of two IN applications.
+        def bn(kind, i, t):  # batch statistics, biased variance, eps 1e-5 (torch.nn.BatchNorm1d.forward)
+            if not add_bn:
+                return t
+            w, b = p[f"{prefix}.network._{kind}_batch_norms.{i}.weight"], p[f"{prefix}.network._{kind}_batch_norms.{i}.bias"]
+            return (t - t.mean(0)) / torch.sqrt(t.var(0, unbiased=False) + 1e-5) * w + b
+
         for i0 in range(n_layers - 1):
             i1 = i0 + 1
             act0 = relu if i0 > 0 else ident
-            hx, he = interaction_network(act0(x), edge_index, act0(edge_attr), p, lp(i0))
-            dx, edge_attr = interaction_network(relu(hx), edge_index, relu(he), p, lp(i1))
+            hx, he = interaction_network(act0(bn("node", i0, x)), edge_index, act0(bn("edge", i0, edge_attr)), p, lp(i0))
+            dx, edge_attr = interaction_network(relu(bn("node", i1, hx)), edge_index, relu(bn("edge", i1, he)), p, lp(i1))
             x = _sqconvex(dx, x, alpha)
             if edge_attrs is not None:
                 edge_attrs.append(edge_attr)

@@ -135,9 +135,12 @@ def case_resin(device):
         "skip1": dict(n_layers=3, residual_type="skip1", alpha=0.5),
         "skip2": dict(n_layers=2, residual_type="skip2", alpha=0.3),
         "skip_top": dict(n_layers=3, residual_type="skip_top", alpha=0.7),
+        "skip2_bn": dict(n_layers=2, residual_type="skip2", alpha=0.3, add_bn=True),
     }.items():
+        kw = dict(kw)
+        rk = {"collect_hidden_edge_embeds": True, **({"add_bn": True} if kw.pop("add_bn", False) else {})}
         m = G.ResIN(node_dim=5, edge_dim=4, object_hidden_dim=12, relational_hidden_dim=20,
-                    residual_kwargs={"collect_hidden_edge_embeds": True}, **kw)
+                    residual_kwargs=rk, **kw)
         load_params(m, z, f"{name}/p0/r.")
         m = m.to(device)
         xo, eo, es = m(x, ei, ea)
@@ -1381,3 +1384,88 @@ def case_tc_step(device, names=None):
             x=tt(z["x"], device), edge_index=tt(z["edge_index_in"], device), particle_id=tt(z["particle_id"], device),
             pt=tt(z["pt"], device), eta=tt(z["eta"], device), reconstructable=tt(z["reconstructable"], device),
             layer=tt(z["layer"], device), sector=tt(z["sector"], device))))
+
+
+def case_oc_sampling(device):
+    """The reference's random sub-sampling switches of the condensation losses (oc.py:222-226,
+    :322-328): ``max_n_rep`` keeps about that many repulsive pairs and rescales the normalisation
+    (an unbiased estimate of the full term; the same pairs in forward and backward - checked by a
+    directional finite difference; reproducible under ``torch.manual_seed``; ``n_rep`` reported
+    before the sampling), ``sample_pids`` thins the hits of interest."""
+    from gnn_tracking_amd.losses_oc import CondensationLossRG, CondensationLossTiger
+
+    z = load("g5_oc.npz")
+    t = {k: tt(z[f"td3/{k}"]) for k in ("beta", "x", "particle_id", "pt", "eta", "reconstructable")}
+    kw = dict(particle_id=t["particle_id"].to(device), reconstructable=t["reconstructable"].float().to(device),
+              pt=t["pt"].float().to(device), eta=t["eta"].float().to(device))
+    beta = t["beta"].float().to(device)
+    x0 = t["x"].float().to(device)
+    full = CondensationLossTiger(lw_repulsive=1.0)(beta=beta, x=x0, **kw)
+    n_rep = int(full.extra_metrics["n_rep"])
+    assert n_rep > 300, "case needs repulsive pairs"
+    sub = CondensationLossTiger(lw_repulsive=1.0, max_n_rep=n_rep // 3)
+
+    def run(x):
+        torch.manual_seed(123)
+        return sub(beta=beta, x=x, **kw)
+
+    r1, r2 = run(x0), run(x0)
+    assert int(r1.extra_metrics["n_rep"]) == n_rep, "n_rep is the count before the sub-sampling"
+    assert float(r1.loss_dct["repulsive"]) == float(r2.loss_dct["repulsive"]), "same seed, same pairs"
+    assert_close(r1.loss_dct["attractive"], full.loss_dct["attractive"], 1e-6, "attractive is not sampled")
+    rel = abs(float(r1.loss_dct["repulsive"]) - float(full.loss_dct["repulsive"])) / float(full.loss_dct["repulsive"])
+    assert rel < 0.3, f"sub-sampled repulsive term off by {rel:.2f} (a third of {n_rep} pairs)"
+    torch.manual_seed(7)
+    assert float(sub(beta=beta, x=x0, **kw).loss_dct["repulsive"]) != float(r1.loss_dct["repulsive"]), "seed ignored"
+    # forward and backward use the same pairs: directional derivative of the sampled repulsive term at a
+    # FIXED keep probability and seed (through the loss class the probability itself moves with x)
+    from gnn_tracking_amd.losses_oc import _CondensationPotentials
+    from gnn_tracking_amd.graph_masks import get_good_node_mask_tensors
+
+    mask = get_good_node_mask_tensors(pt=kw["pt"], particle_id=kw["particle_id"], reconstructable=kw["reconstructable"],
+                                      eta=kw["eta"])
+
+    def rep(x, b):
+        return _CondensationPotentials.apply(b, x, kw["particle_id"], mask, 0.01, 1.0, 0.0, 1, 0.4, 99)[1]
+
+    xg = x0.clone().requires_grad_(True)
+    bg = beta.clone().requires_grad_(True)
+    rep(xg, bg).backward()
+    g = np.random.default_rng(2)
+    d = tt(g.normal(size=tuple(x0.shape)).astype(np.float32), device)
+    eps = 2e-3
+    fd = (float(rep(x0 + eps * d, beta)) - float(rep(x0 - eps * d, beta))) / (2 * eps)
+    an = float((xg.grad * d).sum())
+    assert abs(fd - an) <= 0.05 * max(abs(an), abs(fd)) + 1e-7, f"finite difference {fd:.4e} vs autograd {an:.4e}"
+    assert torch.isfinite(bg.grad).all()
+    full_rep = _CondensationPotentials.apply(beta, x0, kw["particle_id"], mask, 0.01, 1.0, 0.0, 1)[1]
+    assert abs(float(rep(x0, beta)) - float(full_rep)) < 0.3 * float(full_rep)
+    # sample_pids: fewer hits of interest, still a valid loss; reproducible
+    for cls in (CondensationLossRG, CondensationLossTiger):
+        torch.manual_seed(5)
+        a = cls(sample_pids=0.5)(beta=beta, x=x0, **kw)
+        torch.manual_seed(5)
+        b = cls(sample_pids=0.5)(beta=beta, x=x0, **kw)
+        assert torch.isfinite(a.loss) and float(a.loss) == float(b.loss)
+        assert float(a.loss_dct["attractive"]) != float(cls()(beta=beta, x=x0, **kw).loss_dct["attractive"])
+
+
+def case_knn_batched(device, sizes=(1, 5, 70, 130, 2, 64)):
+    """One batched search (``seg_ptr`` = torch_cluster's ``batch``) == the per-event searches,
+    bit for bit: events smaller than k, single-hit events, waves that straddle two events."""
+    g = np.random.default_rng(8)
+    n = sum(sizes)
+    for d, k, r in ((3, 4, None), (8, 16, 0.9), (2, 100, 0.5)):
+        x = tt(g.random((n, d)).astype(np.float32), device)
+        seg_ptr = torch.tensor([0, *np.cumsum(sizes)], dtype=torch.int64, device=device)
+        got = ops.knn_graph(x, k, r, seg_ptr=seg_ptr)
+        parts, off = [], 0
+        for s_ in sizes:
+            if s_ > 1:
+                parts.append(ops.knn_graph(x[off:off + s_].contiguous(), k, r) + off)
+            off += s_
+        want = torch.cat(parts, dim=1)
+        assert torch.equal(got, want), f"batched kNN d={d} k={k} r={r}"
+    from gnn_tracking_amd.losses_ml import radius_graph
+    batch = torch.repeat_interleave(torch.arange(len(sizes), device=device), torch.tensor(sizes, device=device))
+    assert torch.equal(radius_graph(x, 0.5, batch, 100), want)

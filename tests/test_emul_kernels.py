@@ -52,12 +52,14 @@ def test_knn_against_c_oracle_and_goldens():
                                          (2, 3, 4, None)))
         P.case_knn_goldens("cpu", clouds=("tg3",))
         P.case_ml_graph_construction("cpu")
+        P.case_knn_batched("cpu", sizes=(1, 5, 70, 2, 34))
 
 
 def test_condensation_losses_and_mask():
     with emulated():
         P.case_good_node_mask("cpu")
         P.case_condensation_losses("cpu")
+        P.case_oc_sampling("cpu")
 
 
 def test_graph_tcn_emulated():

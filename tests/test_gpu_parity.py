@@ -56,6 +56,8 @@ def test_knn_goldens_and_oracle(dev):
     P.case_knn_goldens(dev)
     P.case_knn_oracle(dev)
     P.case_knn_oracle(dev, shapes=((5000, 8, 64, 1.0), (4097, 3, 256, None), (3000, 24, 16, 2.0)))
+    P.case_knn_batched(dev)
+    P.case_knn_batched(dev, sizes=(3000, 1, 2500, 40, 4000))
 
 
 def test_ml_graph_construction(dev):
@@ -65,6 +67,7 @@ def test_ml_graph_construction(dev):
 def test_condensation_losses(dev):
     P.case_good_node_mask(dev)
     P.case_condensation_losses(dev)
+    P.case_oc_sampling(dev)
 
 
 def test_cpu_tensor_is_rejected(dev):

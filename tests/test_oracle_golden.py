@@ -55,7 +55,8 @@ def test_interaction_network_and_resin():
     z = load("g3b_resin.npz")
     for name, kw in {"skip1": dict(n_layers=3, residual_type="skip1", alpha=0.5),
                      "skip2": dict(n_layers=2, residual_type="skip2", alpha=0.3),
-                     "skip_top": dict(n_layers=3, residual_type="skip_top", alpha=0.7)}.items():
+                     "skip_top": dict(n_layers=3, residual_type="skip_top", alpha=0.7),
+                     "skip2_bn": dict(n_layers=2, residual_type="skip2", alpha=0.3, add_bn=True)}.items():
         p = _params(z, f"{name}/p0/")
         x, e, es = O.resin(tt(z["x"]), tt(z["edge_index"]), tt(z["edge_attr"]), p, "r",
                            collect_hidden_edge_embeds=True, **kw)

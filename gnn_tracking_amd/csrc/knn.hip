@@ -19,18 +19,6 @@
 namespace gnntrk {
 
 typedef unsigned long long u64;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// per-half fused multiply-add: v_pk_fma_f32 (the g++ build of the wave emulator takes the loop)
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
-#ifdef __clang__
-    return __builtin_elementwise_fma(a, b, c);
-#else
-    f32x2 r;
-    r[0] = fmaf(a[0], b[0], c[0]);
-    r[1] = fmaf(a[1], b[1], c[1]);
-    return r;
-#endif
-}
 constexpr int kKnnBlock = 256;
 constexpr int kKnnWaves = 4;
 constexpr int kKnnLdsPerWave = 8 * 1024;  // key buffers of one wave (bytes): 20 waves per CU
@@ -145,30 +133,20 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
             u64 key[kKnnGroup], tq[kKnnGroup];
 #pragma unroll
             for (int u = 0; u < kKnnGroup; ++u) tq[u] = tau[qb + u < nq ? qb + u : nq - 1];
-            // two queries per VALU instruction: packed fp32 subtract / fma (v_pk_add_f32, v_pk_fma_f32 -
-            // every half is its own fmaf chain in dimension order, so the arithmetic contract holds)
 #pragma unroll
-            for (int u = 0; u < kKnnGroup; u += 2) {
-                const int qa = qb + u < nq ? qb + u : nq - 1, qc = qb + u + 1 < nq ? qb + u + 1 : nq - 1;
-                const float *__restrict__ xa = x + (q0 + qa) * stride;  // wave-uniform addresses
-                const float *__restrict__ xb = x + (q0 + qc) * stride;
-                f32x2 d2 = {0.f, 0.f};
+            for (int u = 0; u < kKnnGroup; ++u) {
+                const int q = qb + u < nq ? qb + u : nq - 1;
+                const float *__restrict__ xq = x + (q0 + q) * stride;  // wave-uniform address
+                float d2 = 0.f;
 #pragma unroll
                 for (int d = 0; d < DP; ++d) {
-                    f32x2 qd;
-                    qd[0] = (FULL || d < dim) ? xa[d] : 0.f;
-                    qd[1] = (FULL || d < dim) ? xb[d] : 0.f;
-                    const f32x2 cd = {xc[d], xc[d]};
-                    const f32x2 t = qd - cd;
-                    d2 = fma2(t, t, d2);
+                    const float qd = (FULL || d < dim) ? xq[d] : 0.f;
+                    const float t = __fsub_rn(qd, xc[d]);
+                    d2 = __fmaf_rn(t, t, d2);
                 }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int q = h ? qc : qa;
-                    key[u + h] = ((u64)__float_as_uint(d2[h]) << 32) | (u64)(uint32_t)j;
-                    if (j >= c_end || j == q0 + q || qb + u + h >= nq) key[u + h] = kKeyMax;
-                    if (BATCH && (j < qlo[q] || j >= qhi[q])) key[u + h] = kKeyMax;  // another event's hit
-                }
+                key[u] = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)j;
+                if (j >= c_end || j == q0 + q || qb + u >= nq) key[u] = kKeyMax;
+                if (BATCH && (j < qlo[q] || j >= qhi[q])) key[u] = kKeyMax;  // another event's hit
             }
 #pragma unroll
             for (int u = 0; u < kKnnGroup; ++u) {

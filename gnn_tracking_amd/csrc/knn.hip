@@ -130,7 +130,8 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
         // can only be waited for with lgkmcnt(0): one query per step means one full memory
         // latency per step), then the distances, then the (rare) appends
         for (int qb = 0; qb < nq; qb += kKnnGroup) {
-            u64 key[kKnnGroup], tq[kKnnGroup];
+            u64 tq[kKnnGroup];
+            float d2q[kKnnGroup];
 #pragma unroll
             for (int u = 0; u < kKnnGroup; ++u) tq[u] = tau[qb + u < nq ? qb + u : nq - 1];
 #pragma unroll
@@ -144,18 +145,23 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
                     const float t = __fsub_rn(qd, xc[d]);
                     d2 = __fmaf_rn(t, t, d2);
                 }
-                key[u] = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)j;
-                if (j >= c_end || j == q0 + q || qb + u >= nq) key[u] = kKeyMax;
-                if (BATCH && (j < qlo[q] || j >= qhi[q])) key[u] = kKeyMax;  // another event's hit
+                d2q[u] = d2;
             }
 #pragma unroll
             for (int u = 0; u < kKnnGroup; ++u) {
-                const bool pass = key[u] < tq[u];
+                // cheap prefilter on the distance bits alone (d2 >= 0: its bit pattern orders like the
+                // value); the exact (d2, index) key, the self / range / event exclusions and the append
+                // only run for the rare (query, chunk) steps in which some lane gets past it
+                if (__ballot(__float_as_uint(d2q[u]) <= (uint32_t)(tq[u] >> 32)) == 0ull) continue;
+                const int q = qb + u < nq ? qb + u : nq - 1;
+                u64 key = ((u64)__float_as_uint(d2q[u]) << 32) | (u64)(uint32_t)j;
+                if (j >= c_end || j == q0 + q || qb + u >= nq) key = kKeyMax;
+                if (BATCH && (j < qlo[q] || j >= qhi[q])) key = kKeyMax;  // another event's hit
+                const bool pass = key < tq[u];
                 const u64 mask = __ballot(pass);
                 if (mask != 0ull) {
-                    const int q = qb + u;
                     const int base = cnt[q];
-                    if (pass) keys[q * cap + base + __popcll(mask & ((1ull << lane) - 1ull))] = key[u];
+                    if (pass) keys[q * cap + base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
                     int nc = base + __popcll(mask);
                     knn_wave_sync();
                     if (nc > cap - 64) {  // no room for another full chunk: keep the k best

@@ -63,7 +63,10 @@ __device__ __forceinline__ int knn_segment_of(const int64_t *__restrict__ seg_pt
 // FULL: dim == DP (no per-feature guard on the scalar loads).  BATCH: rows are grouped into
 // segments (the events of a collated batch, `batch` of torch_cluster's knn_graph / radius_graph:
 // metrics/losses/metric_learning.py:97); a query only sees candidates of its own segment.
-template <int DP, bool FULL, bool BATCH>
+// QW > 0: the wave's QW queries are compile-time unrolled and their coordinates are loaded ONCE
+// (QW * DP <= 64 registers held for the whole candidate stream); QW = 0: the
+// query count is a run-time value and the coordinates are re-read (constant cache) per chunk.
+template <int DP, bool FULL, bool BATCH, int QW>
 __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict__ x, int64_t n,
                                                         int dim, int stride, int k, int cap,
                                                         int qw, float max_radius,
@@ -120,6 +123,31 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
 #pragma unroll
         for (int d = 0; d < DP; ++d) v[d] = (FULL || d < dim) ? row[d] : 0.f;
     };
+    // (QW > 0) query coordinates, loaded once: wave-uniform addresses -> scalar registers
+    constexpr int kQ = QW > 0 ? QW : 1;
+    float qv[kQ][DP];
+    if (QW > 0) {
+        // (through a lane offset the optimiser cannot see through: as uniform values the 64
+        // coordinates would be scalar registers, more than a wave has - they would be spilled and
+        // fetched back with v_readlane in the inner loop; as VGPRs they cost occupancy, not time)
+        int lane_zero;
+#ifdef __HIP_DEVICE_COMPILE__
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+#else
+        lane_zero = 0;
+#endif
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const float *__restrict__ xq = x + (q0 + (q < nq ? q : nq - 1)) * stride + lane_zero;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) qv[q][d] = (FULL || d < dim) ? xq[d] : 0.f;
+        }
+    }
+    // (QW > 0) the distance part of every query's threshold, in registers too: the common step
+    // then touches neither LDS nor memory; refreshed after the (rare) sorts
+    uint32_t tau_hi[kQ];
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) tau_hi[q] = (uint32_t)(tau0 >> 32);
     float xc[DP], xn[DP];
     load_chunk(c_begin, xc);
     for (int64_t c0 = c_begin; c0 < c_end; c0 += 64) {
@@ -129,11 +157,15 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
         // reads of the thresholds of the whole group are in flight together (a scalar load
         // can only be waited for with lgkmcnt(0): one query per step means one full memory
         // latency per step), then the distances, then the (rare) appends
-        for (int qb = 0; qb < nq; qb += kKnnGroup) {
+        const int q_stop = QW > 0 ? QW : nq;
+#pragma unroll
+        for (int qb = 0; qb < q_stop; qb += kKnnGroup) {
             u64 tq[kKnnGroup];
             float d2q[kKnnGroup];
+            if (QW == 0) {
 #pragma unroll
-            for (int u = 0; u < kKnnGroup; ++u) tq[u] = tau[qb + u < nq ? qb + u : nq - 1];
+                for (int u = 0; u < kKnnGroup; ++u) tq[u] = tau[qb + u < nq ? qb + u : nq - 1];
+            }
 #pragma unroll
             for (int u = 0; u < kKnnGroup; ++u) {
                 const int q = qb + u < nq ? qb + u : nq - 1;
@@ -141,7 +173,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
                 float d2 = 0.f;
 #pragma unroll
                 for (int d = 0; d < DP; ++d) {
-                    const float qd = (FULL || d < dim) ? xq[d] : 0.f;
+                    const float qd = QW > 0 ? qv[(qb + u) < kQ ? (qb + u) : kQ - 1][d] : ((FULL || d < dim) ? xq[d] : 0.f);
                     const float t = __fsub_rn(qd, xc[d]);
                     d2 = __fmaf_rn(t, t, d2);
                 }
@@ -152,8 +184,10 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
                 // cheap prefilter on the distance bits alone (d2 >= 0: its bit pattern orders like the
                 // value); the exact (d2, index) key, the self / range / event exclusions and the append
                 // only run for the rare (query, chunk) steps in which some lane gets past it
-                if (__ballot(__float_as_uint(d2q[u]) <= (uint32_t)(tq[u] >> 32)) == 0ull) continue;
+                const uint32_t th = QW > 0 ? tau_hi[(qb + u) < kQ ? (qb + u) : kQ - 1] : (uint32_t)(tq[u] >> 32);
+                if (__ballot(__float_as_uint(d2q[u]) <= th) == 0ull) continue;
                 const int q = qb + u < nq ? qb + u : nq - 1;
+                if (QW > 0) tq[u] = tau[q];
                 u64 key = ((u64)__float_as_uint(d2q[u]) << 32) | (u64)(uint32_t)j;
                 if (j >= c_end || j == q0 + q || qb + u >= nq) key = kKeyMax;
                 if (BATCH && (j < qlo[q] || j >= qhi[q])) key = kKeyMax;  // another event's hit
@@ -170,6 +204,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
                         knn_wave_sync();
                         wave_bitonic_sort(b, cap, lane);
                         nc = k;
+                        if (QW > 0) tau_hi[(qb + u) < kQ ? (qb + u) : kQ - 1] = (uint32_t)(b[k - 1] >> 32);
                         if (lane == 0) tau[q] = b[k - 1];
                     }
                     if (lane == 0) cnt[q] = nc;
@@ -303,9 +338,13 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
     int qw = kKnnLdsPerWave / (cap * 8);
     if (qw > 32) qw = 32;
     const int64_t grid = ceil_div(n, (int64_t)qw * kKnnWaves);
-#define KNN_LAUNCH(DP, FULL_, BATCH_)                                                               \
-    hipLaunchKernelGGL((knn_kernel<DP, FULL_, BATCH_>), dim3((unsigned)grid), dim3(kKnnBlock), 0, stream, x, n, \
+#define KNN_LAUNCH_Q(DP, FULL_, BATCH_, QW_)                                                        \
+    hipLaunchKernelGGL((knn_kernel<DP, FULL_, BATCH_, QW_>), dim3((unsigned)grid), dim3(kKnnBlock), 0, stream, x, n, \
                        dim, stride, k, cap, qw, max_radius, seg_ptr, n_seg, nbr, cnt)
+#define KNN_LAUNCH(DP, FULL_, BATCH_)                                                               \
+    if (DP <= 8 && qw == 8) KNN_LAUNCH_Q(DP, FULL_, BATCH_, (DP <= 8 ? 8 : 0));                     \
+    else if (DP <= 8 && qw == 4) KNN_LAUNCH_Q(DP, FULL_, BATCH_, (DP <= 8 ? 4 : 0));                \
+    else KNN_LAUNCH_Q(DP, FULL_, BATCH_, 0)
 #define KNN_CALL(DP)                                                                               \
     if (seg_ptr) {                                                                                 \
         if (dim == DP) KNN_LAUNCH(DP, true, true); else KNN_LAUNCH(DP, false, true);               \
@@ -323,6 +362,7 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
     }
 #undef KNN_CALL
 #undef KNN_LAUNCH
+#undef KNN_LAUNCH_Q
     return check_launch("knn_search");
 }
 

@@ -76,6 +76,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configurations")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--backend", default=None, choices=("nccl", "gloo"),
+                    help="process-group backend (default: nccl = RCCL).  gloo also works with device tensors "
+                         "(through the host) and lets tests run two ranks on ONE GPU")
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY: replace the HIP workload by a CPU toy model (gloo) to exercise the "
                          "launcher / barrier / reduction control flow; the line is marked as a stub")
@@ -628,7 +631,10 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, argv))
 
-    backend = "gloo" if args.stub else None
+    backend = "gloo" if args.stub else args.backend
+    if backend == "gloo" and not args.stub and torch.cuda.is_available():
+        # (ranks may share a device under gloo: map them round-robin before the group is built)
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     rank, local, world = gdist.init_process_group_from_env(backend=backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the process group has WORLD_SIZE={world}")
@@ -648,6 +654,10 @@ def main(argv=None):
             wl = ECWorkload(args, rank, world, dev, workload=args.workload, dtype=args.dtype, index=args.index)
 
     dt, final_loss, ks = timed_steps(wl, world, dev, args.steps, args.warmup, kernel_timer=not args.stub)
+    # sum of |parameters| after the run: equal (to rounding) at every rank count for cfg4, whose
+    # step is the same arithmetic however the shards are spread over ranks
+    param_checksum = (float(sum(p.detach().double().abs().sum() for p in wl.model.parameters()))
+                      if hasattr(wl, "model") else None)
     want_extra = not args.no_extra and not args.stub and args.workload == "cfg3" and args.dtype == "bf16"
     model_for_cpu = (getattr(wl, "first_event_cpu", None), getattr(wl, "model", None))
     describe, info, scaling, wdtype = wl.describe, wl.info, wl.scaling, getattr(wl, "dtype", args.dtype)
@@ -696,6 +706,7 @@ def main(argv=None):
             },
             "edge_layers_per_sec": total * EC_MODEL["L_ec"] / dt,
             "final_loss": final_loss,
+            "param_checksum": param_checksum,
             "roofline": roof,
             "kernels": kernels,
             "cpu_baseline": cpu,

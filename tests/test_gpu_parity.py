@@ -172,3 +172,32 @@ def test_cfg5_condensation_losses_200k(dev):
 
 def test_cfg5_knn_200k(dev):
     P.case_cfg5_knn(dev)
+
+
+def test_bench_cfg4_two_ranks_match_one_rank(dev):
+    """BASELINE config 4's data-parallel path on real device tensors: bench.py's own launcher
+    starts two ranks (gloo, both on this GPU - RCCL needs one GPU per rank), each runs its four
+    of the eight shards as micro-batches, gradients are all-reduced; the parameters after the
+    run must equal the one-rank run's (same arithmetic: the mean over all eight shards)."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    outs = {}
+    for n in (1, 2):
+        cmd = [sys.executable, str(root / "bench.py"), "--gpus", str(n), "--workload", "cfg4", "--events", "16",
+               "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--dtype", "f32"]
+        if n > 1:
+            cmd += ["--backend", "gloo"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[n] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = outs[1], outs[2]
+    assert b["n_gpus"] == 2 and b["rccl_ranks"] == 2 and b["self_launched"] is True
+    assert a["scaling"] == b["scaling"] == "strong"
+    assert a["config"]["global_edges_per_step"] == b["config"]["global_edges_per_step"]
+    assert a["config"]["micro_batches_per_rank"] == 8 and b["config"]["micro_batches_per_rank"] == 4
+    rel = abs(a["param_checksum"] - b["param_checksum"]) / a["param_checksum"]
+    assert rel < 1e-6, f"parameters after the run differ between 1 and 2 ranks: {rel:.2e}"

@@ -1261,7 +1261,7 @@ def case_cfg5_knn(device, n_hits=200_000, n_slice=20_000):
         assert torch.equal(got.cpu(), O.knn_graph_c(xc[:n_slice], k, 1.0)), f"kNN k={k} differs from the C oracle"
 
 
-def case_edge_ordered(device):
+def case_edge_ordered(device, name="skip1_L3_h40"):
     """``W`` / ``edge_embedding`` are handed out as ``EdgeOrdered`` (held in CSR order, behaving
     like ``edge_index``-ordered tensors): metadata without a scatter, every other use
     materialises the reference's ordering, the package's losses take the CSR fast path and
@@ -1269,7 +1269,6 @@ def case_edge_ordered(device):
     from gnn_tracking_amd.edge_order import EdgeOrdered
 
     z = load("g2_ec_variants.npz")
-    name = "skip1_L3_h40"
     x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
     y, pt = tt(z["y"], device).float(), tt(z["pt"], device)
     model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_VARIANTS[name])

@@ -52,7 +52,7 @@ def test_knn_against_c_oracle_and_goldens():
                                          (2, 3, 4, None)))
         P.case_knn_goldens("cpu", clouds=("tg3",))
         P.case_ml_graph_construction("cpu")
-        P.case_knn_batched("cpu", sizes=(1, 5, 70, 2, 34))
+        P.case_knn_batched("cpu", sizes=(1, 5, 40, 2))
 
 
 def test_condensation_losses_and_mask():
@@ -64,7 +64,7 @@ def test_condensation_losses_and_mask():
 
 def test_graph_tcn_emulated():
     with emulated():
-        P.case_graph_tcn("cpu", names=("latent", "all_cut"))
+        P.case_graph_tcn("cpu", names=("all_cut",))  # (test_tc_training_step_emulated runs a full GraphTCN)
 
 
 def test_hinge_loss_emulated():
@@ -81,7 +81,6 @@ def test_gc_fcnn_emulated():
 def test_hetero_fcnn_emulated():
     with emulated():
         P.case_hetero_fcnn("cpu", names=("hetero_d2",))
-        P.case_graph_tcn("cpu", names=("hetero",))
 
 
 def test_graph_cut_emulated():
@@ -112,9 +111,9 @@ def test_focal_losses_emulated():
 
 def test_edge_ordered_outputs_emulated():
     with emulated():
-        P.case_edge_ordered("cpu")
+        P.case_edge_ordered("cpu", name="skip1_L2_h2")
 
 
 def test_tc_training_step_emulated():
     with emulated():
-        P.case_tc_step("cpu")
+        P.case_tc_step("cpu", names=("tiger_orphans",))

@@ -114,7 +114,7 @@ class _CondensationLoss(MultiLossFct, HyperparametersMixin):
 
     def _forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
                  ec_hit_mask: T | None, eta: T, mask_eta: bool) -> MultiLossFctReturn:
-        if ec_hit_mask is not None:
+        if ec_hit_mask is not None and not getattr(ec_hit_mask, "_gnntrk_all_true", False):
             # model outputs already carry the post-EC node mask, data attributes do not
             particle_id = particle_id[ec_hit_mask]
             reconstructable = reconstructable[ec_hit_mask]

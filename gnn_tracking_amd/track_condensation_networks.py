@@ -237,6 +237,9 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
                 data, hit_mask = graph_cut.drop_orphans(data)
             else:
                 hit_mask = torch.ones(data.num_nodes, dtype=torch.bool, device=data.x.device)
+                # (lets the condensation losses skip three boolean-mask gathers and their host
+                # synchronisations: they would select every hit)
+                hit_mask._gnntrk_all_true = True
         if self.ec is None and self.hparams.feed_edge_weights:
             data.edge_weights = data.ec_score.reshape((-1, 1))
 

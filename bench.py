@@ -96,6 +96,10 @@ def launch_ranks(n: int, argv: list[str]) -> int:
     """``python bench.py --gpus N`` without torchrun: start N copies of this script, one per
     GPU, with torchrun's environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     Rank 0 inherits stdout (it prints the line).  Returns the worst exit code."""
+    if "--stub" not in argv:
+        from gnn_tracking_amd import _build
+        if _build.have_hipcc():
+            _build.build_lib()   # (stamp check; the ranks then all find the library up to date)
     port = _free_port()
     procs = []
     for r in range(n):

@@ -598,6 +598,45 @@ def cfg4_short(args, rank: int, world: int, dev) -> dict:
             "final_loss": loss, **wl.info}
 
 
+def cfg5_short(args, dev) -> dict:
+    """BASELINE config 5 as a short run: the object-condensation step on one 200 000-hit event with
+    per-stage HIP-event times (kNN graph build, GraphTCN forward, condensation loss, backward)."""
+    import copy
+    a5 = copy.copy(args)
+    a5.events = None
+    wl = TCWorkload(a5, 0, 1, dev)
+    dt, loss, _ = timed_steps(wl, 1, dev, 3, 2, kernel_timer=False)
+    return {"workload": wl.describe, "steps": 3, "warmup": 2, "ms_per_step": dt / 3 * 1e3,
+            "value": wl.edges_per_step_global * 3 / dt, "unit": "edges/s", "hits_per_s": wl.n_hits * 3 / dt,
+            "final_loss": loss, "stages": wl.stages(), **wl.info}
+
+
+def dbscan_short(dev) -> dict:
+    """postprocessing.DBSCANFastRescan (fastrescanner.py:6-66) on the cfg5 cloud: ONE radius graph at
+    max_eps, then four (eps, min_pts) rescans - what DBSCANHyperParamScannerFast asks per trial."""
+    from gnn_tracking_amd.postprocessing import DBSCANFastRescan
+
+    n, max_eps = 200_000, 0.5
+    x = synthetic.make_pileup_cloud(500, n).to(dev)
+    DBSCANFastRescan(x[:4096], max_eps=max_eps).cluster_device(max_eps, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fr = DBSCANFastRescan(x, max_eps=max_eps)
+    torch.cuda.synchronize()
+    t_graph = time.perf_counter() - t0
+    trials = ((max_eps, 1), (0.6 * max_eps, 2), (0.4 * max_eps, 3), (0.3 * max_eps, 4))
+    t0 = time.perf_counter()
+    n_clusters = [int(fr.cluster_device(eps, mp).max()) + 1 for eps, mp in trials]
+    torch.cuda.synchronize()
+    t_clu = (time.perf_counter() - t0) / len(trials)
+    flops = 2.0 * n * n * 8 * 3   # count + fill pass: sub, mul, add per dimension in fp64
+    return {"workload": f"DBSCANFastRescan on {n} hits in 8-d, max_eps {max_eps}: radius graph + {len(trials)} rescans",
+            "radius_graph_ms": t_graph * 1e3, "radius_graph_edges": int(fr._n_edges),
+            "rescan_ms_per_trial": t_clu * 1e3, "clusters_per_trial": n_clusters,
+            "roofline": {"bound": "valu_f64", "achieved": flops / t_graph / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                         "frac": flops / t_graph / 1e12 / 78.6}}
+
+
 def extras(args, rank: int, world: int, dev) -> dict:
     """Short driver-timed runs of the configurations the headline does not cover: cfg4 at
     every rank count; at N = 1 also cfg3 in fp32 and cfg2 as a HIP graph."""
@@ -621,6 +660,9 @@ def extras(args, rank: int, world: int, dev) -> dict:
         torch.cuda.empty_cache()
         out["cfg2_hipgraph_bf16"] = hipgraph_cfg2(dev, "bf16", 100)
         out["cfg2_hipgraph_f32"] = hipgraph_cfg2(dev, "f32", 100)
+        torch.cuda.empty_cache()
+        out["cfg5_oc_step_f32"] = cfg5_short(args, dev)
+        out["dbscan_rescan_200k"] = dbscan_short(dev)
     except Exception as e:  # the headline line must survive a failing extra
         if world > 1:
             raise   # (a rank that drops out of a collective would hang the others)

@@ -27,7 +27,7 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     if (!a || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
-    const int GT = (P.GT <= 1) ? 1 : 2 * P.KI;
+    const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
     const int D = (P.KI == 1 && P.HT <= 3 && !(a->debug_flags & 64)) ? 2 : 1;  // as launch_bwd16 dispatches
     snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s, %d>", P.KI, P.HT, GT,
              a->mlp.n_layers == 3 ? "true" : "false", a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false", D);
@@ -80,7 +80,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
         return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: more than 16 input chunks / 4 hidden tiles");
     const bool three = a->mlp.n_layers == 3;
     // gradient M tiles: 1 or the maximum of the k-step count (keeps the instantiation list short)
-    const int GT = (P.GT <= 1) ? 1 : 2 * P.KI;
+    const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
     int grid = 0;
     if (a->n_rows > 0) {
         grid = grid16(a->n_rows, kBwd16BlocksPerCu, kWaves);

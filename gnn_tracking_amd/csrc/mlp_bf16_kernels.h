@@ -577,12 +577,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
     // gradient chunk handled by this lane in dX tile T: q = 4T + g.  Lanes without a chunk
     // (and rows past the end) store to a private 8-byte slot of the trash area instead, so
     // that the store is unconditional (see LaneChunks).
-    gh_ptr gptr[GT];
-    gci_ptr gidx[GT];  // optional row permutation of the gradient slice (never NULL, see LaneChunks)
-    int32_t gstride[GT], gin_off[GT];
-    uint32_t gkeep[GT][2];
-    uint32_t gmul_and[GT], gmul_or[GT];  // relu' multiplier (min(x, 1) & and) | or: branch-free "no ReLU" = 1
-    bool gon[GT], gidx_on[GT];
+    constexpr int GTA = GT > 0 ? GT : 1;  // (array extents; GT = 0: no input gradient at all)
+    gh_ptr gptr[GTA];
+    gci_ptr gidx[GTA];  // optional row permutation of the gradient slice (never NULL, see LaneChunks)
+    int32_t gstride[GTA], gin_off[GTA];
+    uint32_t gkeep[GTA][2];
+    uint32_t gmul_and[GTA], gmul_or[GTA];  // relu' multiplier (min(x, 1) & and) | or: branch-free "no ReLU" = 1
+    bool gon[GTA], gidx_on[GTA];
     gh_ptr my_trash = (gh_ptr) reinterpret_cast<uint16_t *>(trash + ((int64_t)(blockIdx.x * kWaves + wv) * 64 + lane) * 8);
 #pragma unroll
     for (int T = 0; T < GT; ++T) {
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         // (tiles past the end run as all-invalid rows: zero upstream gradient, stores
         // redirected - no second loop exit for the accumulators)
         bool valid[D];
-        int32_t srow[D][GT];  // destination rows of the input-gradient slices
+        int32_t srow[D][GTA];  // destination rows of the input-gradient slices
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int64_t tile = tile_of(grp, d);
@@ -1104,6 +1105,7 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
 #define GNNTRK_BWD16_HT(KI_, GT_) \
     GNNTRK_BWD16_CASE(KI_, 1, GT_) GNNTRK_BWD16_CASE(KI_, 2, GT_) GNNTRK_BWD16_CASE(KI_, 3, GT_) \
         GNNTRK_BWD16_CASE(KI_, 4, GT_)
+    GNNTRK_BWD16_HT(1, 0)   // weight gradients only (the encoders of raw dataset features)
     GNNTRK_BWD16_HT(1, 1)
     GNNTRK_BWD16_HT(1, 2)
     GNNTRK_BWD16_HT(2, 1)

@@ -30,7 +30,7 @@ from .track_condensation_networks import (GraphConstructionFCNN, GraphConstructi
                                             HeterogeneousResFCNN, ModularGraphTCN, PreTrainedECGraphTCN,
                                             ResFCNN)
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphTCN",
            "EdgeWeightBCELoss", "falsify_low_pt_edges", "MLGraphConstruction",
            "knn_with_max_radius", "get_good_node_mask", "get_good_node_mask_tensors",

@@ -138,12 +138,19 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+ABI_VERSION = 200   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
+
+
 def bind(lib: C.CDLL) -> C.CDLL:
     """Attach restype/argtypes for every symbol of include/gnntrk.h."""
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    got = lib.gnntrk_version()
+    if got != ABI_VERSION:  # a stale library would be called with the wrong argument lists
+        raise RuntimeError(f"libgnntrk.so reports ABI version {got}, this package binds version {ABI_VERSION}: "
+                           "rebuild it (python -m gnn_tracking_amd._build)")
     return lib
 
 

@@ -68,7 +68,7 @@ class OcArgs(C.Structure):
                 ("n_cp", C.c_void_p), ("n", C.c_int64), ("dim", C.c_int32), ("stride", C.c_int32),
                 ("q_min", C.c_float), ("radius", C.c_float), ("eps_sqrt", C.c_float),
                 ("mode", C.c_int32), ("rep_keep_prob", C.c_float), ("_pad", C.c_int32),
-                ("rep_seed", C.c_uint64)]
+                ("rep_seed", C.c_uint64), ("cap_nbr", C.c_void_p)]
 
 
 _P = C.c_void_p

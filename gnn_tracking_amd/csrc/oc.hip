@@ -157,7 +157,26 @@ struct OcParams {
     int32_t mode;  // 0 RG, 1 Tiger
     float keep;    // probability of keeping a repulsive pair (>= 1: all)
     u64 seed;
+    const int32_t *cap_nbr;  // RG neighbour cap: per hit its max_num_neighbors-th nearest hit inside the radius, -1: fewer
 };
+
+// The radius graph's neighbour cap (oc.py:115-117 radius_graph(max_num_neighbors)), nearest first: the
+// condensation point a only repels hit j if a is among j's max_num_neighbors nearest hits, i.e.
+// (d2(j, a), a) <= (d2(j, cap_j), cap_j) in the kNN search's own order and arithmetic (fmaf chain over
+// the dimensions in order, ties to the lower index: csrc/knn.hip).
+template <int DP>
+__device__ __forceinline__ float oc_d2_chain(const float (&a)[DP], const float *b) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        const float t = __fsub_rn(a[d], b[d]);
+        d2 = __fmaf_rn(t, t, d2);
+    }
+    return d2;
+}
+__device__ __forceinline__ bool oc_cap_ok(float d2, int a, float cap_d2, int cap_idx) {
+    return cap_idx < 0 || d2 < cap_d2 || (d2 == cap_d2 && a <= cap_idx);
+}
 
 // repulsive pair (hit j, condensation point k) kept?  splitmix64 of (seed, j, k) -> 24-bit uniform
 __device__ __forceinline__ bool oc_keep_pair(const OcParams &p, int64_t j, int k) {
@@ -181,6 +200,7 @@ __global__ __launch_bounds__(kOcTpb) void oc_forward_kernel(const OcParams p,
     __shared__ float s_x[kOcChunk][DP];
     __shared__ float s_q[kOcChunk];
     __shared__ long long s_pid[kOcChunk];
+    __shared__ int s_hit[kOcChunk];  // hit index of the staged condensation point
     __shared__ double s_red[kOcTpb / 64];
     const int64_t j = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
     const bool live = j < p.n;
@@ -199,6 +219,17 @@ __global__ __launch_bounds__(kOcTpb) void oc_forward_kernel(const OcParams p,
         mj = p.mask[j] != 0;
         is_cp = gj >= 0 && p.alphas[gj] == (int32_t)j;
     }
+    int cap_idx = -1;
+    float cap_d2 = 0.f;
+    if (live && p.cap_nbr) {
+        cap_idx = p.cap_nbr[j];
+        if (cap_idx >= 0) {
+            float xc[DP];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xc[d] = d < p.dim ? p.x[(int64_t)cap_idx * p.stride + d] : 0.f;
+            cap_d2 = oc_d2_chain<DP>(xj, xc);
+        }
+    }
     const float r2 = p.radius * p.radius;
     double va = 0.0, vr = 0.0, nrep = 0.0;
     for (int k0 = 0; k0 < K; k0 += kOcChunk) {
@@ -211,6 +242,7 @@ __global__ __launch_bounds__(kOcTpb) void oc_forward_kernel(const OcParams p,
                 for (int d = 0; d < DP; ++d) s_x[i][d] = d < p.dim ? p.x[(int64_t)a * p.stride + d] : 0.f;
                 s_q[i] = oc_q(p.beta[a], p.q_min);
                 s_pid[i] = p.pid[a];
+                s_hit[i] = a;
             }
         }
         __syncthreads();
@@ -227,7 +259,7 @@ __global__ __launch_bounds__(kOcTpb) void oc_forward_kernel(const OcParams p,
             if (s_pid[i] == pj) {
                 const bool att = (p.mode == 1) ? (gj == k0 + i) : (gj == k0 + i && mj && !is_cp);
                 if (att) va += (double)(qq * d2);
-            } else if (d2 < r2) {
+            } else if (d2 < r2 && (cap_idx < 0 || oc_cap_ok(oc_d2_chain<DP>(xj, s_x[i]), s_hit[i], cap_d2, cap_idx))) {
                 nrep += 1.0;  // (counted before the sub-sampling, as the reference's n_rep)
                 if (oc_keep_pair(p, j, k0 + i)) vr += (double)(qq * (p.radius - sqrtf(p.eps_sqrt + d2)));
             }
@@ -299,6 +331,7 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_hits_kernel(const OcParams
     __shared__ float s_x[kOcChunk][DP];
     __shared__ float s_q[kOcChunk];
     __shared__ long long s_pid[kOcChunk];
+    __shared__ int s_hit[kOcChunk];
     const int64_t j = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
     const bool live = j < p.n;
     const int K = p.n_cp[0];
@@ -322,6 +355,17 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_hits_kernel(const OcParams
         mj = p.mask[j] != 0;
         is_cp = gj >= 0 && p.alphas[gj] == (int32_t)j;
     }
+    int cap_idx = -1;
+    float cap_d2 = 0.f;
+    if (live && p.cap_nbr) {
+        cap_idx = p.cap_nbr[j];
+        if (cap_idx >= 0) {
+            float xc[DP];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xc[d] = d < p.dim ? p.x[(int64_t)cap_idx * p.stride + d] : 0.f;
+            cap_d2 = oc_d2_chain<DP>(xj, xc);
+        }
+    }
     const float r2 = p.radius * p.radius;
     for (int k0 = 0; k0 < K; k0 += kOcChunk) {
         __syncthreads();
@@ -333,6 +377,7 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_hits_kernel(const OcParams
                 for (int d = 0; d < DP; ++d) s_x[i][d] = d < p.dim ? p.x[(int64_t)a * p.stride + d] : 0.f;
                 s_q[i] = oc_q(p.beta[a], p.q_min);
                 s_pid[i] = p.pid[a];
+                s_hit[i] = a;
             }
         }
         __syncthreads();
@@ -353,7 +398,8 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_hits_kernel(const OcParams
                     cx = ca * 2.f * qj * s_q[i];
                     cq = ca * s_q[i] * d2;
                 }
-            } else if (d2 < r2 && oc_keep_pair(p, j, k0 + i)) {
+            } else if (d2 < r2 && oc_keep_pair(p, j, k0 + i) &&
+                       (cap_idx < 0 || oc_cap_ok(oc_d2_chain<DP>(xj, s_x[i]), s_hit[i], cap_d2, cap_idx))) {
                 const float sd = sqrtf(p.eps_sqrt + d2);
                 cx = sd > 0.f ? -cr * qj * s_q[i] / sd : 0.f;
                 cq = cr * s_q[i] * (p.radius - sd);
@@ -392,6 +438,8 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_cps_kernel(const OcParams 
     __shared__ float s_q[kOcChunk];
     __shared__ long long s_pid[kOcChunk];
     __shared__ int s_att[kOcChunk];  // gid if the hit takes part in the attractive sum, else -2
+    __shared__ int s_cap[kOcChunk];  // neighbour cap of the staged hit: index (-1: none) and distance
+    __shared__ float s_capd2[kOcChunk];
     const int K = p.n_cp[0];
     if (k_base + (int)blockIdx.x * kOcTpb >= K) return;  // (uniform: before any barrier)
     const int kl = blockIdx.x * kOcTpb + threadIdx.x;    // CP inside the batch
@@ -406,8 +454,9 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_cps_kernel(const OcParams 
         xk[d] = 0.f;
         gxk[d] = 0.f;
     }
+    int32_t ak = 0;
     if (live) {
-        const int32_t ak = p.alphas[k];
+        ak = p.alphas[k];
 #pragma unroll
         for (int d = 0; d < DP; ++d) xk[d] = d < p.dim ? p.x[(int64_t)ak * p.stride + d] : 0.f;
         qk = oc_q(p.beta[ak], p.q_min);
@@ -432,6 +481,22 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_cps_kernel(const OcParams 
                 bool att = gj >= 0;
                 if (p.mode == 0) att = att && p.mask[j] != 0 && p.alphas[gj] != (int32_t)j;
                 s_att[i] = att ? gj : -2;
+                int ci = -1;
+                float cd = 0.f;
+                if (p.cap_nbr) {
+                    ci = p.cap_nbr[j];
+                    if (ci >= 0) {
+                        float xa[DP];
+#pragma unroll
+                        for (int d = 0; d < DP; ++d) xa[d] = s_x[i][d];
+                        float xc[DP];
+#pragma unroll
+                        for (int d = 0; d < DP; ++d) xc[d] = d < p.dim ? p.x[(int64_t)ci * p.stride + d] : 0.f;
+                        cd = oc_d2_chain<DP>(xa, xc);
+                    }
+                }
+                s_cap[i] = ci;
+                s_capd2[i] = cd;
             }
         }
         __syncthreads();
@@ -451,7 +516,8 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_cps_kernel(const OcParams 
                     cx = ca * 2.f * s_q[i] * qk;
                     cq = ca * s_q[i] * d2;
                 }
-            } else if (d2 < r2 && oc_keep_pair(p, j0 + i, k)) {
+            } else if (d2 < r2 && oc_keep_pair(p, j0 + i, k) &&
+                       (s_cap[i] < 0 || oc_cap_ok(oc_d2_chain<DP>(s_x[i], xk), ak, s_capd2[i], s_cap[i]))) {
                 const float sd = sqrtf(p.eps_sqrt + d2);
                 cx = sd > 0.f ? -cr * s_q[i] * qk / sd : 0.f;
                 cq = cr * s_q[i] * (p.radius - sd);
@@ -566,6 +632,7 @@ static OcParams oc_params(const gnntrk_oc_args *a) {
     p.q_min = a->q_min; p.radius = a->radius; p.eps_sqrt = a->eps_sqrt; p.mode = a->mode;
     p.keep = a->rep_keep_prob > 0.f ? a->rep_keep_prob : 1.f;   // (0 = field left unset: all pairs)
     p.seed = a->rep_seed;
+    p.cap_nbr = a->cap_nbr;
     return p;
 }
 

@@ -61,7 +61,7 @@ class _CondensationPotentials(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, beta, x, particle_id, mask, q_min: float, radius: float, eps_sqrt: float,
-                mode: int, keep: float = 1.0, seed: int = 0):
+                mode: int, keep: float = 1.0, seed: int = 0, cap_nbr=None):
         _capi.require_device(beta, x, particle_id, mask)
         lib = _capi.load()
         dev = x.device
@@ -80,12 +80,13 @@ class _CondensationPotentials(torch.autograd.Function):
                                              ws.numel(), st), lib)
         a = _capi.OcArgs(ops._p(x_c), ops._p(beta_c), ops._p(pid), ops._p(mask8), ops._p(gid),
                          ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode,
-                         float(keep), 0, int(seed))
+                         float(keep), 0, int(seed), ops._p(cap_nbr))
         out = torch.empty(9, dtype=torch.float32, device=dev)
         ws2 = ops._ws(lib.gnntrk_oc_forward_workspace_bytes(n), x_c)
         _capi.check(lib.gnntrk_oc_forward(C.byref(a), ops._p(out), ops._p(ws2), ws2.numel(), st), lib)
         ctx.save_for_backward(beta_c, x_c, pid, mask8, gid, alphas, n_cp, out)
         ctx.cfg = (q_min, radius, eps_sqrt, mode, beta.dtype, x.dtype, float(keep), int(seed))
+        ctx.cap_nbr = cap_nbr
         return out[0], out[1], out[2], out[3], out[7].detach()
 
     @staticmethod
@@ -99,18 +100,21 @@ class _CondensationPotentials(torch.autograd.Function):
                          for t in (g_att, g_rep, g_cow, g_noise)]).contiguous()
         a = _capi.OcArgs(ops._p(x_c), ops._p(beta_c), ops._p(pid), ops._p(mask8), ops._p(gid),
                          ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode,
-                         keep, 0, seed)
+                         keep, 0, seed, ops._p(ctx.cap_nbr))
         gx = torch.empty_like(x_c)
         gbeta = torch.empty_like(beta_c)
         ws = ops._ws(lib.gnntrk_oc_backward_workspace_bytes(n, dim), x_c)
         _capi.check(lib.gnntrk_oc_backward(C.byref(a), ops._p(g), ops._p(out), ops._p(gx),
                                            ops._p(gbeta), n, ops._p(ws), ws.numel(), ops._stream(x_c)), lib)
-        return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None, None, None
+        return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None, None, None, None
 
 
 class _CondensationLoss(MultiLossFct, HyperparametersMixin):
     _mode = 0
     _eps_sqrt = 1e-9
+
+    def _neighbor_cap(self, x):   # (only the radius-graph variant has one)
+        return None
 
     def _forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
                  ec_hit_mask: T | None, eta: T, mask_eta: bool) -> MultiLossFctReturn:
@@ -132,7 +136,11 @@ class _CondensationLoss(MultiLossFct, HyperparametersMixin):
         # If there are no hits left after masking, then we get a NaN loss.
         assert bool(mask.any()), "No hits left after masking"
         args = (beta, x, particle_id, mask, float(self.hparams.q_min), 1.0, self._eps_sqrt, self._mode)
-        att, rep, cow, noise, n_rep = _CondensationPotentials.apply(*args)
+        cap = self._neighbor_cap(x)
+        if cap is not None:
+            att, rep, cow, noise, n_rep = _CondensationPotentials.apply(*args, 1.0, 0, cap)
+        else:
+            att, rep, cow, noise, n_rep = _CondensationPotentials.apply(*args)
         max_n_rep = int(getattr(self.hparams, "max_n_rep", 0) or 0)
         if max_n_rep > 0 and int(n_rep) > max_n_rep:
             # oc.py:322-328: keep repulsive pairs with probability max_n_rep / n_rep and scale the
@@ -175,17 +183,32 @@ class CondensationLossRG(_CondensationLoss):
         self.save_hyperparameters()
 
     _cap_notice_given = False
+    #: "off" (default): ``max_num_neighbors`` is not applied - every hit inside the unit radius of a
+    #: condensation point contributes (the reference's result whenever no hit has more neighbours than
+    #: the cap).  "nearest": the cap is applied nearest first - a condensation point only repels a hit
+    #: if it is among that hit's ``max_num_neighbors`` nearest hits (one extra kNN search per call;
+    #: what the CPU oracle's radius graph does; torch_cluster itself keeps an implementation-defined
+    #: subset).  Class attribute so that YAML configurations stay those of the reference.
+    neighbor_cap = "off"
+
+    def _neighbor_cap(self, x):
+        if self.neighbor_cap == "off":
+            return None
+        if self.neighbor_cap != "nearest":
+            raise ValueError(f"CondensationLossRG.neighbor_cap must be 'off' or 'nearest', got {self.neighbor_cap!r}")
+        return ops.knn_kth_neighbor(x, int(self.hparams.max_num_neighbors), 1.0)
 
     def forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
                 ec_hit_mask: T | None = None, eta: T, **kwargs) -> MultiLossFctReturn:
-        if not CondensationLossRG._cap_notice_given:
+        if self.neighbor_cap == "off" and not CondensationLossRG._cap_notice_given:
             CondensationLossRG._cap_notice_given = True
             import logging
             logging.getLogger("gnn_tracking_amd").warning(
                 "CondensationLossRG: max_num_neighbors=%s is not applied - every hit inside the unit radius of a "
                 "condensation point contributes.  This equals the reference whenever no hit has more than that many "
                 "neighbours inside the radius; beyond that torch_cluster.radius_graph keeps an implementation-defined "
-                "subset (the first ones found, differently on CPU and GPU).", self.hparams.max_num_neighbors)
+                "subset (the first ones found, differently on CPU and GPU).  CondensationLossRG.neighbor_cap = "
+                "'nearest' applies it nearest first.", self.hparams.max_num_neighbors)
         # NB: like the reference (oc.py:207-213) eta is NOT sliced by ec_hit_mask here
         return self._forward(beta=beta, x=x, particle_id=particle_id,
                              reconstructable=reconstructable, pt=pt, ec_hit_mask=ec_hit_mask,

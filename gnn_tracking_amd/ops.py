@@ -705,6 +705,24 @@ def knn_graph(x: Tensor, k: int, max_radius: Optional[float] = None, seg_ptr: Op
     return ei
 
 
+def knn_kth_neighbor(x: Tensor, k: int, max_radius: Optional[float] = None) -> Tensor:
+    """int32 ``[N]``: for every row the index of its ``k``-th nearest neighbour (inside
+    ``max_radius``), -1 where it has fewer - the last column of one ``gnntrk_knn_search``.  Used
+    for the neighbour cap of ``CondensationLossRG``'s radius graph."""
+    _capi.require_device(x)
+    lib = _capi.load()
+    x = _as_rows(x.detach().to(torch.float32))
+    n, dim = int(x.shape[0]), int(x.shape[1])
+    if n - 1 < k:   # fewer candidates than the cap: it never binds
+        return torch.full((n,), -1, dtype=torch.int32, device=x.device)
+    nbr = torch.empty(n * k, dtype=torch.int32, device=x.device)
+    cnt = torch.empty(n, dtype=torch.int32, device=x.device)
+    r = float(max_radius) if max_radius is not None else -1.0
+    _capi.check(lib.gnntrk_knn_search(_p(x), n, dim, _row_stride(x), int(k), r, _p(nbr), _p(cnt), _stream(x)), lib)
+    last = nbr.view(n, k)[:, k - 1]
+    return torch.where(cnt >= k, last, torch.full_like(last, -1)).contiguous()
+
+
 def knn_scan(x: Tensor, ks: Sequence[int], max_radius: Optional[float] = None) -> dict:
     """``{k: knn_with_max_radius(x, k, max_radius) for k in ks}`` from ONE neighbour search at
     ``max(ks)`` (the k-scan of graph_construction/k_scanner.py:203-285 searches once per k):

@@ -462,6 +462,11 @@ typedef struct gnntrk_oc_args {
     float rep_keep_prob;
     int32_t _pad;
     uint64_t rep_seed;
+    /* CondensationLossRG's radius_graph(max_num_neighbors) cap, nearest first (oc.py:115-117): per hit
+     * the index of its max_num_neighbors-th nearest hit inside the radius (last neighbour of a
+     * gnntrk_knn_search with k = max_num_neighbors), -1 where the hit has fewer.  A condensation point
+     * only repels a hit if it is among that hit's nearest max_num_neighbors.  NULL: no cap. */
+    const int32_t *cap_nbr;
 } gnntrk_oc_args;
 
 size_t gnntrk_oc_forward_workspace_bytes(int64_t n);

@@ -1468,3 +1468,47 @@ def case_knn_batched(device, sizes=(1, 5, 70, 130, 2, 64)):
     from gnn_tracking_amd.losses_ml import radius_graph
     batch = torch.repeat_interleave(torch.arange(len(sizes), device=device), torch.tensor(sizes, device=device))
     assert torch.equal(radius_graph(x, 0.5, batch, 100), want)
+
+
+def case_rg_neighbor_cap(device, caps=(4, 16, 256), n_hits=None):
+    """``CondensationLossRG.neighbor_cap = "nearest"``: the radius graph's ``max_num_neighbors`` cap
+    applied nearest first, against the oracle (whose radius graph truncates nearest first) where the
+    cap binds hard (4 and 16 neighbours on hits with dozens inside the radius): loss terms and
+    gradients; and unchanged results where it does not bind (256)."""
+    from gnn_tracking_amd.losses_oc import CondensationLossRG
+
+    z = load("g5_oc.npz")
+    t = {k: tt(z[f"td3/{k}"])[:n_hits] for k in ("beta", "x", "particle_id", "pt", "eta", "reconstructable")}
+    beta32, x32 = t["beta"].float(), t["x"].float()
+    mask = O.good_node_mask(t["pt"].float(), t["particle_id"], t["reconstructable"].float(), t["eta"].float())
+    kw = dict(particle_id=t["particle_id"].to(device), reconstructable=t["reconstructable"].float().to(device),
+              pt=t["pt"].float().to(device), eta=t["eta"].float().to(device))
+    old = CondensationLossRG.neighbor_cap
+    try:
+        CondensationLossRG.neighbor_cap = "nearest"
+        small = None
+        for cap in caps:
+            bo, xo = beta32.clone().requires_grad_(True), x32.clone().requires_grad_(True)
+            od = O.condensation_loss_rg(beta=bo, x=xo, particle_id=t["particle_id"], mask=mask, max_num_neighbors=cap)
+            (od["attractive"] + 2.0 * od["repulsive"]).backward()
+            b, x = beta32.clone().to(device).requires_grad_(True), x32.clone().to(device).requires_grad_(True)
+            ret = CondensationLossRG(lw_repulsive=2.0, max_num_neighbors=cap)(beta=b, x=x, **kw)
+            (ret.loss_dct["attractive"] + 2.0 * ret.loss_dct["repulsive"]).backward()
+            for k in ("attractive", "repulsive"):
+                assert_close(ret.loss_dct[k], od[k], 2e-5, f"cap {cap} {k}")
+            assert_close(x.grad, xo.grad, 2e-4, f"cap {cap} grad x")
+            assert_close(b.grad, bo.grad, 2e-4, f"cap {cap} grad beta")
+            if cap == 256:   # does not bind on this cloud: must equal the uncapped sum
+                CondensationLossRG.neighbor_cap = "off"
+                off = CondensationLossRG(lw_repulsive=2.0, max_num_neighbors=4)(
+                    beta=beta32.clone().to(device), x=x32.clone().to(device), **kw)
+                CondensationLossRG.neighbor_cap = "nearest"
+                assert_close(off.loss_dct["repulsive"], float(ret.loss_dct["repulsive"]), 1e-6, "cap off == cap that does not bind")
+            else:
+                small = float(ret.loss_dct["repulsive"].detach())
+        CondensationLossRG.neighbor_cap = "off"
+        off = CondensationLossRG(lw_repulsive=2.0, max_num_neighbors=4)(beta=beta32.clone().to(device),
+                                                                        x=x32.clone().to(device), **kw)
+        assert small < 0.9 * float(off.loss_dct["repulsive"]), "the cap should have removed repulsive pairs in this case"
+    finally:
+        CondensationLossRG.neighbor_cap = old

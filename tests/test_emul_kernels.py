@@ -60,6 +60,7 @@ def test_condensation_losses_and_mask():
         P.case_good_node_mask("cpu")
         P.case_condensation_losses("cpu")
         P.case_oc_sampling("cpu")
+        P.case_rg_neighbor_cap("cpu", caps=(4,), n_hits=500)
 
 
 def test_graph_tcn_emulated():

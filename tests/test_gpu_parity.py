@@ -68,6 +68,7 @@ def test_condensation_losses(dev):
     P.case_good_node_mask(dev)
     P.case_condensation_losses(dev)
     P.case_oc_sampling(dev)
+    P.case_rg_neighbor_cap(dev)
 
 
 def test_cpu_tensor_is_rejected(dev):

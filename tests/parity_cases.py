@@ -504,10 +504,11 @@ def case_mlp_bf16_forward(device, rows=75):
             assert (buf[:, out:] == 0).all(), tag + " padding"
 
 
-def case_mlp_bf16_backward(device, rows=75, full=True):
+def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
     from gnn_tracking_amd import _capi, ops_bf16 as B
-    gen = torch.Generator().manual_seed(1)
-    torch.manual_seed(1)  # (the layer initialisations use the global generator)
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)  # (the layer initialisations use the global generator)
+    given = cases
     cases = [
         # (segment dims, gathered?, relu?, need grad?, hidden, out, L, bias, epilogue, n_gout)
         ((5, 5, 4), (True, True, False), (True, True, True), (True, True, True), 40, 4, 3, True, "none", 2),
@@ -523,6 +524,8 @@ def case_mlp_bf16_backward(device, rows=75, full=True):
             ((8, 8, 8, 8), (False,) * 4, (False,) * 4, (True, False, True, False), 16, 16, 3, True, "none", 1),
             ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, (True,) * 5, 30, 9, 3, True, "none", 1),
         ]
+    if given is not None:
+        cases = given
     epi_code = {"none": _capi.EPI_NONE, "relu": _capi.EPI_RELU, "residual": _capi.EPI_RESIDUAL,
                 "sigmoid": _capi.EPI_SIGMOID}
     for dims, gath, relu, need, hid, out, L, bias, epi, n_gout in cases:
@@ -586,6 +589,31 @@ def case_mlp_bf16_backward(device, rows=75, full=True):
             assert_close(gW[i], dW[i], TOL16, f"{tag} gW{i}")
             if bias:
                 assert_close(gb[i], db[i], TOL16, f"{tag} gb{i}")
+
+
+def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choices=(1, 16, 17, 33, 100, 2050)):
+    """Random shapes through the bf16 backward (and the forward recompute inside it): one to four
+    segments with and without gathers / ReLU-on-load / wanted gradients, hidden widths on both
+    sides of the tile boundaries (one k-step and up to three hidden tiles run the two-tile form,
+    the rest the one-tile form; no wanted gradient at all runs the weight-gradient-only form),
+    L = 2 / 3, with and without bias, all four epilogues, one or two upstream terms, row counts
+    around the 16- and 32-row tile sizes."""
+    g = np.random.default_rng(seed)
+    for rnd in range(rounds):
+        cases = []
+        for _ in range(cases_per_round):
+            n_seg = int(g.integers(1, 5))
+            dims = tuple(int(g.integers(1, 13)) for _ in range(n_seg))
+            bias = bool(g.integers(0, 2))
+            while sum((d + 3) // 4 for d in dims) + (1 if bias and all(d % 4 == 0 for d in dims) else 0) > 16:
+                dims = dims[:-1]
+            epi = ("none", "relu", "residual", "sigmoid")[int(g.integers(0, 4))]
+            hid = int(g.choice([1, 7, 15, 16, 31, 40, 47, 48, 62]))
+            out = int(g.integers(1, 17))
+            cases.append((dims, tuple(bool(g.integers(0, 2)) for _ in dims), tuple(bool(g.integers(0, 2)) for _ in dims),
+                          tuple(bool(g.integers(0, 3)) for _ in dims), hid, out, int(g.integers(2, 4)), bias, epi,
+                          1 if epi == "sigmoid" else int(g.integers(1, 3))))
+        case_mlp_bf16_backward(device, rows=int(g.choice(row_choices)), cases=cases, seed=seed + rnd)
 
 
 def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):

@@ -28,3 +28,8 @@ def test_ec_bf16_emulated():
 def test_rows_bf16_emulated():
     with emulated():
         P.case_rows_bf16("cpu")
+
+
+def test_mlp_bf16_stress_emulated():
+    with emulated():
+        P.case_mlp_bf16_stress("cpu", rounds=1, cases_per_round=5, row_choices=(1, 17, 33))

@@ -90,6 +90,10 @@ def test_bf16_mlp_backward(dev):
     P.case_mlp_bf16_backward(dev, rows=100_000, full=False)
 
 
+def test_bf16_mlp_stress(dev):
+    P.case_mlp_bf16_stress(dev, rounds=6)
+
+
 def test_bf16_edge_classifier(dev):
     # all residual layouts / head inputs; includes the pin against the reference's own modules
     # under bf16 autocast (golden G2b) - the report holds the measured distances

@@ -75,6 +75,9 @@ def parse(argv=None):
                     help="graph index built inline in every step (default: as if a new batch arrived every "
                          "step), for the next batch on a side stream, or kept resident per batch (what epochs "
                          ">= 2 over a dataset held in HBM see: 28 B/edge of index next to 42 B/edge of inputs)")
+    ap.add_argument("--node-ids", default="random", choices=("random", "phi"),
+                    help="synthetic events with hit ids random w.r.t. the geometry (default: worst case for the "
+                         "node-row gathers) or numbered by phi (edges join neighbouring ids: best case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configurations")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -257,7 +260,9 @@ class ECWorkload(Workload):
             if args.events:
                 n_ev = args.events
             seed0 = 1 if workload == "cfg2" else 100 + rank * n_ev
-            events = [synthetic.make_event(seed0 + i, n_hits, n_edges, dev) for i in range(n_ev)]
+            events = [synthetic.make_event(seed0 + i, n_hits, n_edges, dev,
+                                           phi_sorted_ids=getattr(args, "node_ids", "random") == "phi")
+                      for i in range(n_ev)]
             if rank == 0 and world == 1:
                 self.first_event_cpu = events[0].cpu()
             self.batches = [G.collate(events)]
@@ -265,7 +270,9 @@ class ECWorkload(Workload):
             b = self.batches[0]
             self.edges_per_step_global = b.num_edges * world
             self.describe = (f"{workload}: per GPU {n_ev} events x {n_hits} hits x {n_edges} edges collated "
-                             f"(N={b.num_nodes}, E={b.num_edges})")
+                             f"(N={b.num_nodes}, E={b.num_edges})"
+                             + ("; hit ids numbered by phi (best-case gather locality)"
+                                if getattr(args, "node_ids", "random") == "phi" else ""))
         self.describe += (f"; ECForGraphTCN(node_indim=14, edge_indim=4, L_ec={EC_MODEL['L_ec']}, "
                           f"hidden_dim={EC_MODEL['hidden_dim']}); step = graph index "
                           + ("(built for the next batch on the loader's side stream during the step) "

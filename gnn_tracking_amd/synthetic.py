@@ -18,7 +18,10 @@ from .data import Data
 
 
 def make_event(seed: int, n_nodes: int, n_edges: int, device="cpu", *, node_dim: int = 14,
-               isolated_frac: float = 0.03, max_offset: int = 64) -> Data:
+               isolated_frac: float = 0.03, max_offset: int = 64, phi_sorted_ids: bool = False) -> Data:
+    """``phi_sorted_ids``: renumber the hits by phi, so that the endpoints of an edge have
+    neighbouring ids (what a dataset written out in detector order looks like: the best case for
+    gather locality).  Default False: ids are random with respect to the geometry (worst case)."""
     assert node_dim >= 6 and n_edges % 2 == 0
     dev = torch.device(device)
     g = torch.Generator(device=dev)
@@ -62,6 +65,12 @@ def make_event(seed: int, n_nodes: int, n_edges: int, device="cpu", *, node_dim:
     pid = torch.randint(2 ** 52, 2 ** 60, (N,), generator=g, device=dev, dtype=torch.int64)
     pid[U(N) < 0.04] = 0
     pt = torch.exp(0.7 * torch.randn(N, generator=g, device=dev))
+    if phi_sorted_ids:
+        order = torch.argsort(x[:, 1])                 # new id -> old id
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(N, device=dev)      # old id -> new id
+        x, pt, pid = x[order].contiguous(), pt[order].contiguous(), pid[order].contiguous()
+        edge_index = rank[edge_index].contiguous()
     return Data(x=x, edge_index=edge_index, edge_attr=edge_attr, y=y, pt=pt, particle_id=pid,
                 eta=x[:, 3].clone(), reconstructable=torch.ones(N, device=dev))
 

@@ -112,6 +112,9 @@ _SIGNATURES = {
                                     _P, _P, _P]),
     "gnntrk_knn_search_batched": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                             _P, C.c_int32, _P, _P, _P]),
+    "gnntrk_knn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "gnntrk_knn_search_ws": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, C.c_int32,
+                                       _P, _P, _P, C.c_size_t, C.c_int32, _P]),
     "gnntrk_knn_emit": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
     "gnntrk_knn_emit_prefix": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "gnntrk_edge_labels": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
@@ -138,7 +141,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 200   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
+ABI_VERSION = 201   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

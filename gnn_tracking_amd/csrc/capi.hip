@@ -71,6 +71,9 @@ int knn_search_launch(const float *, int64_t, int, int, int, float, const int64_
                       hipStream_t);
 int knn_emit_launch(const int32_t *, const int32_t *, int64_t, int, int, int64_t *, int64_t *, int64_t,
                     hipStream_t);
+size_t knn_workspace_bytes(int64_t, int, int);
+int knn_search_ws_launch(const float *, int64_t, int, int, int, float, const int64_t *, int, int32_t *, int32_t *,
+                         void *, size_t, int, hipStream_t);
 int edge_features_launch(const float *, int, int, const int64_t *, int64_t, float *, hipStream_t);
 int edge_labels_launch(const int64_t *, const int64_t *, int64_t, int64_t *, hipStream_t);
 
@@ -205,6 +208,13 @@ int gnntrk_knn_search_batched(const float *x, int64_t n, int32_t dim, int32_t x_
                               float max_radius, const int64_t *seg_ptr, int32_t n_seg, int32_t *nbr,
                               int32_t *cnt, void *stream) {
     return knn_search_launch(x, n, dim, x_stride, k, max_radius, seg_ptr, n_seg, nbr, cnt, (hipStream_t)stream);
+}
+size_t gnntrk_knn_workspace_bytes(int64_t n, int32_t dim, int32_t k) { return knn_workspace_bytes(n, dim, k); }
+int gnntrk_knn_search_ws(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k, float max_radius,
+                         const int64_t *seg_ptr, int32_t n_seg, int32_t *nbr, int32_t *cnt, void *workspace,
+                         size_t workspace_bytes, int32_t flags, void *stream) {
+    return knn_search_ws_launch(x, n, dim, x_stride, k, max_radius, seg_ptr, n_seg, nbr, cnt, workspace,
+                                workspace_bytes, flags, (hipStream_t)stream);
 }
 int gnntrk_knn_emit(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k, int64_t *offsets,
                     int64_t *edge_index, int64_t n_edges, void *stream) {

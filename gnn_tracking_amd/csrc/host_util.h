@@ -25,6 +25,9 @@ size_t sort_pairs_temp_bytes(int64_t n);
 int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
                    uint32_t *vals_out, int64_t n, int end_bit, void *temp, size_t temp_bytes,
                    hipStream_t stream);
+size_t sort_pairs_u64_temp_bytes(int64_t n);
+int sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
+                   uint32_t *vals_out, int64_t n, void *temp, size_t temp_bytes, hipStream_t stream);
 
 // mlp.hip
 int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);

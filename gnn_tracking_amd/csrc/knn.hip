@@ -50,6 +50,15 @@ __device__ inline void wave_bitonic_sort(u64 *buf, int cap, int lane) {
     }
 }
 
+// value of lane `src` (wave-uniform index)
+__device__ __forceinline__ int knn_read_lane(int v, int src) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_readlane(v, src);
+#else
+    return __shfl(v, src);
+#endif
+}
+
 // segment (event) of row q: the last s with seg_ptr[s] <= q (seg_ptr ascending, seg_ptr[0] = 0)
 __device__ __forceinline__ int knn_segment_of(const int64_t *__restrict__ seg_ptr, int n_seg, int64_t q) {
     int lo = 0, hi = n_seg - 1;
@@ -243,6 +252,353 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Pruned search: the SAME result as knn_kernel (bit for bit), without visiting most candidates.
+//
+// The points are sorted by (event, Morton code of the quantised coordinates) and cut into chunks
+// of 64 consecutive sorted points, each with its axis-aligned bounding box.  A wave owns QW
+// consecutive SORTED queries (their coordinates in registers, as above).  Candidate chunks are
+// taken 64 at a time (lane = chunk): for every query the lower bound
+//     LB = fmaf chain over the dimensions of  g_d = max(lo_d - q_d, q_d - hi_d, 0)
+// is compared with the query's current threshold; a chunk is only streamed for the queries whose
+// bound passes.  LB <= d2(q, c) holds for every candidate c of the chunk IN THE KERNEL'S OWN
+// ARITHMETIC: fp32 subtraction and fma round monotonically, |fl(q_d - c_d)| >= g_d for
+// lo_d <= c_d <= hi_d, so by induction over the chain LB_d <= d2_d.  A skipped (query, chunk)
+// pair is therefore one in which every candidate fails the distance prefilter of the brute-force
+// step - nothing that could have been appended is lost, the k smallest (d2, index) keys are
+// the same.  Batches of chunks are visited outwards from the wave's own position in the sorted
+// order and every query's buffer is cut to its k best after a batch that added to it, so the
+// thresholds tighten early (without a radius they start at infinity).
+constexpr int kKnnBoxParts = 64;
+
+// per-dimension min / max of all points: partials of kKnnBoxParts blocks (no atomics)
+__global__ __launch_bounds__(256) void knn_bbox_partial_kernel(const float *__restrict__ x, int64_t n, int dim,
+                                                               int stride, float *__restrict__ part) {
+    __shared__ float s_lo[4][8], s_hi[4][8];
+    float lo[8], hi[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        lo[d] = 3.402823466e38f;
+        hi[d] = -3.402823466e38f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if (d < dim) {
+                const float v = x[i * stride + d];
+                lo[d] = fminf(lo[d], v);
+                hi[d] = fmaxf(hi[d], v);
+            }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+        }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            s_lo[wv][d] = lo[d];
+            s_hi[wv][d] = hi[d];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int d = threadIdx.x;
+        part[blockIdx.x * 16 + d] = fminf(fminf(s_lo[0][d], s_lo[1][d]), fminf(s_lo[2][d], s_lo[3][d]));
+        part[blockIdx.x * 16 + 8 + d] = fmaxf(fmaxf(s_hi[0][d], s_hi[1][d]), fmaxf(s_hi[2][d], s_hi[3][d]));
+    }
+}
+
+// sort key of every point: [event | Morton code of the coordinates quantised inside the bounding
+// box] (the ordering only steers the pruning - any order gives the same neighbours)
+__global__ __launch_bounds__(256) void knn_morton_kernel(const float *__restrict__ x, int64_t n, int dim,
+                                                         int stride, const float *__restrict__ part,
+                                                         const int64_t *__restrict__ seg_ptr, int n_seg,
+                                                         int seg_bits, u64 *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals) {
+    __shared__ float s_lo[8], s_scale[8];
+    const int bits = (64 - seg_bits) / dim < 16 ? (64 - seg_bits) / dim : 16;
+    if (threadIdx.x < 8) {
+        const int d = threadIdx.x;
+        float lo = 3.402823466e38f, hi = -3.402823466e38f;
+        for (int b = 0; b < kKnnBoxParts; ++b) {
+            lo = fminf(lo, part[b * 16 + d]);
+            hi = fmaxf(hi, part[b * 16 + 8 + d]);
+        }
+        const float w = hi - lo;
+        s_lo[d] = lo;
+        s_scale[d] = (d < dim && w > 0.f && w < 3.0e38f) ? (float)(1u << bits) / w : 0.f;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[8];
+    const uint32_t qmax = (1u << bits) - 1u;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        q[d] = 0;
+        if (d < dim) {
+            const float t = (x[i * stride + d] - s_lo[d]) * s_scale[d];
+            q[d] = t >= (float)qmax ? qmax : (t > 0.f ? (uint32_t)t : 0u);  // (NaN -> 0)
+        }
+    }
+    u64 code = 0;
+    for (int b = bits - 1; b >= 0; --b)
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if (d < dim) code = (code << 1) | (u64)((q[d] >> b) & 1u);
+    if (seg_bits > 0) {
+        const u64 sg = (u64)knn_segment_of(seg_ptr, n_seg, i);
+        code |= sg << (64 - seg_bits);
+    }
+    keys[i] = code;
+    vals[i] = (uint32_t)i;
+}
+
+// one wave per chunk of 64 sorted points: gather the rows into the sorted array (rows of DP
+// floats, the tail of the last chunk repeats the last point), remember their original indices
+// (-1 in the tail) and write the chunk's bounding box [lo[DP] | hi[DP]]
+template <int DP>
+__global__ __launch_bounds__(256) void knn_gather_box_kernel(const float *__restrict__ x, int64_t n, int dim,
+                                                             int stride, const uint32_t *__restrict__ order,
+                                                             int n_chunks, float *__restrict__ xs,
+                                                             int32_t *__restrict__ sidx,
+                                                             float *__restrict__ box) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int64_t p = (int64_t)c * 64 + lane;
+    const int64_t i = order[p < n ? p : n - 1];
+    float v[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) v[d] = d < dim ? x[i * stride + d] : 0.f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) xs[p * DP + d] = v[d];
+    sidx[p] = p < n ? (int32_t)i : -1;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        float lo = v[d], hi = v[d];
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if (lane == 0) {
+            box[(int64_t)c * 2 * DP + d] = lo;
+            box[(int64_t)c * 2 * DP + DP + d] = hi;
+        }
+    }
+}
+
+template <int DP, bool BATCH, int QW>
+__global__ __launch_bounds__(kKnnBlock) void knn_pruned_kernel(const float *__restrict__ xs,
+                                                               const int32_t *__restrict__ sidx,
+                                                               const float *__restrict__ box, int64_t n,
+                                                               int n_chunks, int k, int cap, float max_radius,
+                                                               const int64_t *__restrict__ seg_ptr, int n_seg,
+                                                               int32_t *__restrict__ nbr,
+                                                               int32_t *__restrict__ cnt_out) {
+    __shared__ __attribute__((aligned(16))) u64 s_keys[kKnnWaves][kKnnLdsPerWave / 8];
+    __shared__ u64 s_tau[kKnnWaves][QW];
+    __shared__ int s_cnt[kKnnWaves][QW], s_oq[kKnnWaves][QW];
+    __shared__ int s_lo[kKnnWaves][QW], s_hi[kKnnWaves][QW];  // original-index range of each query's event
+    const int lane = threadIdx.x & 63, wv = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u64 *keys = s_keys[wv];
+    u64 *tau = s_tau[wv];
+    int *cnt = s_cnt[wv], *oq = s_oq[wv], *qlo = s_lo[wv], *qhi = s_hi[wv];
+    const int64_t q0 = ((int64_t)blockIdx.x * kKnnWaves + wv) * QW;  // position in the SORTED order
+    if (q0 >= n) return;
+    const int nq = (int)((n - q0 < QW) ? (n - q0) : QW);
+
+    u64 tau0 = kKeyMax;
+    if (max_radius > 0.f) {
+        const float r2 = max_radius * max_radius * 1.000001f + 1e-30f;
+        tau0 = ((u64)__float_as_uint(r2) << 32) | 0xffffffffull;
+    }
+    if (lane < QW) {
+        tau[lane] = tau0;
+        cnt[lane] = 0;
+        const int o = sidx[q0 + (lane < nq ? lane : nq - 1)];
+        oq[lane] = o;
+        if (BATCH) {
+            const int sg = knn_segment_of(seg_ptr, n_seg, o);
+            qlo[lane] = (int)seg_ptr[sg];
+            qhi[lane] = (int)seg_ptr[sg + 1];
+        }
+    }
+    knn_wave_sync();
+    // chunks the wave has to look at: the events of its queries occupy the same positions in the
+    // sorted order as in the original one (the event is the top of the sort key)
+    int c_lo = 0, c_hi = n_chunks;
+    if (BATCH) {
+        c_lo = qlo[0] >> 6;
+        c_hi = (qhi[nq - 1] + 63) >> 6;
+    }
+    c_lo = (int)__builtin_amdgcn_readfirstlane(c_lo);
+    c_hi = (int)__builtin_amdgcn_readfirstlane(c_hi);
+
+    int lane_zero;
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+#else
+    lane_zero = 0;
+#endif
+    float qv[QW][DP];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+        const float *__restrict__ xq = xs + (q0 + (q < nq ? q : nq - 1)) * DP + lane_zero;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) qv[q][d] = xq[d];
+    }
+    uint32_t tau_hi[QW];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) tau_hi[q] = (uint32_t)(tau0 >> 32);
+
+    auto load_chunk = [&](int c, float (&v)[DP], int &id) {
+        const int64_t p = (int64_t)c * 64 + lane;
+        const float *__restrict__ row = xs + p * DP;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) v[d] = row[d];
+        id = sidx[p];
+    };
+
+    const int b_lo = c_lo >> 6, b_hi = (c_hi + 63) >> 6;
+    const int b_own = (int)((q0 >> 6) >> 6);
+    const int span = (b_own - b_lo) > (b_hi - 1 - b_own) ? (b_own - b_lo) : (b_hi - 1 - b_own);
+    for (int t = 0; t <= 2 * span; ++t) {
+        const int off = (t + 1) >> 1;
+        const int b = (t & 1) ? b_own + off : b_own - off;
+        if (b < b_lo || b >= b_hi) continue;
+        // lane = chunk: lower bound of every query's distance to the chunk's box
+        const int c = b * 64 + lane;
+        const bool cvalid = c >= c_lo && c < c_hi;
+        const float *__restrict__ bx = box + (int64_t)(cvalid ? c : c_lo) * 2 * DP;
+        float lo[DP], hi[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            lo[d] = bx[d];
+            hi[d] = bx[DP + d];
+        }
+        int qmask = 0;  // bit u: query u has to look at this lane's chunk
+#pragma unroll
+        for (int u = 0; u < QW; ++u) {
+            float lb = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const float g = fmaxf(fmaxf(__fsub_rn(lo[d], qv[u][d]), __fsub_rn(qv[u][d], hi[d])), 0.f);
+                lb = __fmaf_rn(g, g, lb);
+            }
+            if (cvalid && u < nq && __float_as_uint(lb) <= tau_hi[u]) qmask |= 1 << u;
+        }
+        u64 any = __ballot(qmask != 0);
+        int dirty = 0;
+        if (any != 0ull) {
+            float xc[DP], xn[DP];
+            int ic, in;
+            int ci = __ffsll(any) - 1;
+            load_chunk(b * 64 + ci, xc, ic);
+            while (any != 0ull) {
+                any &= any - 1ull;
+                const int cn = any != 0ull ? __ffsll(any) - 1 : ci;
+                load_chunk(b * 64 + cn, xn, in);  // the next surviving chunk is in flight
+                const int64_t j = (int64_t)(b * 64 + ci) * 64 + lane;  // sorted position of the candidate
+                const int qm = knn_read_lane(qmask, ci);
+#pragma unroll
+                for (int u = 0; u < QW; ++u) {
+                    if (((qm >> u) & 1) == 0) continue;
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) {
+                        const float tt = __fsub_rn(qv[u][d], xc[d]);
+                        d2 = __fmaf_rn(tt, tt, d2);
+                    }
+                    if (__ballot(__float_as_uint(d2) <= tau_hi[u]) == 0ull) continue;
+                    const u64 tq = tau[u];
+                    u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)ic;
+                    if (ic < 0 || j == q0 + u) key = kKeyMax;  // tail of the last chunk / the query itself
+                    if (BATCH && (ic < qlo[u] || ic >= qhi[u])) key = kKeyMax;  // another event's hit
+                    const bool pass = key < tq;
+                    const u64 mask = __ballot(pass);
+                    if (mask != 0ull) {
+                        const int base = cnt[u];
+                        if (pass) keys[u * cap + base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+                        int nc = base + __popcll(mask);
+                        dirty |= 1 << u;
+                        knn_wave_sync();
+                        if (nc > cap - 64) {  // no room for another full chunk: keep the k best
+                            u64 *bq = keys + u * cap;
+                            for (int i = nc + lane; i < cap; i += 64) bq[i] = kKeyMax;
+                            knn_wave_sync();
+                            wave_bitonic_sort(bq, cap, lane);
+                            nc = k;
+                            tau_hi[u] = (uint32_t)(bq[k - 1] >> 32);
+                            if (lane == 0) tau[u] = bq[k - 1];
+                            dirty &= ~(1 << u);
+                        }
+                        if (lane == 0) cnt[u] = nc;
+                        knn_wave_sync();
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < DP; ++d) xc[d] = xn[d];
+                ic = in;
+                ci = cn;
+            }
+        }
+        // a buffer that grew to k or more entries is cut to its k best now: the threshold of the
+        // NEXT batch of boxes is the k-th key found so far
+        dirty = (int)__builtin_amdgcn_readfirstlane(dirty);
+        if (dirty != 0) {
+#pragma unroll
+            for (int u = 0; u < QW; ++u) {
+                if (((dirty >> u) & 1) == 0) continue;
+                const int nc = cnt[u];
+                if (nc < k) continue;
+                u64 *bq = keys + u * cap;
+                for (int i = nc + lane; i < cap; i += 64) bq[i] = kKeyMax;
+                knn_wave_sync();
+                wave_bitonic_sort(bq, cap, lane);
+                tau_hi[u] = (uint32_t)(bq[k - 1] >> 32);
+                if (lane == 0) {
+                    tau[u] = bq[k - 1];
+                    cnt[u] = k;
+                }
+                knn_wave_sync();
+            }
+        }
+    }
+
+    // final: sort every buffer, apply the radius filter (a prefix: keys ascend), emit into the
+    // rows of the ORIGINAL query indices
+    for (int q = 0; q < nq; ++q) {
+        u64 *bq = keys + q * cap;
+        const int nc = cnt[q];
+        const int64_t row = oq[q];
+        for (int i = nc + lane; i < cap; i += 64) bq[i] = kKeyMax;
+        knn_wave_sync();
+        wave_bitonic_sort(bq, cap, lane);
+        const int mm = nc < k ? nc : k;
+        int out = 0;
+        for (int i0 = 0; i0 < mm; i0 += 64) {
+            const int i = i0 + lane;
+            bool ok = false;
+            u64 key = kKeyMax;
+            if (i < mm) {
+                key = bq[i];
+                ok = key != kKeyMax;
+                if (ok && max_radius > 0.f)
+                    ok = __fsqrt_rn(__uint_as_float((uint32_t)(key >> 32))) < max_radius;
+            }
+            if (ok) nbr[row * k + i] = (int32_t)(uint32_t)(key & 0xffffffffull);
+            out += __popcll(__ballot(ok));
+        }
+        if (lane == 0) cnt_out[row] = out;
+        knn_wave_sync();
+    }
+}
+
 // edge_index[0][off[q]+i] = nbr[q][i] (neighbour = source j), edge_index[1][..] = q (target i)
 __global__ __launch_bounds__(256) void knn_emit_kernel(const int32_t *__restrict__ nbr,
                                                        const int32_t *__restrict__ cnt,
@@ -364,6 +720,108 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
 #undef KNN_LAUNCH
 #undef KNN_LAUNCH_Q
     return check_launch("knn_search");
+}
+
+// ---- pruned search: workspace layout and launch -------------------------------------------
+struct KnnWs {
+    size_t part, keys_a, keys_b, vals_a, vals_b, xs, sidx, box, temp, total;
+    int n_chunks, dp;
+};
+static KnnWs knn_ws_layout(int64_t n, int dim) {
+    KnnWs w{};
+    w.dp = dim <= 4 ? 4 : 8;
+    w.n_chunks = (int)ceil_div(n, 64);
+    const size_t rows = (size_t)w.n_chunks * 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += align_up(bytes, 256);
+        return at;
+    };
+    w.part = take((size_t)kKnnBoxParts * 16 * sizeof(float));
+    w.keys_a = take((size_t)n * 8);
+    w.keys_b = take((size_t)n * 8);
+    w.vals_a = take((size_t)n * 4);
+    w.vals_b = take((size_t)n * 4);
+    w.xs = take(rows * w.dp * sizeof(float));
+    w.sidx = take(rows * 4);
+    w.box = take((size_t)w.n_chunks * 2 * w.dp * sizeof(float));
+    w.temp = take(sort_pairs_u64_temp_bytes(n));
+    w.total = o;
+    return w;
+}
+
+// queries per wave of the pruned kernel for this k (0: not covered, use the brute-force kernel)
+static int knn_pruned_qw(int dim, int k, int *cap_out) {
+    int cap = 128;
+    while (cap < k + 64) cap <<= 1;
+    *cap_out = cap;
+    const int qw = kKnnLdsPerWave / (cap * 8);
+    return (dim <= 8 && (qw == 8 || qw == 4)) ? qw : 0;
+}
+
+size_t knn_workspace_bytes(int64_t n, int dim, int k) {
+    int cap;
+    if (n <= 0 || dim < 1 || k < 1 || n > 0x7fffffff || knn_pruned_qw(dim, k, &cap) == 0) return 0;
+    return knn_ws_layout(n, dim).total;
+}
+
+constexpr int64_t kKnnPrunedMinRows = 8192;  // below this the sort + boxes cost more than they save
+
+int knn_search_ws_launch(const float *x, int64_t n, int dim, int stride, int k, float max_radius,
+                         const int64_t *seg_ptr, int n_seg, int32_t *nbr, int32_t *cnt, void *ws,
+                         size_t ws_bytes, int flags, hipStream_t stream) {
+    int cap = 0;
+    const int qw = (n > 0 && dim >= 1 && k >= 1 && n <= 0x7fffffff) ? knn_pruned_qw(dim, k, &cap) : 0;
+    const bool force_brute = (flags & 2) != 0, force_pruned = (flags & 1) != 0;
+    bool pruned = qw != 0 && ws != nullptr && !force_brute && (force_pruned || n >= kKnnPrunedMinRows);
+    if (pruned && seg_ptr && n_seg > 65536) pruned = false;
+    if (!pruned) return knn_search_launch(x, n, dim, stride, k, max_radius, seg_ptr, n_seg, nbr, cnt, stream);
+    if (!x || !nbr || !cnt || stride < dim) return fail(GNNTRK_EINVAL, "knn_search: bad argument");
+    if (seg_ptr && n_seg < 1) return fail(GNNTRK_EINVAL, "knn_search: seg_ptr needs n_seg >= 1");
+    const KnnWs w = knn_ws_layout(n, dim);
+    if (ws_bytes < w.total) return fail(GNNTRK_EINVAL, "knn_search: workspace too small (gnntrk_knn_workspace_bytes)");
+    char *base = static_cast<char *>(ws);
+    float *part = reinterpret_cast<float *>(base + w.part);
+    u64 *keys_a = reinterpret_cast<u64 *>(base + w.keys_a), *keys_b = reinterpret_cast<u64 *>(base + w.keys_b);
+    uint32_t *vals_a = reinterpret_cast<uint32_t *>(base + w.vals_a), *vals_b = reinterpret_cast<uint32_t *>(base + w.vals_b);
+    float *xs = reinterpret_cast<float *>(base + w.xs);
+    int32_t *sidx = reinterpret_cast<int32_t *>(base + w.sidx);
+    float *box = reinterpret_cast<float *>(base + w.box);
+    int seg_bits = 0;
+    if (seg_ptr)
+        while ((1 << seg_bits) < n_seg) ++seg_bits;
+    hipLaunchKernelGGL(knn_bbox_partial_kernel, dim3(kKnnBoxParts), dim3(256), 0, stream, x, n, dim, stride, part);
+    hipLaunchKernelGGL(knn_morton_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, x, n, dim, stride,
+                       (const float *)part, seg_ptr, n_seg, seg_bits, keys_a, vals_a);
+    int rc = check_launch("knn_search(sort keys)");
+    if (rc != GNNTRK_OK) return rc;
+    rc = sort_pairs_u64(keys_a, keys_b, vals_a, vals_b, n, base + w.temp, sort_pairs_u64_temp_bytes(n), stream);
+    if (rc != GNNTRK_OK) return rc;
+    const unsigned gb = (unsigned)ceil_div(w.n_chunks, 4);
+    if (w.dp == 4)
+        hipLaunchKernelGGL((knn_gather_box_kernel<4>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
+                           (const uint32_t *)vals_b, w.n_chunks, xs, sidx, box);
+    else
+        hipLaunchKernelGGL((knn_gather_box_kernel<8>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
+                           (const uint32_t *)vals_b, w.n_chunks, xs, sidx, box);
+    const unsigned grid = (unsigned)ceil_div(n, (int64_t)qw * kKnnWaves);
+#define KNN_PRUNED(DP, QW_)                                                                                  \
+    if (seg_ptr)                                                                                             \
+        hipLaunchKernelGGL((knn_pruned_kernel<DP, true, QW_>), dim3(grid), dim3(kKnnBlock), 0, stream,       \
+                           (const float *)xs, (const int32_t *)sidx, (const float *)box, n, w.n_chunks, k,   \
+                           cap, max_radius, seg_ptr, n_seg, nbr, cnt);                                       \
+    else                                                                                                     \
+        hipLaunchKernelGGL((knn_pruned_kernel<DP, false, QW_>), dim3(grid), dim3(kKnnBlock), 0, stream,      \
+                           (const float *)xs, (const int32_t *)sidx, (const float *)box, n, w.n_chunks, k,   \
+                           cap, max_radius, seg_ptr, n_seg, nbr, cnt)
+    if (w.dp == 4) {
+        if (qw == 8) { KNN_PRUNED(4, 8); } else { KNN_PRUNED(4, 4); }
+    } else {
+        if (qw == 8) { KNN_PRUNED(8, 8); } else { KNN_PRUNED(8, 4); }
+    }
+#undef KNN_PRUNED
+    return check_launch("knn_search(pruned)");
 }
 
 int knn_emit_launch(const int32_t *nbr, const int32_t *cnt, int64_t n, int k_stride, int k, int64_t *offsets,

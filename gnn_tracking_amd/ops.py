@@ -670,6 +670,22 @@ def _wide_mlp(segs: Sequence[Seg], weights, biases, *, n_rows: int, epilogue: in
 
 
 # ------------------------------------------------------------------- kNN graphs
+#: bit 0: pruned search below its row threshold too; bit 1: brute force only (tests, measurements)
+_KNN_FLAGS = int(os.environ.get("GNNTRK_KNN_FLAGS", "0"))
+
+
+def _knn_search(lib, x: Tensor, k: int, r: float, seg_ptr: Optional[Tensor], nbr: Tensor, cnt: Tensor, st) -> None:
+    """``gnntrk_knn_search_ws``: the neighbour search with the workspace of its pruned form
+    (identical output to the brute-force entry points; the library picks the form)."""
+    n, dim = int(x.shape[0]), int(x.shape[1])
+    nb = int(lib.gnntrk_knn_workspace_bytes(n, dim, k))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+    n_seg = int(seg_ptr.numel()) - 1 if seg_ptr is not None else 0
+    _capi.check(lib.gnntrk_knn_search_ws(_p(x), n, dim, _row_stride(x), k, r,
+                                         _p(seg_ptr) if seg_ptr is not None else None, n_seg, _p(nbr), _p(cnt),
+                                         _p(ws) if ws is not None else None, nb, _KNN_FLAGS, st), lib)
+
+
 def knn_graph(x: Tensor, k: int, max_radius: Optional[float] = None, seg_ptr: Optional[Tensor] = None) -> Tensor:
     """``knn_with_max_radius`` (models/graph_construction.py:222-237): int64 ``[2, M]``
     edge index, row 0 = neighbour (source), row 1 = query (target), grouped by query,
@@ -691,12 +707,8 @@ def knn_graph(x: Tensor, k: int, max_radius: Optional[float] = None, seg_ptr: Op
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
     st = _stream(x)
     r = float(max_radius) if max_radius is not None else -1.0
-    if seg_ptr is not None:
-        sp = seg_ptr.to(device=dev, dtype=torch.int64).contiguous()
-        _capi.check(lib.gnntrk_knn_search_batched(_p(x), n, dim, _row_stride(x), kk, r, _p(sp), int(sp.numel()) - 1,
-                                                  _p(nbr), _p(cnt), st), lib)
-    else:
-        _capi.check(lib.gnntrk_knn_search(_p(x), n, dim, _row_stride(x), kk, r, _p(nbr), _p(cnt), st), lib)
+    sp = seg_ptr.to(device=dev, dtype=torch.int64).contiguous() if seg_ptr is not None else None
+    _knn_search(lib, x, kk, r, sp, nbr, cnt, st)
     off = torch.empty(n + 1, dtype=torch.int64, device=dev)
     _capi.check(lib.gnntrk_knn_emit(_p(nbr), _p(cnt), n, kk, _p(off), None, 0, st), lib)
     m = int(off[n].item())  # the one host sync: the output size is data dependent
@@ -718,7 +730,7 @@ def knn_kth_neighbor(x: Tensor, k: int, max_radius: Optional[float] = None) -> T
     nbr = torch.empty(n * k, dtype=torch.int32, device=x.device)
     cnt = torch.empty(n, dtype=torch.int32, device=x.device)
     r = float(max_radius) if max_radius is not None else -1.0
-    _capi.check(lib.gnntrk_knn_search(_p(x), n, dim, _row_stride(x), int(k), r, _p(nbr), _p(cnt), _stream(x)), lib)
+    _knn_search(lib, x, int(k), r, None, nbr, cnt, _stream(x))
     last = nbr.view(n, k)[:, k - 1]
     return torch.where(cnt >= k, last, torch.full_like(last, -1)).contiguous()
 
@@ -744,7 +756,7 @@ def knn_scan(x: Tensor, ks: Sequence[int], max_radius: Optional[float] = None) -
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
     st = _stream(x)
     r = float(max_radius) if max_radius is not None else -1.0
-    _capi.check(lib.gnntrk_knn_search(_p(x), n, dim, _row_stride(x), kmax, r, _p(nbr), _p(cnt), st), lib)
+    _knn_search(lib, x, kmax, r, None, nbr, cnt, st)
     offs = {}
     for k in ks:  # all offset scans first, then ONE host read of the edge counts
         off = torch.empty(n + 1, dtype=torch.int64, device=dev)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNNTRK_VERSION 200 /* 0.2.0: + edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed */
+#define GNNTRK_VERSION 201 /* 0.2.1: + knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
 #define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
 #define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
 #define GNNTRK_MAX_HIDDEN 64
@@ -345,6 +345,18 @@ int gnntrk_knn_search(const float *x, int64_t n, int32_t dim, int32_t x_stride, 
 int gnntrk_knn_search_batched(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k,
                               float max_radius, const int64_t *seg_ptr, int32_t n_seg, int32_t *nbr,
                               int32_t *cnt, void *stream);
+/* The same search with a caller-owned workspace (gnntrk_knn_workspace_bytes; 0 = this shape is
+ * not covered, pass NULL): for dim <= 8, k <= 192 and at least 8192 rows the points are sorted
+ * by (event, Morton code), cut into chunks of 64 with bounding boxes, and a query only streams
+ * the chunks whose box can hold a neighbour closer than its current threshold.  The bound is
+ * evaluated in the search's own arithmetic (monotone fp32 rounding), so nbr / cnt are
+ * bit-identical to gnntrk_knn_search(_batched) - only faster (200 k clustered hits, dim 8: see
+ * DESIGN.md 4.6).  seg_ptr may be NULL (one event).  flags: bit 0 = use the pruned search
+ * below 8192 rows too, bit 1 = brute force regardless (both for tests / measurements). */
+size_t gnntrk_knn_workspace_bytes(int64_t n, int32_t dim, int32_t k);
+int gnntrk_knn_search_ws(const float *x, int64_t n, int32_t dim, int32_t x_stride, int32_t k, float max_radius,
+                         const int64_t *seg_ptr, int32_t n_seg, int32_t *nbr, int32_t *cnt, void *workspace,
+                         size_t workspace_bytes, int32_t flags, void *stream);
 int gnntrk_knn_emit(const int32_t *nbr, const int32_t *cnt, int64_t n, int32_t k, int64_t *offsets,
                     int64_t *edge_index, int64_t n_edges, void *stream);
 /* The k_take <= k_stride nearest neighbours out of a search done with k = k_stride: the same

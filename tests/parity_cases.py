@@ -1498,6 +1498,43 @@ def case_knn_batched(device, sizes=(1, 5, 70, 130, 2, 64)):
     assert torch.equal(radius_graph(x, 0.5, batch, 100), want)
 
 
+def case_knn_pruned(device, shapes=((700, 8, 16, 1.0), (300, 3, 4, None), (513, 2, 70, 0.3), (200, 5, 100, None),
+                                    (64, 4, 5, 0.5), (65, 8, 3, None)), with_oracle=True, batched_sizes=(1, 5, 70, 130, 2, 64)):
+    """The pruned search (sorted chunks + bounding-box lower bounds, ``gnntrk_knn_search_ws``) against
+    the brute-force kernel and the C oracle, bit for bit: clustered clouds with noise (boxes that
+    prune), plain uniform ones (nothing to prune), no radius (thresholds start at infinity), ties
+    (duplicated points), k beyond the first buffer size, events of a collated batch."""
+    g = np.random.default_rng(12)
+    old = ops._KNN_FLAGS
+
+    def search(x, k, r, seg_ptr, flags):
+        ops._KNN_FLAGS = flags
+        try:
+            return ops.knn_graph(x, k, r, seg_ptr=seg_ptr)
+        finally:
+            ops._KNN_FLAGS = old
+
+    for (n, d, k, r) in shapes:
+        centres = g.uniform(-2, 2, size=(max(n // 30, 1), d))
+        x = centres[g.integers(0, len(centres), size=n)] + 0.05 * g.normal(size=(n, d))
+        x[::11] = g.uniform(-2, 2, size=(len(x[::11]), d))      # noise hits
+        x[5::50] = x[4::50][:len(x[5::50])]                     # exact duplicates: ties by index
+        x = tt(x.astype(np.float32))
+        pruned, brute = search(x.to(device), k, r, None, 1), search(x.to(device), k, r, None, 2)
+        assert torch.equal(pruned, brute), f"pruned kNN != brute force: n={n} d={d} k={k} r={r}"
+        if with_oracle:
+            assert torch.equal(pruned.cpu(), O.knn_graph_c(x, k, r)), f"pruned kNN vs oracle n={n} d={d} k={k} r={r}"
+    x = torch.zeros(200, 3)
+    x[100:] = 1.0  # two points only: every box is degenerate
+    assert torch.equal(search(x.to(device), 5, None, None, 1), search(x.to(device), 5, None, None, 2))
+    if batched_sizes:
+        n = sum(batched_sizes)
+        seg_ptr = torch.tensor([0, *np.cumsum(batched_sizes)], dtype=torch.int64, device=device)
+        for d, k, r in ((3, 4, None), (8, 16, 0.9)):
+            x = tt(g.random((n, d)).astype(np.float32), device)
+            assert torch.equal(search(x, k, r, seg_ptr, 1), search(x, k, r, seg_ptr, 2)), f"batched pruned d={d} k={k}"
+
+
 def case_rg_neighbor_cap(device, caps=(4, 16, 256), n_hits=None):
     """``CondensationLossRG.neighbor_cap = "nearest"``: the radius graph's ``max_num_neighbors`` cap
     applied nearest first, against the oracle (whose radius graph truncates nearest first) where the

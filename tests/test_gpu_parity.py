@@ -15,7 +15,7 @@ def dev():
     from gnn_tracking_amd import _capi
 
     lib = _capi.load()  # fails loudly if the extension is missing
-    assert lib.gnntrk_version() == 200
+    assert lib.gnntrk_version() == 201
     return "cuda"
 
 
@@ -58,6 +58,15 @@ def test_knn_goldens_and_oracle(dev):
     P.case_knn_oracle(dev, shapes=((5000, 8, 64, 1.0), (4097, 3, 256, None), (3000, 24, 16, 2.0)))
     P.case_knn_batched(dev)
     P.case_knn_batched(dev, sizes=(3000, 1, 2500, 40, 4000))
+
+
+def test_knn_pruned_equals_brute_force(dev):
+    P.case_knn_pruned(dev)
+    # above the row threshold (the pruned form is what knn_graph runs by default there): many
+    # batches of boxes, both buffer sizes, events
+    P.case_knn_pruned(dev, shapes=((20000, 8, 16, 1.0), (9000, 3, 64, None), (12000, 6, 100, 0.5), (8200, 2, 9, None)),
+                      with_oracle=False, batched_sizes=(3000, 1, 9000, 40, 4500))
+    P.case_knn_pruned(dev, shapes=((9000, 8, 16, 1.0),), batched_sizes=())
 
 
 def test_ml_graph_construction(dev):

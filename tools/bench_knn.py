@@ -14,15 +14,24 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
     x = cloud(500, n)
     xd = x.cuda()
-    for k in (16, 64):
-        ops.knn_graph(xd[:4096], k, 1.0)
+    def timed(k, r, flags):
+        ops._KNN_FLAGS = flags
         dt = 1e9
         for _ in range(3):  # best of three (the first full-size call also pays the allocations)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            ei = ops.knn_graph(xd, k, 1.0)
+            ei = ops.knn_graph(xd, k, r)
             torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
-        print(f"GPU kNN n={n} k={k} r=1: {dt*1e3:.1f} ms, {ei.shape[1]} edges, "
-              f"{n*n*8*2/dt/1e12:.2f} Tflop/s (N^2*D fma)")
+        ops._KNN_FLAGS = 0
+        return dt, ei
+
+    for k, r in ((16, 1.0), (64, 1.0), (16, None)):
+        ops.knn_graph(xd[:4096], k, r)
+        dt_b, ei_b = timed(k, r, 2)
+        dt, ei = timed(k, r, 0)
+        print(f"GPU kNN n={n} k={k} r={r}: pruned {dt*1e3:.2f} ms | brute force {dt_b*1e3:.1f} ms "
+              f"({n*n*8*2/dt_b/1e12:.2f} Tflop/s of N^2*D fma), {ei.shape[1]} edges, identical: {torch.equal(ei, ei_b)}")
+        if r is None:
+            continue
         ns = 20000
         t0 = time.perf_counter(); ref = O.knn_graph_c(x[:ns], k, 1.0); dtc = time.perf_counter() - t0
         got = ops.knn_graph(xd[:ns], k, 1.0).cpu()

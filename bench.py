@@ -416,12 +416,17 @@ class TCWorkload(Workload):
     def stages(self) -> dict:
         s = self.stage.summary()
         n, d, k = self.n_hits, self.DIM, self.n_cp
-        if "graph_build" in s:   # brute-force search: N^2 D multiply-adds on the fp32 vector pipe
+        if "graph_build" in s:
+            # the pruned search visits a data-dependent few per cent of the N^2 pairs, so there is no
+            # fixed flop count to price it with: the figure is the BRUTE-FORCE-EQUIVALENT rate (what an
+            # exhaustive N^2 D search would need to run at to finish in the same time); frac > 1 means
+            # the pruning, not the vector pipe, is doing the work.  Brute force itself: DESIGN.md 4.6
             t = s["graph_build"]["avg_ms"] * 1e-3
-            s["graph_build"]["roofline"] = {"bound": "valu_f32", "achieved": 2.0 * n * n * d / t / 1e12,
-                                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": 2.0 * n * n * d / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                            "note": "includes labels + edge features (HBM-bound tails)"}
+            eq = 2.0 * n * n * d / t / 1e12
+            s["graph_build"]["roofline"] = {"bound": "valu_f32", "achieved": eq, "peak": PEAK_F32_MFMA_TFLOPS,
+                                            "unit": "TFLOP/s (brute-force equivalent)", "frac": eq / PEAK_F32_MFMA_TFLOPS,
+                                            "note": "pruned exact search (bit-identical to brute force) + labels + "
+                                                    "edge features (HBM-bound tails)"}
         if "oc_loss_forward" in s:  # N x K pair pass: 3 D flops for the distance + ~12 for the potentials
             t = s["oc_loss_forward"]["avg_ms"] * 1e-3
             fl = float(n) * k * (3 * d + 12)
@@ -503,12 +508,19 @@ def barrier(world: int) -> None:
 def timed_steps(wl: Workload, world: int, dev, steps: int, warmup: int, *, kernel_timer: bool):
     """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides;
     returns (seconds = max over ranks, last loss, kernel summary)."""
-    for _ in range(warmup):
-        wl.step()
+    # the per-kernel / per-stage HIP-event brackets are armed during the warm-up as well (their
+    # first use costs tens of milliseconds of host time inside the HIP runtime - a one-time cost
+    # like the first launch of a kernel) and emptied before the timed region
     timer = ops.KernelTimer() if kernel_timer else None
     ops.set_kernel_timer(timer)
     if hasattr(wl, "stage"):
         wl.stage.on = True
+    for _ in range(warmup):
+        wl.step()
+    if timer is not None:
+        timer.records.clear()
+    if hasattr(wl, "stage"):
+        wl.stage.rec.clear()
     barrier(world)
     t0 = time.perf_counter()
     for _ in range(steps):

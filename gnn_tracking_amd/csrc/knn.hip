@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
 // thresholds tighten early (without a radius they start at infinity).
 constexpr int kKnnBoxParts = 64;
 
-// per-dimension min / max of all points: partials of kKnnBoxParts blocks (no atomics)
+// per-dimension min / max of all points: partials of up to kKnnBoxParts blocks (no atomics)
 __global__ __launch_bounds__(256) void knn_bbox_partial_kernel(const float *__restrict__ x, int64_t n, int dim,
                                                                int stride, float *__restrict__ part) {
     __shared__ float s_lo[4][8], s_hi[4][8];
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void knn_bbox_partial_kernel(const float *__re
 // sort key of every point: [event | Morton code of the coordinates quantised inside the bounding
 // box] (the ordering only steers the pruning - any order gives the same neighbours)
 __global__ __launch_bounds__(256) void knn_morton_kernel(const float *__restrict__ x, int64_t n, int dim,
-                                                         int stride, const float *__restrict__ part,
+                                                         int stride, const float *__restrict__ part, int n_part,
                                                          const int64_t *__restrict__ seg_ptr, int n_seg,
                                                          int seg_bits, u64 *__restrict__ keys,
                                                          uint32_t *__restrict__ vals) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(const float *__restrict
     if (threadIdx.x < 8) {
         const int d = threadIdx.x;
         float lo = 3.402823466e38f, hi = -3.402823466e38f;
-        for (int b = 0; b < kKnnBoxParts; ++b) {
+        for (int b = 0; b < n_part; ++b) {
             lo = fminf(lo, part[b * 16 + d]);
             hi = fmaxf(hi, part[b * 16 + 8 + d]);
         }
@@ -619,32 +619,86 @@ __global__ __launch_bounds__(256) void knn_emit_kernel(const int32_t *__restrict
     }
 }
 
-// serial-per-block inclusive scan is plenty for n <= a few million counts (HBM-trivial)
+// exclusive scan of min(cnt, k_take) by ONE workgroup (n <= a few million counts): every thread
+// owns a contiguous range, sums it with independent 16-byte loads (the loop is latency bound:
+// eight loads in flight per thread), the 1024 partial sums are scanned by one wave, and
+// the second walk over the (now L2-resident) counts writes the offsets
+template <bool VEC>
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t *__restrict__ cnt_raw, int k_take,
                                                            int64_t n, int64_t *__restrict__ off) {
-    auto cnt = [&](int64_t i) { const int32_t c = cnt_raw[i]; return c < k_take ? c : k_take; };
+    auto clip = [&](int32_t c) { return c < k_take ? c : k_take; };
     __shared__ long long s_part[1024];
-    const int t = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t b = t * per, e = (b + per < n) ? b + per : n;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int64_t per = (n + 1023) / 1024;
+    per = (per + 3) & ~(int64_t)3;  // ranges start on 16-byte boundaries
+    const int64_t b = t * per < n ? t * per : n, e = (b + per < n) ? b + per : n;
     long long s = 0;
-    for (int64_t i = b; i < e; ++i) s += cnt(i);
+    if (VEC) {
+        const int4 *__restrict__ v4 = reinterpret_cast<const int4 *>(cnt_raw + b);
+        const int64_t nv = (e - b) >> 2;
+        int64_t i = 0;
+        for (; i + 8 <= nv; i += 8) {
+            int4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = v4[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (long long)clip(v[u].x) + clip(v[u].y) + clip(v[u].z) + clip(v[u].w);
+        }
+        for (; i < nv; ++i) {
+            const int4 v = v4[i];
+            s += (long long)clip(v.x) + clip(v.y) + clip(v.z) + clip(v.w);
+        }
+        for (int64_t j = b + (nv << 2); j < e; ++j) s += clip(cnt_raw[j]);
+    } else {
+        for (int64_t j = b; j < e; ++j) s += clip(cnt_raw[j]);
+    }
+    // exclusive scan of the 1024 partial sums by wave 0: 16 per lane, shuffles across the lanes
     s_part[t] = s;
     __syncthreads();
-    if (t == 0) {
-        long long run = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const long long v = s_part[i];
-            s_part[i] = run;
-            run += v;
+    if (wv == 0) {
+        long long mine = 0;
+        for (int i = 0; i < 16; ++i) mine += s_part[lane * 16 + i];
+        long long inc = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long o = __shfl(inc, lane >= d ? lane - d : lane);
+            if (lane >= d) inc += o;
         }
-        off[n] = run;
+        long long run0 = inc - mine;
+        for (int i = 0; i < 16; ++i) {
+            const long long v = s_part[lane * 16 + i];
+            s_part[lane * 16 + i] = run0;
+            run0 += v;
+        }
+        if (lane == 63) off[n] = inc;
     }
     __syncthreads();
     long long run = s_part[t];
-    for (int64_t i = b; i < e; ++i) {
-        off[i] = run;
-        run += cnt(i);
+    if (VEC) {
+        const int4 *__restrict__ v4 = reinterpret_cast<const int4 *>(cnt_raw + b);
+        const int64_t nv = (e - b) >> 2;
+        int64_t i = 0;
+        for (; i + 4 <= nv; i += 4) {
+            int4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = v4[i + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t *o = off + b + ((i + u) << 2);
+                o[0] = run; run += clip(v[u].x);
+                o[1] = run; run += clip(v[u].y);
+                o[2] = run; run += clip(v[u].z);
+                o[3] = run; run += clip(v[u].w);
+            }
+        }
+        for (int64_t j = b + (i << 2); j < e; ++j) {
+            off[j] = run;
+            run += clip(cnt_raw[j]);
+        }
+    } else {
+        for (int64_t j = b; j < e; ++j) {
+            off[j] = run;
+            run += clip(cnt_raw[j]);
+        }
     }
 }
 
@@ -791,9 +845,10 @@ int knn_search_ws_launch(const float *x, int64_t n, int dim, int stride, int k, 
     int seg_bits = 0;
     if (seg_ptr)
         while ((1 << seg_bits) < n_seg) ++seg_bits;
-    hipLaunchKernelGGL(knn_bbox_partial_kernel, dim3(kKnnBoxParts), dim3(256), 0, stream, x, n, dim, stride, part);
+    const int n_part = (int)(ceil_div(n, 1024) < kKnnBoxParts ? ceil_div(n, 1024) : kKnnBoxParts);
+    hipLaunchKernelGGL(knn_bbox_partial_kernel, dim3(n_part), dim3(256), 0, stream, x, n, dim, stride, part);
     hipLaunchKernelGGL(knn_morton_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, x, n, dim, stride,
-                       (const float *)part, seg_ptr, n_seg, seg_bits, keys_a, vals_a);
+                       (const float *)part, n_part, seg_ptr, n_seg, seg_bits, keys_a, vals_a);
     int rc = check_launch("knn_search(sort keys)");
     if (rc != GNNTRK_OK) return rc;
     rc = sort_pairs_u64(keys_a, keys_b, vals_a, vals_b, n, base + w.temp, sort_pairs_u64_temp_bytes(n), stream);
@@ -830,7 +885,10 @@ int knn_emit_launch(const int32_t *nbr, const int32_t *cnt, int64_t n, int k_str
         return fail(GNNTRK_EINVAL, "knn_emit: bad argument");
     if (n == 0) return GNNTRK_OK;
     if (!edge_index) {  // phase 1: offsets only (offsets[n] = total edge count)
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, cnt, k, n, offsets);
+        if ((reinterpret_cast<uintptr_t>(cnt) & 15u) == 0)
+            hipLaunchKernelGGL(scan_counts_kernel<true>, dim3(1), dim3(1024), 0, stream, cnt, k, n, offsets);
+        else
+            hipLaunchKernelGGL(scan_counts_kernel<false>, dim3(1), dim3(1024), 0, stream, cnt, k, n, offsets);
         return check_launch("knn_emit(scan)");
     }
     if (m_total > 0)

@@ -85,6 +85,9 @@ struct float2 {
 struct int2 {
     int x, y;
 };
+struct int4 {
+    int x, y, z, w;
+};
 inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
 
 // ------------------------------------------------------------- execution model

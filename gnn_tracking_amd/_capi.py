@@ -134,6 +134,9 @@ _SIGNATURES = {
                                        C.c_size_t, _P]),
     "gnntrk_oc_forward_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnntrk_oc_forward": (C.c_int, [C.POINTER(OcArgs), _P, _P, C.c_size_t, _P]),
+    "gnntrk_oc_spatial_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "gnntrk_oc_forward_spatial": (C.c_int, [C.POINTER(OcArgs), _P, _P, C.c_size_t, _P]),
+    "gnntrk_oc_backward_spatial": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
     "gnntrk_oc_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "gnntrk_oc_backward": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
 }
@@ -141,7 +144,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 201   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
+ABI_VERSION = 202   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

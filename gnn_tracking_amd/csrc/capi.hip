@@ -85,6 +85,10 @@ int oc_select_launch(const float *, const int64_t *, const uint8_t *, int64_t, i
                      int32_t *, int32_t *, void *, size_t, hipStream_t);
 size_t oc_forward_ws_bytes(int64_t);
 int oc_forward_launch(const gnntrk_oc_args *, float *, void *, size_t, hipStream_t);
+size_t oc_spatial_ws_bytes(int64_t, int);
+int oc_forward_spatial_launch(const gnntrk_oc_args *, float *, void *, size_t, hipStream_t);
+int oc_backward_spatial_launch(const gnntrk_oc_args *, const float *, const float *, float *, float *, int64_t, void *,
+                               size_t, hipStream_t);
 size_t oc_backward_ws_bytes(int64_t, int);
 int oc_backward_launch(const gnntrk_oc_args *, const float *, const float *, float *, float *, int64_t, void *,
                        size_t, hipStream_t);
@@ -287,6 +291,15 @@ size_t gnntrk_oc_forward_workspace_bytes(int64_t n) { return oc_forward_ws_bytes
 int gnntrk_oc_forward(const gnntrk_oc_args *args, float *out, void *workspace, size_t workspace_bytes,
                       void *stream) {
     return oc_forward_launch(args, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+size_t gnntrk_oc_spatial_workspace_bytes(int64_t n, int32_t dim) { return oc_spatial_ws_bytes(n, dim); }
+int gnntrk_oc_forward_spatial(const gnntrk_oc_args *args, float *out, void *spatial, size_t spatial_bytes,
+                              void *stream) {
+    return oc_forward_spatial_launch(args, out, spatial, spatial_bytes, (hipStream_t)stream);
+}
+int gnntrk_oc_backward_spatial(const gnntrk_oc_args *args, const float *g, const float *fwd, float *gx,
+                               float *gbeta, int64_t max_cps, void *spatial, size_t spatial_bytes, void *stream) {
+    return oc_backward_spatial_launch(args, g, fwd, gx, gbeta, max_cps, spatial, spatial_bytes, (hipStream_t)stream);
 }
 size_t gnntrk_oc_backward_workspace_bytes(int64_t n, int32_t dim) { return oc_backward_ws_bytes(n, dim); }
 int gnntrk_oc_backward(const gnntrk_oc_args *args, const float *g, const float *fwd, float *gx,

@@ -29,6 +29,14 @@ size_t sort_pairs_u64_temp_bytes(int64_t n);
 int sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
                    uint32_t *vals_out, int64_t n, void *temp, size_t temp_bytes, hipStream_t stream);
 
+// knn.hip: points sorted by (event, Morton code) in chunks of 64 with bounding boxes
+int spatial_dp(int dim);
+int spatial_n_chunks(int64_t n);
+size_t spatial_scratch_bytes(int64_t n);
+int spatial_chunks_build(const float *x, int64_t n, int dim, int stride, const int64_t *seg_ptr, int n_seg,
+                         float *xs, int32_t *sidx, float *box, void *scratch, size_t scratch_bytes,
+                         hipStream_t stream);
+
 // mlp.hip
 int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);
 size_t mlp_backward_ws_bytes(const gnntrk_mlp *m);

@@ -776,16 +776,16 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
     return check_launch("knn_search");
 }
 
-// ---- pruned search: workspace layout and launch -------------------------------------------
-struct KnnWs {
-    size_t part, keys_a, keys_b, vals_a, vals_b, xs, sidx, box, temp, total;
-    int n_chunks, dp;
+// ---- sorted chunks + boxes: shared by the pruned search and the condensation losses (oc.hip) ---
+// Layout of the three outputs for n points of dimension dim (<= 8): rows of DP = 4 or 8 floats.
+int spatial_dp(int dim) { return dim <= 4 ? 4 : 8; }
+int spatial_n_chunks(int64_t n) { return (int)ceil_div(n, 64); }
+// scratch of the build: [box partials | keys a | keys b | vals a | vals b | radix-sort temp]
+struct SpatialScratch {
+    size_t part, keys_a, keys_b, vals_a, vals_b, temp, total;
 };
-static KnnWs knn_ws_layout(int64_t n, int dim) {
-    KnnWs w{};
-    w.dp = dim <= 4 ? 4 : 8;
-    w.n_chunks = (int)ceil_div(n, 64);
-    const size_t rows = (size_t)w.n_chunks * 64;
+static SpatialScratch spatial_scratch_layout(int64_t n) {
+    SpatialScratch w{};
     size_t o = 0;
     auto take = [&](size_t bytes) {
         const size_t at = o;
@@ -797,10 +797,67 @@ static KnnWs knn_ws_layout(int64_t n, int dim) {
     w.keys_b = take((size_t)n * 8);
     w.vals_a = take((size_t)n * 4);
     w.vals_b = take((size_t)n * 4);
+    w.temp = take(sort_pairs_u64_temp_bytes(n));
+    w.total = o;
+    return w;
+}
+size_t spatial_scratch_bytes(int64_t n) { return spatial_scratch_layout(n).total; }
+
+// xs[n_chunks * 64][DP]: the points in (event, Morton) order, the tail of the last chunk repeats the
+// last point; sidx[n_chunks * 64]: their original indices (-1 in the tail); box[n_chunks][2 * DP]
+int spatial_chunks_build(const float *x, int64_t n, int dim, int stride, const int64_t *seg_ptr, int n_seg,
+                         float *xs, int32_t *sidx, float *box, void *scratch, size_t scratch_bytes,
+                         hipStream_t stream) {
+    if (!x || n < 1 || dim < 1 || dim > 8 || stride < dim || !xs || !sidx || !box || !scratch)
+        return fail(GNNTRK_EINVAL, "spatial_chunks: bad argument");
+    const SpatialScratch w = spatial_scratch_layout(n);
+    if (scratch_bytes < w.total) return fail(GNNTRK_EINVAL, "spatial_chunks: scratch too small");
+    char *base = static_cast<char *>(scratch);
+    float *part = reinterpret_cast<float *>(base + w.part);
+    u64 *keys_a = reinterpret_cast<u64 *>(base + w.keys_a), *keys_b = reinterpret_cast<u64 *>(base + w.keys_b);
+    uint32_t *vals_a = reinterpret_cast<uint32_t *>(base + w.vals_a), *vals_b = reinterpret_cast<uint32_t *>(base + w.vals_b);
+    int seg_bits = 0;
+    if (seg_ptr)
+        while ((1 << seg_bits) < n_seg) ++seg_bits;
+    const int n_part = (int)(ceil_div(n, 1024) < kKnnBoxParts ? ceil_div(n, 1024) : kKnnBoxParts);
+    hipLaunchKernelGGL(knn_bbox_partial_kernel, dim3(n_part), dim3(256), 0, stream, x, n, dim, stride, part);
+    hipLaunchKernelGGL(knn_morton_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, x, n, dim, stride,
+                       (const float *)part, n_part, seg_ptr, n_seg, seg_bits, keys_a, vals_a);
+    int rc = check_launch("spatial_chunks(sort keys)");
+    if (rc != GNNTRK_OK) return rc;
+    rc = sort_pairs_u64(keys_a, keys_b, vals_a, vals_b, n, base + w.temp, sort_pairs_u64_temp_bytes(n), stream);
+    if (rc != GNNTRK_OK) return rc;
+    const int n_chunks = spatial_n_chunks(n);
+    const unsigned gb = (unsigned)ceil_div(n_chunks, 4);
+    if (spatial_dp(dim) == 4)
+        hipLaunchKernelGGL((knn_gather_box_kernel<4>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
+                           (const uint32_t *)vals_b, n_chunks, xs, sidx, box);
+    else
+        hipLaunchKernelGGL((knn_gather_box_kernel<8>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
+                           (const uint32_t *)vals_b, n_chunks, xs, sidx, box);
+    return check_launch("spatial_chunks(gather)");
+}
+
+// ---- pruned search: workspace layout and launch -------------------------------------------
+struct KnnWs {
+    size_t xs, sidx, box, scratch, total;
+    int n_chunks, dp;
+};
+static KnnWs knn_ws_layout(int64_t n, int dim) {
+    KnnWs w{};
+    w.dp = spatial_dp(dim);
+    w.n_chunks = spatial_n_chunks(n);
+    const size_t rows = (size_t)w.n_chunks * 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += align_up(bytes, 256);
+        return at;
+    };
     w.xs = take(rows * w.dp * sizeof(float));
     w.sidx = take(rows * 4);
     w.box = take((size_t)w.n_chunks * 2 * w.dp * sizeof(float));
-    w.temp = take(sort_pairs_u64_temp_bytes(n));
+    w.scratch = take(spatial_scratch_bytes(n));
     w.total = o;
     return w;
 }
@@ -836,30 +893,12 @@ int knn_search_ws_launch(const float *x, int64_t n, int dim, int stride, int k, 
     const KnnWs w = knn_ws_layout(n, dim);
     if (ws_bytes < w.total) return fail(GNNTRK_EINVAL, "knn_search: workspace too small (gnntrk_knn_workspace_bytes)");
     char *base = static_cast<char *>(ws);
-    float *part = reinterpret_cast<float *>(base + w.part);
-    u64 *keys_a = reinterpret_cast<u64 *>(base + w.keys_a), *keys_b = reinterpret_cast<u64 *>(base + w.keys_b);
-    uint32_t *vals_a = reinterpret_cast<uint32_t *>(base + w.vals_a), *vals_b = reinterpret_cast<uint32_t *>(base + w.vals_b);
     float *xs = reinterpret_cast<float *>(base + w.xs);
     int32_t *sidx = reinterpret_cast<int32_t *>(base + w.sidx);
     float *box = reinterpret_cast<float *>(base + w.box);
-    int seg_bits = 0;
-    if (seg_ptr)
-        while ((1 << seg_bits) < n_seg) ++seg_bits;
-    const int n_part = (int)(ceil_div(n, 1024) < kKnnBoxParts ? ceil_div(n, 1024) : kKnnBoxParts);
-    hipLaunchKernelGGL(knn_bbox_partial_kernel, dim3(n_part), dim3(256), 0, stream, x, n, dim, stride, part);
-    hipLaunchKernelGGL(knn_morton_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, x, n, dim, stride,
-                       (const float *)part, n_part, seg_ptr, n_seg, seg_bits, keys_a, vals_a);
-    int rc = check_launch("knn_search(sort keys)");
+    const int rc = spatial_chunks_build(x, n, dim, stride, seg_ptr, n_seg, xs, sidx, box, base + w.scratch,
+                                        w.total - w.scratch, stream);
     if (rc != GNNTRK_OK) return rc;
-    rc = sort_pairs_u64(keys_a, keys_b, vals_a, vals_b, n, base + w.temp, sort_pairs_u64_temp_bytes(n), stream);
-    if (rc != GNNTRK_OK) return rc;
-    const unsigned gb = (unsigned)ceil_div(w.n_chunks, 4);
-    if (w.dp == 4)
-        hipLaunchKernelGGL((knn_gather_box_kernel<4>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
-                           (const uint32_t *)vals_b, w.n_chunks, xs, sidx, box);
-    else
-        hipLaunchKernelGGL((knn_gather_box_kernel<8>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
-                           (const uint32_t *)vals_b, w.n_chunks, xs, sidx, box);
     const unsigned grid = (unsigned)ceil_div(n, (int64_t)qw * kKnnWaves);
 #define KNN_PRUNED(DP, QW_)                                                                                  \
     if (seg_ptr)                                                                                             \

@@ -561,6 +561,360 @@ __global__ __launch_bounds__(kOcTpb) void oc_backward_cps_reduce_kernel(const Oc
     gbeta[ak] += acc[DP] * 2.f * a / (1.f - bk * bk) - g[2] / fwd[6];  // coward: mean(1 - beta)
 }
 
+// ---- the same sums without the N x K walk ("spatial" passes) ----------------------------------
+// A repulsive pair needs |x_j - x_k| < radius, so almost all of the N x K pairs of a large event
+// contribute exactly nothing.  The hits are sorted by Morton code into chunks of 64 with bounding
+// boxes (knn.hip: spatial_chunks_build); a (chunk, condensation point) pair is only looked at if
+// the box is closer to the point than the radius (lower bound sum_d max(lo_d - c_d, c_d - hi_d, 0)^2
+// against radius^2 with a 1e-5 relative margin - far above the rounding of either side; the
+// exact test d2 < radius^2 then runs unchanged).  The attractive term has no radius, but it is a
+// sum over (hit, its own condensation point) only: it is taken outside the pair loops.
+//   hit pass  (forward and backward): wave = chunk of 64 sorted hits (lane = hit), the K points
+//             are tested 64 at a time (lane = point) and the survivors walked through LDS;
+//   point pass (backward): wave = condensation point, the chunk boxes are tested 64 at a time
+//             (lane = chunk), the surviving chunks streamed (lane = hit), its own particle's hits
+//             come from a by-gid ordering; one fixed-order wave reduction, no partial buffers.
+// Same pairs, same per-pair arithmetic as the dense kernels above; only the order of the
+// (exactly representable) zero contributions that are skipped differs.
+struct OcSpatial {
+    const float *xs;       // [rows][DP] sorted hits
+    const int32_t *sidx;   // [rows] original hit index, -1 in the tail
+    const float *box;      // [n_chunks][2 DP]
+    const float *hq;       // [rows] q of the sorted hit
+    const long long *hpid; // [rows]
+    const int32_t *hcap;   // [rows] neighbour cap of the sorted hit (-1: none) ...
+    const float *hcapd2;   // ... and its distance
+    const float *cx;       // [K][DP] condensation points
+    const float *cq;       // [K]
+    const long long *cpid; // [K]
+    const uint32_t *gorder;   // hits ordered by gid (point pass)
+    const uint32_t *gkeys;    // the sorted gid keys
+    const int32_t *gstart;    // [K] first position of gid k in gorder
+    int n_chunks;
+};
+
+template <int DP>
+__global__ __launch_bounds__(kOcTpb) void oc_hit_records_kernel(const OcParams p, OcSpatial sp, float *__restrict__ hq,
+                                                                long long *__restrict__ hpid,
+                                                                int32_t *__restrict__ hcap,
+                                                                float *__restrict__ hcapd2) {
+    const int64_t r = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    if (r >= (int64_t)sp.n_chunks * 64) return;
+    const int32_t j = sp.sidx[r];
+    float q = 0.f, cd = 0.f;
+    long long pid = -1;
+    int32_t ci = -1;
+    if (j >= 0) {
+        q = oc_q(p.beta[j], p.q_min);
+        pid = p.pid[j];
+        if (p.cap_nbr) {
+            ci = p.cap_nbr[j];
+            if (ci >= 0) {
+                float xa[DP], xc[DP];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    xa[d] = sp.xs[r * DP + d];
+                    xc[d] = d < p.dim ? p.x[(int64_t)ci * p.stride + d] : 0.f;
+                }
+                cd = oc_d2_chain<DP>(xa, xc);
+            }
+        }
+    }
+    hq[r] = q;
+    hpid[r] = pid;
+    hcap[r] = ci;
+    hcapd2[r] = cd;
+}
+
+template <int DP>
+__global__ __launch_bounds__(kOcTpb) void oc_cp_records_kernel(const OcParams p, float *__restrict__ cx,
+                                                               float *__restrict__ cq, long long *__restrict__ cpid) {
+    const int K = p.n_cp[0];
+    const int k = blockIdx.x * kOcTpb + threadIdx.x;
+    if (k >= K) return;
+    const int32_t a = p.alphas[k];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) cx[(int64_t)k * DP + d] = d < p.dim ? p.x[(int64_t)a * p.stride + d] : 0.f;
+    cq[k] = oc_q(p.beta[a], p.q_min);
+    cpid[k] = p.pid[a];
+}
+
+__device__ __forceinline__ void oc_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ double oc_wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float oc_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// hit pass.  BWD = false: part[chunk][4] = {attractive, repulsive, n_rep_pairs, 0} (oc_finalize_kernel
+// adds them); BWD = true: gx[j], gbeta[j] of every hit (the point pass adds the condensation points' share)
+template <int DP, bool BWD>
+__global__ __launch_bounds__(kOcTpb) void oc_hits_spatial_kernel(const OcParams p, const OcSpatial sp,
+                                                                 const float *__restrict__ g,
+                                                                 const float *__restrict__ fwd,
+                                                                 double *__restrict__ part, float *__restrict__ gx,
+                                                                 float *__restrict__ gbeta) {
+    __shared__ float s_x[kOcTpb / 64][64][DP];
+    __shared__ float s_q[kOcTpb / 64][64];
+    __shared__ long long s_pid[kOcTpb / 64][64];
+    __shared__ int s_hit[kOcTpb / 64][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * (kOcTpb / 64) + wv;
+    if (c >= sp.n_chunks) return;  // (wave-uniform; no workgroup barrier below)
+    const int K = p.n_cp[0];
+    const int64_t r = (int64_t)c * 64 + lane;
+    const int32_t jj = sp.sidx[r];
+    const bool live = jj >= 0;
+    const int64_t j = live ? jj : 0;
+    float xj[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) xj[d] = sp.xs[r * DP + d];
+    const float qj = sp.hq[r];
+    const long long pj = sp.hpid[r];
+    int gj = -1;
+    bool mj = false, is_cp = false;
+    float bj = 0.5f;
+    if (live) {
+        gj = p.gid[j];
+        mj = p.mask[j] != 0;
+        is_cp = gj >= 0 && p.alphas[gj] == jj;
+        bj = p.beta[j];
+    }
+    const int cap_idx = sp.hcap[r];
+    const float cap_d2 = sp.hcapd2[r];
+    float blo[DP], bhi[DP];  // the chunk's box (wave-uniform)
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        blo[d] = sp.box[(int64_t)c * 2 * DP + d];
+        bhi[d] = sp.box[(int64_t)c * 2 * DP + DP + d];
+    }
+    const float r2 = p.radius * p.radius;
+    const float r2m = r2 * 1.00001f + 1e-30f;
+    float ca = 0.f, cr = 0.f;
+    if (BWD) {
+        ca = g[0] / fwd[4];
+        cr = g[1] / fwd[5];
+    }
+    double va = 0.0, vr = 0.0, nrep = 0.0;
+    float gxj[DP];
+    float gqj = 0.f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) gxj[d] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        // lane = condensation point: distance bound to the chunk's box
+        const int k = k0 + lane;
+        const int kc = k < K ? k : K - 1;
+        float ck[DP];
+        float lb = 0.f;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            ck[d] = sp.cx[(int64_t)kc * DP + d];
+            const float gd = fmaxf(fmaxf(blo[d] - ck[d], ck[d] - bhi[d]), 0.f);
+            lb += gd * gd;
+        }
+        unsigned long long near = __ballot(k < K && lb <= r2m);
+        if (near == 0ull) continue;
+        oc_wave_sync();  // (the previous round's readers are done)
+#pragma unroll
+        for (int d = 0; d < DP; ++d) s_x[wv][lane][d] = ck[d];
+        s_q[wv][lane] = sp.cq[kc];
+        s_pid[wv][lane] = sp.cpid[kc];
+        s_hit[wv][lane] = p.alphas[kc];
+        oc_wave_sync();
+        while (near != 0ull) {
+            const int i = __ffsll(near) - 1;
+            near &= near - 1ull;
+            float t[DP];
+            float d2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                t[d] = xj[d] - s_x[wv][i][d];
+                d2 += t[d] * t[d];
+            }
+            if (live && s_pid[wv][i] != pj && d2 < r2 &&
+                (cap_idx < 0 || oc_cap_ok(oc_d2_chain<DP>(xj, s_x[wv][i]), s_hit[wv][i], cap_d2, cap_idx))) {
+                const float qk = s_q[wv][i];
+                if (!BWD) {
+                    nrep += 1.0;  // (counted before the sub-sampling, as the reference's n_rep)
+                    if (oc_keep_pair(p, j, k0 + i)) vr += (double)(qj * qk * (p.radius - sqrtf(p.eps_sqrt + d2)));
+                } else if (oc_keep_pair(p, j, k0 + i)) {
+                    const float sd = sqrtf(p.eps_sqrt + d2);
+                    const float cxr = sd > 0.f ? -cr * qj * qk / sd : 0.f;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) gxj[d] += cxr * t[d];
+                    gqj += cr * qk * (p.radius - sd);
+                }
+            }
+        }
+    }
+    // attractive: the hit and the condensation point of its own particle, at any distance
+    const bool att = live && gj >= 0 && ((p.mode == 1) ? true : (mj && !is_cp));
+    if (att) {
+        float t[DP];
+        float d2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            t[d] = xj[d] - sp.cx[(int64_t)gj * DP + d];
+            d2 += t[d] * t[d];
+        }
+        const float qk = sp.cq[gj];
+        if (!BWD) {
+            va += (double)(qj * qk * d2);
+        } else {
+            const float cxa = ca * 2.f * qj * qk;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) gxj[d] += cxa * t[d];
+            gqj += ca * qk * d2;
+        }
+    }
+    if (!BWD) {
+        const double a = oc_wave_sum(va), rr = oc_wave_sum(vr), cc = oc_wave_sum(nrep);
+        if (lane == 0) {
+            part[(int64_t)c * 4 + 0] = a;
+            part[(int64_t)c * 4 + 1] = rr;
+            part[(int64_t)c * 4 + 2] = cc;
+            part[(int64_t)c * 4 + 3] = 0.0;
+        }
+    } else if (live) {
+        for (int d = 0; d < p.dim; ++d) gx[j * p.stride + d] = gxj[d];
+        const float a = atanhf(bj);
+        float gb = gqj * 2.f * a / (1.f - bj * bj);
+        const bool is_noise = (p.mode == 1) ? !(pj > 0) : (pj == 0);
+        if (is_noise) gb += g[3] / fwd[8];
+        gbeta[j] = gb;
+    }
+}
+
+// gstart[k] = first position of gid k in the by-gid ordering (every k < K owns at least its
+// condensation point)
+__global__ __launch_bounds__(kOcTpb) void oc_gid_keys_kernel(const int32_t *__restrict__ gid, int64_t n,
+                                                             uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    if (i < n) {
+        keys[i] = (uint32_t)gid[i];  // -1 -> 0xffffffff: hits of no particle of interest sort last
+        vals[i] = (uint32_t)i;
+    }
+}
+__global__ __launch_bounds__(kOcTpb) void oc_gid_starts_kernel(const uint32_t *__restrict__ keys, int64_t n,
+                                                               int32_t *__restrict__ gstart) {
+    const int64_t s = (int64_t)blockIdx.x * kOcTpb + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t key = keys[s];
+    if (key != 0xffffffffu && (s == 0 || keys[s - 1] != key)) gstart[key] = (int32_t)s;
+}
+
+// point pass (backward): wave = condensation point k
+template <int DP>
+__global__ __launch_bounds__(kOcTpb) void oc_cps_spatial_kernel(const OcParams p, const OcSpatial sp,
+                                                                const float *__restrict__ g,
+                                                                const float *__restrict__ fwd,
+                                                                float *__restrict__ gx, float *__restrict__ gbeta) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int K = p.n_cp[0];
+    const int k = blockIdx.x * (kOcTpb / 64) + wv;
+    if (k >= K) return;
+    const float ca = g[0] / fwd[4], cr = g[1] / fwd[5];
+    const int32_t ak = p.alphas[k];
+    float xk[DP], gxk[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        xk[d] = sp.cx[(int64_t)k * DP + d];
+        gxk[d] = 0.f;
+    }
+    const float qk = sp.cq[k];
+    const long long pk = sp.cpid[k];
+    float gqk = 0.f;
+    const float r2 = p.radius * p.radius;
+    const float r2m = r2 * 1.00001f + 1e-30f;
+    // repulsive: the chunks whose box reaches into the point's radius
+    for (int c0 = 0; c0 < sp.n_chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const int cc = c < sp.n_chunks ? c : sp.n_chunks - 1;
+        float lb = 0.f;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            const float lo = sp.box[(int64_t)cc * 2 * DP + d], hi = sp.box[(int64_t)cc * 2 * DP + DP + d];
+            const float gd = fmaxf(fmaxf(lo - xk[d], xk[d] - hi), 0.f);
+            lb += gd * gd;
+        }
+        unsigned long long near = __ballot(c < sp.n_chunks && lb <= r2m);
+        while (near != 0ull) {
+            const int i = __ffsll(near) - 1;
+            near &= near - 1ull;
+            const int64_t r = (int64_t)(c0 + i) * 64 + lane;
+            const int32_t jj = sp.sidx[r];
+            float t[DP];
+            float d2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                t[d] = sp.xs[r * DP + d] - xk[d];  // x_j - x_k
+                d2 += t[d] * t[d];
+            }
+            if (jj >= 0 && sp.hpid[r] != pk && d2 < r2 && oc_keep_pair(p, jj, k)) {
+                const int ci = sp.hcap[r];
+                bool ok = true;
+                if (ci >= 0) {
+                    float xa[DP];
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) xa[d] = sp.xs[r * DP + d];
+                    ok = oc_cap_ok(oc_d2_chain<DP>(xa, xk), ak, sp.hcapd2[r], ci);
+                }
+                if (ok) {
+                    const float qj = sp.hq[r];
+                    const float sd = sqrtf(p.eps_sqrt + d2);
+                    const float cxr = sd > 0.f ? -cr * qj * qk / sd : 0.f;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) gxk[d] -= cxr * t[d];
+                    gqk += cr * qj * (p.radius - sd);
+                }
+            }
+        }
+    }
+    // attractive: the hits of particle k (by-gid ordering), at any distance
+    for (int64_t s = sp.gstart[k];; s += 64) {
+        const int64_t t0 = s + lane;
+        const bool mine = t0 < p.n && sp.gkeys[t0 < p.n ? t0 : p.n - 1] == (uint32_t)k;
+        if (mine) {
+            const int64_t j = sp.gorder[t0];
+            const bool att = (p.mode == 1) ? true : (p.mask[j] != 0 && ak != (int32_t)j);
+            if (att) {
+                float t[DP];
+                float d2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    t[d] = (d < p.dim ? p.x[j * p.stride + d] : 0.f) - xk[d];
+                    d2 += t[d] * t[d];
+                }
+                const float qj = oc_q(p.beta[j], p.q_min);
+                const float cxa = ca * 2.f * qj * qk;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) gxk[d] -= cxa * t[d];
+                gqk += ca * qj * d2;
+            }
+        }
+        if (__ballot(mine) != ~0ull) break;  // the run of gid k ended inside this step
+    }
+#pragma unroll
+    for (int d = 0; d < DP; ++d) gxk[d] = oc_wave_sum(gxk[d]);
+    gqk = oc_wave_sum(gqk);
+    if (lane == 0) {
+        for (int d = 0; d < p.dim; ++d) gx[(int64_t)ak * p.stride + d] += gxk[d];
+        const float bk = p.beta[ak];
+        const float a = atanhf(bk);
+        gbeta[ak] += gqk * 2.f * a / (1.f - bk * bk) - g[2] / fwd[6];  // coward: mean(1 - beta)
+    }
+}
+
 // ---- launchers -----------------------------------------------------------------------
 size_t sort_pairs_u64_temp_bytes(int64_t n);
 int sort_pairs_u64(const u64 *keys_in, u64 *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
@@ -694,6 +1048,128 @@ int oc_backward_launch(const gnntrk_oc_args *a, const float *g, const float *fwd
 #undef CALL_BC
     }
     return check_launch("oc_backward");
+}
+
+// ---- spatial passes: workspace layout and launchers ------------------------------------------
+struct OcSpatialWs {
+    size_t xs, sidx, box, hq, hpid, hcap, hcapd2, cx, cq, cpid, part, gkeys_a, gkeys_b, gvals_a, gvals_b, gstart,
+        gtemp, scratch, total;
+    int n_chunks, dp;
+};
+static OcSpatialWs oc_spatial_layout(int64_t n, int dim) {
+    OcSpatialWs w{};
+    w.dp = spatial_dp(dim);
+    w.n_chunks = spatial_n_chunks(n);
+    const size_t rows = (size_t)w.n_chunks * 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += align_up(bytes, 256);
+        return at;
+    };
+    w.xs = take(rows * w.dp * 4);
+    w.sidx = take(rows * 4);
+    w.box = take((size_t)w.n_chunks * 2 * w.dp * 4);
+    w.hq = take(rows * 4);
+    w.hpid = take(rows * 8);
+    w.hcap = take(rows * 4);
+    w.hcapd2 = take(rows * 4);
+    w.cx = take((size_t)n * w.dp * 4);
+    w.cq = take((size_t)n * 4);
+    w.cpid = take((size_t)n * 8);
+    w.part = take((size_t)w.n_chunks * 4 * sizeof(double));
+    w.gkeys_a = take((size_t)n * 4);
+    w.gkeys_b = take((size_t)n * 4);
+    w.gvals_a = take((size_t)n * 4);
+    w.gvals_b = take((size_t)n * 4);
+    w.gstart = take((size_t)n * 4);
+    w.gtemp = take(sort_pairs_temp_bytes(n));
+    w.scratch = take(spatial_scratch_bytes(n));
+    w.total = o;
+    return w;
+}
+size_t oc_spatial_ws_bytes(int64_t n, int dim) {
+    if (n < 1 || n > 0x7fffffff || dim < 1 || dim > 8) return 0;
+    return oc_spatial_layout(n, dim).total;
+}
+static OcSpatial oc_spatial_view(const OcSpatialWs &w, void *ws) {
+    char *b = static_cast<char *>(ws);
+    OcSpatial sp{};
+    sp.xs = reinterpret_cast<const float *>(b + w.xs);
+    sp.sidx = reinterpret_cast<const int32_t *>(b + w.sidx);
+    sp.box = reinterpret_cast<const float *>(b + w.box);
+    sp.hq = reinterpret_cast<const float *>(b + w.hq);
+    sp.hpid = reinterpret_cast<const long long *>(b + w.hpid);
+    sp.hcap = reinterpret_cast<const int32_t *>(b + w.hcap);
+    sp.hcapd2 = reinterpret_cast<const float *>(b + w.hcapd2);
+    sp.cx = reinterpret_cast<const float *>(b + w.cx);
+    sp.cq = reinterpret_cast<const float *>(b + w.cq);
+    sp.cpid = reinterpret_cast<const long long *>(b + w.cpid);
+    sp.gorder = reinterpret_cast<const uint32_t *>(b + w.gvals_b);
+    sp.gkeys = reinterpret_cast<const uint32_t *>(b + w.gkeys_b);
+    sp.gstart = reinterpret_cast<const int32_t *>(b + w.gstart);
+    sp.n_chunks = w.n_chunks;
+    return sp;
+}
+
+int oc_forward_spatial_launch(const gnntrk_oc_args *a, float *out, void *ws, size_t ws_bytes, hipStream_t stream) {
+    int rc = oc_check(a);
+    if (rc) return rc;
+    if (a->dim > 8) return fail(GNNTRK_EUNSUPPORTED, "oc_forward_spatial: dim > 8 (use gnntrk_oc_forward)");
+    const OcSpatialWs w = oc_spatial_layout(a->n, a->dim);
+    if (!out || !ws || ws_bytes < w.total) return fail(GNNTRK_EINVAL, "oc_forward_spatial: workspace too small");
+    const OcParams p = oc_params(a);
+    char *b = static_cast<char *>(ws);
+    rc = spatial_chunks_build(a->x, a->n, a->dim, a->stride, nullptr, 0, reinterpret_cast<float *>(b + w.xs),
+                              reinterpret_cast<int32_t *>(b + w.sidx), reinterpret_cast<float *>(b + w.box),
+                              b + w.scratch, w.total - w.scratch, stream);
+    if (rc) return rc;
+    const OcSpatial sp = oc_spatial_view(w, ws);
+    const int rgrid = oc_grid((int64_t)w.n_chunks * 64), kgrid = oc_grid(a->n), hgrid = (w.n_chunks + 3) / 4;
+    double *part = reinterpret_cast<double *>(b + w.part);
+#define CALL_FS(DP)                                                                                              \
+    hipLaunchKernelGGL(oc_hit_records_kernel<DP>, dim3(rgrid), dim3(kOcTpb), 0, stream, p, sp,                    \
+                       reinterpret_cast<float *>(b + w.hq), reinterpret_cast<long long *>(b + w.hpid),            \
+                       reinterpret_cast<int32_t *>(b + w.hcap), reinterpret_cast<float *>(b + w.hcapd2));         \
+    hipLaunchKernelGGL(oc_cp_records_kernel<DP>, dim3(kgrid), dim3(kOcTpb), 0, stream, p,                         \
+                       reinterpret_cast<float *>(b + w.cx), reinterpret_cast<float *>(b + w.cq),                  \
+                       reinterpret_cast<long long *>(b + w.cpid));                                                \
+    hipLaunchKernelGGL((oc_hits_spatial_kernel<DP, false>), dim3(hgrid), dim3(kOcTpb), 0, stream, p, sp,          \
+                       (const float *)nullptr, (const float *)nullptr, part, (float *)nullptr, (float *)nullptr)
+    if (w.dp == 4) { CALL_FS(4); } else { CALL_FS(8); }
+#undef CALL_FS
+    hipLaunchKernelGGL(oc_finalize_kernel, dim3(1), dim3(kOcTpb), 0, stream, p, (const double *)part, w.n_chunks, out);
+    return check_launch("oc_forward_spatial");
+}
+
+int oc_backward_spatial_launch(const gnntrk_oc_args *a, const float *g, const float *fwd, float *gx, float *gbeta,
+                               int64_t max_cps, void *ws, size_t ws_bytes, hipStream_t stream) {
+    int rc = oc_check(a);
+    if (rc) return rc;
+    if (a->dim > 8) return fail(GNNTRK_EUNSUPPORTED, "oc_backward_spatial: dim > 8 (use gnntrk_oc_backward)");
+    if (!g || !fwd || !gx || !gbeta || max_cps < 1) return fail(GNNTRK_EINVAL, "oc_backward_spatial: bad argument");
+    const OcSpatialWs w = oc_spatial_layout(a->n, a->dim);
+    if (!ws || ws_bytes < w.total) return fail(GNNTRK_EINVAL, "oc_backward_spatial: workspace too small");
+    const OcParams p = oc_params(a);
+    const OcSpatial sp = oc_spatial_view(w, ws);
+    char *b = static_cast<char *>(ws);
+    const int hgrid = (w.n_chunks + 3) / 4, ngrid = oc_grid(a->n);
+    // the by-gid ordering of the hits (for the points' attractive share)
+    uint32_t *gka = reinterpret_cast<uint32_t *>(b + w.gkeys_a), *gkb = reinterpret_cast<uint32_t *>(b + w.gkeys_b);
+    uint32_t *gva = reinterpret_cast<uint32_t *>(b + w.gvals_a), *gvb = reinterpret_cast<uint32_t *>(b + w.gvals_b);
+    hipLaunchKernelGGL(oc_gid_keys_kernel, dim3(ngrid), dim3(kOcTpb), 0, stream, a->gid, a->n, gka, gva);
+    rc = sort_pairs_u32(gka, gkb, gva, gvb, a->n, 32, b + w.gtemp, sort_pairs_temp_bytes(a->n), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(oc_gid_starts_kernel, dim3(ngrid), dim3(kOcTpb), 0, stream, (const uint32_t *)gkb, a->n,
+                       reinterpret_cast<int32_t *>(b + w.gstart));
+    const int cgrid = (int)ceil_div(max_cps, kOcTpb / 64);
+#define CALL_BS(DP)                                                                                              \
+    hipLaunchKernelGGL((oc_hits_spatial_kernel<DP, true>), dim3(hgrid), dim3(kOcTpb), 0, stream, p, sp, g, fwd,   \
+                       (double *)nullptr, gx, gbeta);                                                             \
+    hipLaunchKernelGGL(oc_cps_spatial_kernel<DP>, dim3(cgrid), dim3(kOcTpb), 0, stream, p, sp, g, fwd, gx, gbeta)
+    if (w.dp == 4) { CALL_BS(4); } else { CALL_BS(8); }
+#undef CALL_BS
+    return check_launch("oc_backward_spatial");
 }
 
 }  // namespace gnntrk

@@ -14,6 +14,7 @@ the reference's (as they do between its own CPU and GPU runs).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Any
 
@@ -56,6 +57,18 @@ class MultiLossFct(torch.nn.Module):
     def forward(self, *args: Any, **kwargs: Any) -> MultiLossFctReturn: ...
 
 
+#: "auto": the spatial passes from SPATIAL_MIN_HITS hits on (below, sorting the hits costs more than
+#: the dense N x K walk); "on" / "off": always / never (tests, measurements)
+SPATIAL = os.environ.get("GNNTRK_OC_SPATIAL", "auto")
+SPATIAL_MIN_HITS = 16384
+
+
+def _use_spatial(n: int) -> bool:
+    if SPATIAL not in ("auto", "on", "off"):
+        raise ValueError(f"losses_oc.SPATIAL must be 'auto', 'on' or 'off', got {SPATIAL!r}")
+    return SPATIAL == "on" or (SPATIAL == "auto" and n >= SPATIAL_MIN_HITS)
+
+
 class _CondensationPotentials(torch.autograd.Function):
     """(attractive, repulsive, coward, noise) and their gradients w.r.t. (beta, x)."""
 
@@ -82,8 +95,17 @@ class _CondensationPotentials(torch.autograd.Function):
                          ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode,
                          float(keep), 0, int(seed), ops._p(cap_nbr))
         out = torch.empty(9, dtype=torch.float32, device=dev)
-        ws2 = ops._ws(lib.gnntrk_oc_forward_workspace_bytes(n), x_c)
-        _capi.check(lib.gnntrk_oc_forward(C.byref(a), ops._p(out), ops._p(ws2), ws2.numel(), st), lib)
+        # large events: the pair loops only visit (chunk of hits, condensation point) pairs within the
+        # radius (csrc/oc.hip "spatial" passes; same pairs, same per-pair arithmetic); the buffer the
+        # forward fills is what the backward reads
+        nb = int(lib.gnntrk_oc_spatial_workspace_bytes(n, dim)) if _use_spatial(n) else 0
+        ctx.spatial = None
+        if nb:
+            ctx.spatial = ops._ws(nb, x_c)
+            _capi.check(lib.gnntrk_oc_forward_spatial(C.byref(a), ops._p(out), ops._p(ctx.spatial), nb, st), lib)
+        else:
+            ws2 = ops._ws(lib.gnntrk_oc_forward_workspace_bytes(n), x_c)
+            _capi.check(lib.gnntrk_oc_forward(C.byref(a), ops._p(out), ops._p(ws2), ws2.numel(), st), lib)
         ctx.save_for_backward(beta_c, x_c, pid, mask8, gid, alphas, n_cp, out)
         ctx.cfg = (q_min, radius, eps_sqrt, mode, beta.dtype, x.dtype, float(keep), int(seed))
         ctx.cap_nbr = cap_nbr
@@ -103,9 +125,14 @@ class _CondensationPotentials(torch.autograd.Function):
                          keep, 0, seed, ops._p(ctx.cap_nbr))
         gx = torch.empty_like(x_c)
         gbeta = torch.empty_like(beta_c)
-        ws = ops._ws(lib.gnntrk_oc_backward_workspace_bytes(n, dim), x_c)
-        _capi.check(lib.gnntrk_oc_backward(C.byref(a), ops._p(g), ops._p(out), ops._p(gx),
-                                           ops._p(gbeta), n, ops._p(ws), ws.numel(), ops._stream(x_c)), lib)
+        if ctx.spatial is not None:
+            _capi.check(lib.gnntrk_oc_backward_spatial(C.byref(a), ops._p(g), ops._p(out), ops._p(gx), ops._p(gbeta),
+                                                       n, ops._p(ctx.spatial), ctx.spatial.numel(),
+                                                       ops._stream(x_c)), lib)
+        else:
+            ws = ops._ws(lib.gnntrk_oc_backward_workspace_bytes(n, dim), x_c)
+            _capi.check(lib.gnntrk_oc_backward(C.byref(a), ops._p(g), ops._p(out), ops._p(gx),
+                                               ops._p(gbeta), n, ops._p(ws), ws.numel(), ops._stream(x_c)), lib)
         return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None, None, None, None
 
 

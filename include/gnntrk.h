@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNNTRK_VERSION 201 /* 0.2.1: + knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
+#define GNNTRK_VERSION 202 /* 0.2.2: + oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
 #define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
 #define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
 #define GNNTRK_MAX_HIDDEN 64
@@ -491,6 +491,21 @@ size_t gnntrk_oc_backward_workspace_bytes(int64_t n, int32_t dim);
 int gnntrk_oc_backward(const gnntrk_oc_args *args, const float *g /*[4]*/, const float *fwd /*[9]*/,
                        float *gx, float *gbeta, int64_t max_cps, void *workspace,
                        size_t workspace_bytes, void *stream);
+
+/* The same loss terms and gradients without the N x K walk (dim <= 8; workspace_bytes == 0: not
+ * covered, use the entry points above).  A repulsive pair needs |x_j - x_k| < radius: the hits are
+ * sorted into chunks of 64 with bounding boxes and a (chunk, condensation point) pair is only
+ * looked at when the box reaches into the radius (conservative bound; the exact per-pair test is
+ * unchanged); the attractive term is summed over (hit, its own condensation point) directly.  Same
+ * pairs and per-pair arithmetic as gnntrk_oc_forward / gnntrk_oc_backward, fixed summation order.
+ * `spatial` is ONE caller-owned buffer: the forward fills it (sorted hits, boxes, per-hit and
+ * per-point records), the backward of the same inputs reads it and uses its scratch part. */
+size_t gnntrk_oc_spatial_workspace_bytes(int64_t n, int32_t dim);
+int gnntrk_oc_forward_spatial(const gnntrk_oc_args *args, float *out /*[9]*/, void *spatial, size_t spatial_bytes,
+                              void *stream);
+int gnntrk_oc_backward_spatial(const gnntrk_oc_args *args, const float *g /*[4]*/, const float *fwd /*[9]*/,
+                               float *gx, float *gbeta, int64_t max_cps, void *spatial, size_t spatial_bytes,
+                               void *stream);
 
 #ifdef __cplusplus
 }

@@ -357,6 +357,43 @@ def case_condensation_losses(device, cases=("td1", "td2", "td3")):
             assert_close(b.grad, z[f"{cn}/f32/{strat}/grad_beta"], 2e-4, f"{cn} {strat} grad beta")
 
 
+def case_oc_spatial(device, cases=("td1", "td2", "td3"), sampling=True, caps=(4, 256), cap_hits=None, n_cloud=3000):
+    """The "spatial" passes of the condensation losses (sorted chunks + box culling, csrc/oc.hip) forced
+    on for the small reference cases: the same golden values, sub-sampling switches and neighbour cap
+    as the dense N x K passes; and dense == spatial directly on a clustered cloud with noise."""
+    from gnn_tracking_amd import losses_oc, synthetic
+
+    old = losses_oc.SPATIAL
+    try:
+        losses_oc.SPATIAL = "on"
+        case_condensation_losses(device, cases=cases)
+        if sampling:
+            case_oc_sampling(device)
+        if caps:
+            case_rg_neighbor_cap(device, caps=caps, n_hits=cap_hits)
+        ev = synthetic.make_pileup_event(7, n_cloud, dim=3, n_particles=n_cloud // 10)
+        res = {}
+        for mode in ("on", "off"):
+            losses_oc.SPATIAL = mode
+            for strat, cls in (("rg", losses_oc.CondensationLossRG), ("tiger", losses_oc.CondensationLossTiger)):
+                b = ev["beta"].to(device).requires_grad_(True)
+                x = (ev["x"] * 0.6).to(device).requires_grad_(True)
+                ret = cls(lw_repulsive=2.0, lw_noise=0.5, lw_coward=0.25)(
+                    beta=b, x=x, particle_id=ev["particle_id"].to(device),
+                    reconstructable=ev["reconstructable"].to(device), pt=ev["pt"].to(device), eta=ev["eta"].to(device))
+                ret.loss.backward()
+                res[mode, strat] = ({k: float(v.detach()) for k, v in ret.loss_dct.items()}, x.grad.cpu(), b.grad.cpu())
+        for strat in ("rg", "tiger"):
+            (la, gxa, gba), (lb, gxb, gbb) = res["on", strat], res["off", strat]
+            for k in la:
+                assert abs(la[k] - lb[k]) <= 2e-6 * abs(lb[k]) + 1e-12, f"spatial vs dense {strat} {k}: {la[k]} {lb[k]}"
+            assert la["repulsive"] > 0, "no repulsive pairs: the comparison is vacuous"
+            assert_close(gxa, gxb, 1e-5, f"spatial vs dense {strat} grad x")
+            assert_close(gba, gbb, 1e-5, f"spatial vs dense {strat} grad beta")
+    finally:
+        losses_oc.SPATIAL = old
+
+
 def case_good_node_mask(device):
     from gnn_tracking_amd.graph_masks import get_good_node_mask_tensors
 

@@ -68,6 +68,11 @@ def test_condensation_losses_and_mask():
         P.case_rg_neighbor_cap("cpu", caps=(4,), n_hits=500)
 
 
+def test_condensation_losses_spatial_passes():
+    with emulated():
+        P.case_oc_spatial("cpu", cases=("td1",), sampling=False, caps=(), n_cloud=900)
+
+
 def test_graph_tcn_emulated():
     with emulated():
         P.case_graph_tcn("cpu", names=("all_cut",))  # (test_tc_training_step_emulated runs a full GraphTCN)

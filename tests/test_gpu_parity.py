@@ -15,7 +15,7 @@ def dev():
     from gnn_tracking_amd import _capi
 
     lib = _capi.load()  # fails loudly if the extension is missing
-    assert lib.gnntrk_version() == 201
+    assert lib.gnntrk_version() == 202
     return "cuda"
 
 
@@ -78,6 +78,10 @@ def test_condensation_losses(dev):
     P.case_condensation_losses(dev)
     P.case_oc_sampling(dev)
     P.case_rg_neighbor_cap(dev)
+
+
+def test_condensation_losses_spatial_passes(dev):
+    P.case_oc_spatial(dev)
 
 
 def test_cpu_tensor_is_rejected(dev):

@@ -30,6 +30,7 @@ int sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_o
                    uint32_t *vals_out, int64_t n, void *temp, size_t temp_bytes, hipStream_t stream);
 
 // knn.hip: points sorted by (event, Morton code) in chunks of 64 with bounding boxes
+void scan_counts_launch(const int32_t *cnt, int k_take, int64_t n, int64_t *off, hipStream_t stream);
 int spatial_dp(int dim);
 int spatial_n_chunks(int64_t n);
 size_t spatial_scratch_bytes(int64_t n);

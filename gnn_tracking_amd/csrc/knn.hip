@@ -918,16 +918,21 @@ int knn_search_ws_launch(const float *x, int64_t n, int dim, int stride, int k, 
     return check_launch("knn_search(pruned)");
 }
 
+// off[0..n] = exclusive scan of min(cnt[i], k_take) (also the condensation-point selection's scan)
+void scan_counts_launch(const int32_t *cnt, int k_take, int64_t n, int64_t *off, hipStream_t stream) {
+    if ((reinterpret_cast<uintptr_t>(cnt) & 15u) == 0)
+        hipLaunchKernelGGL(scan_counts_kernel<true>, dim3(1), dim3(1024), 0, stream, cnt, k_take, n, off);
+    else
+        hipLaunchKernelGGL(scan_counts_kernel<false>, dim3(1), dim3(1024), 0, stream, cnt, k_take, n, off);
+}
+
 int knn_emit_launch(const int32_t *nbr, const int32_t *cnt, int64_t n, int k_stride, int k, int64_t *offsets,
                     int64_t *edge_index, int64_t m_total, hipStream_t stream) {
     if (!nbr || !cnt || !offsets || n < 0 || k < 1 || k > k_stride)
         return fail(GNNTRK_EINVAL, "knn_emit: bad argument");
     if (n == 0) return GNNTRK_OK;
     if (!edge_index) {  // phase 1: offsets only (offsets[n] = total edge count)
-        if ((reinterpret_cast<uintptr_t>(cnt) & 15u) == 0)
-            hipLaunchKernelGGL(scan_counts_kernel<true>, dim3(1), dim3(1024), 0, stream, cnt, k, n, offsets);
-        else
-            hipLaunchKernelGGL(scan_counts_kernel<false>, dim3(1), dim3(1024), 0, stream, cnt, k, n, offsets);
+        scan_counts_launch(cnt, k, n, offsets, stream);
         return check_launch("knn_emit(scan)");
     }
     if (m_total > 0)

@@ -695,8 +695,18 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float *__
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + lane;
     float acc = 0.f;
-    if (p < total)
-        for (int w = wv; w < n_part; w += kWaves) acc += part[(int64_t)w * total + p];
+    if (p < total) {
+        // (latency bound: eight loads in flight, added in the same fixed order)
+        int w = wv;
+        for (; w + 7 * kWaves < n_part; w += 8 * kWaves) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(w + u * kWaves) * total + p];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; w < n_part; w += kWaves) acc += part[(int64_t)w * total + p];
+    }
     s_sum[wv][lane] = acc;
     __syncthreads();
     if (wv != 0 || p >= total) return;

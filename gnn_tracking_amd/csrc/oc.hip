@@ -115,33 +115,6 @@ __global__ __launch_bounds__(kOcTpb) void oc_assign_kernel(
     }
 }
 
-__global__ __launch_bounds__(1024) void oc_scan_kernel(const int32_t *__restrict__ cnt, int64_t n,
-                                                       int64_t *__restrict__ off) {
-    __shared__ long long s_part[1024];
-    const int t = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t b = t * per, e = (b + per < n) ? b + per : n;
-    long long s = 0;
-    for (int64_t i = b; i < e; ++i) s += cnt[i];
-    s_part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        long long run = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const long long v = s_part[i];
-            s_part[i] = run;
-            run += v;
-        }
-        off[n] = run;
-    }
-    __syncthreads();
-    long long run = s_part[t];
-    for (int64_t i = b; i < e; ++i) {
-        off[i] = run;
-        run += cnt[i];
-    }
-}
-
 // ---- potentials -----------------------------------------------------------------------
 struct OcParams {
     const float *x;
@@ -655,21 +628,27 @@ __device__ __forceinline__ float oc_wave_sum(float v) {
     return v;
 }
 
-// hit pass.  BWD = false: part[chunk][4] = {attractive, repulsive, n_rep_pairs, 0} (oc_finalize_kernel
-// adds them); BWD = true: gx[j], gbeta[j] of every hit (the point pass adds the condensation points' share)
+// hit pass: workgroup = chunk of 64 sorted hits, its four waves take every fourth round of 64
+// condensation points (the rounds are latency bound: more of them in flight) and their per-hit
+// sums are added in wave order through LDS.  BWD = false: part[chunk][8] = {attractive, repulsive,
+// n_rep_pairs, sum of beta over noise hits, noise hits, hits of interest, 0, 0}
+// (oc_finalize_spatial_kernel adds the chunks); BWD = true: gx[j], gbeta[j] of every hit (the point
+// pass adds the condensation points' share)
+constexpr int kOcHitWaves = kOcTpb / 64;
 template <int DP, bool BWD>
 __global__ __launch_bounds__(kOcTpb) void oc_hits_spatial_kernel(const OcParams p, const OcSpatial sp,
                                                                  const float *__restrict__ g,
                                                                  const float *__restrict__ fwd,
                                                                  double *__restrict__ part, float *__restrict__ gx,
                                                                  float *__restrict__ gbeta) {
-    __shared__ float s_x[kOcTpb / 64][64][DP];
-    __shared__ float s_q[kOcTpb / 64][64];
-    __shared__ long long s_pid[kOcTpb / 64][64];
-    __shared__ int s_hit[kOcTpb / 64][64];
+    __shared__ float s_x[kOcHitWaves][64][DP];
+    __shared__ float s_q[kOcHitWaves][64];
+    __shared__ long long s_pid[kOcHitWaves][64];
+    __shared__ int s_hit[kOcHitWaves][64];
+    __shared__ double s_accd[kOcHitWaves][2][64];     // forward: repulsive, pair count
+    __shared__ float s_accf[kOcHitWaves][DP + 1][64];  // backward: d/dx, d/dq
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.x * (kOcTpb / 64) + wv;
-    if (c >= sp.n_chunks) return;  // (wave-uniform; no workgroup barrier below)
+    const int c = blockIdx.x;
     const int K = p.n_cp[0];
     const int64_t r = (int64_t)c * 64 + lane;
     const int32_t jj = sp.sidx[r];
@@ -680,15 +659,6 @@ __global__ __launch_bounds__(kOcTpb) void oc_hits_spatial_kernel(const OcParams 
     for (int d = 0; d < DP; ++d) xj[d] = sp.xs[r * DP + d];
     const float qj = sp.hq[r];
     const long long pj = sp.hpid[r];
-    int gj = -1;
-    bool mj = false, is_cp = false;
-    float bj = 0.5f;
-    if (live) {
-        gj = p.gid[j];
-        mj = p.mask[j] != 0;
-        is_cp = gj >= 0 && p.alphas[gj] == jj;
-        bj = p.beta[j];
-    }
     const int cap_idx = sp.hcap[r];
     const float cap_d2 = sp.hcapd2[r];
     float blo[DP], bhi[DP];  // the chunk's box (wave-uniform)
@@ -704,60 +674,100 @@ __global__ __launch_bounds__(kOcTpb) void oc_hits_spatial_kernel(const OcParams 
         ca = g[0] / fwd[4];
         cr = g[1] / fwd[5];
     }
-    double va = 0.0, vr = 0.0, nrep = 0.0;
+    double vr = 0.0, nrep = 0.0;
     float gxj[DP];
     float gqj = 0.f;
 #pragma unroll
     for (int d = 0; d < DP; ++d) gxj[d] = 0.f;
 
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        // lane = condensation point: distance bound to the chunk's box
+    // lane = condensation point: distance bound to the chunk's box; the next round's coordinates
+    // are in flight while the survivors of this one are walked
+    auto load_cp = [&](int k0, float (&ck)[DP]) {
         const int k = k0 + lane;
         const int kc = k < K ? k : K - 1;
-        float ck[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) ck[d] = sp.cx[(int64_t)kc * DP + d];
+    };
+    float ck[DP], cn[DP];
+    load_cp(wv * 64, ck);
+    for (int k0 = wv * 64; k0 < K; k0 += kOcHitWaves * 64) {
+        load_cp(k0 + kOcHitWaves * 64 < K ? k0 + kOcHitWaves * 64 : k0, cn);
+        const int k = k0 + lane;
+        const int kc = k < K ? k : K - 1;
         float lb = 0.f;
 #pragma unroll
         for (int d = 0; d < DP; ++d) {
-            ck[d] = sp.cx[(int64_t)kc * DP + d];
             const float gd = fmaxf(fmaxf(blo[d] - ck[d], ck[d] - bhi[d]), 0.f);
             lb += gd * gd;
         }
         unsigned long long near = __ballot(k < K && lb <= r2m);
-        if (near == 0ull) continue;
-        oc_wave_sync();  // (the previous round's readers are done)
+        if (near != 0ull) {
+            oc_wave_sync();  // (the previous round's readers are done)
 #pragma unroll
-        for (int d = 0; d < DP; ++d) s_x[wv][lane][d] = ck[d];
-        s_q[wv][lane] = sp.cq[kc];
-        s_pid[wv][lane] = sp.cpid[kc];
-        s_hit[wv][lane] = p.alphas[kc];
-        oc_wave_sync();
-        while (near != 0ull) {
-            const int i = __ffsll(near) - 1;
-            near &= near - 1ull;
-            float t[DP];
-            float d2 = 0.f;
+            for (int d = 0; d < DP; ++d) s_x[wv][lane][d] = ck[d];
+            s_q[wv][lane] = sp.cq[kc];
+            s_pid[wv][lane] = sp.cpid[kc];
+            s_hit[wv][lane] = p.alphas[kc];
+            oc_wave_sync();
+            while (near != 0ull) {
+                const int i = __ffsll(near) - 1;
+                near &= near - 1ull;
+                float t[DP];
+                float d2 = 0.f;
 #pragma unroll
-            for (int d = 0; d < DP; ++d) {
-                t[d] = xj[d] - s_x[wv][i][d];
-                d2 += t[d] * t[d];
-            }
-            if (live && s_pid[wv][i] != pj && d2 < r2 &&
-                (cap_idx < 0 || oc_cap_ok(oc_d2_chain<DP>(xj, s_x[wv][i]), s_hit[wv][i], cap_d2, cap_idx))) {
-                const float qk = s_q[wv][i];
-                if (!BWD) {
-                    nrep += 1.0;  // (counted before the sub-sampling, as the reference's n_rep)
-                    if (oc_keep_pair(p, j, k0 + i)) vr += (double)(qj * qk * (p.radius - sqrtf(p.eps_sqrt + d2)));
-                } else if (oc_keep_pair(p, j, k0 + i)) {
-                    const float sd = sqrtf(p.eps_sqrt + d2);
-                    const float cxr = sd > 0.f ? -cr * qj * qk / sd : 0.f;
+                for (int d = 0; d < DP; ++d) {
+                    t[d] = xj[d] - s_x[wv][i][d];
+                    d2 += t[d] * t[d];
+                }
+                if (live && s_pid[wv][i] != pj && d2 < r2 &&
+                    (cap_idx < 0 || oc_cap_ok(oc_d2_chain<DP>(xj, s_x[wv][i]), s_hit[wv][i], cap_d2, cap_idx))) {
+                    const float qk = s_q[wv][i];
+                    if (!BWD) {
+                        nrep += 1.0;  // (counted before the sub-sampling, as the reference's n_rep)
+                        if (oc_keep_pair(p, j, k0 + i)) vr += (double)(qj * qk * (p.radius - sqrtf(p.eps_sqrt + d2)));
+                    } else if (oc_keep_pair(p, j, k0 + i)) {
+                        const float sd = sqrtf(p.eps_sqrt + d2);
+                        const float cxr = sd > 0.f ? -cr * qj * qk / sd : 0.f;
 #pragma unroll
-                    for (int d = 0; d < DP; ++d) gxj[d] += cxr * t[d];
-                    gqj += cr * qk * (p.radius - sd);
+                        for (int d = 0; d < DP; ++d) gxj[d] += cxr * t[d];
+                        gqj += cr * qk * (p.radius - sd);
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int d = 0; d < DP; ++d) ck[d] = cn[d];
+    }
+    if (!BWD) {
+        s_accd[wv][0][lane] = vr;
+        s_accd[wv][1][lane] = nrep;
+    } else {
+#pragma unroll
+        for (int d = 0; d < DP; ++d) s_accf[wv][d][lane] = gxj[d];
+        s_accf[wv][DP][lane] = gqj;
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    if (!BWD) {
+        vr = ((s_accd[0][0][lane] + s_accd[1][0][lane]) + s_accd[2][0][lane]) + s_accd[3][0][lane];
+        nrep = ((s_accd[0][1][lane] + s_accd[1][1][lane]) + s_accd[2][1][lane]) + s_accd[3][1][lane];
+    } else {
+#pragma unroll
+        for (int d = 0; d < DP; ++d)
+            gxj[d] = ((s_accf[0][d][lane] + s_accf[1][d][lane]) + s_accf[2][d][lane]) + s_accf[3][d][lane];
+        gqj = ((s_accf[0][DP][lane] + s_accf[1][DP][lane]) + s_accf[2][DP][lane]) + s_accf[3][DP][lane];
+    }
+    int gj = -1;
+    bool mj = false, is_cp = false;
+    float bj = 0.5f;
+    if (live) {
+        gj = p.gid[j];
+        mj = p.mask[j] != 0;
+        is_cp = gj >= 0 && p.alphas[gj] == jj;
+        bj = p.beta[j];
     }
     // attractive: the hit and the condensation point of its own particle, at any distance
+    double va = 0.0;
     const bool att = live && gj >= 0 && ((p.mode == 1) ? true : (mj && !is_cp));
     if (att) {
         float t[DP];
@@ -777,21 +787,51 @@ __global__ __launch_bounds__(kOcTpb) void oc_hits_spatial_kernel(const OcParams 
             gqj += ca * qk * d2;
         }
     }
+    const bool is_noise = live && ((p.mode == 1) ? !(pj > 0) : (pj == 0));
     if (!BWD) {
         const double a = oc_wave_sum(va), rr = oc_wave_sum(vr), cc = oc_wave_sum(nrep);
+        const double ns = oc_wave_sum(is_noise ? (double)bj : 0.0), nn = oc_wave_sum(is_noise ? 1.0 : 0.0),
+                     no = oc_wave_sum(mj ? 1.0 : 0.0);
         if (lane == 0) {
-            part[(int64_t)c * 4 + 0] = a;
-            part[(int64_t)c * 4 + 1] = rr;
-            part[(int64_t)c * 4 + 2] = cc;
-            part[(int64_t)c * 4 + 3] = 0.0;
+            double *o = part + (int64_t)c * 8;
+            o[0] = a; o[1] = rr; o[2] = cc; o[3] = ns; o[4] = nn; o[5] = no; o[6] = 0.0; o[7] = 0.0;
         }
     } else if (live) {
         for (int d = 0; d < p.dim; ++d) gx[j * p.stride + d] = gxj[d];
         const float a = atanhf(bj);
         float gb = gqj * 2.f * a / (1.f - bj * bj);
-        const bool is_noise = (p.mode == 1) ? !(pj > 0) : (pj == 0);
         if (is_noise) gb += g[3] / fwd[8];
         gbeta[j] = gb;
+    }
+}
+
+// the chunks' partial sums -> out[0..8] (as oc_finalize_kernel, without its walk over all hits)
+__global__ __launch_bounds__(kOcTpb) void oc_finalize_spatial_kernel(const OcParams p, const double *__restrict__ part,
+                                                                     int n_part, float *__restrict__ out) {
+    __shared__ double s_red[kOcTpb / 64];
+    const int K = p.n_cp[0];
+    double v[6] = {0, 0, 0, 0, 0, 0}, cow = 0;
+    for (int i = threadIdx.x; i < n_part; i += kOcTpb)
+#pragma unroll
+        for (int u = 0; u < 6; ++u) v[u] += part[(int64_t)i * 8 + u];
+    for (int k = threadIdx.x; k < K; k += kOcTpb) cow += (double)(1.f - p.beta[p.alphas[k]]);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) v[u] = oc_block_sum(v[u], s_red);
+    cow = oc_block_sum(cow, s_red);
+    if (threadIdx.x == 0) {
+        const double eps = 1e-9;
+        const double norm_att = eps + v[5] - (double)K;
+        double norm_rep = eps + ((double)K - 1.0) * (double)p.n;
+        if (p.keep < 1.f) norm_rep *= (double)p.keep;  // oc.py:328
+        out[0] = (float)(v[0] / norm_att);
+        out[1] = (float)(v[1] / norm_rep);
+        out[2] = (float)(cow / (double)K);
+        out[3] = (float)(v[3] / v[4]);
+        out[4] = (float)norm_att;
+        out[5] = (float)norm_rep;
+        out[6] = (float)K;
+        out[7] = (float)v[2];
+        out[8] = (float)v[4];
     }
 }
 
@@ -813,16 +853,18 @@ __global__ __launch_bounds__(kOcTpb) void oc_gid_starts_kernel(const uint32_t *_
     if (key != 0xffffffffu && (s == 0 || keys[s - 1] != key)) gstart[key] = (int32_t)s;
 }
 
-// point pass (backward): wave = condensation point k
+// point pass (backward): workgroup = condensation point k; its four waves take every fourth batch of
+// 64 chunk boxes, wave 0 also the particle's own hits; fixed-order reductions (lanes, then waves)
 template <int DP>
 __global__ __launch_bounds__(kOcTpb) void oc_cps_spatial_kernel(const OcParams p, const OcSpatial sp,
                                                                 const float *__restrict__ g,
                                                                 const float *__restrict__ fwd,
                                                                 float *__restrict__ gx, float *__restrict__ gbeta) {
+    __shared__ float s_acc[kOcHitWaves][DP + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int K = p.n_cp[0];
-    const int k = blockIdx.x * (kOcTpb / 64) + wv;
-    if (k >= K) return;
+    const int k = blockIdx.x;
+    if (k >= K) return;  // (workgroup-uniform)
     const float ca = g[0] / fwd[4], cr = g[1] / fwd[5];
     const int32_t ak = p.alphas[k];
     float xk[DP], gxk[DP];
@@ -837,7 +879,7 @@ __global__ __launch_bounds__(kOcTpb) void oc_cps_spatial_kernel(const OcParams p
     const float r2 = p.radius * p.radius;
     const float r2m = r2 * 1.00001f + 1e-30f;
     // repulsive: the chunks whose box reaches into the point's radius
-    for (int c0 = 0; c0 < sp.n_chunks; c0 += 64) {
+    for (int c0 = wv * 64; c0 < sp.n_chunks; c0 += kOcHitWaves * 64) {
         const int c = c0 + lane;
         const int cc = c < sp.n_chunks ? c : sp.n_chunks - 1;
         float lb = 0.f;
@@ -853,23 +895,17 @@ __global__ __launch_bounds__(kOcTpb) void oc_cps_spatial_kernel(const OcParams p
             near &= near - 1ull;
             const int64_t r = (int64_t)(c0 + i) * 64 + lane;
             const int32_t jj = sp.sidx[r];
-            float t[DP];
+            float xa[DP], t[DP];
             float d2 = 0.f;
 #pragma unroll
             for (int d = 0; d < DP; ++d) {
-                t[d] = sp.xs[r * DP + d] - xk[d];  // x_j - x_k
+                xa[d] = sp.xs[r * DP + d];
+                t[d] = xa[d] - xk[d];  // x_j - x_k
                 d2 += t[d] * t[d];
             }
             if (jj >= 0 && sp.hpid[r] != pk && d2 < r2 && oc_keep_pair(p, jj, k)) {
                 const int ci = sp.hcap[r];
-                bool ok = true;
-                if (ci >= 0) {
-                    float xa[DP];
-#pragma unroll
-                    for (int d = 0; d < DP; ++d) xa[d] = sp.xs[r * DP + d];
-                    ok = oc_cap_ok(oc_d2_chain<DP>(xa, xk), ak, sp.hcapd2[r], ci);
-                }
-                if (ok) {
+                if (ci < 0 || oc_cap_ok(oc_d2_chain<DP>(xa, xk), ak, sp.hcapd2[r], ci)) {
                     const float qj = sp.hq[r];
                     const float sd = sqrtf(p.eps_sqrt + d2);
                     const float cxr = sd > 0.f ? -cr * qj * qk / sd : 0.f;
@@ -881,37 +917,47 @@ __global__ __launch_bounds__(kOcTpb) void oc_cps_spatial_kernel(const OcParams p
         }
     }
     // attractive: the hits of particle k (by-gid ordering), at any distance
-    for (int64_t s = sp.gstart[k];; s += 64) {
-        const int64_t t0 = s + lane;
-        const bool mine = t0 < p.n && sp.gkeys[t0 < p.n ? t0 : p.n - 1] == (uint32_t)k;
-        if (mine) {
-            const int64_t j = sp.gorder[t0];
-            const bool att = (p.mode == 1) ? true : (p.mask[j] != 0 && ak != (int32_t)j);
-            if (att) {
-                float t[DP];
-                float d2 = 0.f;
+    if (wv == 0) {
+        for (int64_t s = sp.gstart[k];; s += 64) {
+            const int64_t t0 = s + lane;
+            const bool mine = t0 < p.n && sp.gkeys[t0 < p.n ? t0 : p.n - 1] == (uint32_t)k;
+            if (mine) {
+                const int64_t j = sp.gorder[t0];
+                const bool att = (p.mode == 1) ? true : (p.mask[j] != 0 && ak != (int32_t)j);
+                if (att) {
+                    float t[DP];
+                    float d2 = 0.f;
 #pragma unroll
-                for (int d = 0; d < DP; ++d) {
-                    t[d] = (d < p.dim ? p.x[j * p.stride + d] : 0.f) - xk[d];
-                    d2 += t[d] * t[d];
+                    for (int d = 0; d < DP; ++d) {
+                        t[d] = (d < p.dim ? p.x[j * p.stride + d] : 0.f) - xk[d];
+                        d2 += t[d] * t[d];
+                    }
+                    const float qj = oc_q(p.beta[j], p.q_min);
+                    const float cxa = ca * 2.f * qj * qk;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) gxk[d] -= cxa * t[d];
+                    gqk += ca * qj * d2;
                 }
-                const float qj = oc_q(p.beta[j], p.q_min);
-                const float cxa = ca * 2.f * qj * qk;
-#pragma unroll
-                for (int d = 0; d < DP; ++d) gxk[d] -= cxa * t[d];
-                gqk += ca * qj * d2;
             }
+            if (__ballot(mine) != ~0ull) break;  // the run of gid k ended inside this step
         }
-        if (__ballot(mine) != ~0ull) break;  // the run of gid k ended inside this step
     }
 #pragma unroll
     for (int d = 0; d < DP; ++d) gxk[d] = oc_wave_sum(gxk[d]);
     gqk = oc_wave_sum(gqk);
     if (lane == 0) {
-        for (int d = 0; d < p.dim; ++d) gx[(int64_t)ak * p.stride + d] += gxk[d];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) s_acc[wv][d] = gxk[d];
+        s_acc[wv][DP] = gqk;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int d = 0; d < p.dim; ++d)
+            gx[(int64_t)ak * p.stride + d] += ((s_acc[0][d] + s_acc[1][d]) + s_acc[2][d]) + s_acc[3][d];
+        const float gq = ((s_acc[0][DP] + s_acc[1][DP]) + s_acc[2][DP]) + s_acc[3][DP];
         const float bk = p.beta[ak];
         const float a = atanhf(bk);
-        gbeta[ak] += gqk * 2.f * a / (1.f - bk * bk) - g[2] / fwd[6];  // coward: mean(1 - beta)
+        gbeta[ak] += gq * 2.f * a / (1.f - bk * bk) - g[2] / fwd[6];  // coward: mean(1 - beta)
     }
 }
 
@@ -961,7 +1007,7 @@ int oc_select_launch(const float *score, const int64_t *pid, const uint8_t *mask
     if (rc) return rc;
     hipLaunchKernelGGL(oc_segment_best_kernel, dim3(grid), dim3(kOcTpb), 0, stream,
                        (const u64 *)keys_b, (const uint32_t *)vals_b, score, mask, n, mode, flag, best);
-    hipLaunchKernelGGL(oc_scan_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t *)flag, n, off);
+    scan_counts_launch(flag, 0x7fffffff, n, off, stream);
     rc = check_hip(hipMemsetAsync(gid, 0xff, (size_t)n * sizeof(int32_t), stream), "oc_select_cps(memset)");
     if (rc) return rc;
     hipLaunchKernelGGL(oc_assign_kernel, dim3(grid), dim3(kOcTpb), 0, stream, (const u64 *)keys_b,
@@ -1077,7 +1123,7 @@ static OcSpatialWs oc_spatial_layout(int64_t n, int dim) {
     w.cx = take((size_t)n * w.dp * 4);
     w.cq = take((size_t)n * 4);
     w.cpid = take((size_t)n * 8);
-    w.part = take((size_t)w.n_chunks * 4 * sizeof(double));
+    w.part = take((size_t)w.n_chunks * 8 * sizeof(double));
     w.gkeys_a = take((size_t)n * 4);
     w.gkeys_b = take((size_t)n * 4);
     w.gvals_a = take((size_t)n * 4);
@@ -1125,7 +1171,7 @@ int oc_forward_spatial_launch(const gnntrk_oc_args *a, float *out, void *ws, siz
                               b + w.scratch, w.total - w.scratch, stream);
     if (rc) return rc;
     const OcSpatial sp = oc_spatial_view(w, ws);
-    const int rgrid = oc_grid((int64_t)w.n_chunks * 64), kgrid = oc_grid(a->n), hgrid = (w.n_chunks + 3) / 4;
+    const int rgrid = oc_grid((int64_t)w.n_chunks * 64), kgrid = oc_grid(a->n), hgrid = w.n_chunks;
     double *part = reinterpret_cast<double *>(b + w.part);
 #define CALL_FS(DP)                                                                                              \
     hipLaunchKernelGGL(oc_hit_records_kernel<DP>, dim3(rgrid), dim3(kOcTpb), 0, stream, p, sp,                    \
@@ -1138,7 +1184,7 @@ int oc_forward_spatial_launch(const gnntrk_oc_args *a, float *out, void *ws, siz
                        (const float *)nullptr, (const float *)nullptr, part, (float *)nullptr, (float *)nullptr)
     if (w.dp == 4) { CALL_FS(4); } else { CALL_FS(8); }
 #undef CALL_FS
-    hipLaunchKernelGGL(oc_finalize_kernel, dim3(1), dim3(kOcTpb), 0, stream, p, (const double *)part, w.n_chunks, out);
+    hipLaunchKernelGGL(oc_finalize_spatial_kernel, dim3(1), dim3(kOcTpb), 0, stream, p, (const double *)part, w.n_chunks, out);
     return check_launch("oc_forward_spatial");
 }
 
@@ -1153,7 +1199,7 @@ int oc_backward_spatial_launch(const gnntrk_oc_args *a, const float *g, const fl
     const OcParams p = oc_params(a);
     const OcSpatial sp = oc_spatial_view(w, ws);
     char *b = static_cast<char *>(ws);
-    const int hgrid = (w.n_chunks + 3) / 4, ngrid = oc_grid(a->n);
+    const int hgrid = w.n_chunks, ngrid = oc_grid(a->n);
     // the by-gid ordering of the hits (for the points' attractive share)
     uint32_t *gka = reinterpret_cast<uint32_t *>(b + w.gkeys_a), *gkb = reinterpret_cast<uint32_t *>(b + w.gkeys_b);
     uint32_t *gva = reinterpret_cast<uint32_t *>(b + w.gvals_a), *gvb = reinterpret_cast<uint32_t *>(b + w.gvals_b);
@@ -1162,7 +1208,7 @@ int oc_backward_spatial_launch(const gnntrk_oc_args *a, const float *g, const fl
     if (rc) return rc;
     hipLaunchKernelGGL(oc_gid_starts_kernel, dim3(ngrid), dim3(kOcTpb), 0, stream, (const uint32_t *)gkb, a->n,
                        reinterpret_cast<int32_t *>(b + w.gstart));
-    const int cgrid = (int)ceil_div(max_cps, kOcTpb / 64);
+    const int cgrid = (int)(max_cps < a->n ? max_cps : a->n);
 #define CALL_BS(DP)                                                                                              \
     hipLaunchKernelGGL((oc_hits_spatial_kernel<DP, true>), dim3(hgrid), dim3(kOcTpb), 0, stream, p, sp, g, fwd,   \
                        (double *)nullptr, gx, gbeta);                                                             \

@@ -775,7 +775,8 @@ constexpr int kFwdBlocksPerCu = 4;
     X(1, 10, 1, false, 1) /* edge encoder    4 -> 40 -> 4       edge_attr[4]            */ \
     X(4, 10, 1, true, 5)  /* relational     14 -> 40 -> 40 -> 4  h[5], h[5], e[4]        */ \
     X(3, 10, 2, true, 3)  /* object          9 -> 40 -> 40 -> 5  h[5], aggr[4]           */ \
-    X(7, 10, 1, true, 8)  /* W head         26 -> 40 -> 40 -> 1  h[5], h[5], 4 x e[4]    */
+    X(7, 10, 1, true, 8)  /* W head         26 -> 40 -> 40 -> 1  h[5], h[5], 4 x e[4]    */ \
+    X(7, 10, 1, false, 7) /* edge encoder   28 -> 40 -> 4       MLGraphConstruction's 2 x 14 edge features */
 
 static bool static_shape(int ksi, int ksh, int kso, bool three, int n_items) {
     bool hit = false;

@@ -68,7 +68,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=("cfg2", "cfg3", "cfg4", "cfg5"))
     ap.add_argument("--events", type=int, default=None, help="override the event count (cfg3: per GPU; cfg4: total)")
-    ap.add_argument("--dtype", default="bf16", choices=("bf16", "f32"),
+    ap.add_argument("--dtype", default=None, choices=("bf16", "f32"),
                     help="storage / MFMA-input type of the activations (cfg3 names bf16 storage, "
                          "fp32 accumulate); parameters and their gradients are fp32 in both")
     ap.add_argument("--index", default="inline", choices=("inline", "prefetch", "resident"),
@@ -87,7 +87,10 @@ def parse(argv=None):
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY: replace the HIP workload by a CPU toy model (gloo) to exercise the "
                          "launcher / barrier / reduction control flow; the line is marked as a stub")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.dtype is None:   # cfg3 / cfg4 name bf16 storage; cfg5's parity bar (1e-5) is an fp32 one
+        a.dtype = "f32" if a.workload == "cfg5" else "bf16"
+    return a
 
 
 # ------------------------------------------------------------------------------- launcher
@@ -355,9 +358,10 @@ class TCWorkload(Workload):
     name, scaling, dtype = "cfg5", "weak", "f32"
     K_NN, DIM = 16, 8
 
-    def __init__(self, args, rank: int, world: int, dev):
+    def __init__(self, args, rank: int, world: int, dev, dtype: str = "f32"):
         import numpy as np
 
+        self.dtype = dtype
         n = args.events or 200_000     # --events overrides the hit count here
         ev = synthetic.make_pileup_event(500 + rank, n, self.DIM)
         g = np.random.default_rng(500 + rank)
@@ -375,7 +379,7 @@ class TCWorkload(Workload):
         self.flat = gdist.FlatParameters(self.model)
         self.module = training.TCModule(
             self.model, loss_fct=G.CondensationLossRG(lw_repulsive=1.0, lw_noise=0.1, lw_coward=0.1),
-            preproc=self.preproc, flat=self.flat, scheduler=None,
+            preproc=self.preproc, flat=self.flat, scheduler=None, bf16=dtype == "bf16",
             optimizer=lambda p: torch.optim.Adam(p, lr=1e-4))
         self.stage = _StageTimer()
         self.n_hits = n
@@ -622,13 +626,13 @@ def cfg4_short(args, rank: int, world: int, dev) -> dict:
             "final_loss": loss, **wl.info}
 
 
-def cfg5_short(args, dev) -> dict:
+def cfg5_short(args, dev, dtype: str = "f32") -> dict:
     """BASELINE config 5 as a short run: the object-condensation step on one 200 000-hit event with
     per-stage HIP-event times (kNN graph build, GraphTCN forward, condensation loss, backward)."""
     import copy
     a5 = copy.copy(args)
     a5.events = None
-    wl = TCWorkload(a5, 0, 1, dev)
+    wl = TCWorkload(a5, 0, 1, dev, dtype=dtype)
     dt, loss, _ = timed_steps(wl, 1, dev, 3, 2, kernel_timer=False)
     return {"workload": wl.describe, "steps": 3, "warmup": 2, "ms_per_step": dt / 3 * 1e3,
             "value": wl.edges_per_step_global * 3 / dt, "unit": "edges/s", "hits_per_s": wl.n_hits * 3 / dt,
@@ -697,6 +701,7 @@ def extras(args, rank: int, world: int, dev) -> dict:
         out["cfg2_hipgraph_f32"] = hipgraph_cfg2(dev, "f32", 100)
         torch.cuda.empty_cache()
         out["cfg5_oc_step_f32"] = cfg5_short(args, dev)
+        out["cfg5_oc_step_bf16"] = cfg5_short(args, dev, "bf16")
         out["dbscan_rescan_200k"] = dbscan_short(dev)
     except Exception as e:  # the headline line must survive a failing extra
         if world > 1:
@@ -730,7 +735,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         if args.workload == "cfg5":
-            wl = TCWorkload(args, rank, world, dev)
+            wl = TCWorkload(args, rank, world, dev, dtype=args.dtype)
         else:
             wl = ECWorkload(args, rank, world, dev, workload=args.workload, dtype=args.dtype, index=args.index)
 

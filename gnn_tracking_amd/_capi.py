@@ -123,6 +123,12 @@ _SIGNATURES = {
     "gnntrk_threshold_compact": (C.c_int, [_P, C.c_int64, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_connected_nodes": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_radius_count": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_double, _P, _P, _P]),
+    "gnntrk_radius_points_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "gnntrk_radius_edges_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnntrk_radius_count_ws": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, C.c_size_t,
+                                         C.c_int32, _P]),
+    "gnntrk_radius_fill_ws": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_double, _P, C.c_int64, _P, _P, _P,
+                                        C.c_size_t, _P, C.c_size_t, C.c_int32, _P]),
     "gnntrk_radius_fill": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P]),
     "gnntrk_dbscan_init": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_int32, _P, _P, _P]),
     "gnntrk_dbscan_propagate": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, _P, _P, C.c_int32, _P, _P]),
@@ -144,7 +150,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 202   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
+ABI_VERSION = 203   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

@@ -250,6 +250,19 @@ int gnntrk_connected_nodes(const int64_t *edge_index, int64_t n_edges, int64_t n
                                   workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+size_t gnntrk_radius_points_workspace_bytes(int64_t n, int32_t dim) { return radius_points_ws_bytes(n, dim); }
+size_t gnntrk_radius_edges_workspace_bytes(int64_t m_edges) { return radius_edges_ws_bytes(m_edges); }
+int gnntrk_radius_count_ws(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius, int32_t *cnt,
+                           int64_t *offsets, void *ws_points, size_t ws_points_bytes, int32_t flags, void *stream) {
+    return radius_count_ws_launch(x, n, dim, x_stride, radius, cnt, offsets, ws_points, ws_points_bytes, flags,
+                                  (hipStream_t)stream);
+}
+int gnntrk_radius_fill_ws(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius,
+                          const int64_t *offsets, int64_t m_edges, int32_t *nbr, double *dist, void *ws_points,
+                          size_t ws_points_bytes, void *ws_edges, size_t ws_edges_bytes, int32_t flags, void *stream) {
+    return radius_fill_ws_launch(x, n, dim, x_stride, radius, offsets, m_edges, nbr, dist, ws_points, ws_points_bytes,
+                                 ws_edges, ws_edges_bytes, flags, (hipStream_t)stream);
+}
 int gnntrk_radius_count(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius, int32_t *cnt,
                         int64_t *offsets, void *stream) {
     return radius_count_launch(x, n, dim, x_stride, radius, cnt, offsets, (hipStream_t)stream);

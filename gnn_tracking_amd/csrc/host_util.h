@@ -75,6 +75,13 @@ int radius_count_launch(const float *x, int64_t n, int dim, int stride, double r
                         int64_t *offsets, hipStream_t stream);
 int radius_fill_launch(const float *x, int64_t n, int dim, int stride, double radius, const int64_t *off,
                        int32_t *nbr, double *dist, hipStream_t stream);
+size_t radius_points_ws_bytes(int64_t n, int dim);
+size_t radius_edges_ws_bytes(int64_t m_edges);
+int radius_count_ws_launch(const float *x, int64_t n, int dim, int stride, double radius, int32_t *cnt,
+                           int64_t *offsets, void *ws_points, size_t ws_bytes, int flags, hipStream_t stream);
+int radius_fill_ws_launch(const float *x, int64_t n, int dim, int stride, double radius, const int64_t *off,
+                          int64_t m_edges, int32_t *nbr, double *dist, void *ws_points, size_t ws_bytes,
+                          void *ws_edges, size_t ws_edges_bytes, int flags, hipStream_t stream);
 int dbscan_init_launch(const int64_t *off, const double *dist, int64_t n, double eps, int min_pts, uint8_t *core,
                        int32_t *root, hipStream_t stream);
 int dbscan_propagate_launch(const int64_t *off, const int32_t *nbr, const double *dist, int64_t n, double eps,

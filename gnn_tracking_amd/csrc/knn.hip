@@ -629,7 +629,8 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t *__rest
     auto clip = [&](int32_t c) { return c < k_take ? c : k_take; };
     __shared__ long long s_part[1024];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    int64_t per = (n + 1023) / 1024;
+    const int nt = blockDim.x, per_lane = nt / 64;  // 256 or 1024 threads
+    int64_t per = (n + nt - 1) / nt;
     per = (per + 3) & ~(int64_t)3;  // ranges start on 16-byte boundaries
     const int64_t b = t * per < n ? t * per : n, e = (b + per < n) ? b + per : n;
     long long s = 0;
@@ -652,21 +653,21 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t *__rest
     } else {
         for (int64_t j = b; j < e; ++j) s += clip(cnt_raw[j]);
     }
-    // exclusive scan of the 1024 partial sums by wave 0: 16 per lane, shuffles across the lanes
+    // exclusive scan of the partial sums by wave 0: nt / 64 per lane, shuffles across the lanes
     s_part[t] = s;
     __syncthreads();
     if (wv == 0) {
         long long mine = 0;
-        for (int i = 0; i < 16; ++i) mine += s_part[lane * 16 + i];
+        for (int i = 0; i < per_lane; ++i) mine += s_part[lane * per_lane + i];
         long long inc = mine;
         for (int d = 1; d < 64; d <<= 1) {
             const long long o = __shfl(inc, lane >= d ? lane - d : lane);
             if (lane >= d) inc += o;
         }
         long long run0 = inc - mine;
-        for (int i = 0; i < 16; ++i) {
-            const long long v = s_part[lane * 16 + i];
-            s_part[lane * 16 + i] = run0;
+        for (int i = 0; i < per_lane; ++i) {
+            const long long v = s_part[lane * per_lane + i];
+            s_part[lane * per_lane + i] = run0;
             run0 += v;
         }
         if (lane == 63) off[n] = inc;
@@ -920,10 +921,11 @@ int knn_search_ws_launch(const float *x, int64_t n, int dim, int stride, int k, 
 
 // off[0..n] = exclusive scan of min(cnt[i], k_take) (also the condensation-point selection's scan)
 void scan_counts_launch(const int32_t *cnt, int k_take, int64_t n, int64_t *off, hipStream_t stream) {
+    const int nt = n < 65536 ? 256 : 1024;
     if ((reinterpret_cast<uintptr_t>(cnt) & 15u) == 0)
-        hipLaunchKernelGGL(scan_counts_kernel<true>, dim3(1), dim3(1024), 0, stream, cnt, k_take, n, off);
+        hipLaunchKernelGGL(scan_counts_kernel<true>, dim3(1), dim3(nt), 0, stream, cnt, k_take, n, off);
     else
-        hipLaunchKernelGGL(scan_counts_kernel<false>, dim3(1), dim3(1024), 0, stream, cnt, k_take, n, off);
+        hipLaunchKernelGGL(scan_counts_kernel<false>, dim3(1), dim3(nt), 0, stream, cnt, k_take, n, off);
 }
 
 int knn_emit_launch(const int32_t *nbr, const int32_t *cnt, int64_t n, int k_stride, int k, int64_t *offsets,

@@ -11,11 +11,17 @@ consume the labels are CPU validation code and stay with the caller.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch import Tensor
 
 from . import _capi, ops
+
+
+#: bit 0: pruned radius graph below its size threshold too; bit 1: brute force only (tests, measurements)
+RADIUS_FLAGS = int(os.environ.get("GNNTRK_RADIUS_FLAGS", "0"))
 
 
 class DBSCANFastRescan:
@@ -46,13 +52,19 @@ class DBSCANFastRescan:
         st = ops._stream(x)
         cnt = torch.empty(max(n, 1), dtype=torch.int32, device=x.device)
         self._off = torch.empty(n + 1, dtype=torch.int64, device=x.device)
-        _capi.check(lib.gnntrk_radius_count(ops._p(x), n, dim, ops._row_stride(x), float(max_eps), ops._p(cnt),
-                                            ops._p(self._off), st), lib)
+        # (the library prunes the N^2 walk with the sorted chunks it builds in ws_p; same output)
+        nb = int(lib.gnntrk_radius_points_workspace_bytes(n, dim))
+        ws_p = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+        _capi.check(lib.gnntrk_radius_count_ws(ops._p(x), n, dim, ops._row_stride(x), float(max_eps), ops._p(cnt),
+                                               ops._p(self._off), ops._p(ws_p), nb, RADIUS_FLAGS, st), lib)
         m = int(self._off[n].item())
         self._nbr = torch.empty(max(m, 1), dtype=torch.int32, device=x.device)
         self._dist = torch.empty(max(m, 1), dtype=torch.float64, device=x.device)
-        _capi.check(lib.gnntrk_radius_fill(ops._p(x), n, dim, ops._row_stride(x), float(max_eps),
-                                           ops._p(self._off), ops._p(self._nbr), ops._p(self._dist), st), lib)
+        ne = int(lib.gnntrk_radius_edges_workspace_bytes(m)) if nb else 0
+        ws_e = torch.empty(ne, dtype=torch.uint8, device=x.device) if ne else None
+        _capi.check(lib.gnntrk_radius_fill_ws(ops._p(x), n, dim, ops._row_stride(x), float(max_eps),
+                                              ops._p(self._off), m, ops._p(self._nbr), ops._p(self._dist),
+                                              ops._p(ws_p), nb, ops._p(ws_e), ne, RADIUS_FLAGS, st), lib)
         self._n_edges = m
         self._max_eps = float(max_eps)
 

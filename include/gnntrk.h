@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNNTRK_VERSION 202 /* 0.2.2: + oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
+#define GNNTRK_VERSION 203 /* 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
 #define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
 #define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
 #define GNNTRK_MAX_HIDDEN 64
@@ -423,6 +423,22 @@ int gnntrk_radius_count(const float *x, int64_t n, int32_t dim, int32_t x_stride
                         int64_t *offsets, void *stream);
 int gnntrk_radius_fill(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius,
                        const int64_t *offsets, int32_t *nbr, double *dist, void *stream);
+/* The same graph with caller-owned workspaces (dim <= 8, from 4096 points on; otherwise these fall
+ * back to the two entries above): points sorted into chunks of 64 with bounding boxes, a chunk of
+ * queries only walks the candidate chunks whose box is within the radius of its own (box-to-box
+ * bound in the graph's own fp64 arithmetic: no neighbour can be lost), the lists are then put into
+ * ascending neighbour order.  cnt / offsets / nbr / dist are identical to radius_count / radius_fill.
+ * ws_points (gnntrk_radius_points_workspace_bytes; 0 = not covered, pass NULL) is filled by the
+ * count pass and read by the fill pass of the same points; ws_edges
+ * (gnntrk_radius_edges_workspace_bytes(M)) stages the unordered lists.  flags: bit 0 = pruned form
+ * below its size threshold too, bit 1 = brute force regardless. */
+size_t gnntrk_radius_points_workspace_bytes(int64_t n, int32_t dim);
+size_t gnntrk_radius_edges_workspace_bytes(int64_t m_edges);
+int gnntrk_radius_count_ws(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius, int32_t *cnt,
+                           int64_t *offsets, void *ws_points, size_t ws_points_bytes, int32_t flags, void *stream);
+int gnntrk_radius_fill_ws(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius,
+                          const int64_t *offsets, int64_t m_edges, int32_t *nbr, double *dist, void *ws_points,
+                          size_t ws_points_bytes, void *ws_edges, size_t ws_edges_bytes, int32_t flags, void *stream);
 int gnntrk_dbscan_init(const int64_t *offsets, const double *dist, int64_t n, double eps, int32_t min_pts,
                        uint8_t *core, int32_t *root, void *stream);
 int gnntrk_dbscan_propagate(const int64_t *offsets, const int32_t *nbr, const double *dist, int64_t n, double eps,

@@ -1051,7 +1051,7 @@ def case_graph_cut(device, sizes=(0, 1, 63, 2048, 2049, 5000), big=0):
 DBSCAN_TRIALS = ((1.0, 1), (0.5, 2), (0.3, 3), (0.2, 5), (0.11, 4), (0.45, 6))
 
 
-def case_dbscan(device, clouds=("d2", "d3", "d8"), trials=DBSCAN_TRIALS):
+def case_dbscan(device, clouds=("d2", "d3", "d8"), trials=DBSCAN_TRIALS, extras=True):
     """DBSCANFastRescan vs the labels of the reference's own class (G11, bit-exact) and the
     neighbourhood graph vs the oracle (ids exact, fp64 distances exact); rescan beyond
     max_eps; empty / single-point / all-noise inputs."""
@@ -1070,12 +1070,41 @@ def case_dbscan(device, clouds=("d2", "d3", "d8"), trials=DBSCAN_TRIALS):
             assert lab.dtype == np.intp
             assert np.array_equal(lab, z[f"{cn}/eps{eps}_mp{mp}"]), f"DBSCAN {cn} eps={eps} min_pts={mp}"
         assert np.array_equal(fr.cluster(1.3, 3), z[f"{cn}/eps1.3_mp3"]), cn + " rescan beyond max_eps"
+    if not extras:
+        return
     one = torch.zeros(1, 3)
     assert dbscan(one.to(device), 0.5, 1).tolist() == [0] and dbscan(one.to(device), 0.5, 2).tolist() == [-1]
     assert dbscan(torch.zeros(0, 3).to(device), 0.5, 1).shape == (0,)
     # a long chain: the component's lowest index has to travel along every link
     chain = torch.stack([torch.arange(300, dtype=torch.float32).flip(0) * 0.9, torch.zeros(300)], 1)
     assert np.array_equal(dbscan(chain.to(device), 1.0, 2), O.dbscan_labels(chain.numpy(), 1.0, 1.0, 2))
+
+
+def case_dbscan_pruned(device, clouds=("d2", "d3", "d8"), trials=DBSCAN_TRIALS, n_big=0, extras=True):
+    """The pruned radius graph (sorted chunks, box-to-box bound, lists re-ordered) forced on: the same
+    golden / oracle comparisons as the brute-force graph, and (n_big) pruned == brute force on a
+    clustered cloud with noise incl. a list longer than the ordering kernel's LDS path."""
+    from gnn_tracking_amd import postprocessing, synthetic
+
+    old = postprocessing.RADIUS_FLAGS
+    try:
+        postprocessing.RADIUS_FLAGS = 1
+        case_dbscan(device, clouds=clouds, trials=trials, extras=extras)
+        if n_big:
+            x = synthetic.make_pileup_cloud(3, n_big, 8)
+            x[:1500] = x[0] + 0.001 * torch.randn(1500, 8)      # one neighbourhood of > 1024 points
+            res = {}
+            for flags in (1, 2):
+                postprocessing.RADIUS_FLAGS = flags
+                fr = postprocessing.DBSCANFastRescan(x.to(device), max_eps=0.4)
+                res[flags] = (fr._off.cpu(), fr._nbr[:fr._n_edges].cpu(), fr._dist[:fr._n_edges].cpu(),
+                              fr.cluster(0.3, 3))
+            assert torch.equal(res[1][0], res[2][0]), "pruned radius graph: offsets"
+            assert torch.equal(res[1][1], res[2][1]), "pruned radius graph: neighbours"
+            assert torch.equal(res[1][2], res[2][2]), "pruned radius graph: distances"
+            assert np.array_equal(res[1][3], res[2][3]), "pruned radius graph: labels"
+    finally:
+        postprocessing.RADIUS_FLAGS = old
 
 
 def case_full_size_properties(device, n_events=32, n_nodes=150_000, n_edges=2_000_000, n_hits=200_000):

@@ -33,7 +33,7 @@ def test_version_and_error_channel(lib_path):
     from gnn_tracking_amd import _capi
 
     lib = _capi.bind(ctypes.CDLL(str(lib_path)))
-    assert lib.gnntrk_version() == 202
+    assert lib.gnntrk_version() == 203
     # argument validation happens on the host, before any launch
     rc = lib.gnntrk_mlp_forward(None, None)
     assert rc == 1 and b"NULL" in lib.gnntrk_last_error()

@@ -15,7 +15,7 @@ def dev():
     from gnn_tracking_amd import _capi
 
     lib = _capi.load()  # fails loudly if the extension is missing
-    assert lib.gnntrk_version() == 202
+    assert lib.gnntrk_version() == 203
     return "cuda"
 
 
@@ -153,6 +153,7 @@ def test_graph_cut(dev):
 
 def test_dbscan(dev):
     P.case_dbscan(dev)
+    P.case_dbscan_pruned(dev, n_big=30000)
 
 
 def test_full_size_properties(dev):

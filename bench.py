@@ -661,8 +661,10 @@ def dbscan_short(dev) -> dict:
     return {"workload": f"DBSCANFastRescan on {n} hits in 8-d, max_eps {max_eps}: radius graph + {len(trials)} rescans",
             "radius_graph_ms": t_graph * 1e3, "radius_graph_edges": int(fr._n_edges),
             "rescan_ms_per_trial": t_clu * 1e3, "clusters_per_trial": n_clusters,
-            "roofline": {"bound": "valu_f64", "achieved": flops / t_graph / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                         "frac": flops / t_graph / 1e12 / 78.6}}
+            "roofline": {"bound": "valu_f64", "achieved": flops / t_graph / 1e12, "peak": 78.6,
+                         "unit": "TFLOP/s (brute-force equivalent)", "frac": flops / t_graph / 1e12 / 78.6,
+                         "note": "pruned walk (identical lists): the rate an exhaustive N^2 D fp64 graph build would "
+                                 "need; frac > 1 = the pruning does the work (brute force: 92.5 ms, frac 0.26)"}}
 
 
 def extras(args, rank: int, world: int, dev) -> dict:

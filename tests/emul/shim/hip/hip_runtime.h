@@ -4,8 +4,8 @@
 // written for hipcc --offload-arch=gfx950 and use HIP / __builtin_amdgcn_* directly.
 // There is no GPU in the build container, so tests/emul/build_emul.py compiles the
 // SAME source files with g++ (optionally -fsanitize=address,undefined) against this
-// header, which stands in for <hip/hip_runtime.h>: every "lane" is a host thread,
-// a workgroup is blockDim.x threads, wave-level builtins (MFMA 16x16x4 f32,
+// header, which stands in for <hip/hip_runtime.h>: every "lane" is a fiber of the calling
+// thread, a workgroup is blockDim.x of them, wave-level builtins (MFMA 16x16x4 f32,
 // shuffles, wave barrier) rendezvous the 64 threads of a wave and reproduce the
 // documented gfx950 lane layouts bit-for-bit (MFMA = k-ordered fmaf chain,
 // A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=4*(l>>4)+r][col=l&15]).
@@ -14,6 +14,7 @@
 #pragma once
 
 #include <pthread.h>
+#include <ucontext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -91,45 +92,37 @@ struct int4 {
 inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
 
 // ------------------------------------------------------------- execution model
+// Every lane of a workgroup is a FIBER (ucontext) of the calling thread; a wave / workgroup
+// collective that not all participants have reached yet switches to the next runnable lane.
+// (One host thread per lane - the first version - spent nine tenths of a test run in futex and
+// clone system calls.)  A full pass over the lanes without any progress is a deadlock: lanes
+// diverged around a collective.
 namespace hipemul {
 
+struct Block;
+extern thread_local Block *cur_block;
+void fiber_yield();
+void note_progress();
+const char *&fiber_waiting_at();
+
 struct Barrier {
-    pthread_mutex_t mu;
-    pthread_cond_t cv;
     unsigned n = 0, count = 0, gen = 0;
     void init(unsigned n_) {
         n = n_;
         count = 0;
         gen = 0;
-        pthread_mutex_init(&mu, nullptr);
-        pthread_cond_init(&cv, nullptr);
     }
-    void destroy() {
-        pthread_mutex_destroy(&mu);
-        pthread_cond_destroy(&cv);
-    }
+    void destroy() {}
     void wait(const char *what) {
-        pthread_mutex_lock(&mu);
-        unsigned g = gen;
+        const unsigned g = gen;
         if (++count == n) {
             count = 0;
             ++gen;
-            pthread_cond_broadcast(&cv);
-        } else {
-            while (g == gen) {
-                timespec ts;
-                clock_gettime(CLOCK_REALTIME, &ts);
-                ts.tv_sec += 60;
-                if (pthread_cond_timedwait(&cv, &mu, &ts) != 0 && g == gen) {
-                    fprintf(stderr,
-                            "hipemul: DEADLOCK at %s (block %u thread %u): lanes diverged "
-                            "around a wave/block collective\n",
-                            what, blockIdx.x, threadIdx.x);
-                    abort();
-                }
-            }
+            note_progress();
+            return;
         }
-        pthread_mutex_unlock(&mu);
+        fiber_waiting_at() = what;
+        while (g == gen) fiber_yield();
     }
 };
 
@@ -142,15 +135,28 @@ struct Wave {
     uint64_t xch[64];
 };
 
+struct Fiber {
+    ucontext_t ctx;
+    bool done = false;
+    const char *waiting_at = "";
+};
+
 struct Block {
     Barrier bar;
     std::vector<Wave> waves;
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    unsigned cur = 0;
+    unsigned long progress = 0;
+    const std::function<void()> *fn = nullptr;
+    dim3 grid, block;
+    unsigned bx = 0, by = 0;
 };
-
-extern thread_local Block *cur_block;
 
 inline Wave &wave() { return cur_block->waves[threadIdx.x >> 6]; }
 inline int lane() { return threadIdx.x & 63; }
+
+void run_block(Block &blk);  // emul_runtime.cpp
 
 template <class F>
 void launch(dim3 grid, dim3 block, F fn) {
@@ -158,28 +164,19 @@ void launch(dim3 grid, dim3 block, F fn) {
         fprintf(stderr, "hipemul: unsupported launch geometry\n");
         abort();
     }
+    const std::function<void()> f = fn;
+    Block blk;
+    blk.fn = &f;
+    blk.grid = grid;
+    blk.block = block;
+    blk.waves.resize(block.x / 64);
+    blk.fibers.resize(block.x);
     for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned b = 0; b < grid.x; ++b) {
-        Block blk;
-        blk.bar.init(block.x);
-        blk.waves.resize(block.x / 64);
-        for (auto &w : blk.waves) w.bar.init(64);
-        std::vector<std::thread> th;
-        th.reserve(block.x);
-        for (unsigned t = 0; t < block.x; ++t) {
-            th.emplace_back([&, t, b, by]() {
-                threadIdx = {t, 0, 0};
-                blockIdx = {b, by, 0};
-                blockDim = {block.x, 1, 1};
-                gridDim = {grid.x, grid.y, 1};
-                cur_block = &blk;
-                fn();
-            });
+        for (unsigned b = 0; b < grid.x; ++b) {
+            blk.bx = b;
+            blk.by = by;
+            run_block(blk);
         }
-        for (auto &x : th) x.join();
-        for (auto &w : blk.waves) w.bar.destroy();
-        blk.bar.destroy();
-    }
 }
 }  // namespace hipemul
 

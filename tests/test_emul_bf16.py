@@ -12,17 +12,17 @@ pytestmark = pytest.mark.emul
 
 def test_mlp_bf16_forward_emulated():
     with emulated():
-        P.case_mlp_bf16_forward("cpu", rows=37)
+        P.case_mlp_bf16_forward("cpu")
 
 
 def test_mlp_bf16_backward_emulated():
     with emulated():
-        P.case_mlp_bf16_backward("cpu", rows=37, full=False)
+        P.case_mlp_bf16_backward("cpu")
 
 
 def test_ec_bf16_emulated():
     with emulated():
-        P.case_ec_bf16("cpu", names=("alpha0",))
+        P.case_ec_bf16("cpu")
 
 
 def test_rows_bf16_emulated():
@@ -32,4 +32,14 @@ def test_rows_bf16_emulated():
 
 def test_mlp_bf16_stress_emulated():
     with emulated():
-        P.case_mlp_bf16_stress("cpu", rounds=1, cases_per_round=5, row_choices=(1, 17, 33))
+        P.case_mlp_bf16_stress("cpu", rounds=2, cases_per_round=6, row_choices=(1, 17, 33, 100))
+
+
+def test_graph_tcn_bf16_emulated():
+    with emulated():
+        P.case_graph_tcn_bf16("cpu")
+
+
+def test_bf16_reproducible_emulated():
+    with emulated():
+        P.case_bf16_reproducible("cpu")

@@ -96,6 +96,22 @@ class KernelTimer:
 
 _TIMER: Optional[KernelTimer] = None
 
+# Timing events come from a pool that can be filled ahead of a timed region: the HIP runtime grows
+# its event storage in steps, and a step costs the host tens of milliseconds (bench.py)
+_EVENT_POOL: list = []
+
+
+def reserve_timing_events(n: int) -> None:
+    """Create (and record once, which is what allocates them) ``n`` timing events now."""
+    while len(_EVENT_POOL) < n:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _EVENT_POOL.append(e)
+
+
+def timing_event():
+    return _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+
 
 def set_kernel_timer(t: Optional[KernelTimer]) -> None:
     global _TIMER
@@ -126,8 +142,8 @@ class _timed:
 
     def __enter__(self):
         if self.on:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0 = timing_event()
+            self.e1 = timing_event()
             self.e0.record()
 
     def __exit__(self, *exc):

@@ -16,10 +16,11 @@ import bench  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--hits", type=int, default=200_000)
+ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"))
 a = ap.parse_args()
 args = bench.parse(["--workload", "cfg5", "--events", str(a.hits)])
 dev = torch.device("cuda", 0)
-wl = bench.TCWorkload(args, 0, 1, dev)
+wl = bench.TCWorkload(args, 0, 1, dev, dtype=a.dtype)
 for _ in range(2):
     wl.step()
 torch.cuda.synchronize()

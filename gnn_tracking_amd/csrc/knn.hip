@@ -619,86 +619,71 @@ __global__ __launch_bounds__(256) void knn_emit_kernel(const int32_t *__restrict
     }
 }
 
-// exclusive scan of min(cnt, k_take) by ONE workgroup (n <= a few million counts): every thread
-// owns a contiguous range, sums it with independent 16-byte loads (the loop is latency bound:
-// eight loads in flight per thread), the 1024 partial sums are scanned by one wave, and
-// the second walk over the (now L2-resident) counts writes the offsets
+// exclusive scan of min(cnt, k_take) by ONE workgroup (n <= a few million counts): every WAVE owns
+// a contiguous segment and walks it in chunks of 256 counts (one 16-byte load per lane, the next
+// chunk in flight), first for the segment totals, then - after the totals of the waves are scanned
+// - again for the offsets: lane-local prefix, shuffle scan across the lanes, four 8-byte stores per
+// lane into consecutive addresses.  (A thread-per-range walk wrote 64 cache lines per store
+// instruction and took 0.1 ms for 200 k counts, the serial first version 0.36 ms.)
 template <bool VEC>
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t *__restrict__ cnt_raw, int k_take,
                                                            int64_t n, int64_t *__restrict__ off) {
     auto clip = [&](int32_t c) { return c < k_take ? c : k_take; };
-    __shared__ long long s_part[1024];
+    __shared__ long long s_wave[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int nt = blockDim.x, per_lane = nt / 64;  // 256 or 1024 threads
-    int64_t per = (n + nt - 1) / nt;
-    per = (per + 3) & ~(int64_t)3;  // ranges start on 16-byte boundaries
-    const int64_t b = t * per < n ? t * per : n, e = (b + per < n) ? b + per : n;
+    const int nw = blockDim.x >> 6;  // 4 or 16 waves
+    int64_t per = (n + nw - 1) / nw;
+    per = (per + 255) & ~(int64_t)255;  // segments of whole chunks (16-byte aligned lane loads)
+    const int64_t b = wv * per < n ? wv * per : n, e = (b + per < n) ? b + per : n;
+    auto load4 = [&](int64_t at, int (&v)[4]) {  // counts at..at+3 of this lane (0 beyond e)
+        if (VEC && at + 3 < e) {
+            const int4 q = *reinterpret_cast<const int4 *>(cnt_raw + at);
+            v[0] = clip(q.x); v[1] = clip(q.y); v[2] = clip(q.z); v[3] = clip(q.w);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = at + u < e ? clip(cnt_raw[at + u]) : 0;
+        }
+    };
+    constexpr int kU = 8;  // chunks per step: their loads are in flight together (the walk is latency bound)
     long long s = 0;
-    if (VEC) {
-        const int4 *__restrict__ v4 = reinterpret_cast<const int4 *>(cnt_raw + b);
-        const int64_t nv = (e - b) >> 2;
-        int64_t i = 0;
-        for (; i + 8 <= nv; i += 8) {
-            int4 v[8];
+    for (int64_t c0 = b; c0 < e; c0 += 256 * kU) {
+        int v[kU][4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = v4[i + u];
+        for (int u = 0; u < kU; ++u) load4(c0 + 256 * u + 4 * lane, v[u]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += (long long)clip(v[u].x) + clip(v[u].y) + clip(v[u].z) + clip(v[u].w);
-        }
-        for (; i < nv; ++i) {
-            const int4 v = v4[i];
-            s += (long long)clip(v.x) + clip(v.y) + clip(v.z) + clip(v.w);
-        }
-        for (int64_t j = b + (nv << 2); j < e; ++j) s += clip(cnt_raw[j]);
-    } else {
-        for (int64_t j = b; j < e; ++j) s += clip(cnt_raw[j]);
+        for (int u = 0; u < kU; ++u) s += (long long)v[u][0] + v[u][1] + v[u][2] + v[u][3];
     }
-    // exclusive scan of the partial sums by wave 0: nt / 64 per lane, shuffles across the lanes
-    s_part[t] = s;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) s_wave[wv] = s;
     __syncthreads();
-    if (wv == 0) {
-        long long mine = 0;
-        for (int i = 0; i < per_lane; ++i) mine += s_part[lane * per_lane + i];
-        long long inc = mine;
-        for (int d = 1; d < 64; d <<= 1) {
-            const long long o = __shfl(inc, lane >= d ? lane - d : lane);
-            if (lane >= d) inc += o;
-        }
-        long long run0 = inc - mine;
-        for (int i = 0; i < per_lane; ++i) {
-            const long long v = s_part[lane * per_lane + i];
-            s_part[lane * per_lane + i] = run0;
-            run0 += v;
-        }
-        if (lane == 63) off[n] = inc;
+    long long run = 0, total = 0;
+    for (int w = 0; w < nw; ++w) {
+        const long long v = s_wave[w];
+        if (w < wv) run += v;
+        total += v;
     }
-    __syncthreads();
-    long long run = s_part[t];
-    if (VEC) {
-        const int4 *__restrict__ v4 = reinterpret_cast<const int4 *>(cnt_raw + b);
-        const int64_t nv = (e - b) >> 2;
-        int64_t i = 0;
-        for (; i + 4 <= nv; i += 4) {
-            int4 v[4];
+    if (t == 0) off[n] = total;
+    for (int64_t c0 = b; c0 < e; c0 += 256 * kU) {
+        int v[kU][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = v4[i + u];
+        for (int u = 0; u < kU; ++u) load4(c0 + 256 * u + 4 * lane, v[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int64_t *o = off + b + ((i + u) << 2);
-                o[0] = run; run += clip(v[u].x);
-                o[1] = run; run += clip(v[u].y);
-                o[2] = run; run += clip(v[u].z);
-                o[3] = run; run += clip(v[u].w);
+        for (int u = 0; u < kU; ++u) {
+            if (c0 + 256 * u >= e) break;  // (wave-uniform)
+            const long long mine = (long long)v[u][0] + v[u][1] + v[u][2] + v[u][3];
+            long long inc = mine;
+            for (int d = 1; d < 64; d <<= 1) {
+                const long long o = __shfl(inc, lane >= d ? lane - d : lane);
+                if (lane >= d) inc += o;
             }
-        }
-        for (int64_t j = b + (i << 2); j < e; ++j) {
-            off[j] = run;
-            run += clip(cnt_raw[j]);
-        }
-    } else {
-        for (int64_t j = b; j < e; ++j) {
-            off[j] = run;
-            run += clip(cnt_raw[j]);
+            long long at = run + inc - mine;
+            const int64_t i0 = c0 + 256 * u + 4 * lane;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (i0 + w < e) off[i0 + w] = at;
+                at += v[u][w];
+            }
+            run += __shfl(inc, 63);
         }
     }
 }

@@ -68,19 +68,32 @@ def _take(v: Tensor, idx: Tensor) -> Tensor:
     return v.index_select(0, idx)
 
 
-def edge_cut(data, w: Tensor, threshold: float):
-    """``mask = w > threshold; data.edge_subgraph(mask)`` -> ``(data', mask)``."""
+def edge_cut(data, w: Tensor, threshold: float, lazy: tuple = ()):
+    """``mask = w > threshold; data.edge_subgraph(mask)`` -> ``(data', mask)``.
+
+    ``lazy``: names of edge attributes the caller will read through a fused row gather instead
+    (``ModularGraphTCN`` feeds ``edge_attr`` to the next encoder that way: the kept rows of a
+    112-byte-per-edge tensor are then never copied).  Those attributes come back as ``None`` and
+    ``data'._lazy_rows[name] = (uncut tensor, int32 kept-edge index)``; only honoured for this
+    package's ``Data`` and for tensors that do not require a gradient."""
     mask, idx = threshold_compact(w, threshold)
     if not isinstance(data, Data):  # a foreign container (e.g. PyG): its own edge_subgraph
         return data.edge_subgraph(mask), mask
+    idx32 = idx
     idx = idx.long()
     out = copy.copy(data)
+    lazy_rows = {}
     for k in data.keys():
         v = getattr(data, k)
         if k == "edge_index":
             out.edge_index = v.index_select(1, idx)
         elif data.is_edge_attr(k):
-            setattr(out, k, _take(v, idx))
+            if k in lazy and torch.is_tensor(v) and v.dim() == 2 and not v.requires_grad:
+                lazy_rows[k] = (v, idx32)
+                setattr(out, k, None)
+            else:
+                setattr(out, k, _take(v, idx))
+    out._lazy_rows = lazy_rows
     return out, mask
 
 

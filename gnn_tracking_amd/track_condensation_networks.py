@@ -232,7 +232,11 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
             data.ec_edge_embedding = edge_order.as_tensor(ec_result.get("edge_embedding", None))
             edge_weights_unmasked = data.edge_weights.squeeze()
             # threshold cut and orphan masking: device stream compactions (graph_cut.py)
-            data, edge_mask = graph_cut.edge_cut(data, data.edge_weights, self.hparams.ec_threshold)
+            # (edge_attr of the kept edges is only read by the next encoder: through a fused gather,
+            # unless something else below needs the rows themselves)
+            lazy = () if (self.hparams.mask_orphan_nodes or self.hparams.use_ec_embeddings_for_hc
+                          or self.hparams.feed_edge_weights) else ("edge_attr",)
+            data, edge_mask = graph_cut.edge_cut(data, data.edge_weights, self.hparams.ec_threshold, lazy=lazy)
             if self.hparams.mask_orphan_nodes:
                 data, hit_mask = graph_cut.drop_orphans(data)
             else:
@@ -243,7 +247,8 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
         if self.ec is None and self.hparams.feed_edge_weights:
             data.edge_weights = data.ec_score.reshape((-1, 1))
 
-        _edge_attrs, _xs = [data.edge_attr], [data.x]
+        lazy_ea = getattr(data, "_lazy_rows", {}).get("edge_attr") if self.ec is not None else None
+        _edge_attrs, _xs = [data.edge_attr if lazy_ea is None else lazy_ea[0]], [data.x]
         if self.hparams.use_ec_embeddings_for_hc:
             assert data.ec_edge_embedding is not None
             assert data.ec_node_embedding is not None
@@ -258,7 +263,11 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
                       else _edge_attrs[0]).to(cdt)
         # relu(encoder(.)) with the ReLU fused as the kernels' epilogue
         h_hc = self.hc_node_encoder(x, layer=getattr(data, "layer", None), epilogue=_capi.EPI_RELU)
-        edge_attr_hc = self.hc_edge_encoder.fused([ops.Seg(edge_attrs)], epilogue=_capi.EPI_RELU)
+        if lazy_ea is None:
+            edge_attr_hc = self.hc_edge_encoder.fused([ops.Seg(edge_attrs)], epilogue=_capi.EPI_RELU)
+        else:   # rows of the uncut tensor, gathered inside the kernel by the kept-edge index
+            edge_attr_hc = self.hc_edge_encoder.fused([ops.Seg(edge_attrs, lazy_ea[1])], epilogue=_capi.EPI_RELU,
+                                                      n_rows=int(lazy_ea[1].numel()))
 
         h_hc, _, _ = self.hc_in(h_hc, data.edge_index, edge_attr_hc)
         # epsilon + (1 - 2 epsilon) * sigmoid(.): the clamped-sigmoid epilogue

@@ -15,6 +15,7 @@
 // weights are read-only LDS fragments.  Latency is covered by a one-tile software prefetch
 // plus the 4-6 waves per SIMD the small register footprint allows.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -741,7 +742,11 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
     // loop-carried weight-gradient accumulators are updated in place
     const int64_t span = sch.end - sch.cur, gstep = sch.step;
     const int n_grp = (int)__builtin_amdgcn_readfirstlane((uint32_t)(span > 0 ? (span + gstep - 1) / gstep : 0));
-    for (int grp = 0; grp < n_grp; ++grp) {
+    // Only the LAST unit of the whole range can hold rows past the end (every wave's trip count is
+    // exact).  The body is instantiated twice: without the validity masks for the bulk (their
+    // selects are a tenth of the loop's VALU work) and with them for that one unit.
+    auto tile_step = [&](auto tail_tag, int grp) __attribute__((always_inline)) {
+        constexpr bool kTail = decltype(tail_tag)::value;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             load_raw<KI>(L, rid[d], nxt[d]);
@@ -750,14 +755,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 #pragma unroll
         for (int d = 0; d < D; ++d) ids_of(grp + 2, d);
 
-        // (tiles past the end run as all-invalid rows: zero upstream gradient, stores
-        // redirected - no second loop exit for the accumulators)
+        // (kTail: rows past the end run as invalid rows: zero upstream gradient, stores redirected)
         bool valid[D];
         int32_t srow[D][GTA];  // destination rows of the input-gradient slices
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int64_t tile = tile_of(grp, d);
-            valid[d] = tile < n_tiles && tile * kTileRows + c < a.n_rows;
+            valid[d] = !kTail || (tile < n_tiles && tile * kTileRows + c < a.n_rows);
             const int32_t rc = clamp_row(tile);
 #pragma unroll
             for (int T = 0; T < GT; ++T) {
@@ -949,7 +953,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             cur[d] = nxt[d];
             gcur[d] = gnxt[d];
         }
-    }
+    };
+    const int64_t n_units = (n_tiles + D - 1) / D;
+    const bool last_is_partial = n_units * D * kTileRows != a.n_rows;
+    const int has_tail = (int)__builtin_amdgcn_readfirstlane(
+        (uint32_t)((n_grp > 0 && last_is_partial && sch.cur + (int64_t)(n_grp - 1) * sch.step == n_units - 1) ? 1 : 0));
+    const int n_main = n_grp - has_tail;
+    for (int grp = 0; grp < n_main; ++grp) tile_step(std::false_type{}, grp);
+    if (has_tail) tile_step(std::true_type{}, n_main);
 
     // ---- partial block (parameter layout: W1, b1, [W2, b2,] W3, b3) ------------------------
     // The four waves of the workgroup are summed in wave order through LDS (the weight-fragment

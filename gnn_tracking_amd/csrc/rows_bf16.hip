@@ -76,7 +76,27 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
         for (int i = 0; i < 4 * NCH; ++i) s[i] = 0.f;
         const bool on = n < n_seg;
         const int32_t k0 = on ? rowptr[n] : 0, k1 = on ? rowptr[n + 1] : 0;
-        for (int32_t k = k0 + j; k < k1; k += 4) {
+        int32_t k = k0 + j;
+        if (WIDE && NCH == 2) {
+            // two rows per step: both 16-byte loads are in flight before the first is used (the walk
+            // is latency bound: ~13 rows per segment over four lanes); same order of the additions
+            for (; k + 4 < k1; k += 8) {
+                const int64_t ra = pos ? (int64_t)pos[k] : (int64_t)k, rb = pos ? (int64_t)pos[k + 4] : (int64_t)(k + 4);
+                const u32x4 va = *reinterpret_cast<const u32x4 *>(rows + ra * row_stride);
+                const u32x4 vb = *reinterpret_cast<const u32x4 *>(rows + rb * row_stride);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s[2 * w + 0] += bf16_lo(va[w]);
+                    s[2 * w + 1] += bf16_hi(va[w]);
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s[2 * w + 0] += bf16_lo(vb[w]);
+                    s[2 * w + 1] += bf16_hi(vb[w]);
+                }
+            }
+        }
+        for (; k < k1; k += 4) {
             const int64_t r = pos ? (int64_t)pos[k] : (int64_t)k;
             const uint16_t *p = rows + r * row_stride;
             if (WIDE) {

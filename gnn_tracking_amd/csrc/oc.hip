@@ -890,23 +890,37 @@ __global__ __launch_bounds__(kOcTpb) void oc_cps_spatial_kernel(const OcParams p
             lb += gd * gd;
         }
         unsigned long long near = __ballot(c < sp.n_chunks && lb <= r2m);
-        while (near != 0ull) {
-            const int i = __ffsll(near) - 1;
-            near &= near - 1ull;
+        if (near == 0ull) continue;
+        // the next surviving chunk's rows are in flight while this one is evaluated
+        float xa[DP], xn[DP];
+        int32_t jj, jn;
+        long long pj, pn;
+        float qj, qn;
+        auto load_rows = [&](int i, float (&x)[DP], int32_t &id, long long &pid, float &q) {
             const int64_t r = (int64_t)(c0 + i) * 64 + lane;
-            const int32_t jj = sp.sidx[r];
-            float xa[DP], t[DP];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) x[d] = sp.xs[r * DP + d];
+            id = sp.sidx[r];
+            pid = sp.hpid[r];
+            q = sp.hq[r];
+        };
+        int i = __ffsll(near) - 1;
+        load_rows(i, xa, jj, pj, qj);
+        while (near != 0ull) {
+            near &= near - 1ull;
+            const int in = near != 0ull ? __ffsll(near) - 1 : i;
+            load_rows(in, xn, jn, pn, qn);
+            const int64_t r = (int64_t)(c0 + i) * 64 + lane;
+            float t[DP];
             float d2 = 0.f;
 #pragma unroll
             for (int d = 0; d < DP; ++d) {
-                xa[d] = sp.xs[r * DP + d];
                 t[d] = xa[d] - xk[d];  // x_j - x_k
                 d2 += t[d] * t[d];
             }
-            if (jj >= 0 && sp.hpid[r] != pk && d2 < r2 && oc_keep_pair(p, jj, k)) {
+            if (jj >= 0 && pj != pk && d2 < r2 && oc_keep_pair(p, jj, k)) {
                 const int ci = sp.hcap[r];
                 if (ci < 0 || oc_cap_ok(oc_d2_chain<DP>(xa, xk), ak, sp.hcapd2[r], ci)) {
-                    const float qj = sp.hq[r];
                     const float sd = sqrtf(p.eps_sqrt + d2);
                     const float cxr = sd > 0.f ? -cr * qj * qk / sd : 0.f;
 #pragma unroll
@@ -914,6 +928,12 @@ __global__ __launch_bounds__(kOcTpb) void oc_cps_spatial_kernel(const OcParams p
                     gqk += cr * qj * (p.radius - sd);
                 }
             }
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xa[d] = xn[d];
+            jj = jn;
+            pj = pn;
+            qj = qn;
+            i = in;
         }
     }
     // attractive: the hits of particle k (by-gid ordering), at any distance

@@ -404,6 +404,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_pruned_kernel(const float *__re
     __shared__ u64 s_tau[kKnnWaves][QW];
     __shared__ int s_cnt[kKnnWaves][QW], s_oq[kKnnWaves][QW];
     __shared__ int s_lo[kKnnWaves][QW], s_hi[kKnnWaves][QW];  // original-index range of each query's event
+    __shared__ float s_gbox[kKnnWaves][2 * DP];                // bounding box of the wave's queries
     const int lane = threadIdx.x & 63, wv = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u64 *keys = s_keys[wv];
     u64 *tau = s_tau[wv];
@@ -455,6 +456,23 @@ __global__ __launch_bounds__(kKnnBlock) void knn_pruned_kernel(const float *__re
     uint32_t tau_hi[QW];
 #pragma unroll
     for (int q = 0; q < QW; ++q) tau_hi[q] = (uint32_t)(tau0 >> 32);
+    // the queries' own bounding box: a batch of chunks none of which comes closer to THIS box than
+    // the largest threshold cannot pass any query's test (box-to-box gap <= point-to-box gap in
+    // every dimension, same monotone chain) - one cheap test instead of QW
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            float lo = qv[0][d], hi = qv[0][d];
+#pragma unroll
+            for (int q = 1; q < QW; ++q) {
+                lo = fminf(lo, qv[q][d]);
+                hi = fmaxf(hi, qv[q][d]);
+            }
+            s_gbox[wv][d] = lo;
+            s_gbox[wv][DP + d] = hi;
+        }
+    }
+    knn_wave_sync();
 
     auto load_chunk = [&](int c, float (&v)[DP], int &id) {
         const int64_t p = (int64_t)c * 64 + lane;
@@ -480,6 +498,18 @@ __global__ __launch_bounds__(kKnnBlock) void knn_pruned_kernel(const float *__re
         for (int d = 0; d < DP; ++d) {
             lo[d] = bx[d];
             hi[d] = bx[DP + d];
+        }
+        {
+            uint32_t tau_max = tau_hi[0];
+#pragma unroll
+            for (int u = 1; u < QW; ++u) tau_max = tau_hi[u] > tau_max ? tau_hi[u] : tau_max;
+            float lbg = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const float g = fmaxf(fmaxf(__fsub_rn(lo[d], s_gbox[wv][DP + d]), __fsub_rn(s_gbox[wv][d], hi[d])), 0.f);
+                lbg = __fmaf_rn(g, g, lbg);
+            }
+            if (__ballot(cvalid && __float_as_uint(lbg) <= tau_max) == 0ull) continue;
         }
         int qmask = 0;  // bit u: query u has to look at this lane's chunk
 #pragma unroll

@@ -776,7 +776,9 @@ constexpr int kFwdBlocksPerCu = 4;
     X(4, 10, 1, true, 5)  /* relational     14 -> 40 -> 40 -> 4  h[5], h[5], e[4]        */ \
     X(3, 10, 2, true, 3)  /* object          9 -> 40 -> 40 -> 5  h[5], aggr[4]           */ \
     X(7, 10, 1, true, 8)  /* W head         26 -> 40 -> 40 -> 1  h[5], h[5], 4 x e[4]    */ \
-    X(7, 10, 1, false, 7) /* edge encoder   28 -> 40 -> 4       MLGraphConstruction's 2 x 14 edge features */
+    X(7, 10, 1, false, 7) /* edge encoder   28 -> 40 -> 4       MLGraphConstruction's 2 x 14 edge features */ \
+    X(2, 10, 1, true, 2)  /* beta / cluster heads  5 -> 40 -> 40 -> 1 (or 2..4)   h[5]  */ \
+    X(2, 10, 2, true, 2)  /* cluster head          5 -> 40 -> 40 -> 5..8          h[5]  */
 
 static bool static_shape(int ksi, int ksh, int kso, bool three, int n_items) {
     bool hit = false;

@@ -84,7 +84,7 @@ def case_graph_index(device):
 
 
 def case_mlp(device, shapes=((14, 40, 4, 3), (9, 40, 5, 3), (14, 14, 5, 2), (26, 40, 1, 3),
-                             (4, 2, 4, 2), (30, 33, 7, 3), (48, 64, 16, 3), (28, 40, 4, 2)), rows=77):
+                             (4, 2, 4, 2), (30, 33, 7, 3), (48, 64, 16, 3), (28, 40, 4, 2), (5, 40, 1, 3), (5, 40, 8, 3)), rows=77):
     torch.manual_seed(0)
     for (i, h, o, L) in shapes:
         for bias in (True, False):

@@ -1,3 +1,5 @@
+"""Per-step wall times and stage times of the cfg5 step with bench.py's timers off / on
+(finds one-time host costs that a short timed region would average in): python tools/diag_cfg5.py [f32|bf16]"""
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

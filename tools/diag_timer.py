@@ -1,3 +1,5 @@
+"""cProfile of the first cfg5 step that runs with the kernel timer armed (after reserving the timing
+events): python tools/diag_timer.py [f32|bf16]"""
 import sys, time, torch, cProfile, pstats, io
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

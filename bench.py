@@ -443,7 +443,7 @@ class TCWorkload(Workload):
         return s
 
     def roofline(self, ks):
-        roof, kernels = roofline_of(ks, "f32")
+        roof, kernels = roofline_of(ks, self.dtype)
         return roof, kernels
 
     def cpu_baseline(self, iters: int) -> dict:

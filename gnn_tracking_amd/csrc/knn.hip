@@ -884,7 +884,7 @@ static int knn_pruned_qw(int dim, int k, int *cap_out) {
     while (cap < k + 64) cap <<= 1;
     *cap_out = cap;
     const int qw = kKnnLdsPerWave / (cap * 8);
-    return (dim <= 8 && (qw == 8 || qw == 4)) ? qw : 0;
+    return (dim <= 8 && (qw == 8 || qw == 4 || qw == 2)) ? qw : 0;
 }
 
 size_t knn_workspace_bytes(int64_t n, int dim, int k) {
@@ -926,9 +926,9 @@ int knn_search_ws_launch(const float *x, int64_t n, int dim, int stride, int k, 
                            (const float *)xs, (const int32_t *)sidx, (const float *)box, n, w.n_chunks, k,   \
                            cap, max_radius, seg_ptr, n_seg, nbr, cnt)
     if (w.dp == 4) {
-        if (qw == 8) { KNN_PRUNED(4, 8); } else { KNN_PRUNED(4, 4); }
+        if (qw == 8) { KNN_PRUNED(4, 8); } else if (qw == 4) { KNN_PRUNED(4, 4); } else { KNN_PRUNED(4, 2); }
     } else {
-        if (qw == 8) { KNN_PRUNED(8, 8); } else { KNN_PRUNED(8, 4); }
+        if (qw == 8) { KNN_PRUNED(8, 8); } else if (qw == 4) { KNN_PRUNED(8, 4); } else { KNN_PRUNED(8, 2); }
     }
 #undef KNN_PRUNED
     return check_launch("knn_search(pruned)");

@@ -270,20 +270,21 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const float *__restrict_
 // order and every query's buffer is cut to its k best after a batch that added to it, so the
 // thresholds tighten early (without a radius they start at infinity).
 constexpr int kKnnBoxParts = 64;
+constexpr int kSpMaxDim = 16;  // dimensions the sorted-chunk structure covers
 
 // per-dimension min / max of all points: partials of up to kKnnBoxParts blocks (no atomics)
 __global__ __launch_bounds__(256) void knn_bbox_partial_kernel(const float *__restrict__ x, int64_t n, int dim,
                                                                int stride, float *__restrict__ part) {
-    __shared__ float s_lo[4][8], s_hi[4][8];
-    float lo[8], hi[8];
+    __shared__ float s_lo[4][kSpMaxDim], s_hi[4][kSpMaxDim];
+    float lo[kSpMaxDim], hi[kSpMaxDim];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < kSpMaxDim; ++d) {
         lo[d] = 3.402823466e38f;
         hi[d] = -3.402823466e38f;
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d)
+        for (int d = 0; d < kSpMaxDim; ++d)
             if (d < dim) {
                 const float v = x[i * stride + d];
                 lo[d] = fminf(lo[d], v);
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void knn_bbox_partial_kernel(const float *__re
             }
     }
 #pragma unroll
-    for (int d = 0; d < 8; ++d)
+    for (int d = 0; d < kSpMaxDim; ++d)
         for (int o = 32; o > 0; o >>= 1) {
             lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
             hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
@@ -299,16 +300,16 @@ __global__ __launch_bounds__(256) void knn_bbox_partial_kernel(const float *__re
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
+        for (int d = 0; d < kSpMaxDim; ++d) {
             s_lo[wv][d] = lo[d];
             s_hi[wv][d] = hi[d];
         }
     }
     __syncthreads();
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < kSpMaxDim) {
         const int d = threadIdx.x;
-        part[blockIdx.x * 16 + d] = fminf(fminf(s_lo[0][d], s_lo[1][d]), fminf(s_lo[2][d], s_lo[3][d]));
-        part[blockIdx.x * 16 + 8 + d] = fmaxf(fmaxf(s_hi[0][d], s_hi[1][d]), fmaxf(s_hi[2][d], s_hi[3][d]));
+        part[blockIdx.x * 2 * kSpMaxDim + d] = fminf(fminf(s_lo[0][d], s_lo[1][d]), fminf(s_lo[2][d], s_lo[3][d]));
+        part[blockIdx.x * 2 * kSpMaxDim + kSpMaxDim + d] = fmaxf(fmaxf(s_hi[0][d], s_hi[1][d]), fmaxf(s_hi[2][d], s_hi[3][d]));
     }
 }
 
@@ -319,14 +320,14 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(const float *__restrict
                                                          const int64_t *__restrict__ seg_ptr, int n_seg,
                                                          int seg_bits, u64 *__restrict__ keys,
                                                          uint32_t *__restrict__ vals) {
-    __shared__ float s_lo[8], s_scale[8];
+    __shared__ float s_lo[kSpMaxDim], s_scale[kSpMaxDim];
     const int bits = (64 - seg_bits) / dim < 16 ? (64 - seg_bits) / dim : 16;
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < kSpMaxDim) {
         const int d = threadIdx.x;
         float lo = 3.402823466e38f, hi = -3.402823466e38f;
         for (int b = 0; b < n_part; ++b) {
-            lo = fminf(lo, part[b * 16 + d]);
-            hi = fmaxf(hi, part[b * 16 + 8 + d]);
+            lo = fminf(lo, part[b * 2 * kSpMaxDim + d]);
+            hi = fmaxf(hi, part[b * 2 * kSpMaxDim + kSpMaxDim + d]);
         }
         const float w = hi - lo;
         s_lo[d] = lo;
@@ -335,10 +336,10 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(const float *__restrict
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    uint32_t q[8];
+    uint32_t q[kSpMaxDim];
     const uint32_t qmax = (1u << bits) - 1u;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < kSpMaxDim; ++d) {
         q[d] = 0;
         if (d < dim) {
             const float t = (x[i * stride + d] - s_lo[d]) * s_scale[d];
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(const float *__restrict
     u64 code = 0;
     for (int b = bits - 1; b >= 0; --b)
 #pragma unroll
-        for (int d = 0; d < 8; ++d)
+        for (int d = 0; d < kSpMaxDim; ++d)
             if (d < dim) code = (code << 1) | (u64)((q[d] >> b) & 1u);
     if (seg_bits > 0) {
         const u64 sg = (u64)knn_segment_of(seg_ptr, n_seg, i);
@@ -794,7 +795,7 @@ int knn_search_launch(const float *x, int64_t n, int dim, int stride, int k, flo
 
 // ---- sorted chunks + boxes: shared by the pruned search and the condensation losses (oc.hip) ---
 // Layout of the three outputs for n points of dimension dim (<= 8): rows of DP = 4 or 8 floats.
-int spatial_dp(int dim) { return dim <= 4 ? 4 : 8; }
+int spatial_dp(int dim) { return dim <= 4 ? 4 : dim <= 8 ? 8 : 16; }
 int spatial_n_chunks(int64_t n) { return (int)ceil_div(n, 64); }
 // scratch of the build: [box partials | keys a | keys b | vals a | vals b | radix-sort temp]
 struct SpatialScratch {
@@ -808,7 +809,7 @@ static SpatialScratch spatial_scratch_layout(int64_t n) {
         o += align_up(bytes, 256);
         return at;
     };
-    w.part = take((size_t)kKnnBoxParts * 16 * sizeof(float));
+    w.part = take((size_t)kKnnBoxParts * 2 * kSpMaxDim * sizeof(float));
     w.keys_a = take((size_t)n * 8);
     w.keys_b = take((size_t)n * 8);
     w.vals_a = take((size_t)n * 4);
@@ -824,7 +825,7 @@ size_t spatial_scratch_bytes(int64_t n) { return spatial_scratch_layout(n).total
 int spatial_chunks_build(const float *x, int64_t n, int dim, int stride, const int64_t *seg_ptr, int n_seg,
                          float *xs, int32_t *sidx, float *box, void *scratch, size_t scratch_bytes,
                          hipStream_t stream) {
-    if (!x || n < 1 || dim < 1 || dim > 8 || stride < dim || !xs || !sidx || !box || !scratch)
+    if (!x || n < 1 || dim < 1 || dim > kSpMaxDim || stride < dim || !xs || !sidx || !box || !scratch)
         return fail(GNNTRK_EINVAL, "spatial_chunks: bad argument");
     const SpatialScratch w = spatial_scratch_layout(n);
     if (scratch_bytes < w.total) return fail(GNNTRK_EINVAL, "spatial_chunks: scratch too small");
@@ -848,8 +849,11 @@ int spatial_chunks_build(const float *x, int64_t n, int dim, int stride, const i
     if (spatial_dp(dim) == 4)
         hipLaunchKernelGGL((knn_gather_box_kernel<4>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
                            (const uint32_t *)vals_b, n_chunks, xs, sidx, box);
-    else
+    else if (spatial_dp(dim) == 8)
         hipLaunchKernelGGL((knn_gather_box_kernel<8>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
+                           (const uint32_t *)vals_b, n_chunks, xs, sidx, box);
+    else
+        hipLaunchKernelGGL((knn_gather_box_kernel<16>), dim3(gb), dim3(256), 0, stream, x, n, dim, stride,
                            (const uint32_t *)vals_b, n_chunks, xs, sidx, box);
     return check_launch("spatial_chunks(gather)");
 }
@@ -884,7 +888,8 @@ static int knn_pruned_qw(int dim, int k, int *cap_out) {
     while (cap < k + 64) cap <<= 1;
     *cap_out = cap;
     const int qw = kKnnLdsPerWave / (cap * 8);
-    return (dim <= 8 && (qw == 8 || qw == 4 || qw == 2)) ? qw : 0;
+    if (dim > kSpMaxDim || !(qw == 8 || qw == 4 || qw == 2)) return 0;
+    return (dim > 8 && qw == 8) ? 4 : qw;  // 16 coordinates per query: four queries fill the registers
 }
 
 size_t knn_workspace_bytes(int64_t n, int dim, int k) {
@@ -927,8 +932,10 @@ int knn_search_ws_launch(const float *x, int64_t n, int dim, int stride, int k, 
                            cap, max_radius, seg_ptr, n_seg, nbr, cnt)
     if (w.dp == 4) {
         if (qw == 8) { KNN_PRUNED(4, 8); } else if (qw == 4) { KNN_PRUNED(4, 4); } else { KNN_PRUNED(4, 2); }
-    } else {
+    } else if (w.dp == 8) {
         if (qw == 8) { KNN_PRUNED(8, 8); } else if (qw == 4) { KNN_PRUNED(8, 4); } else { KNN_PRUNED(8, 2); }
+    } else {
+        if (qw == 4) { KNN_PRUNED(16, 4); } else { KNN_PRUNED(16, 2); }
     }
 #undef KNN_PRUNED
     return check_launch("knn_search(pruned)");

@@ -346,7 +346,7 @@ int gnntrk_knn_search_batched(const float *x, int64_t n, int32_t dim, int32_t x_
                               float max_radius, const int64_t *seg_ptr, int32_t n_seg, int32_t *nbr,
                               int32_t *cnt, void *stream);
 /* The same search with a caller-owned workspace (gnntrk_knn_workspace_bytes; 0 = this shape is
- * not covered, pass NULL): for dim <= 8 and at least 8192 rows the points are sorted
+ * not covered, pass NULL): for dim <= 16 and at least 8192 rows the points are sorted
  * by (event, Morton code), cut into chunks of 64 with bounding boxes, and a query only streams
  * the chunks whose box can hold a neighbour closer than its current threshold.  The bound is
  * evaluated in the search's own arithmetic (monotone fp32 rounding), so nbr / cnt are

@@ -1565,7 +1565,8 @@ def case_knn_batched(device, sizes=(1, 5, 70, 130, 2, 64)):
 
 
 def case_knn_pruned(device, shapes=((700, 8, 16, 1.0), (300, 3, 4, None), (513, 2, 70, 0.3), (200, 5, 100, None),
-                                    (64, 4, 5, 0.5), (65, 8, 3, None), (400, 3, 256, 0.8)), with_oracle=True,
+                                    (64, 4, 5, 0.5), (65, 8, 3, None), (400, 3, 256, 0.8), (600, 12, 16, 1.0),
+                                    (300, 16, 70, None)), with_oracle=True,
                     batched_sizes=(1, 5, 70, 130, 2, 64)):
     """The pruned search (sorted chunks + bounding-box lower bounds, ``gnntrk_knn_search_ws``) against
     the brute-force kernel and the C oracle, bit for bit: clustered clouds with noise (boxes that

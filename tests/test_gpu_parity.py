@@ -65,7 +65,7 @@ def test_knn_pruned_equals_brute_force(dev):
     # above the row threshold (the pruned form is what knn_graph runs by default there): many
     # batches of boxes, both buffer sizes, events
     P.case_knn_pruned(dev, shapes=((20000, 8, 16, 1.0), (9000, 3, 64, None), (12000, 6, 100, 0.5), (8200, 2, 9, None),
-                                   (10000, 8, 256, 1.0)),
+                                   (10000, 8, 256, 1.0), (9000, 12, 16, 1.5), (8500, 16, 100, None)),
                       with_oracle=False, batched_sizes=(3000, 1, 9000, 40, 4500))
     P.case_knn_pruned(dev, shapes=((9000, 8, 16, 1.0),), batched_sizes=())
 

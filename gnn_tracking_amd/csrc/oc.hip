@@ -1155,7 +1155,7 @@ static OcSpatialWs oc_spatial_layout(int64_t n, int dim) {
     return w;
 }
 size_t oc_spatial_ws_bytes(int64_t n, int dim) {
-    if (n < 1 || n > 0x7fffffff || dim < 1 || dim > 8) return 0;
+    if (n < 1 || n > 0x7fffffff || dim < 1 || dim > 16) return 0;
     return oc_spatial_layout(n, dim).total;
 }
 static OcSpatial oc_spatial_view(const OcSpatialWs &w, void *ws) {
@@ -1181,7 +1181,7 @@ static OcSpatial oc_spatial_view(const OcSpatialWs &w, void *ws) {
 int oc_forward_spatial_launch(const gnntrk_oc_args *a, float *out, void *ws, size_t ws_bytes, hipStream_t stream) {
     int rc = oc_check(a);
     if (rc) return rc;
-    if (a->dim > 8) return fail(GNNTRK_EUNSUPPORTED, "oc_forward_spatial: dim > 8 (use gnntrk_oc_forward)");
+    if (a->dim > 16) return fail(GNNTRK_EUNSUPPORTED, "oc_forward_spatial: dim > 16 (use gnntrk_oc_forward)");
     const OcSpatialWs w = oc_spatial_layout(a->n, a->dim);
     if (!out || !ws || ws_bytes < w.total) return fail(GNNTRK_EINVAL, "oc_forward_spatial: workspace too small");
     const OcParams p = oc_params(a);
@@ -1202,7 +1202,7 @@ int oc_forward_spatial_launch(const gnntrk_oc_args *a, float *out, void *ws, siz
                        reinterpret_cast<long long *>(b + w.cpid));                                                \
     hipLaunchKernelGGL((oc_hits_spatial_kernel<DP, false>), dim3(hgrid), dim3(kOcTpb), 0, stream, p, sp,          \
                        (const float *)nullptr, (const float *)nullptr, part, (float *)nullptr, (float *)nullptr)
-    if (w.dp == 4) { CALL_FS(4); } else { CALL_FS(8); }
+    if (w.dp == 4) { CALL_FS(4); } else if (w.dp == 8) { CALL_FS(8); } else { CALL_FS(16); }
 #undef CALL_FS
     hipLaunchKernelGGL(oc_finalize_spatial_kernel, dim3(1), dim3(kOcTpb), 0, stream, p, (const double *)part, w.n_chunks, out);
     return check_launch("oc_forward_spatial");
@@ -1212,7 +1212,7 @@ int oc_backward_spatial_launch(const gnntrk_oc_args *a, const float *g, const fl
                                int64_t max_cps, void *ws, size_t ws_bytes, hipStream_t stream) {
     int rc = oc_check(a);
     if (rc) return rc;
-    if (a->dim > 8) return fail(GNNTRK_EUNSUPPORTED, "oc_backward_spatial: dim > 8 (use gnntrk_oc_backward)");
+    if (a->dim > 16) return fail(GNNTRK_EUNSUPPORTED, "oc_backward_spatial: dim > 16 (use gnntrk_oc_backward)");
     if (!g || !fwd || !gx || !gbeta || max_cps < 1) return fail(GNNTRK_EINVAL, "oc_backward_spatial: bad argument");
     const OcSpatialWs w = oc_spatial_layout(a->n, a->dim);
     if (!ws || ws_bytes < w.total) return fail(GNNTRK_EINVAL, "oc_backward_spatial: workspace too small");
@@ -1233,7 +1233,7 @@ int oc_backward_spatial_launch(const gnntrk_oc_args *a, const float *g, const fl
     hipLaunchKernelGGL((oc_hits_spatial_kernel<DP, true>), dim3(hgrid), dim3(kOcTpb), 0, stream, p, sp, g, fwd,   \
                        (double *)nullptr, gx, gbeta);                                                             \
     hipLaunchKernelGGL(oc_cps_spatial_kernel<DP>, dim3(cgrid), dim3(kOcTpb), 0, stream, p, sp, g, fwd, gx, gbeta)
-    if (w.dp == 4) { CALL_BS(4); } else { CALL_BS(8); }
+    if (w.dp == 4) { CALL_BS(4); } else if (w.dp == 8) { CALL_BS(8); } else { CALL_BS(16); }
 #undef CALL_BS
     return check_launch("oc_backward_spatial");
 }

@@ -508,7 +508,7 @@ int gnntrk_oc_backward(const gnntrk_oc_args *args, const float *g /*[4]*/, const
                        float *gx, float *gbeta, int64_t max_cps, void *workspace,
                        size_t workspace_bytes, void *stream);
 
-/* The same loss terms and gradients without the N x K walk (dim <= 8; workspace_bytes == 0: not
+/* The same loss terms and gradients without the N x K walk (dim <= 16; workspace_bytes == 0: not
  * covered, use the entry points above).  A repulsive pair needs |x_j - x_k| < radius: the hits are
  * sorted into chunks of 64 with bounding boxes and a (chunk, condensation point) pair is only
  * looked at when the box reaches into the radius (conservative bound; the exact per-pair test is

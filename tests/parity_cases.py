@@ -371,25 +371,26 @@ def case_oc_spatial(device, cases=("td1", "td2", "td3"), sampling=True, caps=(4,
             case_oc_sampling(device)
         if caps:
             case_rg_neighbor_cap(device, caps=caps, n_hits=cap_hits)
-        ev = synthetic.make_pileup_event(7, n_cloud, dim=3, n_particles=n_cloud // 10)
         res = {}
-        for mode in ("on", "off"):
-            losses_oc.SPATIAL = mode
-            for strat, cls in (("rg", losses_oc.CondensationLossRG), ("tiger", losses_oc.CondensationLossTiger)):
-                b = ev["beta"].to(device).requires_grad_(True)
-                x = (ev["x"] * 0.6).to(device).requires_grad_(True)
-                ret = cls(lw_repulsive=2.0, lw_noise=0.5, lw_coward=0.25)(
-                    beta=b, x=x, particle_id=ev["particle_id"].to(device),
-                    reconstructable=ev["reconstructable"].to(device), pt=ev["pt"].to(device), eta=ev["eta"].to(device))
-                ret.loss.backward()
-                res[mode, strat] = ({k: float(v.detach()) for k, v in ret.loss_dct.items()}, x.grad.cpu(), b.grad.cpu())
-        for strat in ("rg", "tiger"):
-            (la, gxa, gba), (lb, gxb, gbb) = res["on", strat], res["off", strat]
-            for k in la:
-                assert abs(la[k] - lb[k]) <= 2e-6 * abs(lb[k]) + 1e-12, f"spatial vs dense {strat} {k}: {la[k]} {lb[k]}"
-            assert la["repulsive"] > 0, "no repulsive pairs: the comparison is vacuous"
-            assert_close(gxa, gxb, 1e-5, f"spatial vs dense {strat} grad x")
-            assert_close(gba, gbb, 1e-5, f"spatial vs dense {strat} grad beta")
+        for dim_c, scale in ((3, 0.6), (12, 0.35)):
+          ev = synthetic.make_pileup_event(7, n_cloud, dim=dim_c, n_particles=n_cloud // 10)
+          for mode in ("on", "off"):
+              losses_oc.SPATIAL = mode
+              for strat, cls in (("rg", losses_oc.CondensationLossRG), ("tiger", losses_oc.CondensationLossTiger)):
+                  b = ev["beta"].to(device).requires_grad_(True)
+                  x = (ev["x"] * scale).to(device).requires_grad_(True)
+                  ret = cls(lw_repulsive=2.0, lw_noise=0.5, lw_coward=0.25)(
+                      beta=b, x=x, particle_id=ev["particle_id"].to(device),
+                      reconstructable=ev["reconstructable"].to(device), pt=ev["pt"].to(device), eta=ev["eta"].to(device))
+                  ret.loss.backward()
+                  res[mode, strat] = ({k: float(v.detach()) for k, v in ret.loss_dct.items()}, x.grad.cpu(), b.grad.cpu())
+          for strat in ("rg", "tiger"):
+              (la, gxa, gba), (lb, gxb, gbb) = res["on", strat], res["off", strat]
+              for k in la:
+                  assert abs(la[k] - lb[k]) <= 2e-6 * abs(lb[k]) + 1e-12, f"spatial vs dense {strat} {k}: {la[k]} {lb[k]}"
+              assert la["repulsive"] > 0, "no repulsive pairs: the comparison is vacuous"
+              assert_close(gxa, gxb, 1e-5, f"spatial vs dense {strat} grad x")
+              assert_close(gba, gbb, 1e-5, f"spatial vs dense {strat} grad beta")
     finally:
         losses_oc.SPATIAL = old
 

@@ -580,8 +580,11 @@ __global__ __launch_bounds__(kKnnBlock) void knn_pruned_kernel(const float *__re
         }
         // a buffer that grew to k or more entries is cut to its k best now: the threshold of the
         // NEXT batch of boxes is the k-th key found so far
+        // (only while the thresholds still move much: after the wave's own batch and its two
+        // neighbours; a sort costs ~600 VALU instructions per query, a later one tightens little -
+        // the buffers are still cut whenever they fill up)
         dirty = (int)__builtin_amdgcn_readfirstlane(dirty);
-        if (dirty != 0) {
+        if (dirty != 0 && t <= 2) {
 #pragma unroll
             for (int u = 0; u < QW; ++u) {
                 if (((dirty >> u) & 1) == 0) continue;

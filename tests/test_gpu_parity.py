@@ -221,3 +221,30 @@ def test_bench_cfg4_two_ranks_match_one_rank(dev):
     assert a["config"]["micro_batches_per_rank"] == 8 and b["config"]["micro_batches_per_rank"] == 4
     rel = abs(a["param_checksum"] - b["param_checksum"]) / a["param_checksum"]
     assert rel < 1e-6, f"parameters after the run differ between 1 and 2 ranks: {rel:.2e}"
+
+
+def test_bench_cfg5_step_runs_in_both_storage_modes(dev):
+    """bench.py --workload cfg5 end to end (the object-condensation step: pruned kNN graph build ->
+    GraphTCN -> spatial condensation-loss passes -> backward -> Adam) on a reduced event, fp32 and bf16
+    storage: one JSON line with the stage times, a finite loss that the two modes agree on to bf16
+    accuracy, the same graph."""
+    import json
+    import math
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    outs = {}
+    for dt in ("f32", "bf16"):
+        cmd = [sys.executable, str(root / "bench.py"), "--workload", "cfg5", "--events", "30000", "--dtype", dt,
+               "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[dt] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for dt, o in outs.items():
+        assert o["dtype"] == dt and o["config"]["workload"].startswith("cfg5")
+        assert set(o["stages"]) >= {"graph_build", "model_forward", "oc_loss_forward", "backward"}
+        assert math.isfinite(o["final_loss"]) and o["value"] > 0
+    assert outs["f32"]["config"]["edges_built"] == outs["bf16"]["config"]["edges_built"]
+    assert abs(outs["f32"]["final_loss"] - outs["bf16"]["final_loss"]) <= 0.02 * abs(outs["f32"]["final_loss"])

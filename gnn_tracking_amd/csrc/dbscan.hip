@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kRTpb) void radius_kernel(const float *__restrict__
 
 // ---- the same graph without the N^2 walk --------------------------------------------------------
 // Points sorted by Morton code into chunks of 64 with bounding boxes (knn.hip: spatial_chunks_build,
-// dim <= 8).  A wave owns kRQ consecutive sorted QUERIES (coordinates in registers); the candidate
+// dim <= 16).  A wave owns four (two beyond 8 dimensions) consecutive sorted QUERIES (coordinates in registers); the candidate
 // chunks are tested 64 at a time (lane = chunk) query point against box,
 //     LB = sum over d of max(lo_d - q_d, q_d - hi_d, 0)^2     in fp32, compared with r^2 (1 + 1e-5)
 // (the fp32 evaluation is within a few 1e-7 of the exact bound, which in turn is <= the fp64 d2 of
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kRTpb) void radius_kernel(const float *__restrict__
 // ascending neighbour index (the contract of radius_fill) on its way from the staging arrays to the
 // output.
 constexpr int kRWaves = kRTpb / 64;
-constexpr int kRQ = 4;  // queries per wave
+constexpr int radius_queries_per_wave(int d) { return d > 8 ? 2 : 4; }  // (register budget: fp32 + fp64 copies)
 
 template <int D, bool FILL>
 __global__ __launch_bounds__(kRTpb) void radius_pruned_kernel(const float *__restrict__ xs,
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(kRTpb) void radius_pruned_kernel(const float *__res
                                                               double r2, int32_t *__restrict__ cnt,
                                                               const int64_t *__restrict__ off,
                                                               int32_t *__restrict__ nbr, double *__restrict__ dist) {
+    constexpr int kRQ = radius_queries_per_wave(D);
     const int lane = threadIdx.x & 63, wv = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t q0 = ((int64_t)blockIdx.x * kRWaves + wv) * kRQ;  // position in the sorted order
     if (q0 >= n) return;
@@ -382,7 +383,7 @@ constexpr int64_t kRadiusPrunedMinRows = 4096;
 constexpr int64_t kRadiusPrunedMaxDegree = 256;  // denser graphs: nothing to prune, ordering would dominate
 
 size_t radius_points_ws_bytes(int64_t n, int dim) {
-    if (n < 1 || n > 0x7fffffff || dim < 1 || dim > 8) return 0;
+    if (n < 1 || n > 0x7fffffff || dim < 1 || dim > 16) return 0;
     return radius_ws_layout(n, dim).total;
 }
 size_t radius_edges_ws_bytes(int64_t m_edges) {
@@ -391,7 +392,7 @@ size_t radius_edges_ws_bytes(int64_t m_edges) {
 
 int radius_count_ws_launch(const float *x, int64_t n, int dim, int stride, double radius, int32_t *cnt,
                            int64_t *offsets, void *ws_points, size_t ws_bytes, int flags, hipStream_t stream) {
-    const bool pruned = ws_points && dim <= 8 && !(flags & 2) && ((flags & 1) || n >= kRadiusPrunedMinRows) && n > 0;
+    const bool pruned = ws_points && dim <= 16 && !(flags & 2) && ((flags & 1) || n >= kRadiusPrunedMinRows) && n > 0;
     if (!pruned) return radius_count_launch(x, n, dim, stride, radius, cnt, offsets, stream);
     int rc = check_points(x, n, dim, stride, radius, "radius_count");
     if (rc) return rc;
@@ -405,15 +406,15 @@ int radius_count_ws_launch(const float *x, int64_t n, int dim, int stride, doubl
     rc = spatial_chunks_build(x, n, dim, stride, nullptr, 0, xs, sidx, box, b + w.scratch, w.total - w.scratch, stream);
     if (rc) return rc;
     const double r2 = radius * radius;
-    const unsigned grid = (unsigned)ceil_div(n, (int64_t)kRWaves * kRQ);
-    if (w.dp == 4)
-        hipLaunchKernelGGL((radius_pruned_kernel<4, false>), dim3(grid), dim3(kRTpb), 0, stream, (const float *)xs,
-                           (const int32_t *)sidx, (const float *)box, n, w.n_chunks, r2, cnt,
-                           (const int64_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
-    else
-        hipLaunchKernelGGL((radius_pruned_kernel<8, false>), dim3(grid), dim3(kRTpb), 0, stream, (const float *)xs,
-                           (const int32_t *)sidx, (const float *)box, n, w.n_chunks, r2, cnt,
-                           (const int64_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
+    const unsigned grid = (unsigned)ceil_div(n, (int64_t)kRWaves * radius_queries_per_wave(w.dp));
+#define GNNTRK_RP_COUNT(D_)                                                                                         \
+    hipLaunchKernelGGL((radius_pruned_kernel<D_, false>), dim3(grid), dim3(kRTpb), 0, stream, (const float *)xs,     \
+                       (const int32_t *)sidx, (const float *)box, n, w.n_chunks, r2, cnt, (const int64_t *)nullptr, \
+                       (int32_t *)nullptr, (double *)nullptr)
+    if (w.dp == 4) GNNTRK_RP_COUNT(4);
+    else if (w.dp == 8) GNNTRK_RP_COUNT(8);
+    else GNNTRK_RP_COUNT(16);
+#undef GNNTRK_RP_COUNT
     scan_counts_launch(cnt, 0x7fffffff, n, offsets, stream);
     return check_launch("radius_count(pruned)");
 }
@@ -421,7 +422,7 @@ int radius_count_ws_launch(const float *x, int64_t n, int dim, int stride, doubl
 int radius_fill_ws_launch(const float *x, int64_t n, int dim, int stride, double radius, const int64_t *off,
                           int64_t m_edges, int32_t *nbr, double *dist, void *ws_points, size_t ws_bytes,
                           void *ws_edges, size_t ws_edges_bytes, int flags, hipStream_t stream) {
-    const bool pruned = ws_points && ws_edges && dim <= 8 && !(flags & 2) && n > 0 &&
+    const bool pruned = ws_points && ws_edges && dim <= 16 && !(flags & 2) && n > 0 &&
                         ((flags & 1) || (n >= kRadiusPrunedMinRows && m_edges <= kRadiusPrunedMaxDegree * n));
     if (!pruned) return radius_fill_launch(x, n, dim, stride, radius, off, nbr, dist, stream);
     int rc = check_points(x, n, dim, stride, radius, "radius_fill");
@@ -438,13 +439,14 @@ int radius_fill_ws_launch(const float *x, int64_t n, int dim, int stride, double
     double *t_dist = reinterpret_cast<double *>(static_cast<char *>(ws_edges) +
                                                 align_up((size_t)(m_edges > 0 ? m_edges : 1) * 4, 256));
     const double r2 = radius * radius;
-    const unsigned grid = (unsigned)ceil_div(n, (int64_t)kRWaves * kRQ);
-    if (w.dp == 4)
-        hipLaunchKernelGGL((radius_pruned_kernel<4, true>), dim3(grid), dim3(kRTpb), 0, stream, xs, sidx, box, n,
-                           w.n_chunks, r2, (int32_t *)nullptr, off, t_nbr, t_dist);
-    else
-        hipLaunchKernelGGL((radius_pruned_kernel<8, true>), dim3(grid), dim3(kRTpb), 0, stream, xs, sidx, box, n,
-                           w.n_chunks, r2, (int32_t *)nullptr, off, t_nbr, t_dist);
+    const unsigned grid = (unsigned)ceil_div(n, (int64_t)kRWaves * radius_queries_per_wave(w.dp));
+#define GNNTRK_RP_FILL(D_)                                                                                     \
+    hipLaunchKernelGGL((radius_pruned_kernel<D_, true>), dim3(grid), dim3(kRTpb), 0, stream, xs, sidx, box, n, \
+                       w.n_chunks, r2, (int32_t *)nullptr, off, t_nbr, t_dist)
+    if (w.dp == 4) GNNTRK_RP_FILL(4);
+    else if (w.dp == 8) GNNTRK_RP_FILL(8);
+    else GNNTRK_RP_FILL(16);
+#undef GNNTRK_RP_FILL
     hipLaunchKernelGGL(radius_order_kernel, dim3((unsigned)ceil_div(n, kRWaves)), dim3(kRTpb), 0, stream, off, n,
                        (const int32_t *)t_nbr, (const double *)t_dist, nbr, dist);
     return check_launch("radius_fill(pruned)");

@@ -423,7 +423,7 @@ int gnntrk_radius_count(const float *x, int64_t n, int32_t dim, int32_t x_stride
                         int64_t *offsets, void *stream);
 int gnntrk_radius_fill(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius,
                        const int64_t *offsets, int32_t *nbr, double *dist, void *stream);
-/* The same graph with caller-owned workspaces (dim <= 8, from 4096 points on; otherwise these fall
+/* The same graph with caller-owned workspaces (dim <= 16, from 4096 points on; otherwise these fall
  * back to the two entries above): points sorted into chunks of 64 with bounding boxes, a chunk of
  * queries only walks the candidate chunks whose box is within the radius of its own (box-to-box
  * bound in the graph's own fp64 arithmetic: no neighbour can be lost), the lists are then put into

@@ -1091,9 +1091,9 @@ def case_dbscan_pruned(device, clouds=("d2", "d3", "d8"), trials=DBSCAN_TRIALS, 
     try:
         postprocessing.RADIUS_FLAGS = 1
         case_dbscan(device, clouds=clouds, trials=trials, extras=extras)
-        if n_big:
-            x = synthetic.make_pileup_cloud(3, n_big, 8)
-            x[:1500] = x[0] + 0.001 * torch.randn(1500, 8)      # one neighbourhood of > 1024 points
+        for dim_c in ((8, 12) if n_big else ()):
+            x = synthetic.make_pileup_cloud(3, n_big, dim_c)
+            x[:1500] = x[0] + 0.001 * torch.randn(1500, dim_c)      # one neighbourhood of > 1024 points
             res = {}
             for flags in (1, 2):
                 postprocessing.RADIUS_FLAGS = flags

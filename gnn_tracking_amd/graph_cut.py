@@ -68,8 +68,12 @@ def _take(v: Tensor, idx: Tensor) -> Tensor:
     return v.index_select(0, idx)
 
 
-def edge_cut(data, w: Tensor, threshold: float, lazy: tuple = ()):
+def edge_cut(data, w: Tensor, threshold: float, lazy: tuple = (), only=None):
     """``mask = w > threshold; data.edge_subgraph(mask)`` -> ``(data', mask)``.
+
+    ``only``: if given, the edge attributes (besides ``edge_index``) the caller will read from
+    ``data'``; the others come back as ``None`` instead of being copied (``ModularGraphTCN`` keeps the
+    cut graph to itself and reads two or three of them).
 
     ``lazy``: names of edge attributes the caller will read through a fused row gather instead
     (``ModularGraphTCN`` feeds ``edge_attr`` to the next encoder that way: the kept rows of a
@@ -88,7 +92,9 @@ def edge_cut(data, w: Tensor, threshold: float, lazy: tuple = ()):
         if k == "edge_index":
             out.edge_index = v.index_select(1, idx)
         elif data.is_edge_attr(k):
-            if k in lazy and torch.is_tensor(v) and v.dim() == 2 and not v.requires_grad:
+            if only is not None and k not in only:
+                setattr(out, k, None)
+            elif k in lazy and torch.is_tensor(v) and v.dim() == 2 and not v.requires_grad:
                 lazy_rows[k] = (v, idx32)
                 setattr(out, k, None)
             else:

@@ -236,7 +236,13 @@ class ModularGraphTCN(nn.Module, HyperparametersMixin):
             # unless something else below needs the rows themselves)
             lazy = () if (self.hparams.mask_orphan_nodes or self.hparams.use_ec_embeddings_for_hc
                           or self.hparams.feed_edge_weights) else ("edge_attr",)
-            data, edge_mask = graph_cut.edge_cut(data, data.edge_weights, self.hparams.ec_threshold, lazy=lazy)
+            # (the cut graph stays inside this function: only what is read below is carried over)
+            only = None
+            if not self.hparams.mask_orphan_nodes:
+                only = {"edge_attr"} | ({"ec_edge_embedding"} if self.hparams.use_ec_embeddings_for_hc else set()) \
+                    | ({"edge_weights"} if self.hparams.feed_edge_weights else set())
+            data, edge_mask = graph_cut.edge_cut(data, data.edge_weights, self.hparams.ec_threshold, lazy=lazy,
+                                                 only=only)
             if self.hparams.mask_orphan_nodes:
                 data, hit_mask = graph_cut.drop_orphans(data)
             else:

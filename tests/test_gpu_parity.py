@@ -248,3 +248,17 @@ def test_bench_cfg5_step_runs_in_both_storage_modes(dev):
         assert math.isfinite(o["final_loss"]) and o["value"] > 0
     assert outs["f32"]["config"]["edges_built"] == outs["bf16"]["config"]["edges_built"]
     assert abs(outs["f32"]["final_loss"] - outs["bf16"]["final_loss"]) <= 0.02 * abs(outs["f32"]["final_loss"])
+
+
+def test_pruned_paths_random_stress(dev):
+    """tools/gpu_stress_pruned.py, a short run: the sorted-chunk kNN search, the DBSCAN radius graph
+    and the spatial condensation-loss passes against their exhaustive forms on random sizes around
+    the chunk / batch boundaries, 1..16 dimensions, k up to 448, event splits."""
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "gpu_stress_pruned.py"), "5", "10"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "pruned stress ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

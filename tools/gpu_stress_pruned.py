@@ -57,8 +57,8 @@ for rnd in range(rounds):
     postprocessing.RADIUS_FLAGS = 0
     assert all(torch.equal(a, b) for a, b in zip(rg[1], rg[2])), f"radius graph n={n} d={d} eps={eps}"
     # condensation losses
-    if n >= 50:
-        ev = synthetic.make_pileup_event(int(g.integers(1, 1000)), n, dim=d, n_particles=max(n // 12, 2))
+    ev = synthetic.make_pileup_event(int(g.integers(1, 1000)), n, dim=d, n_particles=max(n // 12, 2)) if n >= 50 else None
+    if ev is not None and bool(((ev["pt"] > 0.9) & (ev["particle_id"] > 0) & (ev["eta"].abs() < 4.0)).any()):
         out = {}
         for mode in ("on", "off"):
             losses_oc.SPATIAL = mode
@@ -72,6 +72,9 @@ for rnd in range(rounds):
             out[mode] = (float(ret.loss.detach()), xx.grad.clone(), b.grad.clone())
         losses_oc.SPATIAL = "auto"
         la, lb = out["on"][0], out["off"][0]
+        if la != la and lb != lb:   # (no noise hit in a tiny event: the noise term is NaN in both, as in the reference)
+            print(f"round {rnd}: n={n} d={d}: loss NaN in both forms", flush=True)
+            continue
         assert abs(la - lb) <= 1e-5 * abs(lb) + 1e-9, f"OC loss n={n} d={d}: {la} vs {lb}"
         for a, b_ in zip(out["on"][1:], out["off"][1:]):
             assert (a - b_).abs().max().item() <= 1e-4 * max(1.0, b_.abs().max().item()), f"OC grads n={n} d={d}"

@@ -65,35 +65,55 @@ def _compile(src: pathlib.Path, verbose: bool) -> pathlib.Path:
     want = _stamp(src)
     if obj.exists() and stamp.exists() and stamp.read_text() == want:
         return obj
-    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
+    tmp = obj.with_suffix(f".o.tmp{os.getpid()}")
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        tmp.unlink(missing_ok=True)
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError(f"hipcc failed on {src.name}")
     if verbose and r.stderr.strip():
         sys.stderr.write(r.stderr)
+    os.replace(tmp, obj)   # (a reader never sees a half-written object)
     stamp.write_text(want)
     return obj
 
 
 def build_lib(verbose: bool = False, jobs: int | None = None) -> pathlib.Path:
+    """Compile what changed and relink.  Safe under concurrent callers (ranks started by torchrun or
+    Lightning DDP after a source edit): one process builds under an exclusive file lock, the others
+    wait and then find everything up to date; outputs are moved into place atomically."""
+    import fcntl
+
     OBJ.mkdir(parents=True, exist_ok=True)
+    with open(OBJ / ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(verbose, jobs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool, jobs: int | None) -> pathlib.Path:
     srcs = sorted(CSRC.glob("*.hip"))
     jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
     newest = max(o.stat().st_mtime for o in objs)
     if not LIB.exists() or LIB.stat().st_mtime < newest:
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB),
+        tmp = LIB.with_suffix(f".so.tmp{os.getpid()}")
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp),
                *map(str, objs)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            tmp.unlink(missing_ok=True)
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("link of libgnntrk.so failed")
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "gnntrk_device_cu_count": (C.c_int, []),
     "gnntrk_graph_index_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gnntrk_graph_index_build": (C.c_int, [_P, C.POINTER(GraphIndex), _P, C.c_size_t, _P]),
+    "gnntrk_graph_index_build_ex": (C.c_int, [_P, C.POINTER(GraphIndex), _P, C.c_size_t, C.c_int32, _P]),
     "gnntrk_mlp_forward": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
     "gnntrk_rows_to_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P]),
     "gnntrk_segment_sum_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32,

@@ -64,7 +64,7 @@ int focal_backward_launch(const float *, const float *, const int64_t *, const f
                           int, int64_t, const float *, float *, hipStream_t);
 // graph_index.hip
 size_t graph_index_ws_bytes(int64_t, int64_t);
-int graph_index_build(const int64_t *, const gnntrk_graph_index *, void *, size_t, hipStream_t);
+int graph_index_build(const int64_t *, const gnntrk_graph_index *, void *, size_t, int, hipStream_t);
 
 // knn.hip
 int knn_search_launch(const float *, int64_t, int, int, int, float, const int64_t *, int, int32_t *, int32_t *,
@@ -108,7 +108,11 @@ size_t gnntrk_graph_index_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
 }
 int gnntrk_graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *out,
                              void *workspace, size_t workspace_bytes, void *stream) {
-    return graph_index_build(edge_index, out, workspace, workspace_bytes, (hipStream_t)stream);
+    return graph_index_build(edge_index, out, workspace, workspace_bytes, 0, (hipStream_t)stream);
+}
+int gnntrk_graph_index_build_ex(const int64_t *edge_index, const gnntrk_graph_index *out, void *workspace,
+                                size_t workspace_bytes, int32_t flags, void *stream) {
+    return graph_index_build(edge_index, out, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
 
 int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream) {

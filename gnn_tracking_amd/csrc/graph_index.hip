@@ -1,12 +1,580 @@
 // Graph index: stable target-sorted (CSR) and source-sorted views of a COO edge list.
-// See gnntrk_graph_index in include/gnntrk.h.  HBM-bound integer work: coalesced
-// streams over E, one gather (src[perm[k]]), two stable device radix sorts.
+// See gnntrk_graph_index in include/gnntrk.h (replaces the gather / scatter bookkeeping of PyG's
+// MessagePassing.propagate, models/interaction_network.py:36,67).  HBM-bound integer work.
+//
+// Own two-level counting sort (round 3; the library radix sort stays for shapes outside it):
+//
+//   a node id is split into (bucket = id >> 8, low = id & 255).  The edge list is cut into chunks of
+//   consecutive edges (one workgroup each).
+//     1. count   per (bucket, chunk) edge counts: LDS histogram per chunk, written into a dense
+//                bucket-major table
+//     2. scan    one exclusive scan over the flattened table = the output offset of every
+//                (bucket, chunk) run
+//     3. split   every edge goes to its bucket's region (position from an LDS cursor per bucket) as
+//                one 8-byte record {low | payload, value}
+//     4. sort    one workgroup per bucket (256 nodes, a few thousand edges, held in LDS): histogram
+//                over `low` -> row pointers of the bucket's nodes; the rank of a record inside its
+//                node's list is the number of records of that node with a smaller value (edge id /
+//                CSR position), so the result is the STABLE order whatever order step 3's cursors
+//                handed out - deterministic, bit-identical to a stable sort.
+//   Run twice: by target over the COO list (value = edge id, payload = source) and by source over
+//   the CSR list (value = CSR position).  Row pointers, `src[perm]`, `tgt` and the inverse
+//   permutation fall out of step 4 - no key extraction, gather or boundary passes.
+//
+//   What makes steps 1 / 3 stream: a collated batch is a list of events with disjoint id ranges and
+//   contiguous edge ranges, so a chunk only touches the few hundred buckets of its own event: the
+//   counters of a chunk live in an LDS window of 8192 buckets around the chunk's first id and the
+//   runs it writes are hundreds of bytes long.  Ids outside the window (one giant unsorted graph)
+//   take global atomics on the table itself - slower, same result.  A bucket beyond the LDS
+//   capacity (hub nodes) is ranked from global memory in tiles - slower, same result.
+//
+//   Algorithmic bytes per edge: count 8 + split 16 + 8 + sort 8 + 12, then 4 + 4 + 8 + 8 + 8 = 84
+//   (+ 0.3 table entries per edge x 12 B); the library path moved about 260.
 #include "host_util.h"
 
 namespace gnntrk {
 
 constexpr int kTpb = 256;
 
+// ------------------------------------------------------------------ own counting sort
+constexpr int kSH = 8;                  // nodes per bucket = 256
+constexpr int kBins = 1 << kSH;
+constexpr int kSortTpb = 512;
+constexpr int kSortR = 12;              // records a thread of the bucket sort holds in registers
+constexpr int kCap = kSortTpb * kSortR; // records of a bucket the bucket sort holds in LDS (6144)
+constexpr int kWin = 4096;              // bucket counters a chunk holds in LDS
+constexpr int kSplitTpb = 1024;
+constexpr int kSplitR = 4;              // edges per thread and tile of the split
+constexpr int kSplitTile = kSplitTpb * kSplitR;
+constexpr int kMaxChunks = 512;
+constexpr int64_t kMaxTable = (int64_t)96 << 20;   // table entries (4 B each)
+constexpr int kScanTpb = 256, kScanItems = 16, kScanTile = kScanTpb * kScanItems;
+
+// first sort: key = target (COO row 1), payload = source (row 0), value = edge id
+struct KeysCoo {
+    const int64_t *src, *tgt;
+    int64_t N;
+    __device__ __forceinline__ uint32_t key(int64_t e, int *bad) const {
+        int64_t v = tgt[e];
+        if (v < 0 || v >= N) {
+            atomicAdd(bad, 1);
+            v = v < 0 ? 0 : N - 1;
+        }
+        return (uint32_t)v;
+    }
+    __device__ __forceinline__ uint32_t payload(int64_t e, int *bad) const {
+        int64_t v = src[e];
+        if (v < 0 || v >= N) {
+            atomicAdd(bad, 1);
+            v = v < 0 ? 0 : N - 1;
+        }
+        return (uint32_t)v;
+    }
+};
+// second sort: key = source of the CSR-ordered list (already validated), value = CSR position
+struct KeysCsr {
+    const int32_t *src;
+    __device__ __forceinline__ uint32_t key(int64_t e, int *) const { return (uint32_t)src[e]; }
+    __device__ __forceinline__ uint32_t payload(int64_t, int *) const { return 0u; }
+};
+
+// The LDS window of a chunk starts a third of its width below the bucket of the chunk's first id: a
+// chunk that begins inside event A and runs into event B sees ids from A's first to B's last
+__device__ __forceinline__ int gi_window_start(uint32_t first_key) {
+    const int b = (int)(first_key >> kSH) - kWin / 3;
+    return b < 0 ? 0 : b;
+}
+
+// step 1.  tbl[bucket * n_chunks + chunk] = edges of the chunk in the bucket (tbl zeroed before);
+// range[chunk] = (first, last) touched window slot
+template <class K>
+__global__ __launch_bounds__(kSplitTpb) void gi_count_kernel(K keys, int64_t E, int chunk, int n_chunks, int NB,
+                                                             uint32_t *__restrict__ tbl, int2 *__restrict__ range,
+                                                             int *__restrict__ bad) {
+    __shared__ uint32_t s_cnt[kWin];
+    __shared__ int s_lo, s_hi;
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const int64_t e0 = (int64_t)c * chunk, e1 = e0 + chunk < E ? e0 + chunk : E;
+    for (int d = tid; d < kWin; d += kSplitTpb) s_cnt[d] = 0;
+    if (tid == 0) {
+        s_lo = kWin;
+        s_hi = -1;
+    }
+    __syncthreads();
+    int nobad = 0;
+    const int w0 = gi_window_start(keys.key(e0, &nobad));   // (e0 is counted below)
+    for (int64_t e = e0 + tid; e < e1; e += kSplitTpb) {
+        const uint32_t b = keys.key(e, bad) >> kSH;
+        const uint32_t d = b - (uint32_t)w0;
+        if (d < (uint32_t)kWin)
+            atomicAdd(&s_cnt[d], 1u);
+        else
+            atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u);
+    }
+    __syncthreads();
+    int lo = kWin, hi = -1;
+    for (int d = tid; d < kWin; d += kSplitTpb) {
+        const uint32_t v = s_cnt[d];
+        if (v) {
+            tbl[(size_t)(w0 + d) * n_chunks + c] = v;
+            lo = d < lo ? d : lo;
+            hi = d > hi ? d : hi;
+        }
+    }
+    if (hi >= 0) {
+        atomicMin(&s_lo, lo);
+        atomicMax(&s_hi, hi);
+    }
+    __syncthreads();
+    if (tid == 0) range[c] = int2{s_lo, s_hi};
+    (void)NB;
+}
+
+// step 2: exclusive scan of tbl[0 .. T] in place (tbl[T] = total), three kernels
+__global__ __launch_bounds__(kScanTpb) void gi_scan_sums_kernel(const uint32_t *__restrict__ v, int64_t n,
+                                                                uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s[kScanTpb];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * kScanTile + (int64_t)tid * kScanItems;
+    uint32_t t = 0;
+    if (i0 + kScanItems <= n) {
+#pragma unroll
+        for (int q = 0; q < kScanItems / 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(v + i0 + 4 * q);
+            t += a.x + a.y + a.z + a.w;
+        }
+    } else {
+        for (int q = 0; q < kScanItems; ++q) t += i0 + q < n ? v[i0 + q] : 0u;
+    }
+    s[tid] = t;
+    __syncthreads();
+    for (int d = kScanTpb / 2; d > 0; d >>= 1) {
+        if (tid < d) s[tid] += s[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) sums[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(1024) void gi_scan_tiles_kernel(uint32_t *__restrict__ sums, int n) {
+    __shared__ uint32_t s[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint32_t mine = 0;
+    for (int i = lo; i < hi; ++i) mine += sums[i];
+    s[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? s[tid - d] : 0u;
+        __syncthreads();
+        s[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s[tid] - mine;
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t c = sums[i];
+        sums[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(kScanTpb) void gi_scan_apply_kernel(uint32_t *__restrict__ v, int64_t n,
+                                                                 const uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s[kScanTpb];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * kScanTile + (int64_t)tid * kScanItems;
+    uint32_t x[kScanItems];
+    const bool full = i0 + kScanItems <= n;
+    if (full) {
+#pragma unroll
+        for (int q = 0; q < kScanItems / 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(v + i0 + 4 * q);
+            x[4 * q] = a.x;
+            x[4 * q + 1] = a.y;
+            x[4 * q + 2] = a.z;
+            x[4 * q + 3] = a.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kScanItems; ++q) x[q] = i0 + q < n ? v[i0 + q] : 0u;
+    }
+    uint32_t t = 0;
+#pragma unroll
+    for (int q = 0; q < kScanItems; ++q) t += x[q];
+    s[tid] = t;
+    __syncthreads();
+    for (int d = 1; d < kScanTpb; d <<= 1) {
+        const uint32_t u = tid >= d ? s[tid - d] : 0u;
+        __syncthreads();
+        s[tid] += u;
+        __syncthreads();
+    }
+    uint32_t run = sums[blockIdx.x] + s[tid] - t;
+#pragma unroll
+    for (int q = 0; q < kScanItems; ++q) {
+        const uint32_t c = x[q];
+        x[q] = run;
+        run += c;
+    }
+    if (full) {
+#pragma unroll
+        for (int q = 0; q < kScanItems / 4; ++q)
+            *reinterpret_cast<uint4 *>(v + i0 + 4 * q) = uint4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+    } else {
+#pragma unroll
+        for (int q = 0; q < kScanItems; ++q)
+            if (i0 + q < n) v[i0 + q] = x[q];
+    }
+}
+
+// base[b] = first record of bucket b (b <= NB), taken before step 3's cursors touch the table
+__global__ __launch_bounds__(kTpb) void gi_bases_kernel(const uint32_t *__restrict__ tbl, int n_chunks, int NB,
+                                                        uint32_t *__restrict__ base) {
+    const int b = blockIdx.x * kTpb + threadIdx.x;
+    if (b <= NB) base[b] = tbl[(size_t)b * n_chunks];
+}
+
+// exclusive scan of one value per thread over a workgroup of kSplitTpb threads (wave shuffles + one
+// LDS round for the 16 wave totals); also returns the total
+__device__ __forceinline__ uint32_t gi_block_exscan(uint32_t v, uint32_t *s_wsum, uint32_t *total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl(inc, lane - d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSplitTpb / 64; ++w) {
+        const uint32_t t = s_wsum[w];
+        pre += w < wv ? t : 0u;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return pre + inc - v;
+}
+
+// step 3.  part[pos] = {lo: value (edge id / CSR position), hi: low << pbits | payload}.
+// A tile of 4096 edges is first grouped by bucket in LDS (rank inside the tile's bucket from an LDS
+// counter, tile-local starts from a scan over the chunk's touched window range), then written out
+// with consecutive lanes on consecutive records of a run: the stores coalesce (a scattered 8-byte
+// store per lane costs the address path about 8 cycles per lane).
+template <class K>
+__global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, int chunk, int n_chunks, int pbits,
+                                                             uint32_t *__restrict__ tbl,
+                                                             const int2 *__restrict__ range,
+                                                             uint2 *__restrict__ part, int *__restrict__ bad) {
+    __shared__ uint32_t s_off[kWin];     // next free record of the (bucket, chunk) run
+    __shared__ uint32_t s_cnt[kWin];     // tile: records per bucket, then the tile-local start
+    __shared__ uint2 s_stage[kSplitTile];
+    __shared__ uint16_t s_slot[kSplitTile];
+    __shared__ uint32_t s_wsum[kSplitTpb / 64];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const int64_t e0 = (int64_t)c * chunk, e1 = e0 + chunk < E ? e0 + chunk : E;
+    int nobad = 0;
+    const int w0 = gi_window_start(keys.key(e0, &nobad));
+    const int2 r = range[c];
+    const int n_r = r.y >= r.x ? r.y - r.x + 1 : 0;         // touched window slots
+    const int per = (n_r + kSplitTpb - 1) / kSplitTpb;      // ... per thread in the scans (1 for a collated batch)
+    for (int d = r.x + tid; d <= r.y; d += kSplitTpb) {
+        s_off[d] = tbl[(size_t)(w0 + d) * n_chunks + c];
+        s_cnt[d] = 0;
+    }
+    __syncthreads();
+    // the next tile's keys / payloads are loaded while the current tile goes through its LDS phases
+    uint32_t nk[kSplitR], np[kSplitR];
+#pragma unroll
+    for (int q = 0; q < kSplitR; ++q) {
+        const int64_t e = e0 + (int64_t)q * kSplitTpb + tid;
+        nk[q] = e < e1 ? keys.key(e, &nobad) : 0u;
+        np[q] = e < e1 ? keys.payload(e, bad) : 0u;
+    }
+    for (int64_t t0 = e0; t0 < e1; t0 += kSplitTile) {
+        uint2 rec[kSplitR];
+        uint32_t slot[kSplitR], rk[kSplitR];
+#pragma unroll
+        for (int q = 0; q < kSplitR; ++q) {
+            const int64_t e = t0 + (int64_t)q * kSplitTpb + tid;
+            slot[q] = 0xffffffffu;
+            if (e < e1) {
+                const uint32_t v = nk[q], p = np[q];
+                const uint32_t b = v >> kSH, low = v & (kBins - 1);
+                const uint32_t d = b - (uint32_t)w0;
+                rec[q] = uint2{(uint32_t)e, (low << pbits) | p};
+                if (d < (uint32_t)kWin) {
+                    slot[q] = d;
+                    rk[q] = atomicAdd(&s_cnt[d], 1u);
+                } else {   // outside the chunk's LDS window: cursor in the table itself, direct store
+                    part[atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u)] = rec[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kSplitR; ++q) {
+            const int64_t e = t0 + kSplitTile + (int64_t)q * kSplitTpb + tid;
+            nk[q] = e < e1 ? keys.key(e, &nobad) : 0u;
+            np[q] = e < e1 ? keys.payload(e, bad) : 0u;
+        }
+        __syncthreads();
+        // tile-local starts: exclusive scan of the counts over the touched range
+        const int d0 = r.x + tid * per;
+        uint32_t mine = 0;
+        for (int i = 0; i < per; ++i)
+            if (d0 + i <= r.y) mine += s_cnt[d0 + i];
+        uint32_t tile_n;
+        uint32_t run = gi_block_exscan(mine, s_wsum, &tile_n);
+        for (int i = 0; i < per; ++i)
+            if (d0 + i <= r.y) {
+                const uint32_t cn = s_cnt[d0 + i];
+                s_cnt[d0 + i] = run;
+                run += cn;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kSplitR; ++q)
+            if (slot[q] != 0xffffffffu) {
+                const uint32_t sp = s_cnt[slot[q]] + rk[q];
+                s_stage[sp] = rec[q];
+                s_slot[sp] = (uint16_t)slot[q];
+            }
+        __syncthreads();
+        for (uint32_t j = tid; j < tile_n; j += kSplitTpb) {
+            const uint32_t d = s_slot[j];
+            part[s_off[d] - s_cnt[d] + j] = s_stage[j];
+        }
+        __syncthreads();
+        // advance the run cursors by the tile's counts (count = next start - own start; the last
+        // touched entry ends at tile_n), then clear the counters for the next tile
+        for (int i = 0; i < per; ++i)
+            if (d0 + i <= r.y) {
+                const int d = d0 + i;
+                s_off[d] += (d == r.y ? tile_n : s_cnt[d + 1]) - s_cnt[d];
+            }
+        __syncthreads();
+        for (int i = 0; i < per; ++i)
+            if (d0 + i <= r.y) s_cnt[d0 + i] = 0;
+        __syncthreads();
+    }
+}
+
+// step 4 outputs
+struct OutCsr {   // first sort
+    int32_t *perm, *tgt, *src, *rowptr;
+    uint32_t pmask;
+    __device__ __forceinline__ void ranked(uint32_t k, uint32_t val, uint32_t hi) const {
+        perm[k] = (int32_t)val;
+        src[k] = (int32_t)(hi & pmask);
+    }
+    __device__ __forceinline__ void slot(uint32_t k, uint32_t node) const { tgt[k] = (int32_t)node; }
+};
+struct OutSrc {   // second sort
+    int32_t *spos, *spos_inv, *rowptr;
+    __device__ __forceinline__ void ranked(uint32_t k, uint32_t val, uint32_t) const {
+        spos[k] = (int32_t)val;
+        if (spos_inv) spos_inv[val] = (int32_t)k;
+    }
+    __device__ __forceinline__ void slot(uint32_t, uint32_t) const {}
+};
+
+template <class O>
+__global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *__restrict__ part,
+                                                                  const uint32_t *__restrict__ base_arr, int NB,
+                                                                  int64_t N, int64_t E, int pbits, O out) {
+    __shared__ uint32_t s_hist[kBins], s_start[kBins], s_wsum[kBins / 64];
+    __shared__ uint2 s_rec[kCap];
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t base = base_arr[b], M = base_arr[b + 1] - base;
+    const uint32_t node0 = (uint32_t)b << kSH;
+    const bool fits = M <= (uint32_t)kCap;
+    if (tid < kBins) s_hist[tid] = 0;
+    __syncthreads();
+    // the bucket's records: all loads of a thread in flight at once, kept in registers until placed
+    uint2 rec[kSortR];
+    uint32_t ord[kSortR];
+    if (fits) {
+#pragma unroll
+        for (int q = 0; q < kSortR; ++q) {
+            const uint32_t i = tid + q * kSortTpb;
+            rec[q] = i < M ? part[base + i] : uint2{0u, 0u};
+        }
+#pragma unroll
+        for (int q = 0; q < kSortR; ++q)
+            if (tid + q * kSortTpb < M) ord[q] = atomicAdd(&s_hist[rec[q].y >> pbits], 1u);
+    } else {
+        for (uint32_t i = tid; i < M; i += kSortTpb) atomicAdd(&s_hist[part[base + i].y >> pbits], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 256 node counts (waves 0..3: shuffle scan + wave totals)
+    uint32_t inc = 0, cnt_mine = 0;
+    if (tid < kBins) {
+        cnt_mine = s_hist[tid];
+        inc = cnt_mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl(inc, lane - d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) s_wsum[wv] = inc;
+    }
+    __syncthreads();
+    if (tid < kBins) {
+        uint32_t pre = 0;
+#pragma unroll
+        for (int w = 0; w < kBins / 64; ++w) pre += w < wv ? s_wsum[w] : 0u;
+        const uint32_t st = pre + inc - cnt_mine;
+        s_start[tid] = st;
+        if ((int64_t)node0 + tid < N) out.rowptr[node0 + tid] = (int32_t)(base + st);
+    }
+    if (b == NB - 1 && tid == 0) out.rowptr[N] = (int32_t)E;
+    __syncthreads();
+    if (fits) {
+#pragma unroll
+        for (int q = 0; q < kSortR; ++q)
+            if (tid + q * kSortTpb < M) s_rec[s_start[rec[q].y >> pbits] + ord[q]] = rec[q];
+        __syncthreads();
+        for (uint32_t j = tid; j < M; j += kSortTpb) {
+            const uint2 r = s_rec[j];
+            const uint32_t low = r.y >> pbits, st = s_start[low], n = s_hist[low];
+            uint32_t cnt = 0;
+            for (uint32_t t = 0; t < n; ++t) cnt += s_rec[st + t].x < r.x ? 1u : 0u;
+            out.ranked(base + st + cnt, r.x, r.y);
+            out.slot(base + j, node0 + low);
+        }
+    } else {
+        // a bucket beyond the LDS capacity: groups of consecutive nodes whose lists fit are taken one
+        // after the other (one pass over the bucket's records per group, served by the L2); a single
+        // node beyond the capacity (a hub) is ranked against tiles of its own list streamed through
+        // LDS - quadratic in the hub's degree, same result
+        __shared__ uint32_t s_cur[kBins];
+        int g0 = 0;
+        while (g0 < kBins) {
+            const uint32_t st0 = s_start[g0];
+            int g1 = g0;
+            while (g1 < kBins && (g1 + 1 < kBins ? s_start[g1 + 1] : M) - st0 <= (uint32_t)kCap) ++g1;
+            if (g1 == g0) {   // hub node g0
+                const uint32_t n = s_hist[g0];
+                for (uint32_t i0 = 0; i0 < M; i0 += kSortTpb) {
+                    const uint32_t i = i0 + tid;
+                    const uint2 r = i < M ? part[base + i] : uint2{0u, 0u};
+                    const bool have = i < M && (int)(r.y >> pbits) == g0;
+                    uint32_t cnt = 0;
+                    for (uint32_t t0 = 0; t0 < M; t0 += kCap) {
+                        const uint32_t tn = M - t0 < (uint32_t)kCap ? M - t0 : (uint32_t)kCap;
+                        __syncthreads();
+                        for (uint32_t t = tid; t < tn; t += kSortTpb) s_rec[t] = part[base + t0 + t];
+                        __syncthreads();
+                        if (have)
+                            for (uint32_t t = 0; t < tn; ++t) {
+                                const uint2 q = s_rec[t];
+                                cnt += ((int)(q.y >> pbits) == g0 && q.x < r.x) ? 1u : 0u;
+                            }
+                    }
+                    if (have) out.ranked(base + st0 + cnt, r.x, r.y);
+                }
+                for (uint32_t j = tid; j < n; j += kSortTpb) out.slot(base + st0 + j, node0 + (uint32_t)g0);
+                g0 += 1;
+                continue;
+            }
+            const uint32_t n_g = (g1 < kBins ? s_start[g1] : M) - st0;
+            __syncthreads();
+            if (tid < kBins) s_cur[tid] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < M; i += kSortTpb) {
+                const uint2 r = part[base + i];
+                const int low = (int)(r.y >> pbits);
+                if (low >= g0 && low < g1) s_rec[s_start[low] - st0 + atomicAdd(&s_cur[low], 1u)] = r;
+            }
+            __syncthreads();
+            for (uint32_t j = tid; j < n_g; j += kSortTpb) {
+                const uint2 r = s_rec[j];
+                const uint32_t low = r.y >> pbits, st = s_start[low] - st0, n = s_hist[low];
+                uint32_t cnt = 0;
+                for (uint32_t t = 0; t < n; ++t) cnt += s_rec[st + t].x < r.x ? 1u : 0u;
+                out.ranked(base + st0 + st + cnt, r.x, r.y);
+                out.slot(base + st0 + j, node0 + low);
+            }
+            g0 = g1;
+        }
+    }
+}
+
+struct OwnPlan {
+    bool ok;      // the own sort can run this shape
+    bool dense;   // ... but most buckets would overflow the LDS capacity: the library form is faster
+    int NB, n_chunks, chunk, bitsN;
+    int64_t T;   // table entries (+ 1 total)
+    int n_tiles;
+    size_t off_range, off_base, off_tbl, off_sums, off_part, bytes;
+};
+
+static int bits_for(int64_t n) {
+    int b = 1;
+    while (b < 32 && ((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+static OwnPlan own_plan(int64_t N, int64_t E) {
+    OwnPlan p{};
+    p.ok = false;
+    if (N < 1 || E < 1) return p;
+    p.bitsN = bits_for(N > 1 ? N : 2);
+    if (p.bitsN + kSH > 32) return p;
+    p.NB = (int)ceil_div(N, kBins);
+    int nc = (int)ceil_div(E, 16384);
+    if (nc > kMaxChunks) nc = kMaxChunks;
+    int64_t chunk = ceil_div(E, nc);
+    chunk = ceil_div(chunk, kSplitTpb) * kSplitTpb;
+    p.chunk = (int)chunk;
+    p.n_chunks = (int)ceil_div(E, chunk);
+    p.T = (int64_t)p.NB * p.n_chunks;
+    if (p.T > kMaxTable) return p;
+    p.dense = E / p.NB > kCap * 3 / 4;   // very dense (multi)graphs
+    p.n_tiles = (int)ceil_div(p.T + 1, kScanTile);
+    size_t o = 256;
+    p.off_range = o;
+    o += align_up((size_t)p.n_chunks * sizeof(int2), 256);
+    p.off_base = o;
+    o += align_up((size_t)(p.NB + 1) * 4, 256);
+    p.off_tbl = o;
+    o += align_up((size_t)(p.T + 1) * 4, 256);
+    p.off_sums = o;
+    o += align_up((size_t)p.n_tiles * 4, 256);
+    p.off_part = o;
+    o += align_up((size_t)E * 8, 256);
+    p.bytes = o;
+    p.ok = true;
+    return p;
+}
+
+template <class K, class O>
+static int own_sort(const OwnPlan &p, K keys, O out, int pbits, int64_t N, int64_t E, char *ws, int *bad,
+                    hipStream_t stream) {
+    int2 *range = reinterpret_cast<int2 *>(ws + p.off_range);
+    uint32_t *base = reinterpret_cast<uint32_t *>(ws + p.off_base);
+    uint32_t *tbl = reinterpret_cast<uint32_t *>(ws + p.off_tbl);
+    uint32_t *sums = reinterpret_cast<uint32_t *>(ws + p.off_sums);
+    uint2 *part = reinterpret_cast<uint2 *>(ws + p.off_part);
+    int rc = check_hip(hipMemsetAsync(tbl, 0, (size_t)(p.T + 1) * 4, stream), "graph_index_build(memset)");
+    if (rc) return rc;
+    hipLaunchKernelGGL((gi_count_kernel<K>), dim3(p.n_chunks), dim3(kSplitTpb), 0, stream, keys, E, p.chunk,
+                       p.n_chunks, p.NB, tbl, range, bad);
+    hipLaunchKernelGGL(gi_scan_sums_kernel, dim3(p.n_tiles), dim3(kScanTpb), 0, stream, tbl, p.T + 1, sums);
+    hipLaunchKernelGGL(gi_scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, sums, p.n_tiles);
+    hipLaunchKernelGGL(gi_scan_apply_kernel, dim3(p.n_tiles), dim3(kScanTpb), 0, stream, tbl, p.T + 1, sums);
+    hipLaunchKernelGGL(gi_bases_kernel, dim3((int)ceil_div(p.NB + 1, kTpb)), dim3(kTpb), 0, stream, tbl, p.n_chunks,
+                       p.NB, base);
+    hipLaunchKernelGGL((gi_split_kernel<K>), dim3(p.n_chunks), dim3(kSplitTpb), 0, stream, keys, E, p.chunk,
+                       p.n_chunks, pbits, tbl, range, part, bad);
+    hipLaunchKernelGGL((gi_bucket_sort_kernel<O>), dim3(p.NB), dim3(kSortTpb), 0, stream, part, base, p.NB, N, E,
+                       pbits, out);
+    return GNNTRK_OK;
+}
+
+// -------------------------------------------- library path (shapes outside the own sort)
 __global__ __launch_bounds__(kTpb) void gi_keys_kernel(const int64_t *__restrict__ ids, int64_t E,
                                                        int64_t N, uint32_t *__restrict__ keys,
                                                        uint32_t *__restrict__ vals,
@@ -64,20 +632,52 @@ static int stream_grid(int64_t n) {
     return (int)(g < 1 ? 1 : g);
 }
 
-static int bits_for(int64_t n) {
-    int b = 1;
-    while (b < 32 && ((int64_t)1 << b) < n) ++b;
-    return b;
-}
-
-size_t graph_index_ws_bytes(int64_t N, int64_t E) {
-    (void)N;
+static size_t library_ws_bytes(int64_t E) {
     const size_t arr = align_up((size_t)(E > 0 ? E : 1) * sizeof(uint32_t), 256);
     return 256 /* flags */ + 3 * arr + align_up(sort_pairs_temp_bytes(E), 256);
 }
 
+size_t graph_index_ws_bytes(int64_t N, int64_t E) {
+    const size_t lib = library_ws_bytes(E);
+    const OwnPlan p = own_plan(N, E);
+    return p.ok && p.bytes > lib ? p.bytes : lib;
+}
+
+static int library_build(const int64_t *edge_index, const gnntrk_graph_index *o, char *p, int *bad, int64_t N,
+                         int64_t E, hipStream_t stream) {
+    p += 256;
+    const size_t arr = align_up((size_t)(E > 0 ? E : 1) * sizeof(uint32_t), 256);
+    uint32_t *keys_a = reinterpret_cast<uint32_t *>(p);
+    p += arr;
+    uint32_t *vals_a = reinterpret_cast<uint32_t *>(p);
+    p += arr;
+    uint32_t *keys_b = reinterpret_cast<uint32_t *>(p);
+    p += arr;
+    void *temp = p;
+    const size_t temp_bytes = sort_pairs_temp_bytes(E);
+    const int bits = bits_for(N > 1 ? N : 2);
+    const int grid = stream_grid(E + 1);
+    const int64_t *src = edge_index, *tgt = edge_index + E;
+    hipLaunchKernelGGL(gi_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt, E, N, keys_a, vals_a, bad);
+    // the sorted keys ARE the CSR targets: sort straight into the output array
+    uint32_t *tgt_sorted = reinterpret_cast<uint32_t *>(o->tgt);
+    int rc = sort_pairs_u32(keys_a, tgt_sorted, vals_a, reinterpret_cast<uint32_t *>(o->perm), E, bits, temp,
+                            temp_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt_sorted, E, N, o->rowptr_t);
+    hipLaunchKernelGGL(gi_gather_src_kernel, dim3(grid), dim3(kTpb), 0, stream, src,
+                       reinterpret_cast<const uint32_t *>(o->perm), E, N, o->src, keys_a, vals_a, bad);
+    rc = sort_pairs_u32(keys_a, keys_b, vals_a, reinterpret_cast<uint32_t *>(o->spos), E, bits, temp, temp_bytes,
+                        stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, keys_b, E, N, o->rowptr_s);
+    if (o->spos_inv)
+        hipLaunchKernelGGL(gi_invert_kernel, dim3(grid), dim3(kTpb), 0, stream, o->spos, E, o->spos_inv);
+    return GNNTRK_OK;
+}
+
 int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, void *ws,
-                      size_t ws_bytes, hipStream_t stream) {
+                      size_t ws_bytes, int flags, hipStream_t stream) {
     if (!o) return fail(GNNTRK_EINVAL, "graph_index_build: NULL output descriptor");
     const int64_t E = o->n_edges, N = o->n_nodes;
     if (E < 0 || N < 0 || E > 0x7fffffff || N > 0x7fffffff)
@@ -90,41 +690,22 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, vo
 
     char *p = reinterpret_cast<char *>(ws);
     int *bad = reinterpret_cast<int *>(p);
-    p += 256;
-    const size_t arr = align_up((size_t)(E > 0 ? E : 1) * sizeof(uint32_t), 256);
-    uint32_t *keys_a = reinterpret_cast<uint32_t *>(p);
-    p += arr;
-    uint32_t *vals_a = reinterpret_cast<uint32_t *>(p);
-    p += arr;
-    uint32_t *keys_b = reinterpret_cast<uint32_t *>(p);
-    p += arr;
-    void *temp = p;
-    const size_t temp_bytes = sort_pairs_temp_bytes(E);
-
     int rc = check_hip(hipMemsetAsync(bad, 0, 256, stream), "graph_index_build(memset)");
     if (rc) return rc;
-    const int bits = bits_for(N > 1 ? N : 2);
-    const int grid = stream_grid(E + 1);
     if (E > 0) {
-        const int64_t *src = edge_index, *tgt = edge_index + E;
-        hipLaunchKernelGGL(gi_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt, E, N, keys_a,
-                           vals_a, bad);
-        // the sorted keys ARE the CSR targets: sort straight into the output array
-        uint32_t *tgt_sorted = reinterpret_cast<uint32_t *>(o->tgt);
-        rc = sort_pairs_u32(keys_a, tgt_sorted, vals_a, reinterpret_cast<uint32_t *>(o->perm), E, bits,
-                            temp, temp_bytes, stream);
+        const OwnPlan plan = own_plan(N, E);
+        if (plan.ok && !(flags & 1) && (!plan.dense || (flags & 2))) {
+            const KeysCoo k1{edge_index, edge_index + E, N};
+            const OutCsr o1{o->perm, o->tgt, o->src, o->rowptr_t, (uint32_t)(((uint64_t)1 << plan.bitsN) - 1)};
+            rc = own_sort(plan, k1, o1, plan.bitsN, N, E, p, bad, stream);
+            if (rc) return rc;
+            const KeysCsr k2{o->src};
+            const OutSrc o2{o->spos, o->spos_inv, o->rowptr_s};
+            rc = own_sort(plan, k2, o2, 0, N, E, p, bad, stream);
+        } else {
+            rc = library_build(edge_index, o, p, bad, N, E, stream);
+        }
         if (rc) return rc;
-        hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt_sorted, E, N,
-                           o->rowptr_t);
-        hipLaunchKernelGGL(gi_gather_src_kernel, dim3(grid), dim3(kTpb), 0, stream, src,
-                           reinterpret_cast<const uint32_t *>(o->perm), E, N, o->src, keys_a, vals_a, bad);
-        rc = sort_pairs_u32(keys_a, keys_b, vals_a, reinterpret_cast<uint32_t *>(o->spos), E, bits,
-                            temp, temp_bytes, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, keys_b, E, N,
-                           o->rowptr_s);
-        if (o->spos_inv)
-            hipLaunchKernelGGL(gi_invert_kernel, dim3(grid), dim3(kTpb), 0, stream, o->spos, E, o->spos_inv);
     } else {
         rc = check_hip(hipMemsetAsync(o->rowptr_t, 0, (size_t)(N + 1) * 4, stream), "memset");
         if (rc) return rc;

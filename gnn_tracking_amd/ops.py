@@ -178,10 +178,12 @@ def clear_graph_index_cache() -> None:
 
 
 _VALIDATE = bool(os.environ.get("GNNTRK_VALIDATE"))
+#: bit 0: library radix-sort form of the graph index (tests, measurements; identical arrays)
+_GI_FLAGS = int(os.environ.get("GNNTRK_GI_FLAGS", "0"))
 
 
 def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
-                validate: Optional[bool] = None) -> GraphIndex:
+                validate: Optional[bool] = None, flags: Optional[int] = None) -> GraphIndex:
     """Build (or fetch) the index of ``edge_index`` ([2,E] int64, unsorted COO).
 
     Cached per tensor OBJECT (weakref + version counter), so the L layers of a
@@ -213,8 +215,8 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     d = _capi.GraphIndex(n_nodes, E, _p(gi.perm), _p(gi.tgt), _p(gi.src), _p(gi.rowptr_t),
                          _p(gi.rowptr_s), _p(gi.spos), _p(gi.spos_inv))
     ws = _ws(lib.gnntrk_graph_index_workspace_bytes(n_nodes, E), ei)
-    _capi.check(lib.gnntrk_graph_index_build(_p(ei), C.byref(d), _p(ws), ws.numel(),
-                                             _stream(ei)), lib)
+    _capi.check(lib.gnntrk_graph_index_build_ex(_p(ei), C.byref(d), _p(ws), ws.numel(),
+                                                _GI_FLAGS if flags is None else int(flags), _stream(ei)), lib)
     if _VALIDATE if validate is None else validate:
         bad = int(ws[:4].view(torch.int32).item())  # first workspace word: ids out of range
         if bad:

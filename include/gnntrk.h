@@ -84,6 +84,16 @@ typedef struct gnntrk_graph_index {
 size_t gnntrk_graph_index_workspace_bytes(int64_t n_nodes, int64_t n_edges);
 int gnntrk_graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *out,
                              void *workspace, size_t workspace_bytes, void *stream);
+/* The same with `flags` (tests, measurements; both forms give identical arrays):
+ *   bit 0: the library radix-sort form (two stable rocPRIM sorts + gather / boundary passes)
+ *   bit 1: the own form also where the library form would be chosen for speed (dense graphs)
+ *   default: the library's own two-level counting sort (buckets of 256 nodes ranked in LDS; made
+ *   for collated batches - events with disjoint id ranges and contiguous edge ranges -, correct for
+ *   any edge list); shapes outside it (more than 2^24 nodes, average degree in the thousands) take
+ *   the library form by themselves.
+ * The first int32 of the workspace holds the number of node ids outside [0, N) afterwards. */
+int gnntrk_graph_index_build_ex(const int64_t *edge_index, const gnntrk_graph_index *out, void *workspace,
+                                size_t workspace_bytes, int32_t flags, void *stream);
 
 /* ------------------------------------------------------------- fused gather-MLP
  * One kernel family replaces, for every MLP site of the path

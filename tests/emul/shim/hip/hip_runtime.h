@@ -89,6 +89,12 @@ struct int2 {
 struct int4 {
     int x, y, z, w;
 };
+struct uint2 {
+    unsigned x, y;
+};
+struct uint4 {
+    unsigned x, y, z, w;
+};
 inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
 
 // ------------------------------------------------------------- execution model
@@ -353,6 +359,13 @@ inline unsigned atomicAdd(unsigned *p, unsigned v) {
 }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
     return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+inline int atomicMin(int *p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED,
+                                                   __ATOMIC_RELAXED)) {
+    }
+    return old;
 }
 inline int atomicMax(int *p, int v) {
     int old = __atomic_load_n(p, __ATOMIC_RELAXED);

@@ -63,24 +63,53 @@ def load_params(module, z, prefix):
 
 
 # --------------------------------------------------------------------- cases
-def case_graph_index(device):
+def _check_graph_index(gi, eic, N, tag):
+    order = torch.argsort(eic[1], stable=True)
+    assert torch.equal(gi.perm.cpu().long(), order), tag + ": perm is the stable target sort"
+    assert torch.equal(gi.tgt.cpu().long(), eic[1][order]), tag
+    assert torch.equal(gi.src.cpu().long(), eic[0][order]), tag
+    cnt = torch.bincount(eic[1], minlength=N)
+    rp = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)])
+    assert torch.equal(gi.rowptr_t.cpu().long(), rp), tag
+    so = torch.argsort(gi.src.cpu().long(), stable=True)
+    assert torch.equal(gi.spos.cpu().long(), so), tag + ": spos is the stable source sort"
+    inv = torch.empty_like(so)
+    inv[so] = torch.arange(so.numel())
+    assert torch.equal(gi.spos_inv.cpu().long(), inv), tag + ": spos_inv inverts spos"
+    cnt = torch.bincount(eic[0], minlength=N)
+    rp = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)])
+    assert torch.equal(gi.rowptr_s.cpu().long(), rp), tag
+
+
+def case_graph_index(device, big=False):
+    """Both forms of the build (own two-level counting sort / library radix sort) against torch's
+    stable argsort: uniform random lists, a collated batch (disjoint id ranges, shuffled inside an
+    event), hub nodes and a dense multigraph (buckets beyond the LDS capacity: the tiled ranking),
+    an unsorted list wider than a chunk's LDS window of buckets (global-atomic counters)."""
     g = np.random.default_rng(0)
-    for N, E in ((1, 0), (5, 1), (50, 300), (1000, 20000)):
-        ei = tt(g.integers(0, N, size=(2, E)), device).long()
-        gi = ops.graph_index(ei, N, cache=False)
+    cases = [("tiny", g.integers(0, 1, size=(2, 0)), 1), ("one", g.integers(0, 5, size=(2, 1)), 5),
+             ("small", g.integers(0, 50, size=(2, 300)), 50), ("uniform", g.integers(0, 1000, size=(2, 20000)), 1000)]
+    # collated events: ids of event i in [off_i, off_i + n_i), edges of an event contiguous
+    offs, parts = 0, []
+    for n, e in ((700, 5000), (300, 2500), (1, 3), (900, 9000)):
+        parts.append(g.integers(0, n, size=(2, e)) + offs)
+        offs += n
+    cases.append(("collated", np.concatenate(parts, axis=1), offs))
+    hub = g.integers(0, 600, size=(2, 30000))
+    hub[1, ::2] = 17           # half of the edges end in one node (15 000 > the LDS capacity)
+    hub[0, 1::3] = 300
+    cases.append(("hub", hub, 600))
+    cases.append(("dense", g.integers(0, 7, size=(2, 12000)), 7))
+    # more than 1024 touched buckets per chunk: several window slots per thread in the split's scans
+    cases.append(("spread", g.integers(0, 300_000, size=(2, 20000)), 300_000))
+    if big:   # more buckets than a chunk's LDS window (8192 x 256 nodes), ids unsorted
+        cases.append(("wide", g.integers(0, 3_000_000, size=(2, 400_000)), 3_000_000))
+    for tag, arr, N in cases:
+        ei = tt(arr, device).long()
         eic = ei.cpu()
-        order = torch.argsort(eic[1], stable=True)
-        assert torch.equal(gi.perm.cpu().long(), order), "perm is the stable target sort"
-        assert torch.equal(gi.tgt.cpu().long(), eic[1][order])
-        assert torch.equal(gi.src.cpu().long(), eic[0][order])
-        cnt = torch.bincount(eic[1], minlength=N)
-        rp = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)])
-        assert torch.equal(gi.rowptr_t.cpu().long(), rp)
-        so = torch.argsort(gi.src.cpu().long(), stable=True)
-        assert torch.equal(gi.spos.cpu().long(), so), "spos is the stable source sort"
-        cnt = torch.bincount(eic[0], minlength=N)
-        rp = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)])
-        assert torch.equal(gi.rowptr_s.cpu().long(), rp)
+        for flags in (0, 1, 2):   # default choice / library sort / own sort forced
+            gi = ops.graph_index(ei, N, cache=False, flags=flags)
+            _check_graph_index(gi, eic, N, f"{tag} flags={flags}")
 
 
 def case_mlp(device, shapes=((14, 40, 4, 3), (9, 40, 5, 3), (14, 14, 5, 2), (26, 40, 1, 3),

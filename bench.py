@@ -7,7 +7,7 @@ ECForGraphTCN edge classifier on synthetic TrackML-shaped hit graphs.
 
 Without torchrun's environment ``--gpus N`` (N > 1) makes this script launch its own N ranks
 (one process per GPU, RCCL); either way the line is only printed when the process group
-really has N ranks (``rccl_ranks``).
+really has N ranks (``ranks``, with the collective ``backend``; ``rccl_ranks`` only under nccl = RCCL).
 
 Workloads (BASELINE.json ``configs``):
 
@@ -737,11 +737,14 @@ def main(argv=None):
     if backend == "gloo" and not args.stub and torch.cuda.is_available():
         # (ranks may share a device under gloo: map them round-robin before the group is built)
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-    rank, local, world = gdist.init_process_group_from_env(backend=backend)
+    rank, local, world = gdist.init_process_group_from_env(
+        backend=backend, timeout_s=float(os.environ.get("GNNTRK_DIST_TIMEOUT_S", "180")))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the process group has WORLD_SIZE={world}")
     if world > 1:
         assert torch.distributed.is_initialized() and torch.distributed.get_world_size() == args.gpus
+    # the collective library really in use: "nccl" (= RCCL on ROCm) / "gloo"; "none" for one process
+    dist_backend = torch.distributed.get_backend() if world > 1 else "none"
     if args.stub:
         dev = torch.device("cpu")
         wl: Workload = StubWorkload(args, rank, world, dev)
@@ -789,7 +792,9 @@ def main(argv=None):
             "value": total / dt,
             "unit": "edges/s",
             "n_gpus": world,
-            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "ranks": world,
+            "backend": dist_backend,
+            **({"rccl_ranks": torch.distributed.get_world_size()} if dist_backend == "nccl" else {}),
             "self_launched": bool(os.environ.get("GNNTRK_BENCH_SELF_LAUNCHED")),
             "steps": args.steps,
             "warmup": args.warmup,
@@ -803,7 +808,9 @@ def main(argv=None):
                 "workload": describe,
                 "graph_index": args.index,
                 "global_edges_per_step": edges_per_step,
-                "parallelism": f"dp{world} (events sharded, flat-gradient RCCL all-reduce)",
+                "parallelism": (f"dp{world} (events sharded, flat-gradient all-reduce over "
+                                + {"nccl": "RCCL", "gloo": "gloo (host; test configuration)"}.get(dist_backend, dist_backend)
+                                + ")" if world > 1 else "dp1 (single process, no collective)"),
                 **info,
             },
             "edge_layers_per_sec": total * EC_MODEL["L_ec"] / dt,

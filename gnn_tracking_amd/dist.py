@@ -17,9 +17,13 @@ import torch.distributed as dist
 from torch import nn
 
 
-def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, int]:
+def init_process_group_from_env(backend: str | None = None, timeout_s: float = 180.0) -> tuple[int, int, int]:
     """(rank, local_rank, world_size) from torchrun's env; initialises the group when
-    world_size > 1 (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests)."""
+    world_size > 1 (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests).
+
+    The rendezvous and the first collective are bounded by ``timeout_s``: a rank that cannot join
+    (RCCL initialisation failure, a peer that died, an unreachable master) raises with the
+    library's message instead of waiting in a barrier for ever."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -33,7 +37,20 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
         if backend == "nccl":
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        import datetime
+
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=timeout_s), **kw)
+            # one tiny all-reduce NOW: communicator set-up errors (RCCL: IPC handles, xGMI topology)
+            # surface here, with the backend's own message, not in the middle of the first step
+            probe = torch.ones(1, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all-reduce over {world} ranks returned {probe.item()}")
+        except Exception as e:
+            raise RuntimeError(f"rank {rank}/{world}: process group ({backend}) could not be set up within "
+                               f"{timeout_s:.0f} s: {type(e).__name__}: {e}") from e
     return rank, local, world
 
 

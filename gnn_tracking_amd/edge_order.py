@@ -24,10 +24,12 @@ from torch import Tensor
 from torch.utils._pytree import tree_map
 
 # attribute / method names that only look at metadata
-_META = frozenset({"shape", "dtype", "device", "ndim", "is_cuda", "layout", "requires_grad", "is_leaf",
+_META = frozenset({"shape", "dtype", "device", "ndim", "is_cuda", "layout", "requires_grad",
                    "size", "dim", "numel", "nelement", "__len__", "element_size", "is_floating_point",
                    "is_complex", "is_sparse", "is_quantized", "is_meta", "names", "itemsize", "nbytes",
-                   "is_contiguous", "stride", "storage_offset", "grad", "_version", "is_cpu", "is_nested"})
+                   "is_contiguous", "stride", "storage_offset", "is_cpu", "is_nested"})
+# (``is_leaf``, ``grad``, ``grad_fn``, ``retain_grad``, ``_version`` are NOT metadata of the wrapper: they
+#  are answered by the materialised tensor, which is the one autograd knows)
 
 
 def _fname(func) -> str:

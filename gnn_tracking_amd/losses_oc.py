@@ -74,7 +74,10 @@ class _CondensationPotentials(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, beta, x, particle_id, mask, q_min: float, radius: float, eps_sqrt: float,
-                mode: int, keep: float = 1.0, seed: int = 0, cap_nbr=None):
+                mode: int, keep: float = 1.0, seed: int = 0, cap_nbr=None, stash=None):
+        """``stash`` (a dict): the condensation-point selection of a call is left in it / taken from
+        it, so that a second pass over the same hits (``max_n_rep`` sub-sampling) does not select -
+        sort and scan - again."""
         _capi.require_device(beta, x, particle_id, mask)
         lib = _capi.load()
         dev = x.device
@@ -84,13 +87,18 @@ class _CondensationPotentials(torch.autograd.Function):
         mask8 = mask.to(torch.uint8).contiguous()
         n, dim = int(x_c.shape[0]), int(x_c.shape[1])
         st = ops._stream(x_c)
-        alphas = torch.empty(n, dtype=torch.int32, device=dev)
-        gid = torch.empty(n, dtype=torch.int32, device=dev)
-        n_cp = torch.zeros(1, dtype=torch.int32, device=dev)
-        ws = ops._ws(lib.gnntrk_oc_select_workspace_bytes(n), x_c)
-        _capi.check(lib.gnntrk_oc_select_cps(ops._p(beta_c), ops._p(pid), ops._p(mask8), n, mode,
-                                             ops._p(alphas), ops._p(gid), ops._p(n_cp), ops._p(ws),
-                                             ws.numel(), st), lib)
+        if stash is not None and "sel" in stash:
+            alphas, gid, n_cp = stash["sel"]
+        else:
+            alphas = torch.empty(n, dtype=torch.int32, device=dev)
+            gid = torch.empty(n, dtype=torch.int32, device=dev)
+            n_cp = torch.zeros(1, dtype=torch.int32, device=dev)
+            ws = ops._ws(lib.gnntrk_oc_select_workspace_bytes(n), x_c)
+            _capi.check(lib.gnntrk_oc_select_cps(ops._p(beta_c), ops._p(pid), ops._p(mask8), n, mode,
+                                                 ops._p(alphas), ops._p(gid), ops._p(n_cp), ops._p(ws),
+                                                 ws.numel(), st), lib)
+            if stash is not None:
+                stash["sel"] = (alphas, gid, n_cp)
         a = _capi.OcArgs(ops._p(x_c), ops._p(beta_c), ops._p(pid), ops._p(mask8), ops._p(gid),
                          ops._p(alphas), ops._p(n_cp), n, dim, dim, q_min, radius, eps_sqrt, mode,
                          float(keep), 0, int(seed), ops._p(cap_nbr))
@@ -109,7 +117,9 @@ class _CondensationPotentials(torch.autograd.Function):
         ctx.save_for_backward(beta_c, x_c, pid, mask8, gid, alphas, n_cp, out)
         ctx.cfg = (q_min, radius, eps_sqrt, mode, beta.dtype, x.dtype, float(keep), int(seed))
         ctx.cap_nbr = cap_nbr
-        return out[0], out[1], out[2], out[3], out[7].detach()
+        n_rep = out[7].clone()   # a plain count: no gradient, no hold on this node's saved tensors
+        ctx.mark_non_differentiable(n_rep)
+        return out[0], out[1], out[2], out[3], n_rep
 
     @staticmethod
     def backward(ctx, g_att, g_rep, g_cow, g_noise, _g_nrep):
@@ -133,7 +143,7 @@ class _CondensationPotentials(torch.autograd.Function):
             ws = ops._ws(lib.gnntrk_oc_backward_workspace_bytes(n, dim), x_c)
             _capi.check(lib.gnntrk_oc_backward(C.byref(a), ops._p(g), ops._p(out), ops._p(gx),
                                                ops._p(gbeta), n, ops._p(ws), ws.numel(), ops._stream(x_c)), lib)
-        return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None, None, None, None
+        return gbeta.to(bdt), gx.to(xdt), None, None, None, None, None, None, None, None, None, None
 
 
 class _CondensationLoss(MultiLossFct, HyperparametersMixin):
@@ -164,11 +174,9 @@ class _CondensationLoss(MultiLossFct, HyperparametersMixin):
         assert bool(mask.any()), "No hits left after masking"
         args = (beta, x, particle_id, mask, float(self.hparams.q_min), 1.0, self._eps_sqrt, self._mode)
         cap = self._neighbor_cap(x)
-        if cap is not None:
-            att, rep, cow, noise, n_rep = _CondensationPotentials.apply(*args, 1.0, 0, cap)
-        else:
-            att, rep, cow, noise, n_rep = _CondensationPotentials.apply(*args)
         max_n_rep = int(getattr(self.hparams, "max_n_rep", 0) or 0)
+        stash = {} if max_n_rep > 0 else None
+        att, rep, cow, noise, n_rep = _CondensationPotentials.apply(*args, 1.0, 0, cap, stash)
         if max_n_rep > 0 and int(n_rep) > max_n_rep:
             # oc.py:322-328: keep repulsive pairs with probability max_n_rep / n_rep and scale the
             # normalisation accordingly.  The pairs are chosen by a hash of (seed, hit, condensation
@@ -176,7 +184,7 @@ class _CondensationLoss(MultiLossFct, HyperparametersMixin):
             # generator, so runs are reproducible under torch.manual_seed.  n_rep is reported
             # before the sub-sampling, as the reference does.
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            att, rep, cow, noise, _ = _CondensationPotentials.apply(*args, max_n_rep / float(n_rep), seed)
+            att, rep, cow, noise, _ = _CondensationPotentials.apply(*args, max_n_rep / float(n_rep), seed, cap, stash)
         losses = {"attractive": att, "repulsive": rep, "coward": cow, "noise": noise}
         weights = {"attractive": 1.0, "repulsive": self.hparams.lw_repulsive,
                    "noise": self.hparams.lw_noise, "coward": self.hparams.lw_coward}

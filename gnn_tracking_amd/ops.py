@@ -221,6 +221,7 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
         bad = int(ws[:4].view(torch.int32).item())  # first workspace word: ids out of range
         if bad:
             raise IndexError(f"edge_index: {bad} node ids out of range [0, {n_nodes})")
+    gi._built_from = (weakref.ref(edge_index), edge_index._version)
     if cache:
         _cache_put(edge_index, n_nodes, gi)
     return gi
@@ -924,14 +925,22 @@ def edge_targets_csr(y: Tensor, gi: GraphIndex, pt: Optional[Tensor] = None, pt_
 
 def _csr_fast_path(w, edge_index):
     """(values in CSR order, graph index) when ``w`` is a model output still held in CSR
-    order (edge_order.EdgeOrdered) for the graph of ``edge_index``; else None."""
+    order (edge_order.EdgeOrdered) for the graph of ``edge_index``; else None.
+
+    ``edge_index`` has to be the very tensor the graph index was built from (same object, same
+    version): a caller who permutes ``edge_index`` and the labels together gets the ordinary
+    path - the labels are gathered through W's own permutation here."""
     from .edge_order import EdgeOrdered
 
     if not isinstance(w, EdgeOrdered):
         return None
     gi = w.graph_index
-    if edge_index is not None and int(edge_index.shape[1]) != gi.n_edges:
-        return None
+    if edge_index is not None:
+        if int(edge_index.shape[1]) != gi.n_edges:
+            return None
+        src = getattr(gi, "_built_from", None)
+        if src is not None and not (src[0]() is edge_index and src[1] == edge_index._version):
+            return None
     return w.csr.reshape(-1), gi
 
 

@@ -97,7 +97,8 @@ def make_pileup_cloud(seed: int, n_hits: int, dim: int = 8, *, n_clusters: int =
     return torch.from_numpy(x[g.permutation(n_hits)])
 
 
-def make_pileup_event(seed: int, n_hits: int, dim: int = 8, *, n_particles: int = 14000) -> dict:
+def make_pileup_event(seed: int, n_hits: int, dim: int = 8, *, n_particles: int = 14000,
+                      n_clusters: int = 6000) -> dict:
     """Config-5 inputs of the condensation losses on the cloud above: int64 particle ids
     (10 % noise hits with id 0), per-particle pt (log-normal: roughly a seventh of the
     particles pass the 0.9 GeV cut, K of a few thousand at 200 k hits), eta, beta ~ U(0.01, 0.99).
@@ -105,7 +106,7 @@ def make_pileup_event(seed: int, n_hits: int, dim: int = 8, *, n_particles: int 
     import numpy as np
 
     g = np.random.default_rng(seed)
-    x = make_pileup_cloud(seed, n_hits, dim)
+    x = make_pileup_cloud(seed, n_hits, dim, n_clusters=n_clusters)
     pid = torch.from_numpy(g.integers(1, n_particles + 1, size=n_hits)).long() * (2 ** 40)
     pid[torch.from_numpy(g.random(n_hits) < 0.1)] = 0
     pt_of = torch.from_numpy(np.exp(g.normal(-0.5, 0.9, size=n_particles + 1))).float()

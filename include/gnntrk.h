@@ -434,10 +434,12 @@ int gnntrk_radius_count(const float *x, int64_t n, int32_t dim, int32_t x_stride
 int gnntrk_radius_fill(const float *x, int64_t n, int32_t dim, int32_t x_stride, double radius,
                        const int64_t *offsets, int32_t *nbr, double *dist, void *stream);
 /* The same graph with caller-owned workspaces (dim <= 16, from 4096 points on; otherwise these fall
- * back to the two entries above): points sorted into chunks of 64 with bounding boxes, a chunk of
- * queries only walks the candidate chunks whose box is within the radius of its own (box-to-box
- * bound in the graph's own fp64 arithmetic: no neighbour can be lost), the lists are then put into
- * ascending neighbour order.  cnt / offsets / nbr / dist are identical to radius_count / radius_fill.
+ * back to the two entries above): points sorted into chunks of 64 with bounding boxes; every query
+ * walks only the candidate chunks whose box its own point can reach - per-query point-to-box bound
+ * `sum_d max(lo_d - q_d, q_d - hi_d, 0)^2 <= r^2 (1 + 1e-5)` evaluated in fp32: the relative margin
+ * of 1e-5 covers the fp32 rounding of the bound ((D + 2) ulp) against the graph's fp64 distances,
+ * so no neighbour can be lost; the survivors are decided by the graph's own fp64 arithmetic -; the
+ * lists are then put into ascending neighbour order.  cnt / offsets / nbr / dist are identical to radius_count / radius_fill.
  * ws_points (gnntrk_radius_points_workspace_bytes; 0 = not covered, pass NULL) is filled by the
  * count pass and read by the fill pass of the same points; ws_edges
  * (gnntrk_radius_edges_workspace_bytes(M)) stages the unordered lists.  flags: bit 0 = pruned form

@@ -911,6 +911,115 @@ def g14_tc_step():
     npz("g14_tc_step.npz", **arrs)
 
 
+# G14b: the same step at built-graph scale (a scaled-down cfg5 event), incl. the cfg5 model itself
+TC_STEP_B_CASES = {
+    # bench.py --workload cfg5: model, kNN and loss weights exactly as TCWorkload builds them
+    "cfg5_rg": dict(loss="rg", gtcn=dict(h_outdim=8, hidden_dim=40, L_ec=3, L_hc=3, alpha_latent=0.9,
+                                         n_embedding_coords=8), loss_w=(1.0, 0.1, 0.1)),
+    "tiger_orphans_h24": dict(loss="tiger", gtcn=dict(h_outdim=4, hidden_dim=24, L_ec=2, L_hc=2,
+                                                      mask_orphan_nodes=True, feed_edge_weights=True),
+                              loss_w=(2.0, 0.25, 0.5)),
+}
+TC_B_MLGC = dict(embedding_slice=(0, 8), max_radius=1.0, max_num_neighbors=16)
+TC_B_HITS = 1500
+
+
+def tc_b_event():
+    """1500 hits of the cfg5 generator (gnn_tracking_amd/synthetic.py: Gaussian clusters in a
+    radius-3 ball of the 8-d latent slice + 10 % noise; 45 clusters keep the occupancy of the
+    200 000-hit event), 14 node features as bench.py's TCWorkload builds them."""
+    sys.path.insert(0, str(REPO))
+    from gnn_tracking_amd import synthetic
+
+    ev = synthetic.make_pileup_event(514, TC_B_HITS, 8, n_particles=105, n_clusters=45)
+    g = np.random.default_rng(514)
+    extra = torch.from_numpy(g.uniform(0, 1.5, size=(TC_B_HITS, 6)).astype(np.float32))
+    return dict(x=torch.cat([ev["x"], extra], dim=1), particle_id=ev["particle_id"], pt=ev["pt"], eta=ev["eta"],
+                reconstructable=ev["reconstructable"], layer=torch.from_numpy(g.integers(0, 10, size=TC_B_HITS)),
+                sector=torch.zeros(TC_B_HITS, dtype=torch.long))
+
+
+def gap_threshold(w: torch.Tensor, min_gap: float = 2e-6) -> tuple[float, float]:
+    """A threshold inside a gap of the sorted weights that is at least ``min_gap`` wide, as close
+    to the median as such a gap lies (the cut should keep a sizeable share of the edges and no
+    weight may sit within rounding of the threshold); returns (threshold, half the gap)."""
+    wq = w.detach().sort().values.double()
+    gaps = wq[1:] - wq[:-1]
+    ok = torch.nonzero(gaps >= min_gap).flatten()
+    assert ok.numel() > 0, f"no gap of {min_gap:.0e} between the edge weights"
+    j = int(ok[(ok - len(wq) // 2).abs().argmin()])
+    return float((wq[j] + wq[j + 1]) / 2), float(gaps[j] / 2)
+
+
+def g14b_tc_step_event():
+    """G14 at built-graph scale: the reference's own ``TCModule`` step on a
+    1500-hit event (about 16 000 kNN edges, thousands kept by the cut), with the cfg5 model of
+    bench.py (``GraphTCN(14, 28, h_outdim=8, hidden 40, L_ec=3, L_hc=3, alpha_latent=0.9)`` +
+    ``CondensationLossRG``) and a Tiger / orphan-masking variant.  The 28 edge features of the
+    built graph are not stored (1.8 MB): their float64 column sums are."""
+    from gnn_tracking.training.tc import TCModule
+
+    print("G14b TC training step at built-graph scale")
+    raw = tc_b_event()
+    arrs = dict(raw)
+    for name, cfg in TC_STEP_B_CASES.items():
+        def fresh():
+            return Data(edge_index=torch.zeros(2, 0, dtype=torch.long), true_edge_index=torch.zeros(2, 0, dtype=torch.long),
+                        **raw)
+        torch.manual_seed(33)
+        probe = GraphTCN(14, 28, **cfg["gtcn"])
+        pre = MLGraphConstruction(ml=None, **TC_B_MLGC)
+        thr, half = gap_threshold(probe._gtcn.ec(pre(fresh()))["W"])
+        torch.manual_seed(33)
+        model = GraphTCN(14, 28, ec_threshold=thr, **cfg["gtcn"])
+        lw_rep, lw_cow, lw_noise = cfg["loss_w"]
+        loss_cls = CondensationLossTiger if cfg["loss"] == "tiger" else CondensationLossRG
+        mod = TCModule(model=model, loss_fct=loss_cls(lw_repulsive=lw_rep, lw_coward=lw_cow, lw_noise=lw_noise),
+                       preproc=MLGraphConstruction(ml=None, **TC_B_MLGC))
+        p0 = sd(model)
+        data = mod.data_preproc(fresh())
+        out = mod(data, _preprocessed=True)
+        loss, metrics = mod.get_losses(out, data)
+        loss.backward()
+        grads = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v))
+                 for k, v in model.named_parameters()}
+        conf = mod.configure_optimizers()   # (keep the dict: the scheduler holds the optimizer weakly)
+        conf["optimizer"].step()
+        p1 = sd(model)
+        gk = dict(cfg["gtcn"])
+        okw = dict(L_ec=gk.pop("L_ec"), L_hc=gk.pop("L_hc"), ec_threshold=thr)
+        for k in ("mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc", "alpha_latent",
+                  "n_embedding_coords"):
+            if k in gk:
+                okw[k] = gk[k]
+        graph, oo, terms, total, og, op = O.tc_training_step(raw, p0, mlgc=TC_B_MLGC, gtcn=okw, loss_kind=cfg["loss"],
+                                                            loss_weights=cfg["loss_w"])
+        assert torch.equal(graph["edge_index"], data.edge_index) and torch.equal(graph["y"], data.y)
+        worst = max(close(graph["edge_attr"], data.edge_attr, 0.0, "edge_attr"),
+                    close(oo["W"], out["W"], 1e-6, "W"), close(oo["H"], out["H"], 1e-5, "H"),
+                    close(oo["B"], out["B"], 1e-6, "B"), close(total, loss, 1e-6, "loss"))
+        assert torch.equal(oo["ec_hit_mask"], out["ec_hit_mask"]) and torch.equal(oo["ec_edge_mask"], out["ec_edge_mask"])
+        for k in ("attractive", "repulsive", "coward", "noise"):
+            worst = max(worst, close(terms[k], metrics[k], 1e-6, name + " " + k))
+            arrs[f"{name}/{k}"] = metrics[k]
+        for k in grads:
+            worst = max(worst, close(og[k], grads[k], 1e-5, f"{name} grad {k}"),
+                        close(op[k], p1[k], 1e-6, f"{name} adam {k}"))
+            arrs[f"{name}/p0/{k}"], arrs[f"{name}/p1/{k}"], arrs[f"{name}/grad/{k}"] = p0[k], p1[k], grads[k]
+        arrs[f"{name}/ec_threshold"] = np.float64(thr)
+        arrs[f"{name}/threshold_margin"] = np.float64(half)
+        arrs[f"{name}/edge_index"], arrs[f"{name}/y"] = data.edge_index, data.y
+        arrs[f"{name}/edge_attr_colsum"] = data.edge_attr.double().sum(0)
+        arrs[f"{name}/edge_attr_head"] = data.edge_attr[:64]
+        for k in ("W", "H", "B", "ec_hit_mask", "ec_edge_mask"):
+            arrs[f"{name}/{k}"] = out[k]
+        arrs[f"{name}/loss"] = loss
+        print(f"   {name}: {int(out['ec_edge_mask'].sum())} of {data.edge_index.shape[1]} edges kept "
+              f"(threshold margin {half:.1e}), {int(out['ec_hit_mask'].sum())} of {TC_B_HITS} hits, "
+              f"loss {loss.item():.6f}, oracle == reference (max diff {worst:.2e})")
+    npz("g14b_tc_step_event.npz", **arrs)
+
+
 if __name__ == "__main__":
     assert REF.is_dir(), "needs /root/reference (build container only)"
     only = set(sys.argv[1:])  # e.g. "g7 g10": regenerate just these files
@@ -922,7 +1031,7 @@ if __name__ == "__main__":
     for tag, fn in (("g2", g2_ec_variants), ("g2b", g2b_ec_autocast), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
                     ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g8", g8_hinge),
                     ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan), ("g12", g12_gc_resin), ("g13", g13_focal),
-                    ("g14", g14_tc_step)):
+                    ("g14", g14_tc_step), ("g14b", g14b_tc_step_event)):
         if want(tag):
             fn()
     print("goldens written; oracle pinned against the reference.")

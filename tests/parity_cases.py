@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import pathlib
 
+import math
+
 import numpy as np
 import torch
 
@@ -277,14 +279,24 @@ def case_edge_cases(device, modes=("f32",)):
             assert_close(out["edge_embedding"].float(), ref["edge_embedding"], tol_o, tag + " edge")
             loss = (out["node_embedding"].float() * rn.to(device)).sum() + (out["W"].reshape(-1) * rw.to(device)).sum()
             loss.backward()
+            want_all = math.sqrt(sum(float(gk.double().pow(2).sum()) for gk in rg if gk is not None))
+            err_all = 0.0
             for (k, v), gk in zip(model.named_parameters(), rg):
                 got = v.grad if v.grad is not None else torch.zeros_like(v)
                 want = gk if gk is not None else torch.zeros_like(v)
                 assert torch.isfinite(got).all(), f"{tag} grad {k} not finite"
-                if mode == "f32":
+                if mode == "f32" or E == 0:
                     assert_close(got, want, tol_g, f"{tag} grad {k}")
-                elif E == 0:
-                    assert_close(got, want, tol_g, f"{tag} grad {k}")
+                else:
+                    # bf16 storage against the fp32 oracle.  On a handful of rows a single ReLU gate that
+                    # rounds to the other side moves a small parameter gradient by tens of per cent, so
+                    # the bound per parameter is relative to its own norm PLUS half a per cent of the
+                    # whole gradient's; the whole gradient must agree to 5 % (measured: about 1 %).
+                    wn = want.double().norm().item()
+                    err = (got.detach().cpu().double() - want.double()).norm().item()
+                    err_all += err * err
+                    assert err <= 0.1 * wn + 0.005 * want_all + 1e-4, f"{tag} grad {k}: L2 error {err:.3e} of {wn:.3e}"
+            assert math.sqrt(err_all) <= 0.05 * want_all + 1e-4, f"{tag}: gradient L2 error {math.sqrt(err_all):.3e} of {want_all:.3e}"
 
 
 # ----------------------------------------------------------------- kNN / graphs
@@ -1422,7 +1434,9 @@ def case_edge_ordered(device, name="skip1_L3_h40"):
     assert_close(w, z[f"{name}/W"], TOL_OUT, "W")
     assert_close(w.detach().cpu(), z[f"{name}/W"], TOL_OUT, "W.cpu()")
     assert_close(e, z[f"{name}/edge_embedding"], TOL_OUT, "edge_embedding")
-    assert torch.equal((w > 0.5).cpu(), tt(z[f"{name}/W"]) > 0.5) or True  # (weights next to 0.5 may flip)
+    w_ref = tt(z[f"{name}/W"])
+    clear = (w_ref - 0.5).abs() > 1e-4   # (weights within the output tolerance of 0.5 may flip)
+    assert int(clear.sum()) > 0.9 * E and torch.equal((w > 0.5).cpu()[clear], (w_ref > 0.5)[clear]), "comparison"
     assert_close(w[5:9], z[f"{name}/W"][5:9], TOL_OUT, "slice")
     assert_close(torch.cat([w, w])[E:], z[f"{name}/W"], TOL_OUT, "torch.cat")
     assert_close(w * 2 + 1, 2 * z[f"{name}/W"] + 1, TOL_OUT, "arithmetic")
@@ -1430,6 +1444,27 @@ def case_edge_ordered(device, name="skip1_L3_h40"):
     import copy
     import pickle
     assert_close(pickle.loads(pickle.dumps(w.detach().cpu())), z[f"{name}/W"], TOL_OUT, "pickle")
+    # a caller that hands the loss ANOTHER edge_index tensor (here: edges and labels permuted together)
+    # gets the reference's elementwise semantics - falsification through the edge_index it passed
+    pi = torch.randperm(E, generator=torch.Generator().manual_seed(5)).to(ei.device)
+    ei2, y2 = ei[:, pi].contiguous(), y[pi].contiguous()
+    w2 = model(G.Data(x=x, edge_index=ei, edge_attr=ea))["W"]
+    got = G.EdgeWeightBCELoss(pt_thld=0.9)(w=w2, y=y2, pt=pt, edge_index=ei2)
+    want = torch.nn.functional.binary_cross_entropy(w2.in_edge_index_order(), (y2.bool() & (pt[ei2[0]] > 0.9)).float())
+    assert_close(got, want, 1e-6, "loss with a foreign edge_index")
+    # autograd attributes are those of the materialised tensor
+    w3 = model(G.Data(x=x, edge_index=ei, edge_attr=ea))["W"]
+    assert w3.grad_fn is not None and not w3.is_leaf
+    w3.retain_grad()
+    (w3 * 2).sum().backward()
+    assert w3.grad is not None and bool((w3.grad == 2).all())
+    # what a training loop does to an output dict: torch.save / load round trip
+    import io
+    buf = io.BytesIO()
+    torch.save({"W": out["W"].detach(), "edge_embedding": out["edge_embedding"].detach()}, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert_close(back["W"], z[f"{name}/W"], TOL_OUT, "torch.save round trip")
     # haughty focal loss needs raw and falsified labels: it materialises and still agrees
     hl = G.HaughtyFocalLoss(pt_thld=0.9)(w=model(G.Data(x=x, edge_index=ei, edge_attr=ea))["W"], y=y, pt=pt,
                                           edge_index=ei)
@@ -1507,6 +1542,147 @@ def case_tc_step(device, names=None):
             x=tt(z["x"], device), edge_index=tt(z["edge_index_in"], device), particle_id=tt(z["particle_id"], device),
             pt=tt(z["pt"], device), eta=tt(z["eta"], device), reconstructable=tt(z["reconstructable"], device),
             layer=tt(z["layer"], device), sector=tt(z["sector"], device))))
+
+
+# ---- the same step at built-graph scale (golden G14b, generated by the reference's own TCModule)
+TC_STEP_B_CASES = {
+    "cfg5_rg": dict(loss="rg", gtcn=dict(h_outdim=8, hidden_dim=40, L_ec=3, L_hc=3, alpha_latent=0.9,
+                                         n_embedding_coords=8), loss_w=(1.0, 0.1, 0.1)),
+    "tiger_orphans_h24": dict(loss="tiger", gtcn=dict(h_outdim=4, hidden_dim=24, L_ec=2, L_hc=2,
+                                                      mask_orphan_nodes=True, feed_edge_weights=True),
+                              loss_w=(2.0, 0.25, 0.5)),
+}
+TC_B_MLGC = dict(embedding_slice=(0, 8), max_radius=1.0, max_num_neighbors=16)
+
+
+def _check_after_adam(model, grads_ref: dict, p1_ref: dict, tag: str, lr_step: float = 3.4e-4):
+    """Parameters after the step within 1e-6; where a gradient ELEMENT vanishes analytically (dead
+    ReLU units, the translation-invariant last cluster bias) Adam turns rounding noise into a step
+    of a tenth of lr: those elements only have to stay within one step."""
+    for k, v in model.state_dict().items():
+        ref1 = tt(p1_ref[k]).double()
+        got = v.detach().cpu().double()
+        tol = torch.full_like(ref1, 1e-6)
+        if k in grads_ref:
+            tol[tt(grads_ref[k]).abs() < 1e-6] = lr_step
+        bad = (got - ref1).abs() > tol * torch.clamp_min(ref1.abs(), 1.0)
+        assert not bool(bad.any()), f"{tag} after Adam {k}: max|diff| {(got - ref1).abs().max().item():.3e}"
+
+
+def case_tc_step_event(device, names=None):
+    """Row H at built-graph scale (golden G14b: the reference's own ``TCModule`` on a 1500-hit event
+    of the cfg5 generator - 21 617 kNN edges, about 1 600 kept by the cut - with the cfg5 model of
+    bench.py and a Tiger / orphan-masking variant): built graph and both masks bit-exact (the
+    golden's threshold sits in a gap of the weights of 2e-6), W / H / B and the loss terms 1e-5,
+    all gradients 1e-4, parameters after the module's own Adam step 1e-6."""
+    from gnn_tracking_amd import training
+    from gnn_tracking_amd.losses_oc import CondensationLossRG, CondensationLossTiger
+
+    z = load("g14b_tc_step_event.npz")
+    raw = {k: tt(z[k], device) for k in ("x", "particle_id", "pt", "eta", "reconstructable", "layer", "sector")}
+    for name, cfg in TC_STEP_B_CASES.items():
+        if names is not None and name not in names:
+            continue
+        model = G.GraphTCN(14, 28, ec_threshold=float(z[f"{name}/ec_threshold"]), **cfg["gtcn"])
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        lw_rep, lw_cow, lw_noise = cfg["loss_w"]
+        loss_cls = CondensationLossTiger if cfg["loss"] == "tiger" else CondensationLossRG
+        mod = training.TCModule(model, loss_fct=loss_cls(lw_repulsive=lw_rep, lw_coward=lw_cow, lw_noise=lw_noise),
+                                preproc=G.MLGraphConstruction(ml=None, **TC_B_MLGC))
+        data = mod.data_preproc(G.Data(edge_index=torch.zeros(2, 0, dtype=torch.long, device=raw["x"].device), **raw))
+        assert torch.equal(data.edge_index.cpu(), tt(z[f"{name}/edge_index"])), name + " built edge_index"
+        assert torch.equal(data.y.cpu(), tt(z[f"{name}/y"])), name + " edge labels"
+        assert torch.equal(data.edge_attr[:64].cpu(), tt(z[f"{name}/edge_attr_head"])), name + " edge features"
+        assert_close(data.edge_attr.double().sum(0), z[f"{name}/edge_attr_colsum"], 1e-9, name + " edge feature sums")
+        out = mod(data, _preprocessed=True)
+        margin = float(z[f"{name}/threshold_margin"])
+        w_err = (out["W"].detach().cpu() - tt(z[f"{name}/W"])).abs().max().item()
+        assert w_err < 0.25 * margin, f"{name}: |W - W_ref| {w_err:.1e} against a threshold margin of {margin:.1e}"
+        assert torch.equal(out["ec_edge_mask"].cpu(), tt(z[f"{name}/ec_edge_mask"])), name + " edge mask"
+        assert torch.equal(out["ec_hit_mask"].cpu(), tt(z[f"{name}/ec_hit_mask"])), name + " hit mask"
+        assert int(out["ec_edge_mask"].sum()) > 1000
+        for k in ("W", "H", "B"):
+            assert_close(out[k], z[f"{name}/{k}"], TOL_OUT, f"{name} {k}")
+        loss, metrics = mod.get_losses(out, data)
+        for k in ("attractive", "repulsive", "coward", "noise"):
+            assert_close(metrics[k], z[f"{name}/{k}"], 2e-5, f"{name} {k}")
+        assert_close(loss, z[f"{name}/loss"], 2e-5, name + " loss")
+        mod.zero_grad()
+        loss.backward()
+        grads_ref = {}
+        for k, v in model.named_parameters():
+            gk = v.grad if v.grad is not None else torch.zeros_like(v)
+            grads_ref[k] = z[f"{name}/grad/{k}"]
+            assert_close(gk, grads_ref[k], TOL_GRAD, f"{name} grad {k}")
+        mod.configure_optimizers().step()
+        _check_after_adam(model, grads_ref, {k: z[f"{name}/p1/{k}"] for k in model.state_dict()}, name)
+
+
+def case_tc_step_oracle(device, n_hits=6000, loss="rg"):
+    """The HIP ``TCModule`` step on the first ``n_hits`` hits of the cfg5 event (bench.py's own
+    generator, model, kNN and loss settings; above the row thresholds of the pruned kNN search?
+    no - 6 000 hits run the brute-force search; the spatial loss passes start at 16 384) against
+    ``oracle.tc_training_step``: built graph bit-exact, EC cut identical (threshold placed in a gap
+    of the ORACLE's weights, stated below), loss terms 1e-5, all gradients 1e-4, parameters after
+    Adam 1e-6."""
+    from gnn_tracking_amd import synthetic, training
+    from gnn_tracking_amd.losses_oc import CondensationLossRG, CondensationLossTiger
+
+    ev = synthetic.make_pileup_event(500, 200_000, 8)
+    g = np.random.default_rng(500)
+    extra = torch.from_numpy(g.uniform(0, 1.5, size=(200_000, 6)).astype(np.float32))
+    raw = {"x": torch.cat([ev["x"], extra], dim=1)[:n_hits].contiguous()}
+    raw.update({k: ev[k][:n_hits].contiguous() for k in ("particle_id", "pt", "eta", "reconstructable")})
+    gt = dict(h_outdim=8, hidden_dim=40, L_ec=3, L_hc=3, alpha_latent=0.9, n_embedding_coords=8)
+    mlgc = dict(embedding_slice=(0, 8), max_radius=1.0, max_num_neighbors=16)
+    lw = (1.0, 0.1, 0.1)   # lw_repulsive, lw_coward, lw_noise
+    torch.manual_seed(0)
+    model = G.GraphTCN(14, 28, **gt)
+    p0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    okw = dict(L_ec=3, L_hc=3, alpha_latent=0.9, n_embedding_coords=8)
+    # threshold: in a gap (>= 2e-6) of the oracle's own edge weights nearest to the median
+    ei = O.knn_with_max_radius(raw["x"][:, :8], 16, 1.0)
+    _, ea = O.ml_graph_construction_edges(raw["x"], raw["particle_id"], ei)
+    pe = {k[len("_gtcn.ec."):]: v for k, v in p0.items() if k.startswith("_gtcn.ec.")}
+    w0 = O.ec_for_graph_tcn(raw["x"], ei, ea, pe, L_ec=3)["W"].double().sort().values
+    gaps = w0[1:] - w0[:-1]
+    ok = torch.nonzero(gaps >= 2e-6).flatten()
+    j = int(ok[(ok - len(w0) // 2).abs().argmin()])
+    thr, margin = float((w0[j] + w0[j + 1]) / 2), float(gaps[j] / 2)
+    graph, oo, terms, total, og, op = O.tc_training_step(raw, p0, mlgc=mlgc, gtcn=dict(okw, ec_threshold=thr),
+                                                        loss_kind=loss, loss_weights=lw)
+    model = G.GraphTCN(14, 28, ec_threshold=thr, **gt)
+    model.load_state_dict(p0)
+    model = model.to(device)
+    loss_cls = CondensationLossTiger if loss == "tiger" else CondensationLossRG
+    mod = training.TCModule(model, loss_fct=loss_cls(lw_repulsive=lw[0], lw_coward=lw[1], lw_noise=lw[2]),
+                            preproc=G.MLGraphConstruction(ml=None, **mlgc))
+    dev = torch.device(device)
+    data = mod.data_preproc(G.Data(edge_index=torch.zeros(2, 0, dtype=torch.long, device=dev),
+                                   **{k: v.to(dev) for k, v in raw.items()}))
+    tag = f"TC step {n_hits} hits"
+    assert torch.equal(data.edge_index.cpu(), graph["edge_index"]), tag + ": built graph"
+    assert torch.equal(data.y.cpu(), graph["y"]) and torch.equal(data.edge_attr.cpu(), graph["edge_attr"]), tag
+    out = mod(data, _preprocessed=True)
+    w_err = (out["W"].detach().cpu() - oo["W"]).abs().max().item()
+    assert w_err < 0.25 * margin, f"{tag}: |W - W_oracle| {w_err:.1e}, threshold margin {margin:.1e}"
+    assert torch.equal(out["ec_edge_mask"].cpu(), oo["ec_edge_mask"]), tag + ": EC cut"
+    assert torch.equal(out["ec_hit_mask"].cpu(), oo["ec_hit_mask"])
+    for k in ("W", "H", "B"):
+        assert_close(out[k], oo[k], TOL_OUT, f"{tag} {k}")
+    l, metrics = mod.get_losses(out, data)
+    for k in ("attractive", "repulsive", "coward", "noise"):
+        assert_close(metrics[k], terms[k], 2e-5, f"{tag} {k}")
+    assert_close(l, total, 2e-5, tag + " loss")
+    mod.zero_grad()
+    l.backward()
+    for k, v in model.named_parameters():
+        assert_close(v.grad if v.grad is not None else torch.zeros_like(v), og[k], TOL_GRAD, f"{tag} grad {k}")
+    mod.configure_optimizers().step()
+    _check_after_adam(model, og, op, tag)
+    return {"hits": n_hits, "edges": int(graph["edge_index"].shape[1]), "kept": int(oo["ec_edge_mask"].sum()),
+            "threshold_margin": margin, "w_err": w_err}
 
 
 def case_oc_sampling(device):

@@ -31,10 +31,35 @@ def test_self_launch_two_ranks():
                         "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_env())
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["self_launched"] is True
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and "rccl_ranks" not in d and d["self_launched"] is True
     assert d["steps"] == 3 and d["warmup"] == 1 and d["data"] == "stub"
     assert d["config"]["global_edges_per_step"] == 128          # both ranks' work is counted
     assert abs(d["value"] - 128 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_self_launch_eight_ranks_dry_run():
+    """What the driver's 8-GPU run exercises, without the GPUs: bench.py --gpus 8 starts eight ranks,
+    they rendezvous, reduce and print ONE line (world size 8, every rank's work counted)."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--stub", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["backend"] == "gloo" and d["self_launched"] is True
+    assert d["config"]["global_edges_per_step"] == 64 * 8
+
+
+def test_a_rank_that_cannot_join_fails_loudly_not_for_ever():
+    """World size 2 announced, only rank 0 started: the bounded rendezvous raises (non-zero exit,
+    the backend's message on stderr) instead of hanging in the store / barrier."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               GNNTRK_DIST_TIMEOUT_S="8")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--stub", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and "could not be set up" in r.stderr, r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_under_torchrun_two_ranks():
@@ -47,7 +72,7 @@ def test_under_torchrun_two_ranks():
                        capture_output=True, text=True, timeout=300, env=_env())
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["self_launched"] is False
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and "rccl_ranks" not in d and d["self_launched"] is False
 
 
 def test_rank_count_mismatch_is_refused():

@@ -129,3 +129,9 @@ def test_edge_ordered_outputs_emulated():
 def test_tc_training_step_emulated():
     with emulated():
         P.case_tc_step("cpu")
+
+
+def test_tc_training_step_event_scale_emulated():
+    """golden G14b (1500 hits, 21 617 built edges), the Tiger / orphan-masking variant"""
+    with emulated():
+        P.case_tc_step_event("cpu", names=("tiger_orphans_h24",))

@@ -181,6 +181,18 @@ def test_tc_training_step(dev):
     P.case_tc_step(dev)
 
 
+def test_tc_training_step_event_scale(dev):
+    """golden G14b: the reference's own TCModule on a 1500-hit event, cfg5 model + Tiger variant"""
+    P.case_tc_step_event(dev)
+
+
+def test_tc_training_step_vs_oracle_6k_hits(dev):
+    """the cfg5 step (bench.py's event, model, kNN, loss) on 6000 hits against oracle.tc_training_step,
+    every value compared; and on 20 000 hits (pruned kNN search + spatial loss passes in the path)"""
+    print(P.case_tc_step_oracle(dev, n_hits=6000))
+    print(P.case_tc_step_oracle(dev, n_hits=20000))
+
+
 # ---- BASELINE.json configs on their own workloads ---------------------------------------
 def test_cfg1_cfg2_event_vs_oracle(dev):
     P.case_cfg12_event(dev)
@@ -195,10 +207,11 @@ def test_cfg5_knn_200k(dev):
 
 
 def test_bench_cfg4_two_ranks_match_one_rank(dev):
-    """BASELINE config 4's data-parallel path on real device tensors: bench.py's own launcher
-    starts two ranks (gloo, both on this GPU - RCCL needs one GPU per rank), each runs its four
-    of the eight shards as micro-batches, gradients are all-reduced; the parameters after the
-    run must equal the one-rank run's (same arithmetic: the mean over all eight shards)."""
+    """BASELINE config 4 on its own workload - ALL 256 events (hits ~ U(100 k, 200 k), 8 size-balanced
+    shards of 32 events): bench.py's own launcher starts two ranks (gloo, both on this GPU - RCCL
+    needs one GPU per rank), each runs its four of the eight shards as micro-batches, gradients are
+    all-reduced; the parameters after the run must equal the one-rank run's (same arithmetic: the
+    mean over all eight shards).  The line names the backend and only claims RCCL under nccl."""
     import json
     import pathlib
     import subprocess
@@ -207,18 +220,22 @@ def test_bench_cfg4_two_ranks_match_one_rank(dev):
     root = pathlib.Path(__file__).resolve().parent.parent
     outs = {}
     for n in (1, 2):
-        cmd = [sys.executable, str(root / "bench.py"), "--gpus", str(n), "--workload", "cfg4", "--events", "16",
+        cmd = [sys.executable, str(root / "bench.py"), "--gpus", str(n), "--workload", "cfg4",
                "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--dtype", "f32"]
         if n > 1:
             cmd += ["--backend", "gloo"]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[n] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     a, b = outs[1], outs[2]
-    assert b["n_gpus"] == 2 and b["rccl_ranks"] == 2 and b["self_launched"] is True
+    assert a["backend"] == "none" and "rccl_ranks" not in a
+    assert b["n_gpus"] == 2 and b["backend"] == "gloo" and "rccl_ranks" not in b and b["self_launched"] is True
+    assert "RCCL" not in b["config"]["parallelism"]
     assert a["scaling"] == b["scaling"] == "strong"
-    assert a["config"]["global_edges_per_step"] == b["config"]["global_edges_per_step"]
+    assert a["config"]["events"] == b["config"]["events"] == 256
+    assert a["config"]["global_edges_per_step"] == b["config"]["global_edges_per_step"] > 4e8
     assert a["config"]["micro_batches_per_rank"] == 8 and b["config"]["micro_batches_per_rank"] == 4
+    assert a["config"]["shard_edges_max_over_mean"] < 1.01 and b["config"]["rank_edges_max_over_mean"] < 1.01
     rel = abs(a["param_checksum"] - b["param_checksum"]) / a["param_checksum"]
     assert rel < 1e-6, f"parameters after the run differ between 1 and 2 ranks: {rel:.2e}"
 

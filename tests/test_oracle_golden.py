@@ -246,3 +246,27 @@ def test_tc_training_step_oracle():
         for k, v in grads.items():
             assert_close(v, z[f"{name}/grad/{k}"], 1e-5, f"{name} grad {k}")
             assert_close(after[k], z[f"{name}/p1/{k}"], 1e-6, f"{name} adam {k}")
+
+
+def test_tc_training_step_oracle_at_event_scale():
+    """oracle.tc_training_step against the reference's own TCModule step on a 1500-hit event
+    (golden G14b: the cfg5 model of bench.py + a Tiger / orphan-masking variant)."""
+    z = load("g14b_tc_step_event.npz")
+    raw = {k: tt(z[k]) for k in ("x", "particle_id", "pt", "eta", "reconstructable")}
+    for name, cfg in P.TC_STEP_B_CASES.items():
+        gk = dict(cfg["gtcn"])
+        okw = dict(L_ec=gk.pop("L_ec"), L_hc=gk.pop("L_hc"), ec_threshold=float(z[f"{name}/ec_threshold"]))
+        for k in ("mask_orphan_nodes", "feed_edge_weights", "use_ec_embeddings_for_hc", "alpha_latent",
+                  "n_embedding_coords"):
+            if k in gk:
+                okw[k] = gk[k]
+        graph, out, terms, total, grads, after = O.tc_training_step(
+            raw, _params(z, f"{name}/p0/"), mlgc=P.TC_B_MLGC, gtcn=okw, loss_kind=cfg["loss"],
+            loss_weights=cfg["loss_w"])
+        assert torch.equal(graph["edge_index"], tt(z[f"{name}/edge_index"]))
+        assert torch.equal(out["ec_edge_mask"], tt(z[f"{name}/ec_edge_mask"]))
+        assert int(out["ec_edge_mask"].sum()) > 1000
+        assert_close(total, z[f"{name}/loss"], 1e-6, name + " loss")
+        for k, v in grads.items():
+            assert_close(v, z[f"{name}/grad/{k}"], 1e-5, f"{name} grad {k}")
+            assert_close(after[k], z[f"{name}/p1/{k}"], 1e-6, f"{name} adam {k}")

@@ -62,6 +62,11 @@ class GraphIndex(C.Structure):
                 ("rowptr_s", C.c_void_p), ("spos", C.c_void_p), ("spos_inv", C.c_void_p)]
 
 
+class GraphIndexCarry(C.Structure):
+    _fields_ = [("edge_label", C.c_void_p), ("label_csr", C.c_void_p), ("edge_rows", C.c_void_p),
+                ("rows_csr_bf16", C.c_void_p), ("rows_stride", C.c_int32), ("out_stride", C.c_int32)]
+
+
 class OcArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("beta", C.c_void_p), ("particle_id", C.c_void_p),
                 ("mask", C.c_void_p), ("gid", C.c_void_p), ("alphas", C.c_void_p),
@@ -80,6 +85,10 @@ _SIGNATURES = {
     "gnntrk_graph_index_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gnntrk_graph_index_build": (C.c_int, [_P, C.POINTER(GraphIndex), _P, C.c_size_t, _P]),
     "gnntrk_graph_index_build_ex": (C.c_int, [_P, C.POINTER(GraphIndex), _P, C.c_size_t, C.c_int32, _P]),
+    "gnntrk_graph_index_workspace_bytes_carry": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "gnntrk_graph_index_build_carry": (C.c_int, [_P, C.POINTER(GraphIndex), C.POINTER(GraphIndexCarry), _P, C.c_size_t,
+                                                 C.c_int32, _P]),
+    "gnntrk_bce_csr": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_mlp_forward": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
     "gnntrk_rows_to_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P]),
     "gnntrk_segment_sum_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32,
@@ -151,7 +160,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 203   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
+ABI_VERSION = 300   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

@@ -11,6 +11,7 @@ static_assert(sizeof(gnntrk_mlp) == 64, "gnntrk_mlp layout");
 static_assert(sizeof(gnntrk_mlp_fwd_args) == 448, "gnntrk_mlp_fwd_args layout");
 static_assert(sizeof(gnntrk_mlp_bwd_args) == 760, "gnntrk_mlp_bwd_args layout");
 static_assert(sizeof(gnntrk_graph_index) == 72, "gnntrk_graph_index layout");
+static_assert(sizeof(gnntrk_graph_index_carry) == 40, "gnntrk_graph_index_carry layout");
 
 namespace gnntrk {
 
@@ -58,13 +59,16 @@ int bce_backward_launch(const float *, const float *, const int64_t *, const flo
                         int64_t, const float *, float *, hipStream_t);
 int edge_targets_csr_launch(const void *, int, const int32_t *, const int32_t *, const float *, float, int64_t, float *,
                             hipStream_t);
+int bce_csr_launch(const float *, const uint8_t *, const int32_t *, const float *, float, int64_t, float *, float *, void *,
+                   size_t, hipStream_t);
 int focal_forward_launch(const float *, const float *, const int64_t *, const float *, float, float, float, float,
                          int, int64_t, float *, void *, size_t, hipStream_t);
 int focal_backward_launch(const float *, const float *, const int64_t *, const float *, float, float, float, float,
                           int, int64_t, const float *, float *, hipStream_t);
 // graph_index.hip
-size_t graph_index_ws_bytes(int64_t, int64_t);
-int graph_index_build(const int64_t *, const gnntrk_graph_index *, void *, size_t, int, hipStream_t);
+size_t graph_index_ws_bytes(int64_t, int64_t, int);
+int graph_index_build(const int64_t *, const gnntrk_graph_index *, const gnntrk_graph_index_carry *, void *, size_t, int,
+                      hipStream_t);
 
 // knn.hip
 int knn_search_launch(const float *, int64_t, int, int, int, float, const int64_t *, int, int32_t *, int32_t *,
@@ -104,15 +108,23 @@ const char *gnntrk_last_error(void) { return g_err; }
 int gnntrk_device_cu_count(void) { return cu_count(); }
 
 size_t gnntrk_graph_index_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
-    return graph_index_ws_bytes(n_nodes, n_edges);
+    return graph_index_ws_bytes(n_nodes, n_edges, 0);
 }
 int gnntrk_graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *out,
                              void *workspace, size_t workspace_bytes, void *stream) {
-    return graph_index_build(edge_index, out, workspace, workspace_bytes, 0, (hipStream_t)stream);
+    return graph_index_build(edge_index, out, nullptr, workspace, workspace_bytes, 0, (hipStream_t)stream);
 }
 int gnntrk_graph_index_build_ex(const int64_t *edge_index, const gnntrk_graph_index *out, void *workspace,
                                 size_t workspace_bytes, int32_t flags, void *stream) {
-    return graph_index_build(edge_index, out, workspace, workspace_bytes, flags, (hipStream_t)stream);
+    return graph_index_build(edge_index, out, nullptr, workspace, workspace_bytes, flags, (hipStream_t)stream);
+}
+size_t gnntrk_graph_index_workspace_bytes_carry(int64_t n_nodes, int64_t n_edges, int32_t carry_rows) {
+    return graph_index_ws_bytes(n_nodes, n_edges, carry_rows);
+}
+int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph_index *out,
+                                   const gnntrk_graph_index_carry *carry, void *workspace, size_t workspace_bytes,
+                                   int32_t flags, void *stream) {
+    return graph_index_build(edge_index, out, carry, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
 
 int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream) {
@@ -191,6 +203,11 @@ int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
     return bce_backward_launch(w, y, src_node, pt, pt_thld, n, gscale, gw, (hipStream_t)stream);
 }
 
+int gnntrk_bce_csr(const float *w, const uint8_t *label_csr, const int32_t *src_csr, const float *pt, float pt_thld,
+                   int64_t n, float *loss, float *gw_unit, void *workspace, size_t workspace_bytes, void *stream) {
+    return bce_csr_launch(w, label_csr, src_csr, pt, pt_thld, n, loss, gw_unit, workspace, workspace_bytes,
+                          (hipStream_t)stream);
+}
 int gnntrk_edge_targets_csr(const void *y, int32_t y_is_u8, const int32_t *perm, const int32_t *src_csr,
                             const float *pt, float pt_thld, int64_t n, float *out, void *stream) {
     return edge_targets_csr_launch(y, y_is_u8, perm, src_csr, pt, pt_thld, n, out, (hipStream_t)stream);

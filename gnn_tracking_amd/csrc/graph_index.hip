@@ -31,6 +31,7 @@
 //   Algorithmic bytes per edge: count 8 + split 16 + 8 + sort 8 + 12, then 4 + 4 + 8 + 8 + 8 = 84
 //   (+ 0.3 table entries per edge x 12 B); the library path moved about 260.
 #include "host_util.h"
+#include "tile_bf16.h"
 
 namespace gnntrk {
 
@@ -40,8 +41,8 @@ constexpr int kTpb = 256;
 constexpr int kSH = 8;                  // nodes per bucket = 256
 constexpr int kBins = 1 << kSH;
 constexpr int kSortTpb = 512;
-constexpr int kSortR = 12;              // records a thread of the bucket sort holds in registers
-constexpr int kCap = kSortTpb * kSortR; // records of a bucket the bucket sort holds in LDS (6144)
+constexpr int kSortR = 10;              // records a thread of the bucket sort holds in registers
+constexpr int kCap = kSortTpb * kSortR; // records of a bucket the bucket sort holds in LDS (5120)
 constexpr int kWin = 4096;              // bucket counters a chunk holds in LDS
 constexpr int kSplitTpb = 1024;
 constexpr int kSplitR = 4;              // edges per thread and tile of the split
@@ -50,10 +51,16 @@ constexpr int kMaxChunks = 512;
 constexpr int64_t kMaxTable = (int64_t)96 << 20;   // table entries (4 B each)
 constexpr int kScanTpb = 256, kScanItems = 16, kScanTile = kScanTpb * kScanItems;
 
-// first sort: key = target (COO row 1), payload = source (row 0), value = edge id
+// first sort: key = target (COO row 1), payload = source (row 0), value = edge id.  Two per-edge
+// inputs of the caller can ride along into CSR order (gnntrk_graph_index_carry): a 1-byte label in
+// bit 31 of the value (edge ids are below 2^31), a row of four floats as four bf16 in a second
+// 8-byte record array
 struct KeysCoo {
     const int64_t *src, *tgt;
     int64_t N;
+    const uint8_t *label;
+    const float *rows;
+    int rows_stride;
     __device__ __forceinline__ uint32_t key(int64_t e, int *bad) const {
         int64_t v = tgt[e];
         if (v < 0 || v >= N) {
@@ -70,12 +77,21 @@ struct KeysCoo {
         }
         return (uint32_t)v;
     }
+    __device__ __forceinline__ uint32_t value(int64_t e) const {
+        return (uint32_t)e | ((label && label[e]) ? 0x80000000u : 0u);
+    }
+    __device__ __forceinline__ uint2 row(int64_t e) const {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(rows + e * rows_stride);
+        return uint2{bf16x2_pack(v[0], v[1]), bf16x2_pack(v[2], v[3])};
+    }
 };
 // second sort: key = source of the CSR-ordered list (already validated), value = CSR position
 struct KeysCsr {
     const int32_t *src;
     __device__ __forceinline__ uint32_t key(int64_t e, int *) const { return (uint32_t)src[e]; }
     __device__ __forceinline__ uint32_t payload(int64_t, int *) const { return 0u; }
+    __device__ __forceinline__ uint32_t value(int64_t e) const { return (uint32_t)e; }
+    __device__ __forceinline__ uint2 row(int64_t) const { return uint2{0u, 0u}; }
 };
 
 // The LDS window of a chunk starts a third of its width below the bucket of the chunk's first id: a
@@ -258,16 +274,17 @@ __device__ __forceinline__ uint32_t gi_block_exscan(uint32_t v, uint32_t *s_wsum
     return pre + inc - v;
 }
 
-// step 3.  part[pos] = {lo: value (edge id / CSR position), hi: low << pbits | payload}.
+// step 3.  part[pos] = {lo: value (edge id [| label << 31] / CSR position), hi: low << pbits | payload}.
 // A tile of 4096 edges is first grouped by bucket in LDS (rank inside the tile's bucket from an LDS
 // counter, tile-local starts from a scan over the chunk's touched window range), then written out
-// with consecutive lanes on consecutive records of a run: the stores coalesce (a scattered 8-byte
-// store per lane costs the address path about 8 cycles per lane).
-template <class K>
+// with consecutive lanes on consecutive records of a run: the stores coalesce.  ROWS: the
+// caller's per-edge rows (four floats -> four bf16) take the same way into part_rows[pos].
+template <class K, bool ROWS>
 __global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, int chunk, int n_chunks, int pbits,
                                                              uint32_t *__restrict__ tbl,
                                                              const int2 *__restrict__ range,
-                                                             uint2 *__restrict__ part, int *__restrict__ bad) {
+                                                             uint2 *__restrict__ part, uint2 *__restrict__ part_rows,
+                                                             int *__restrict__ bad) {
     __shared__ uint32_t s_off[kWin];     // next free record of the (bucket, chunk) run
     __shared__ uint32_t s_cnt[kWin];     // tile: records per bucket, then the tile-local start
     __shared__ uint2 s_stage[kSplitTile];
@@ -286,39 +303,44 @@ __global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, 
     }
     __syncthreads();
     // the next tile's keys / payloads are loaded while the current tile goes through its LDS phases
-    uint32_t nk[kSplitR], np[kSplitR];
+    uint32_t nk[kSplitR], np[kSplitR], nv[kSplitR];
+    uint2 nr[ROWS ? kSplitR : 1];
+    auto prefetch = [&](int64_t t0) {
 #pragma unroll
-    for (int q = 0; q < kSplitR; ++q) {
-        const int64_t e = e0 + (int64_t)q * kSplitTpb + tid;
-        nk[q] = e < e1 ? keys.key(e, &nobad) : 0u;
-        np[q] = e < e1 ? keys.payload(e, bad) : 0u;
-    }
+        for (int q = 0; q < kSplitR; ++q) {
+            const int64_t e = t0 + (int64_t)q * kSplitTpb + tid;
+            const bool in = e < e1;
+            nk[q] = in ? keys.key(e, &nobad) : 0u;
+            np[q] = in ? keys.payload(e, bad) : 0u;
+            nv[q] = in ? keys.value(e) : 0u;
+            if (ROWS) nr[q] = in ? keys.row(e) : uint2{0u, 0u};
+        }
+    };
+    prefetch(e0);
     for (int64_t t0 = e0; t0 < e1; t0 += kSplitTile) {
-        uint2 rec[kSplitR];
+        uint2 rec[kSplitR], row[ROWS ? kSplitR : 1];
         uint32_t slot[kSplitR], rk[kSplitR];
 #pragma unroll
         for (int q = 0; q < kSplitR; ++q) {
             const int64_t e = t0 + (int64_t)q * kSplitTpb + tid;
             slot[q] = 0xffffffffu;
+            if (ROWS) row[q] = nr[q];
             if (e < e1) {
-                const uint32_t v = nk[q], p = np[q];
+                const uint32_t v = nk[q], pl = np[q];
                 const uint32_t b = v >> kSH, low = v & (kBins - 1);
                 const uint32_t d = b - (uint32_t)w0;
-                rec[q] = uint2{(uint32_t)e, (low << pbits) | p};
+                rec[q] = uint2{nv[q], (low << pbits) | pl};
                 if (d < (uint32_t)kWin) {
                     slot[q] = d;
                     rk[q] = atomicAdd(&s_cnt[d], 1u);
-                } else {   // outside the chunk's LDS window: cursor in the table itself, direct store
-                    part[atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u)] = rec[q];
+                } else {   // outside the chunk's LDS window: cursor in the table itself, direct stores
+                    const uint32_t pos = atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u);
+                    part[pos] = rec[q];
+                    if (ROWS) part_rows[pos] = row[q];
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < kSplitR; ++q) {
-            const int64_t e = t0 + kSplitTile + (int64_t)q * kSplitTpb + tid;
-            nk[q] = e < e1 ? keys.key(e, &nobad) : 0u;
-            np[q] = e < e1 ? keys.payload(e, bad) : 0u;
-        }
+        prefetch(t0 + kSplitTile);
         __syncthreads();
         // tile-local starts: exclusive scan of the counts over the touched range
         const int d0 = r.x + tid * per;
@@ -334,17 +356,29 @@ __global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, 
                 run += cn;
             }
         __syncthreads();
+        uint32_t sp[kSplitR];
 #pragma unroll
         for (int q = 0; q < kSplitR; ++q)
             if (slot[q] != 0xffffffffu) {
-                const uint32_t sp = s_cnt[slot[q]] + rk[q];
-                s_stage[sp] = rec[q];
-                s_slot[sp] = (uint16_t)slot[q];
+                sp[q] = s_cnt[slot[q]] + rk[q];
+                s_stage[sp[q]] = rec[q];
+                s_slot[sp[q]] = (uint16_t)slot[q];
             }
         __syncthreads();
         for (uint32_t j = tid; j < tile_n; j += kSplitTpb) {
             const uint32_t d = s_slot[j];
             part[s_off[d] - s_cnt[d] + j] = s_stage[j];
+        }
+        if (ROWS) {   // the rows through the same staging image
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kSplitR; ++q)
+                if (slot[q] != 0xffffffffu) s_stage[sp[q]] = row[q];
+            __syncthreads();
+            for (uint32_t j = tid; j < tile_n; j += kSplitTpb) {
+                const uint32_t d = s_slot[j];
+                part_rows[s_off[d] - s_cnt[d] + j] = s_stage[j];
+            }
         }
         __syncthreads();
         // advance the run cursors by the tile's counts (count = next start - own start; the last
@@ -361,19 +395,31 @@ __global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, 
     }
 }
 
-// step 4 outputs
+// step 4 outputs.  kValMask: bits of a record's value that order it; kPos: the kernel keeps the
+// slot -> partition position map (the carried rows are fetched from part_rows at write-out)
+template <bool ROWS>
 struct OutCsr {   // first sort
+    static constexpr uint32_t kValMask = 0x7fffffffu;
+    static constexpr bool kPos = ROWS;
     int32_t *perm, *tgt, *src, *rowptr;
     uint32_t pmask;
-    __device__ __forceinline__ void ranked(uint32_t k, uint32_t val, uint32_t hi) const {
-        perm[k] = (int32_t)val;
+    uint8_t *label_csr;
+    const uint2 *part_rows;
+    uint16_t *rows_csr;
+    int rows_out_stride;
+    __device__ __forceinline__ void ranked(uint32_t k, uint32_t val, uint32_t hi, uint32_t pos) const {
+        perm[k] = (int32_t)(val & kValMask);
         src[k] = (int32_t)(hi & pmask);
+        if (label_csr) label_csr[k] = (uint8_t)(val >> 31);
+        if (ROWS) *reinterpret_cast<uint2 *>(rows_csr + (size_t)k * rows_out_stride) = part_rows[pos];
     }
     __device__ __forceinline__ void slot(uint32_t k, uint32_t node) const { tgt[k] = (int32_t)node; }
 };
 struct OutSrc {   // second sort
+    static constexpr uint32_t kValMask = 0xffffffffu;
+    static constexpr bool kPos = false;
     int32_t *spos, *spos_inv, *rowptr;
-    __device__ __forceinline__ void ranked(uint32_t k, uint32_t val, uint32_t) const {
+    __device__ __forceinline__ void ranked(uint32_t k, uint32_t val, uint32_t, uint32_t) const {
         spos[k] = (int32_t)val;
         if (spos_inv) spos_inv[val] = (int32_t)k;
     }
@@ -384,8 +430,10 @@ template <class O>
 __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *__restrict__ part,
                                                                   const uint32_t *__restrict__ base_arr, int NB,
                                                                   int64_t N, int64_t E, int pbits, O out) {
+    constexpr uint32_t VM = O::kValMask;
     __shared__ uint32_t s_hist[kBins], s_start[kBins], s_wsum[kBins / 64];
     __shared__ uint2 s_rec[kCap];
+    __shared__ uint16_t s_pos[O::kPos ? kCap : 1];
     const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t base = base_arr[b], M = base_arr[b + 1] - base;
     const uint32_t node0 = (uint32_t)b << kSH;
@@ -434,14 +482,18 @@ __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *_
     if (fits) {
 #pragma unroll
         for (int q = 0; q < kSortR; ++q)
-            if (tid + q * kSortTpb < M) s_rec[s_start[rec[q].y >> pbits] + ord[q]] = rec[q];
+            if (tid + q * kSortTpb < M) {
+                const uint32_t sl = s_start[rec[q].y >> pbits] + ord[q];
+                s_rec[sl] = rec[q];
+                if (O::kPos) s_pos[sl] = (uint16_t)(tid + q * kSortTpb);
+            }
         __syncthreads();
         for (uint32_t j = tid; j < M; j += kSortTpb) {
             const uint2 r = s_rec[j];
             const uint32_t low = r.y >> pbits, st = s_start[low], n = s_hist[low];
             uint32_t cnt = 0;
-            for (uint32_t t = 0; t < n; ++t) cnt += s_rec[st + t].x < r.x ? 1u : 0u;
-            out.ranked(base + st + cnt, r.x, r.y);
+            for (uint32_t t = 0; t < n; ++t) cnt += (s_rec[st + t].x & VM) < (r.x & VM) ? 1u : 0u;
+            out.ranked(base + st + cnt, r.x, r.y, base + (O::kPos ? (uint32_t)s_pos[j] : 0u));
             out.slot(base + j, node0 + low);
         }
     } else {
@@ -450,11 +502,14 @@ __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *_
         // node beyond the capacity (a hub) is ranked against tiles of its own list streamed through
         // LDS - quadratic in the hub's degree, same result
         __shared__ uint32_t s_cur[kBins];
+        // (with carried rows the last third of the record image holds 32-bit partition positions)
+        constexpr uint32_t kCapG = O::kPos ? (uint32_t)kCap * 2 / 3 : (uint32_t)kCap;
+        uint32_t *s_pos32 = reinterpret_cast<uint32_t *>(s_rec + kCapG);
         int g0 = 0;
         while (g0 < kBins) {
             const uint32_t st0 = s_start[g0];
             int g1 = g0;
-            while (g1 < kBins && (g1 + 1 < kBins ? s_start[g1 + 1] : M) - st0 <= (uint32_t)kCap) ++g1;
+            while (g1 < kBins && (g1 + 1 < kBins ? s_start[g1 + 1] : M) - st0 <= kCapG) ++g1;
             if (g1 == g0) {   // hub node g0
                 const uint32_t n = s_hist[g0];
                 for (uint32_t i0 = 0; i0 < M; i0 += kSortTpb) {
@@ -470,10 +525,10 @@ __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *_
                         if (have)
                             for (uint32_t t = 0; t < tn; ++t) {
                                 const uint2 q = s_rec[t];
-                                cnt += ((int)(q.y >> pbits) == g0 && q.x < r.x) ? 1u : 0u;
+                                cnt += ((int)(q.y >> pbits) == g0 && (q.x & VM) < (r.x & VM)) ? 1u : 0u;
                             }
                     }
-                    if (have) out.ranked(base + st0 + cnt, r.x, r.y);
+                    if (have) out.ranked(base + st0 + cnt, r.x, r.y, base + i);
                 }
                 for (uint32_t j = tid; j < n; j += kSortTpb) out.slot(base + st0 + j, node0 + (uint32_t)g0);
                 g0 += 1;
@@ -486,15 +541,19 @@ __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *_
             for (uint32_t i = tid; i < M; i += kSortTpb) {
                 const uint2 r = part[base + i];
                 const int low = (int)(r.y >> pbits);
-                if (low >= g0 && low < g1) s_rec[s_start[low] - st0 + atomicAdd(&s_cur[low], 1u)] = r;
+                if (low >= g0 && low < g1) {
+                    const uint32_t sl = s_start[low] - st0 + atomicAdd(&s_cur[low], 1u);
+                    s_rec[sl] = r;
+                    if (O::kPos) s_pos32[sl] = i;
+                }
             }
             __syncthreads();
             for (uint32_t j = tid; j < n_g; j += kSortTpb) {
                 const uint2 r = s_rec[j];
                 const uint32_t low = r.y >> pbits, st = s_start[low] - st0, n = s_hist[low];
                 uint32_t cnt = 0;
-                for (uint32_t t = 0; t < n; ++t) cnt += s_rec[st + t].x < r.x ? 1u : 0u;
-                out.ranked(base + st0 + st + cnt, r.x, r.y);
+                for (uint32_t t = 0; t < n; ++t) cnt += (s_rec[st + t].x & VM) < (r.x & VM) ? 1u : 0u;
+                out.ranked(base + st0 + st + cnt, r.x, r.y, base + (O::kPos ? s_pos32[j] : 0u));
                 out.slot(base + st0 + j, node0 + low);
             }
             g0 = g1;
@@ -508,7 +567,7 @@ struct OwnPlan {
     int NB, n_chunks, chunk, bitsN;
     int64_t T;   // table entries (+ 1 total)
     int n_tiles;
-    size_t off_range, off_base, off_tbl, off_sums, off_part, bytes;
+    size_t off_range, off_base, off_tbl, off_sums, off_part, off_rows, bytes;
 };
 
 static int bits_for(int64_t n) {
@@ -517,7 +576,7 @@ static int bits_for(int64_t n) {
     return b;
 }
 
-static OwnPlan own_plan(int64_t N, int64_t E) {
+static OwnPlan own_plan(int64_t N, int64_t E, bool rows) {
     OwnPlan p{};
     p.ok = false;
     if (N < 1 || E < 1) return p;
@@ -545,12 +604,14 @@ static OwnPlan own_plan(int64_t N, int64_t E) {
     o += align_up((size_t)p.n_tiles * 4, 256);
     p.off_part = o;
     o += align_up((size_t)E * 8, 256);
+    p.off_rows = o;   // the carried rows in partition order
+    if (rows) o += align_up((size_t)E * 8, 256);
     p.bytes = o;
     p.ok = true;
     return p;
 }
 
-template <class K, class O>
+template <class K, class O, bool ROWS>
 static int own_sort(const OwnPlan &p, K keys, O out, int pbits, int64_t N, int64_t E, char *ws, int *bad,
                     hipStream_t stream) {
     int2 *range = reinterpret_cast<int2 *>(ws + p.off_range);
@@ -567,8 +628,9 @@ static int own_sort(const OwnPlan &p, K keys, O out, int pbits, int64_t N, int64
     hipLaunchKernelGGL(gi_scan_apply_kernel, dim3(p.n_tiles), dim3(kScanTpb), 0, stream, tbl, p.T + 1, sums);
     hipLaunchKernelGGL(gi_bases_kernel, dim3((int)ceil_div(p.NB + 1, kTpb)), dim3(kTpb), 0, stream, tbl, p.n_chunks,
                        p.NB, base);
-    hipLaunchKernelGGL((gi_split_kernel<K>), dim3(p.n_chunks), dim3(kSplitTpb), 0, stream, keys, E, p.chunk,
-                       p.n_chunks, pbits, tbl, range, part, bad);
+    uint2 *part_rows = reinterpret_cast<uint2 *>(ws + p.off_rows);
+    hipLaunchKernelGGL((gi_split_kernel<K, ROWS>), dim3(p.n_chunks), dim3(kSplitTpb), 0, stream, keys, E, p.chunk,
+                       p.n_chunks, pbits, tbl, range, part, part_rows, bad);
     hipLaunchKernelGGL((gi_bucket_sort_kernel<O>), dim3(p.NB), dim3(kSortTpb), 0, stream, part, base, p.NB, N, E,
                        pbits, out);
     return GNNTRK_OK;
@@ -637,10 +699,18 @@ static size_t library_ws_bytes(int64_t E) {
     return 256 /* flags */ + 3 * arr + align_up(sort_pairs_temp_bytes(E), 256);
 }
 
-size_t graph_index_ws_bytes(int64_t N, int64_t E) {
+size_t graph_index_ws_bytes(int64_t N, int64_t E, int carry_rows) {
     const size_t lib = library_ws_bytes(E);
-    const OwnPlan p = own_plan(N, E);
+    const OwnPlan p = own_plan(N, E, carry_rows != 0);
     return p.ok && p.bytes > lib ? p.bytes : lib;
+}
+
+// the carried per-edge inputs behind the library form: plain gathers through perm
+__global__ __launch_bounds__(kTpb) void gi_gather_label_kernel(const uint8_t *__restrict__ label,
+                                                               const int32_t *__restrict__ perm, int64_t E,
+                                                               uint8_t *__restrict__ out) {
+    for (int64_t k = (int64_t)blockIdx.x * kTpb + threadIdx.x; k < E; k += (int64_t)gridDim.x * kTpb)
+        out[k] = label[perm[k]] ? 1 : 0;
 }
 
 static int library_build(const int64_t *edge_index, const gnntrk_graph_index *o, char *p, int *bad, int64_t N,
@@ -676,8 +746,8 @@ static int library_build(const int64_t *edge_index, const gnntrk_graph_index *o,
     return GNNTRK_OK;
 }
 
-int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, void *ws,
-                      size_t ws_bytes, int flags, hipStream_t stream) {
+int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, const gnntrk_graph_index_carry *cy,
+                      void *ws, size_t ws_bytes, int flags, hipStream_t stream) {
     if (!o) return fail(GNNTRK_EINVAL, "graph_index_build: NULL output descriptor");
     const int64_t E = o->n_edges, N = o->n_nodes;
     if (E < 0 || N < 0 || E > 0x7fffffff || N > 0x7fffffff)
@@ -685,7 +755,16 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, vo
     if (!o->rowptr_t || !o->rowptr_s || (E > 0 && (!o->perm || !o->tgt || !o->src || !o->spos)))
         return fail(GNNTRK_EINVAL, "graph_index_build: NULL output array");
     if (E > 0 && !edge_index) return fail(GNNTRK_EINVAL, "graph_index_build: NULL edge_index");
-    if (!ws || ws_bytes < graph_index_ws_bytes(N, E))
+    const uint8_t *label = cy ? cy->edge_label : nullptr;
+    const float *rows = cy ? cy->edge_rows : nullptr;
+    if (E > 0 && label && !cy->label_csr) return fail(GNNTRK_EINVAL, "graph_index_build: carried label without output");
+    if (E > 0 && rows &&
+        (!cy->rows_csr_bf16 || cy->rows_stride < 4 || cy->rows_stride % 4 != 0 || ((uintptr_t)rows & 15) != 0 ||
+         cy->out_stride < 4 || cy->out_stride % 4 != 0 || ((uintptr_t)cy->rows_csr_bf16 & 7) != 0))
+        return fail(GNNTRK_EINVAL,
+                    "graph_index_build: carried rows must be 16-byte aligned fp32 [E, 4] with a row stride that is a "
+                    "multiple of 4 floats; the bf16 output 8-byte aligned with a stride that is a multiple of 4");
+    if (!ws || ws_bytes < graph_index_ws_bytes(N, E, rows != nullptr))
         return fail(GNNTRK_EINVAL, "graph_index_build: workspace too small");
 
     char *p = reinterpret_cast<char *>(ws);
@@ -693,17 +772,32 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, vo
     int rc = check_hip(hipMemsetAsync(bad, 0, 256, stream), "graph_index_build(memset)");
     if (rc) return rc;
     if (E > 0) {
-        const OwnPlan plan = own_plan(N, E);
+        const OwnPlan plan = own_plan(N, E, rows != nullptr);
         if (plan.ok && !(flags & 1) && (!plan.dense || (flags & 2))) {
-            const KeysCoo k1{edge_index, edge_index + E, N};
-            const OutCsr o1{o->perm, o->tgt, o->src, o->rowptr_t, (uint32_t)(((uint64_t)1 << plan.bitsN) - 1)};
-            rc = own_sort(plan, k1, o1, plan.bitsN, N, E, p, bad, stream);
+            const KeysCoo k1{edge_index, edge_index + E, N, label, rows, rows ? cy->rows_stride : 0};
+            const uint32_t pmask = (uint32_t)(((uint64_t)1 << plan.bitsN) - 1);
+            if (rows) {
+                const OutCsr<true> o1{o->perm, o->tgt, o->src, o->rowptr_t, pmask, label ? cy->label_csr : nullptr,
+                                      reinterpret_cast<const uint2 *>(p + plan.off_rows), cy->rows_csr_bf16,
+                                      cy->out_stride};
+                rc = own_sort<KeysCoo, OutCsr<true>, true>(plan, k1, o1, plan.bitsN, N, E, p, bad, stream);
+            } else {
+                const OutCsr<false> o1{o->perm, o->tgt, o->src, o->rowptr_t, pmask, label ? cy->label_csr : nullptr,
+                                       nullptr, nullptr, 0};
+                rc = own_sort<KeysCoo, OutCsr<false>, false>(plan, k1, o1, plan.bitsN, N, E, p, bad, stream);
+            }
             if (rc) return rc;
             const KeysCsr k2{o->src};
             const OutSrc o2{o->spos, o->spos_inv, o->rowptr_s};
-            rc = own_sort(plan, k2, o2, 0, N, E, p, bad, stream);
+            rc = own_sort<KeysCsr, OutSrc, false>(plan, k2, o2, 0, N, E, p, bad, stream);
         } else {
             rc = library_build(edge_index, o, p, bad, N, E, stream);
+            if (rc) return rc;
+            if (label)
+                hipLaunchKernelGGL(gi_gather_label_kernel, dim3(stream_grid(E)), dim3(kTpb), 0, stream, label, o->perm, E,
+                                   cy->label_csr);
+            if (rows)
+                rc = rows_to_bf16_launch(rows, 4, cy->rows_stride, o->perm, E, cy->rows_csr_bf16, cy->out_stride, stream);
         }
         if (rc) return rc;
     } else {

@@ -162,6 +162,68 @@ __global__ __launch_bounds__(kTpb) void bce_bwd_kernel(const float *__restrict__
     }
 }
 
+// BCE of CSR-ordered edge weights against the 1-byte CSR-ordered labels the graph-index build
+// carried along (gnntrk_graph_index_carry), forward AND the gradient for a unit upstream value in
+// ONE pass: t = label != 0 [&& pt[src_csr[k]] > thld]; loss partial as above;
+// gw_unit[k] = (1 / n) (w - t) / max((1 - w) w, 1e-12)  (= bce_bwd_kernel with gscale = 1).
+__device__ __forceinline__ float bce_csr_one(float wi, float t, float gs, double &acc) {
+    const float lw = fmaxf(logf(wi), -100.f);
+    const float l1w = fmaxf(log1pf(-wi), -100.f);
+    acc += (double)(-(t * lw + (1.f - t) * l1w));
+    return gs * (wi - t) / fmaxf((1.f - wi) * wi, 1e-12f);
+}
+// four consecutive edges per thread and step (16-byte weight / gradient accesses, one 4-byte label
+// word); `vec`: the three arrays are 16 / 4 / 16-byte aligned.  The loss partial of a thread sums its
+// edges in ascending order whatever the access width, so both forms give the same bits.
+__global__ __launch_bounds__(kTpb) void bce_csr_kernel(const float *__restrict__ w, const uint8_t *__restrict__ label,
+                                                       const int32_t *__restrict__ src_csr,
+                                                       const float *__restrict__ pt, float thld, int64_t n, bool vec,
+                                                       double *__restrict__ part, float *__restrict__ gw_unit) {
+    __shared__ double sh[kTpb / 64];
+    double acc = 0.0;
+    const float gs = 1.f / (float)n;
+    for (int64_t e0 = ((int64_t)blockIdx.x * kTpb + threadIdx.x) * 4; e0 < n; e0 += (int64_t)gridDim.x * kTpb * 4) {
+        float wi[4], t[4], g[4];
+        const bool full = vec && e0 + 4 <= n;
+        if (full) {
+            const float4 wv = *reinterpret_cast<const float4 *>(w + e0);
+            const uint32_t lv = *reinterpret_cast<const uint32_t *>(label + e0);
+            wi[0] = wv.x; wi[1] = wv.y; wi[2] = wv.z; wi[3] = wv.w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = ((lv >> (8 * q)) & 0xffu) ? 1.f : 0.f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = e0 + q < n;
+                wi[q] = in ? w[e0 + q] : 0.5f;
+                t[q] = (in && label[e0 + q]) ? 1.f : 0.f;
+            }
+        }
+        if (thld > 0.f) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (e0 + q < n) t[q] = (t[q] != 0.f && pt[src_csr[e0 + q]] > thld) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double a = 0.0;
+            g[q] = bce_csr_one(wi[q], t[q], gs, a);
+            if (e0 + q < n) acc += a;
+        }
+        if (gw_unit) {
+            if (full) {
+                *reinterpret_cast<float4 *>(gw_unit + e0) = make_float4(g[0], g[1], g[2], g[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (e0 + q < n) gw_unit[e0 + q] = g[q];
+            }
+        }
+    }
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
 // Labels of the edges in CSR (target-sorted) order, pt-falsified: the once-per-batch gather that
 // lets the loss run on the CSR-ordered edge weights the classification head produces.
 //   out[k] = y[perm[k]]                                          (thld <= 0)
@@ -312,6 +374,21 @@ int bce_backward_launch(const float *w, const float *y, const int64_t *src_node,
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(stream_grid(n)), dim3(kTpb), 0, stream, w, y, src_node,
                        pt, thld, n, gscale, gw);
     return check_launch("bce_backward");
+}
+
+int bce_csr_launch(const float *w, const uint8_t *label, const int32_t *src_csr, const float *pt, float thld, int64_t n,
+                   float *loss, float *gw_unit, void *ws, size_t ws_bytes, hipStream_t stream) {
+    if (!w || !label || !loss || n < 1) return fail(GNNTRK_EINVAL, "bce_csr: bad argument");
+    if (thld > 0.f && (!src_csr || !pt)) return fail(GNNTRK_EINVAL, "bce_csr: pt threshold needs the CSR source ids and pt");
+    if (!ws || ws_bytes < bce_ws_bytes(n)) return fail(GNNTRK_EINVAL, "bce_csr: workspace too small");
+    const int g = bce_grid(n);
+    double *part = reinterpret_cast<double *>(ws);
+    const bool vec = (((uintptr_t)w | (uintptr_t)gw_unit) & 15) == 0 && ((uintptr_t)label & 3) == 0;
+    hipLaunchKernelGGL(bce_csr_kernel, dim3(g), dim3(kTpb), 0, stream, w, label, src_csr, pt, thld, n, vec, part,
+                       gw_unit);
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(kTpb), 0, stream, reinterpret_cast<const double *>(part), g, n,
+                       loss);
+    return check_launch("bce_csr");
 }
 
 int edge_targets_csr_launch(const void *y, int y_is_u8, const int32_t *perm, const int32_t *src_csr, const float *pt,

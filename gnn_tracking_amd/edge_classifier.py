@@ -81,15 +81,24 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
         assert_feat_dim(x, self.hparams.node_indim)
         assert_feat_dim(edge_attr, self.hparams.edge_indim)
-        gi = ops.graph_index(edge_index, x.shape[0])
+        bf16 = precision.use_bf16()
+        # two per-edge inputs ride along into CSR order inside the graph-index build instead of being
+        # gathered through the permutation afterwards: the dataset's 1-byte labels (for this package's
+        # losses, which find them on the index) and, in bf16 storage, the four fp32 edge features
+        y = getattr(data, "y", None)
+        gi = ops.graph_index(edge_index, x.shape[0],
+                             carry_label=y if isinstance(y, Tensor) and self.training else None,
+                             carry_rows=edge_attr if bf16 and edge_attr.shape[1] == 4 else None)
         E = gi.n_edges
 
-        if precision.use_bf16():
+        if bf16:
             # bf16 storage: the dataset's fp32 features are converted once (edge_attr permuted
             # into CSR order in the same pass); everything downstream is bf16 rows, W is fp32
             h = self.ec_node_encoder.fused([ops.Seg(ops_bf16.to_rows16(x))], epilogue=_capi.EPI_RELU)
-            e = self.ec_edge_encoder.fused([ops.Seg(ops_bf16.to_rows16(edge_attr, gi.perm))],
-                                           n_rows=E, epilogue=_capi.EPI_RELU)
+            ea_csr = ops.carried_rows(gi, edge_attr)
+            if ea_csr is None:
+                ea_csr = ops_bf16.to_rows16(edge_attr, gi.perm)
+            e = self.ec_edge_encoder.fused([ops.Seg(ea_csr)], n_rows=E, epilogue=_capi.EPI_RELU)
         else:
             h = self.ec_node_encoder.fused([ops.Seg(x)], epilogue=_capi.EPI_RELU)
             e = self.ec_edge_encoder.fused([ops.Seg(edge_attr, gi.perm, False, "perm")],

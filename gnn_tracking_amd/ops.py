@@ -180,10 +180,14 @@ def clear_graph_index_cache() -> None:
 _VALIDATE = bool(os.environ.get("GNNTRK_VALIDATE"))
 #: bit 0: library radix-sort form of the graph index (tests, measurements; identical arrays)
 _GI_FLAGS = int(os.environ.get("GNNTRK_GI_FLAGS", "0"))
+#: per-edge inputs ride along in the graph-index build (False: gathered through perm afterwards;
+#: tests, measurements - identical results)
+CARRY = os.environ.get("GNNTRK_GI_CARRY", "1") != "0"
 
 
 def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
-                validate: Optional[bool] = None, flags: Optional[int] = None) -> GraphIndex:
+                validate: Optional[bool] = None, flags: Optional[int] = None,
+                carry_label: Optional[Tensor] = None, carry_rows: Optional[Tensor] = None) -> GraphIndex:
     """Build (or fetch) the index of ``edge_index`` ([2,E] int64, unsorted COO).
 
     Cached per tensor OBJECT (weakref + version counter), so the L layers of a
@@ -193,6 +197,11 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     build's count of node ids outside ``[0, n_nodes)`` (sources and targets) and raise
     ``IndexError`` as torch's ``index_select`` would.  It costs a host synchronisation, so it
     is off by default; ids out of range then give undefined results.
+
+    ``carry_label`` (1-byte ``[E]``: the dataset's bool ``y``) / ``carry_rows`` (fp32 ``[E, 4]``:
+    ``edge_attr``): per-edge inputs that ride along into CSR order INSIDE the build
+    (``gnntrk_graph_index_carry``) instead of being gathered through ``perm`` afterwards; the
+    results are left on the index (``carried_label`` / ``carried_rows`` below return them).
     """
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
@@ -214,9 +223,25 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     gi = GraphIndex(n_nodes, E, mk(E), mk(E), mk(E), mk(n_nodes + 1), mk(n_nodes + 1), mk(E), mk(E))
     d = _capi.GraphIndex(n_nodes, E, _p(gi.perm), _p(gi.tgt), _p(gi.src), _p(gi.rowptr_t),
                          _p(gi.rowptr_s), _p(gi.spos), _p(gi.spos_inv))
-    ws = _ws(lib.gnntrk_graph_index_workspace_bytes(n_nodes, E), ei)
-    _capi.check(lib.gnntrk_graph_index_build_ex(_p(ei), C.byref(d), _p(ws), ws.numel(),
-                                                _GI_FLAGS if flags is None else int(flags), _stream(ei)), lib)
+    cy = _capi.GraphIndexCarry()
+    lab = rows = None
+    if CARRY and carry_label is not None and E > 0 and _carry_label_ok(carry_label, E):
+        lab = carry_label.detach().view(torch.uint8).contiguous().view(-1)
+        lab_csr = torch.empty(E, dtype=torch.uint8, device=dev)
+        cy.edge_label, cy.label_csr = _p(lab), _p(lab_csr)
+    if CARRY and carry_rows is not None and E > 0 and _carry_rows_ok(carry_rows, E):
+        from . import ops_bf16
+        rows = carry_rows.detach()
+        rows_csr = ops_bf16.empty_rows(E, 4, dev)
+        cy.edge_rows, cy.rows_csr_bf16 = _p(rows), _p(rows_csr)
+        cy.rows_stride, cy.out_stride = int(rows.stride(0)), int(rows_csr.stride(0))
+    ws = _ws(lib.gnntrk_graph_index_workspace_bytes_carry(n_nodes, E, int(rows is not None)), ei)
+    _capi.check(lib.gnntrk_graph_index_build_carry(_p(ei), C.byref(d), C.byref(cy), _p(ws), ws.numel(),
+                                                   _GI_FLAGS if flags is None else int(flags), _stream(ei)), lib)
+    if lab is not None:
+        gi._label_csr = (id(carry_label), carry_label._version, weakref.ref(carry_label), lab_csr)
+    if rows is not None:
+        gi._rows_csr = (id(carry_rows), carry_rows._version, weakref.ref(carry_rows), rows_csr)
     if _VALIDATE if validate is None else validate:
         bad = int(ws[:4].view(torch.int32).item())  # first workspace word: ids out of range
         if bad:
@@ -225,6 +250,32 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     if cache:
         _cache_put(edge_index, n_nodes, gi)
     return gi
+
+
+def _carry_label_ok(y: Tensor, E: int) -> bool:
+    return y.dtype in (torch.bool, torch.uint8) and y.numel() == E and y.device.type != "meta"
+
+
+def _carry_rows_ok(r: Tensor, E: int) -> bool:
+    return (r.dtype == torch.float32 and r.dim() == 2 and tuple(r.shape) == (E, 4) and r.stride(1) == 1
+            and r.stride(0) >= 4 and r.stride(0) % 4 == 0 and r.data_ptr() % 16 == 0)
+
+
+def _carried(gi: GraphIndex, slot: str, t: Tensor):
+    hit = getattr(gi, slot, None)
+    if hit is not None and hit[0] == id(t) and hit[1] == t._version and hit[2]() is t:
+        return hit[3]
+    return None
+
+
+def carried_label(gi: GraphIndex, y: Tensor):
+    """uint8 ``[E]`` ``y[perm]`` if the build of ``gi`` carried exactly this ``y`` along, else None."""
+    return _carried(gi, "_label_csr", y)
+
+
+def carried_rows(gi: GraphIndex, rows: Tensor):
+    """bf16 ``[E, 4]`` ``rows[perm]`` if the build of ``gi`` carried exactly this tensor along, else None."""
+    return _carried(gi, "_rows_csr", rows)
 
 
 _GI_CACHE_MAX = 4   # live entries: the EC graph, the cut graph and a prefetched batch or two
@@ -868,6 +919,29 @@ class _BCE(torch.autograd.Function):
         return gw, None, None, None, None
 
 
+class _BCECsr(torch.autograd.Function):
+    """BCE of CSR-ordered weights against carried 1-byte CSR labels: loss and the unit gradient in
+    one pass (``gnntrk_bce_csr``); the backward is one scaling of the saved unit gradient."""
+
+    @staticmethod
+    def forward(ctx, w, label_csr, src_csr, pt, pt_thld: float):
+        _capi.require_device(w, label_csr)
+        lib = _capi.load()
+        w = w.contiguous().view(-1)
+        n = w.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=w.device)
+        gw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        ws = _ws(lib.gnntrk_bce_workspace_bytes(n), w)
+        _capi.check(lib.gnntrk_bce_csr(_p(w), _p(label_csr), _p(src_csr), _p(pt), pt_thld, n, _p(loss), _p(gw),
+                                       _p(ws), ws.numel(), _stream(w)), lib)
+        ctx.gw = gw
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.gw * g.to(torch.float32), None, None, None, None
+
+
 class _Focal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, y, src_nodes, pt, pt_thld: float, alpha: float, gamma: float, pos_weight: float,
@@ -982,6 +1056,12 @@ def bce_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None,
     fast = _csr_fast_path(w, edge_index)
     if fast is not None:  # the weights are still in CSR order: labels go there, W stays put
         w_csr, gi = fast
+        lab = carried_label(gi, y)
+        if lab is not None:  # ... and the labels came along with the graph-index build: one fused pass
+            ptf = pt.detach().to(torch.float32).contiguous() if pt_thld > 0.0 else None
+            if pt_thld > 0.0:
+                assert pt is not None
+            return _BCECsr.apply(w_csr, lab, gi.src if pt_thld > 0.0 else None, ptf, float(pt_thld))
         return _BCE.apply(w_csr, edge_targets_csr(y, gi, pt, float(pt_thld)), None, None, 0.0)
     y = y.to(torch.float32)
     src_nodes = None

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNNTRK_VERSION 203 /* 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
+#define GNNTRK_VERSION 300 /* 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
 #define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
 #define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
 #define GNNTRK_MAX_HIDDEN 64
@@ -94,6 +94,27 @@ int gnntrk_graph_index_build(const int64_t *edge_index, const gnntrk_graph_index
  * The first int32 of the workspace holds the number of node ids outside [0, N) afterwards. */
 int gnntrk_graph_index_build_ex(const int64_t *edge_index, const gnntrk_graph_index *out, void *workspace,
                                 size_t workspace_bytes, int32_t flags, void *stream);
+
+/* Per-edge inputs of the caller that ride along into CSR order inside the build (instead of a random
+ * gather through `perm` afterwards; models/edge_classifier.py:97 reads `data.edge_attr`, training/
+ * ec.py:43 `data.y` - both in edge_index order, both needed in CSR order by this library):
+ *   edge_label  1-byte labels (the dataset's bool `y`)  ->  label_csr[k] = edge_label[perm[k]] != 0
+ *   edge_rows   fp32 [E, 4] rows (`edge_attr`)          ->  rows_csr_bf16[k] = bf16(edge_rows[perm[k]]), RNE
+ * Either input may be NULL.  The label travels in bit 31 of the edge id, the row as a second 8-byte
+ * record: sequential reads, run-wise writes.  Identical to the gathers (which the library form of the
+ * build runs instead). */
+typedef struct gnntrk_graph_index_carry {
+    const uint8_t *edge_label; /* [E] or NULL */
+    uint8_t *label_csr;        /* [E] out */
+    const float *edge_rows;    /* [E, 4] fp32, 16-byte aligned, or NULL */
+    uint16_t *rows_csr_bf16;   /* [E, out_stride] bf16 out, 8-byte aligned */
+    int32_t rows_stride;       /* floats per input row (multiple of 4) */
+    int32_t out_stride;        /* bf16 per output row (multiple of 4) */
+} gnntrk_graph_index_carry;
+size_t gnntrk_graph_index_workspace_bytes_carry(int64_t n_nodes, int64_t n_edges, int32_t carry_rows);
+int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph_index *out,
+                                   const gnntrk_graph_index_carry *carry, void *workspace, size_t workspace_bytes,
+                                   int32_t flags, void *stream);
 
 /* ------------------------------------------------------------- fused gather-MLP
  * One kernel family replaces, for every MLP site of the path
@@ -307,6 +328,16 @@ int gnntrk_bce_forward(const float *w, const float *y, const int64_t *src_node,
 int gnntrk_bce_backward(const float *w, const float *y, const int64_t *src_node,
                         const float *pt, float pt_thld, int64_t n, const float *gscale,
                         float *gw, void *stream);
+
+/* EdgeWeightBCELoss (metrics/losses/ec.py:95-121) on CSR-ordered edge weights against the 1-byte
+ * CSR-ordered labels a graph-index build carried along (gnntrk_graph_index_carry.label_csr), forward
+ * and the gradient for a unit upstream value in ONE pass over the edges:
+ *   t = label_csr[k] != 0 [&& pt[src_csr[k]] > pt_thld]      (falsify_low_pt_edges, ec.py:71-92)
+ *   loss = mean of the per-edge BCE (torch's log clamp at -100);
+ *   gw_unit[k] = d loss / d w[k] (NULL: not wanted) - the caller scales it by the upstream gradient.
+ * workspace: gnntrk_bce_workspace_bytes(n). */
+int gnntrk_bce_csr(const float *w, const uint8_t *label_csr, const int32_t *src_csr, const float *pt, float pt_thld,
+                   int64_t n, float *loss, float *gw_unit, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Edge labels in the CSR order of a graph index, pt-falsified (metrics/losses/ec.py:71-92):
  *   out[k] = y[perm[k]]                                           pt_thld <= 0

@@ -114,6 +114,48 @@ def case_graph_index(device, big=False):
             _check_graph_index(gi, eic, N, f"{tag} flags={flags}")
 
 
+def case_graph_index_carry(device):
+    """Per-edge inputs carried into CSR order inside the build (gnntrk_graph_index_carry): identical to
+    the gathers through perm, in both forms of the build, incl. buckets beyond the LDS capacity; and
+    the fused CSR BCE (loss + unit gradient in one pass) against torch's BCE on the gathered labels."""
+    from gnn_tracking_amd import ops_bf16
+    g = np.random.default_rng(1)
+    cases = [("small", g.integers(0, 50, size=(2, 300)), 50), ("uniform", g.integers(0, 1000, size=(2, 20000)), 1000)]
+    hub = g.integers(0, 600, size=(2, 30000))
+    hub[1, ::2] = 17
+    cases.append(("hub", hub, 600))
+    cases.append(("dense", g.integers(0, 7, size=(2, 12000)), 7))
+    for tag, arr, N in cases:
+        ei = tt(arr, device).long()
+        E = ei.shape[1]
+        y = tt(g.random(E) < 0.3, device)
+        rows = tt(g.normal(size=(E, 4)).astype(np.float32) * 3, device)
+        pt = tt(g.lognormal(size=N).astype(np.float32), device)
+        for flags in (0, 1, 2):
+            gi = ops.graph_index(ei, N, cache=False, flags=flags, carry_label=y, carry_rows=rows)
+            _check_graph_index(gi, ei.cpu(), N, f"{tag} carry flags={flags}")
+            lab, rc = ops.carried_label(gi, y), ops.carried_rows(gi, rows)
+            assert lab is not None and rc is not None
+            perm = gi.perm.long()
+            assert torch.equal(lab.cpu(), y[perm].to(torch.uint8).cpu()), f"{tag} flags={flags}: carried labels"
+            want = ops_bf16.to_rows16(rows, gi.perm)
+            assert torch.equal(rc.cpu().view(torch.int16), want.cpu().view(torch.int16)), f"{tag} flags={flags}: carried rows"
+            assert ops.carried_label(gi, y.clone()) is None, "another tensor must not match"
+        # fused BCE on CSR-ordered weights
+        for thld in (0.0, 0.9):
+            w = tt(g.uniform(0.001, 0.999, size=E).astype(np.float32), device).requires_grad_(True)
+            loss = ops._BCECsr.apply(w, lab, gi.src if thld > 0 else None, pt if thld > 0 else None, thld)
+            (loss * 1.5).backward()
+            wr = w.detach().clone().requires_grad_(True)
+            t = y[perm].float()
+            if thld > 0:
+                t = t * (pt[gi.src.long()] > thld).float()
+            ref = torch.nn.functional.binary_cross_entropy(wr, t)
+            (ref * 1.5).backward()
+            assert_close(loss, ref, 1e-6, f"{tag} fused BCE thld={thld}")
+            assert_close(w.grad, wr.grad, 1e-6, f"{tag} fused BCE gradient thld={thld}")
+
+
 def case_mlp(device, shapes=((14, 40, 4, 3), (9, 40, 5, 3), (14, 14, 5, 2), (26, 40, 1, 3),
                              (4, 2, 4, 2), (30, 33, 7, 3), (48, 64, 16, 3), (28, 40, 4, 2), (5, 40, 1, 3), (5, 40, 8, 3)), rows=77):
     torch.manual_seed(0)
@@ -756,6 +798,38 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):
         assert rep["node_embedding"] <= BF16_PIN_EMB and rep["edge_embedding"] <= BF16_PIN_EMB, (name, rep)
         assert rep["loss"] <= 5e-3 and rep["grad_rel_l2"] <= 0.06, (name, rep)
     return report
+
+
+def case_ec_carry_equals_gather(device, name="skip1_L3_h40"):
+    """The training step with the labels / edge features carried along by the graph-index build and the
+    fused CSR BCE is BIT-IDENTICAL to the step with the gathers through perm and the two-pass BCE
+    (bf16 storage, bool labels, pt falsification on and off)."""
+    z = load("g2_ec_variants.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y, pt = tt(z["y"], device).bool(), tt(z["pt"], device)
+    res = {}
+    for thld in (0.0, 0.9):
+        for carry in (True, False):
+            ops.CARRY = carry
+            try:
+                model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_VARIANTS[name])
+                load_params(model, z, f"{name}/p0/")
+                model = model.to(device)
+                ops.clear_graph_index_cache()
+                with G.bf16_storage():
+                    out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y))
+                    gi = out["W"].graph_index
+                    assert (ops.carried_label(gi, y) is not None) == carry and (ops.carried_rows(gi, ea) is not None) == carry
+                    loss = G.EdgeWeightBCELoss(pt_thld=thld)(w=out["W"], y=y, pt=pt, edge_index=ei)
+                    loss.backward()
+                res[carry] = (loss.detach().clone(), out["W"].csr.detach().clone(),
+                              {k: v.grad.clone() for k, v in model.named_parameters()})
+            finally:
+                ops.CARRY = True
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1]), f"thld={thld}"
+        for k in res[True][2]:
+            assert torch.equal(res[True][2][k], res[False][2][k]), f"thld={thld} grad {k}"
+        assert_close(res[True][0], z[f"{name}/loss"], 0.01, "loss vs fp32 golden") if thld == 0.9 else None
 
 
 BF16_PIN_W = 2.0 ** -8       # one ulp of the reference's bf16 W on [0.5, 1)

@@ -33,7 +33,7 @@ def test_version_and_error_channel(lib_path):
     from gnn_tracking_amd import _capi
 
     lib = _capi.bind(ctypes.CDLL(str(lib_path)))
-    assert lib.gnntrk_version() == 203
+    assert lib.gnntrk_version() == 300
     # argument validation happens on the host, before any launch
     rc = lib.gnntrk_mlp_forward(None, None)
     assert rc == 1 and b"NULL" in lib.gnntrk_last_error()
@@ -47,6 +47,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.MlpFwdArgs) == 448
     assert _capi.MlpFwdArgs.n_rows.offset == 392
     assert ctypes.sizeof(_capi.GraphIndex) == 72
+    assert ctypes.sizeof(_capi.GraphIndexCarry) == 40
     assert ctypes.sizeof(_capi.MlpBwdArgs) == 760
 
 

@@ -17,6 +17,12 @@ def test_graph_index():
         P.case_graph_index("cpu")
 
 
+def test_graph_index_carry_and_fused_bce():
+    with emulated():
+        P.case_graph_index_carry("cpu")
+        P.case_ec_carry_equals_gather("cpu")
+
+
 def test_fused_mlp_forward_backward():
     with emulated():
         P.case_mlp("cpu")

@@ -15,12 +15,17 @@ def dev():
     from gnn_tracking_amd import _capi
 
     lib = _capi.load()  # fails loudly if the extension is missing
-    assert lib.gnntrk_version() >= 203
+    assert lib.gnntrk_version() == 300
     return "cuda"
 
 
 def test_graph_index(dev):
     P.case_graph_index(dev, big=True)
+
+
+def test_graph_index_carry_and_fused_bce(dev):
+    P.case_graph_index_carry(dev)
+    P.case_ec_carry_equals_gather(dev)
 
 
 def test_fused_mlp_forward_backward(dev):

@@ -22,7 +22,7 @@ LIB_PATH = _PKG / "libgnntrk.so"
 
 class Seg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("dim", C.c_int32),
-                ("stride", C.c_int32), ("relu", C.c_int32), ("_pad", C.c_int32)]
+                ("stride", C.c_int32), ("relu", C.c_int32), ("rows", C.c_int32)]
 
 
 class Mlp(C.Structure):
@@ -40,7 +40,7 @@ class MlpFwdArgs(C.Structure):
 
 class GTerm(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("stride", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("rows", C.c_int32)]
 
 
 class GSeg(C.Structure):

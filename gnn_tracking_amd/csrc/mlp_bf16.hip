@@ -6,7 +6,7 @@
 
 namespace gnntrk {
 
-int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, int KI, int HT, int GT, int grid, float *part,
+int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, float *part,
                      uint8_t *trash, hipStream_t stream);  // mlp_bf16_g32.hip
 
 
@@ -29,8 +29,12 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
     const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
     const int D = (P.KI == 1 && P.HT <= 3 && !(a->debug_flags & 64)) ? 2 : 1;  // as launch_bwd16 dispatches
-    snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s, %d>", P.KI, P.HT, GT,
-             a->mlp.n_layers == 3 ? "true" : "false", a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false", D);
+    const bool g32 = a->epilogue == GNNTRK_EPI_SIGMOID;
+    BufPlan B;
+    make_buf_plan(B, P, a, GT);
+    const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, g32, a->debug_flags);
+    snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s, %d, %s>", P.KI, P.HT, GT,
+             a->mlp.n_layers == 3 ? "true" : "false", g32 ? "true" : "false", D, io[0] ? io : "IoNone");
     return GNNTRK_OK;
 }
 
@@ -87,7 +91,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
         float *part = reinterpret_cast<float *>(ws);
         uint8_t *trash = reinterpret_cast<uint8_t *>(ws) + bwd16_partial_bytes(&a->mlp);
         rc = (a->epilogue == GNNTRK_EPI_SIGMOID)
-                 ? launch_bwd16_g32(a, P.KI, P.HT, GT, grid, part, trash, stream)
+                 ? launch_bwd16_g32(a, P, GT, grid, part, trash, stream)
                  : launch_bwd16<false>(a, P, GT, grid, part, trash, stream);
         if (rc) return rc;
     }

@@ -5,11 +5,8 @@
 
 namespace gnntrk {
 
-int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, int KI, int HT, int GT, int grid, float *part,
+int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, float *part,
                      uint8_t *trash, hipStream_t stream) {
-    SlotPlan P;
-    P.KI = KI;
-    P.HT = HT;
     return launch_bwd16<true>(a, P, GT, grid, part, trash, stream);
 }
 

@@ -15,6 +15,8 @@
 // weights are read-only LDS fragments.  Latency is covered by a one-tile software prefetch
 // plus the 4-6 waves per SIMD the small register footprint allows.
 #pragma once
+#include <cstdio>
+#include <cstring>
 #include <type_traits>
 
 #include <hip/hip_runtime.h>
@@ -538,7 +540,10 @@ __device__ __forceinline__ void pack_backward_weights(uint32_t *img, const AugWe
                           [&](int m, int f) {
                               const int q = m >> 2;
                               if (q >= P.n_gchunks) return 0.f;
-                              return w.w1(f, slot_col(P, seg, 4 * P.gchunk[q] + (m & 3)));
+                              // (pad slots and the ones slot have no input gradient: zero columns, so the
+                              //  pad elements of a gradient row are +0 without a mask)
+                              const int col = slot_col(P, seg, 4 * P.gchunk[q] + (m & 3));
+                              return col >= 0 ? w.w1(f, col) : 0.f;
                           },
                           tid, nthreads);
 }
@@ -548,9 +553,108 @@ struct RawGout {
     u32x4 v;
 };
 
-template <int KI, int HT, int GT, bool THREE, bool G32, int D>
+// ---- buffer-addressed I/O of the backward tile loop ----------------------------------------
+// The generic I/O above gives every lane its own pointers (lanes of one load read different
+// tensors): per tile and half about 45 VALU instructions of 64-bit address arithmetic, "no index"
+// selects, pad masks and store redirections next to about 95 of arithmetic - in a kernel whose
+// issue port is full.  For the shapes of the default models the same accesses are made through
+// WAVE-UNIFORM buffer descriptors (tile_bf16.h): one access per TENSOR, executed by all lanes; a
+// lane that takes no part carries the offset 2^31 and falls out in the hardware range check, as do
+// rows past the end; rows of the tile itself go through the scalar offset, gathered rows through
+// `(id << log2(row bytes)) + lane constant`.  What an access looks like is split into a
+// compile-time shape (which lanes, which id streams, width: BufOpShape, one IoXxx class per
+// supported shape) and run-time arguments (BufOpArgs); the host builds both from the segment list
+// (make_buf_plan) and takes the buffer form when the shape matches an IoXxx class, every tensor
+// states its size (gnntrk_seg.rows) and stays below 2^31 bytes with power-of-two row sizes.
+// Padding elements of input rows are read as stored: every producer of padded bf16 rows in this
+// library writes them as zero (include/gnntrk.h).
+constexpr int kBufLoads = 6, kBufIds = 3, kBufStores = 6, kBufGouts = 2;
+constexpr uint32_t kBufOut = 0x80000000u;   // lane offset of a lane that takes no part
+
+struct BufOpShape {
+    uint8_t w16;       // 16-byte access (else 8 bytes; the fp32 upstream gradient: 4)
+    uint8_t gathered;  // rows through an id stream (else the tile's own rows)
+    int8_t sa, sb;     // id streams of the lanes that take part (sb = -1: one stream)
+    uint8_t part;      // bit g: lane group g takes part
+    uint8_t use_b;     // bit g: lane group g reads stream sb
+    uint8_t slot;      // loads: dword of the B operand the data lands in (0 / 2); stores: gradient tile T
+    uint8_t _pad;
+};
+// (what the tile loop needs at compile time; `part` / `use_b` only feed lane constants in the prologue)
+__host__ __device__ constexpr bool same_shape(const BufOpShape &x, const BufOpShape &y) {
+    return x.w16 == y.w16 && x.gathered == y.gathered && x.sa == y.sa && x.sb == y.sb && x.slot == y.slot;
+}
+struct BufOpArgs {
+    const void *ptr;
+    uint32_t bytes;
+    uint8_t shift;    // log2(bytes per row)
+    uint8_t off8[4];  // byte offset inside the row per lane group
+    uint8_t _pad[3];
+};
+struct BufPlan {
+    int32_t ok, n_load, n_ids, n_sids, n_store, n_gout;
+    int32_t ones_dword;   // dword of the B operand holding the ones slot (-1: none), its lane group, its value
+    int32_t ones_group;
+    uint32_t ones_bits;
+    int32_t any_relu;
+    int32_t gate_mode;    // relu' on the input gradients: 0 no segment, 1 every segment, 2 mixed
+    uint32_t rmin[4][2];  // per lane group and chunk of the pair: 0 (ReLU on load) or 0x80008000
+    BufOpShape load_s[kBufLoads], gout_s[kBufGouts], store_s[kBufStores];
+    BufOpArgs load[kBufLoads], gout[kBufGouts], store[kBufStores];
+    BufOpArgs ids[kBufIds], sids[kBufIds];   // int32 id streams of the loads (one unit ahead) / of the stores
+};
+
+struct IoNone {   // the generic per-lane I/O
+    static constexpr int NL = 0, NI = 0, NSI = 0, NS = 0, NG = 0, kOnesDword = -1;
+    static constexpr BufOpShape load[1] = {}, gout[1] = {}, store[1] = {};
+};
+// relational model of an interaction network (interaction_network.py:75-89): x[tgt] | x[src] (16-byte
+// node rows, one descriptor, two id streams), e (8-byte rows of the tile); upstream gradient
+// g_e~ + g_aggr[tgt]; gradient slices g_x_i (tile rows), g_x_j (rows through the source-sort
+// permutation), g_e
+struct IoRelational {
+    static constexpr int NL = 2, NI = 2, NSI = 1, NS = 3, NG = 2, kOnesDword = 2;
+    static constexpr BufOpShape load[2] = {{1, 1, 0, 1, 0b0011, 0b0010, 0, 0}, {0, 0, -1, -1, 0b0100, 0, 0, 0}};
+    static constexpr BufOpShape gout[2] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 1, 0, -1, 0b0001, 0, 0, 0}};
+    static constexpr BufOpShape store[3] = {{0, 0, -1, -1, 0b0011, 0, 0, 0}, {0, 1, 0, -1, 0b1100, 0, 0, 0},
+                                            {0, 0, -1, -1, 0b0001, 0, 1, 0}};
+};
+// object model (interaction_network.py:92-103): x (16-byte rows) | aggr (8-byte rows), all rows of
+// the tile; one upstream term; gradient slices g_x, g_aggr
+struct IoObject {
+    static constexpr int NL = 2, NI = 0, NSI = 0, NS = 2, NG = 1, kOnesDword = 2;
+    static constexpr BufOpShape load[2] = {{1, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 0, -1, -1, 0b0010, 0, 0, 0}};
+    static constexpr BufOpShape gout[1] = {{0, 0, -1, -1, 0b0011, 0, 0, 0}};
+    static constexpr BufOpShape store[2] = {{0, 0, -1, -1, 0b0011, 0, 0, 0}, {0, 0, -1, -1, 0b0100, 0, 0, 0}};
+};
+// the edge-weight head (edge_classifier.py:108-116): h[src] | h[tgt] (16-byte node rows, one descriptor,
+// two id streams), four 8-byte edge tensors of the tile's rows; fp32 upstream gradient of the one
+// weight per edge; gradient slices g_h[src] (rows through the source-sort permutation), g_h[tgt],
+// g_e0 .. g_e3
+struct IoHead {
+    static constexpr int NL = 5, NI = 2, NSI = 1, NS = 6, NG = 1, kOnesDword = 2;
+    static constexpr BufOpShape load[5] = {{1, 1, 0, 1, 0b0011, 0b0010, 0, 0}, {0, 0, -1, -1, 0b0100, 0, 0, 0},
+                                           {0, 0, -1, -1, 0b0100, 0, 2, 0}, {0, 0, -1, -1, 0b1000, 0, 0, 0},
+                                           {0, 0, -1, -1, 0b1000, 0, 2, 0}};
+    static constexpr BufOpShape gout[1] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}};
+    static constexpr BufOpShape store[6] = {{0, 1, 0, -1, 0b0011, 0, 0, 0}, {0, 0, -1, -1, 0b1100, 0, 0, 0},
+                                            {0, 0, -1, -1, 0b0001, 0, 1, 0}, {0, 0, -1, -1, 0b0010, 0, 1, 0},
+                                            {0, 0, -1, -1, 0b0100, 0, 1, 0}, {0, 0, -1, -1, 0b1000, 0, 1, 0}};
+};
+// bias-free encoder of 8-byte rows (edge_classifier.py:66-69 on the four edge features): one tensor,
+// rows of the tile, weight gradients only
+struct IoEncoder8 {
+    static constexpr int NL = 1, NI = 0, NSI = 0, NS = 0, NG = 1, kOnesDword = -1;
+    static constexpr BufOpShape load[1] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}};
+    static constexpr BufOpShape gout[1] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}};
+    static constexpr BufOpShape store[1] = {};
+};
+
+template <int KI, int HT, int GT, bool THREE, bool G32, int D, class IO = IoNone>
 __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
-                                                              uint8_t *trash) {
+                                                              uint8_t *trash, const BufPlan bp) {
+    constexpr bool BUF = IO::NL > 0;
+    static_assert(!BUF || KI == 1, "buffer-addressed I/O: one k-step");
     using I = BwdImg<KI, HT, GT, THREE>;
     using F = FwdImg<KI, HT>;
     using S = BwdStage<KI, HT>;
@@ -615,6 +719,46 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         gkeep[T][0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
         gkeep[T][1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
     }
+    // buffer-addressed I/O: descriptors (SGPRs) and lane-constant offsets of every access
+    constexpr int NLA = BUF ? IO::NL : 1, NIA = IO::NI > 0 ? IO::NI : 1, NSIA = IO::NSI > 0 ? IO::NSI : 1,
+                  NSA = IO::NS > 0 ? IO::NS : 1, NGA = IO::NG > 0 ? IO::NG : 1;
+    buf_rsrc_t r_ld[NLA], r_id[NIA], r_sid[NSIA], r_go[NGA], r_st[NSA];
+    uint32_t v_ld[NLA], v_go[NGA], v_st[NSA];   // lane offsets (kBufOut: the lane takes no part)
+    bool b_ld[NLA];                             // the lane reads id stream sb of a two-stream load
+    uint32_t ones_v = 0u, rmin_v[2] = {0x80008000u, 0x80008000u};
+    const uint32_t v_c4 = 4u * (uint32_t)c;
+    if constexpr (BUF) {
+        auto lane_off = [&](const BufOpShape &sh, const BufOpArgs &ar, bool gathered) -> uint32_t {
+            const bool on = (sh.part >> g) & 1;
+            const uint32_t off = g == 0 ? ar.off8[0] : g == 1 ? ar.off8[1] : g == 2 ? ar.off8[2] : ar.off8[3];
+            return on ? (gathered ? off : ((uint32_t)c << ar.shift) + off) : kBufOut;
+        };
+#pragma unroll
+        for (int i = 0; i < IO::NL; ++i) {
+            r_ld[i] = buf_make(bp.load[i].ptr, bp.load[i].bytes);
+            v_ld[i] = lane_off(bp.load_s[i], bp.load[i], IO::load[i].gathered);
+            b_ld[i] = (bp.load_s[i].use_b >> g) & 1;
+        }
+#pragma unroll
+        for (int i = 0; i < IO::NI; ++i) r_id[i] = buf_make(bp.ids[i].ptr, bp.ids[i].bytes);
+#pragma unroll
+        for (int i = 0; i < IO::NSI; ++i) r_sid[i] = buf_make(bp.sids[i].ptr, bp.sids[i].bytes);
+#pragma unroll
+        for (int i = 0; i < IO::NG; ++i) {
+            r_go[i] = buf_make(bp.gout[i].ptr, bp.gout[i].bytes);
+            v_go[i] = lane_off(bp.gout_s[i], bp.gout[i], IO::gout[i].gathered);
+        }
+#pragma unroll
+        for (int i = 0; i < IO::NS; ++i) {
+            r_st[i] = buf_make(bp.store[i].ptr, bp.store[i].bytes);
+            v_st[i] = lane_off(bp.store_s[i], bp.store[i], IO::store[i].gathered);
+        }
+        ones_v = g == bp.ones_group ? bp.ones_bits : 0u;
+        rmin_v[0] = g == 0 ? bp.rmin[0][0] : g == 1 ? bp.rmin[1][0] : g == 2 ? bp.rmin[2][0] : bp.rmin[3][0];
+        rmin_v[1] = g == 0 ? bp.rmin[0][1] : g == 1 ? bp.rmin[1][1] : g == 2 ? bp.rmin[2][1] : bp.rmin[3][1];
+    }
+    const bool any_relu = BUF && bp.any_relu != 0;
+    const int gate_mode = BUF ? bp.gate_mode : 2;
     // W1 column of the input slot 16 ts + c (partials of dW1')
     int32_t col1[2 * KI];
 #pragma unroll
@@ -686,20 +830,84 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
     int32_t grow[D][2];
     RawTile<KI> cur[D], nxt[D];
     RawGout gcur[D], gnxt[D];
+    // buffer form: ids of the load streams (one unit ahead of the raw loads), raw results per access
+    uint32_t idv[D][NIA];
+    struct RawBuf {
+        u32x4 w16[NLA];   // (an 8-byte access uses the first two dwords)
+    };
+    RawBuf bcur[D], bnxt[BUF ? 1 : D];
     // D = 1: one 16-row tile per iteration.  D = 2: a wave owns SUPER tiles of 32 consecutive rows
     // and walks the two 16-row halves stage by stage (two independent dependency chains in one
     // instruction stream: the LDS round trips and MFMA latencies of one half hide behind the
     // other), and the weight-gradient contractions run over all 32 rows with K = 32 MFMAs.
     auto tile_of = [&](int64_t grp, int d) { return (sch.cur + grp * sch.step) * D + d; };
-    auto ids_of = [&](int64_t grp, int d) {
-        const int32_t row = clamp_row(tile_of(grp, d));
-        load_row_ids<KI>(L, row, rid[d]);
-        const int32_t i0 = go_idx0[row], i1 = go_idx1[row];
-        grow[d][0] = gi0_on ? i0 : row;
-        grow[d][1] = gi1_on ? i1 : row;
+    // first row of half d of unit grp as a scalar (buffer form: rows past the end fall out in the
+    // range check of the descriptors, so nothing is clamped; units past the wave's last one read
+    // rows of other waves, or nothing)
+    // (32-bit scalar arithmetic: the launcher takes the buffer form only for tensors below 2^31 bytes,
+    //  so even two units past the end the byte offsets stay below 2^32)
+    const uint32_t u_cur = (uint32_t)sch.cur, u_step = (uint32_t)sch.step;
+    auto row0_of = [&](int grp, int d) -> uint32_t {
+        return ((u_cur + (uint32_t)grp * u_step) * (uint32_t)D + (uint32_t)d) * (uint32_t)kTileRows;
     };
-    auto load_gout = [&](int d, RawGout &r) {
-        if (G32) {
+    auto ids_of = [&](int grp, int d) {
+        if constexpr (BUF) {
+            const uint32_t r0 = row0_of(grp, d);
+#pragma unroll
+            for (int i = 0; i < IO::NI; ++i) idv[d][i] = buf_load_u32(r_id[i], v_c4, r0 << 2);
+        } else {
+            const int32_t row = clamp_row(tile_of(grp, d));
+            load_row_ids<KI>(L, row, rid[d]);
+            const int32_t i0 = go_idx0[row], i1 = go_idx1[row];
+            grow[d][0] = gi0_on ? i0 : row;
+            grow[d][1] = gi1_on ? i1 : row;
+        }
+    };
+    // one access of the buffer form: lane offset + scalar offset from the shape
+    auto buf_addr = [&](const BufOpShape &sh, const BufOpArgs &ar, uint32_t v_lane, bool use_b, const uint32_t *ids,
+                        uint32_t r0, uint32_t &voff, uint32_t &soff) {
+        if (sh.gathered) {
+            uint32_t id = ids[sh.sa < 0 ? 0 : sh.sa];
+            if (sh.sb >= 0) id = use_b ? ids[sh.sb] : id;
+            voff = (id << ar.shift) + v_lane;
+            soff = 0u;
+        } else {
+            voff = v_lane;
+            soff = r0 << ar.shift;
+        }
+    };
+    auto load_raw_buf = [&](int grp, int d, RawBuf &t) {
+        const uint32_t r0 = row0_of(grp, d);
+#pragma unroll
+        for (int i = 0; i < IO::NL; ++i) {
+            uint32_t voff, soff;
+            buf_addr(IO::load[i], bp.load[i], v_ld[i], b_ld[i], idv[d], r0, voff, soff);
+            if (IO::load[i].w16) {
+                t.w16[i] = buf_load_u32x4(r_ld[i], voff, soff);
+            } else {
+                const u32x2 h = buf_load_u32x2(r_ld[i], voff, soff);
+                t.w16[i][0] = h[0];
+                t.w16[i][1] = h[1];
+            }
+        }
+    };
+    auto load_gout = [&](int grp, int d, RawGout &r) {
+        if constexpr (BUF) {
+            const uint32_t r0 = row0_of(grp, d);
+            r.v = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < IO::NG; ++t) {
+                uint32_t voff, soff;
+                buf_addr(IO::gout[t], bp.gout[t], v_go[t], false, idv[d], r0, voff, soff);
+                if (G32) {   // fp32 upstream gradient of a one-column output (the edge-weight head)
+                    r.v[0] = buf_load_u32(r_go[t], voff, soff);
+                } else {
+                    const u32x2 h = buf_load_u32x2(r_go[t], voff, soff);
+                    r.v[2 * t] = h[0];
+                    r.v[2 * t + 1] = h[1];
+                }
+            }
+        } else if (G32) {
             const float GNNTRK_GLOBAL *p = (gcf_ptr) reinterpret_cast<const float *>(gp0) + (int64_t)grow[d][0] * gs0;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) r.v[r4] = __float_as_uint(p[gcol[r4]]);
@@ -714,15 +922,19 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             r.v[3] = two_terms ? t1[1] : 0u;
         }
     };
+    auto load_unit = [&](int grp, int d, RawTile<KI> &t, RawBuf &tb, RawGout &go) {
+        if constexpr (BUF)
+            load_raw_buf(grp, d, tb);
+        else
+            load_raw<KI>(L, rid[d], t);
+        load_gout(grp, d, go);
+    };
 
     if (sch.cur < sch.end) {
 #pragma unroll
         for (int d = 0; d < D; ++d) ids_of(0, d);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            load_raw<KI>(L, rid[d], cur[d]);
-            load_gout(d, gcur[d]);
-        }
+        for (int d = 0; d < D; ++d) load_unit(0, d, cur[d], bcur[d], gcur[d]);
 #pragma unroll
         for (int d = 0; d < D; ++d) ids_of(1, d);
     }
@@ -747,26 +959,35 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
     // selects are a tenth of the loop's VALU work) and with them for that one unit.
     auto tile_step = [&](auto tail_tag, int grp) __attribute__((always_inline)) {
         constexpr bool kTail = decltype(tail_tag)::value;
+        // generic form: the next unit's raw data into a second set of registers, rotated at the end of
+        // the step.  Buffer form: issued below, as soon as S0 / S1 have consumed the current unit's
+        // registers - straight into them (no rotation moves, a dozen registers less).
+        if constexpr (!BUF) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            load_raw<KI>(L, rid[d], nxt[d]);
-            load_gout(d, gnxt[d]);
+            for (int d = 0; d < D; ++d) load_unit(grp + 1, d, nxt[d], bnxt[d], gnxt[d]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) ids_of(grp + 2, d);
         }
-#pragma unroll
-        for (int d = 0; d < D; ++d) ids_of(grp + 2, d);
 
         // (kTail: rows past the end run as invalid rows: zero upstream gradient, stores redirected)
         bool valid[D];
         int32_t srow[D][GTA];  // destination rows of the input-gradient slices
+        uint32_t sidv[D][NSIA];  // buffer form: ids of the store streams, this unit's rows
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int64_t tile = tile_of(grp, d);
             valid[d] = !kTail || (tile < n_tiles && tile * kTileRows + c < a.n_rows);
-            const int32_t rc = clamp_row(tile);
+            if constexpr (BUF) {
+                const uint32_t r0 = row0_of(grp, d);
 #pragma unroll
-            for (int T = 0; T < GT; ++T) {
-                const int32_t v = gidx[T][rc];
-                srow[d][T] = gidx_on[T] ? v : rc;
+                for (int i = 0; i < IO::NSI; ++i) sidv[d][i] = buf_load_u32(r_sid[i], v_c4, r0 << 2);
+            } else {
+                const int32_t rc = clamp_row(tile);
+#pragma unroll
+                for (int T = 0; T < GT; ++T) {
+                    const int32_t v = gidx[T][rc];
+                    srow[d][T] = gidx_on[T] ? v : rc;
+                }
             }
         }
 
@@ -777,10 +998,42 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             u32x4 B[D][KI];
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                finish_inputs<KI>(L, cur[d], B[d]);
+                if constexpr (BUF) {
+                    // the accesses cover disjoint (lane group, dword) positions and return zero
+                    // elsewhere: OR them together; pads are stored as zero; ones slot; optional ReLU
+                    u32x4 m = IO::load[0].w16 ? bcur[d].w16[0] : u32x4{0u, 0u, 0u, 0u};
+                    if (!IO::load[0].w16) {
+                        m[IO::load[0].slot] = bcur[d].w16[0][0];
+                        m[IO::load[0].slot + 1] = bcur[d].w16[0][1];
+                    }
+#pragma unroll
+                    for (int i = 1; i < IO::NL; ++i) {
+                        if (IO::load[i].w16) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) m[w] |= bcur[d].w16[i][w];
+                        } else {
+                            m[IO::load[i].slot] |= bcur[d].w16[i][0];
+                            m[IO::load[i].slot + 1] |= bcur[d].w16[i][1];
+                        }
+                    }
+                    if (IO::kOnesDword >= 0) m[IO::kOnesDword >= 0 ? IO::kOnesDword : 0] |= ones_v;
+                    if (any_relu) {
+                        m[0] = i16x2_max(m[0], rmin_v[0]);
+                        m[1] = i16x2_max(m[1], rmin_v[0]);
+                        m[2] = i16x2_max(m[2], rmin_v[1]);
+                        m[3] = i16x2_max(m[3], rmin_v[1]);
+                    }
+                    B[d][0] = m;
+                } else {
+                    finish_inputs<KI>(L, cur[d], B[d]);
+                }
 #pragma unroll
                 for (int kk = 0; kk < KI; ++kk)
                     *reinterpret_cast<u32x4 *>(stIn[d] + c * S::kInRow + ((64 * kk + 16 * g) ^ in_swz)) = B[d][kk];
+            }
+            if constexpr (BUF) {   // (the raw input registers are free: the next unit's rows go straight into them)
+#pragma unroll
+                for (int d = 0; d < D; ++d) load_raw_buf(grp + 1, d, bcur[d]);
             }
             hidden_chain_d<KI, HT, THREE, D>(wimg, B, lane, P1, P2);
         }
@@ -801,7 +1054,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 gy[2] = bf16_lo(gcur[d].v[1]) + bf16_lo(gcur[d].v[3]);
                 gy[3] = bf16_hi(gcur[d].v[1]) + bf16_hi(gcur[d].v[3]);
             }
-            if (!(out_lane && valid[d])) gy = zero;
+            if constexpr (BUF) {   // (lanes without output features loaded zeros)
+                if (G32) gy[1] = gy[2] = gy[3] = 0.f;
+                if (kTail && !valid[d]) gy = zero;
+            } else {
+                if (!(out_lane && valid[d])) gy = zero;
+            }
             if (need_y) {
                 const f32x4 y = contract_hidden<HT>(wimg + F::kA3, PL(d), lane, zero);
 #pragma unroll
@@ -818,8 +1076,17 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 for (int r = 0; r < 4; ++r) gy[r] *= a.cb;
             }
             g3[d] = pack_tile(gy);
-            g3[d][0] &= okeep[0];
-            g3[d][1] &= okeep[1];
+            if constexpr (!BUF) {   // (buffer form: lanes / features without data loaded zeros)
+                g3[d][0] &= okeep[0];
+                g3[d][1] &= okeep[1];
+            }
+        }
+
+        if constexpr (BUF) {   // (the upstream-gradient registers are free: next unit's terms, then the ids after it)
+#pragma unroll
+            for (int d = 0; d < D; ++d) load_gout(grp + 1, d, gcur[d]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) ids_of(grp + 2, d);
         }
 
         // ---- S2 / S3 interleaved: every dW stage reuses the staging images --------------
@@ -920,13 +1187,37 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             for (int d = 0; d < D; ++d) {
                 u32x2 gi = pack_tile(accs[d]);
                 const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn[d] + c * S::kInRow + (gin_off[T] ^ in_swz));
-                gi[0] = u16x2_mul(gi[0], (i16x2_min(xin[0], k_one) & gmul_and[T]) | gmul_or[T]);
-                gi[1] = u16x2_mul(gi[1], (i16x2_min(xin[1], k_one) & gmul_and[T]) | gmul_or[T]);
-                gi[0] &= gkeep[T][0];
-                gi[1] &= gkeep[T][1];
-                // (lanes without a chunk already point at their trash slot with stride 0)
-                const gh_ptr dst = gptr[T] + (int64_t)srow[d][T] * gstride[T];
-                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(valid[d] ? dst : my_trash) = gi;
+                if constexpr (BUF) {
+                    // relu' of the inputs: none / all of the segments (a uniform branch) or mixed; the pad
+                    // slots of a gradient row come out as +0 by themselves (zero columns of W1'^T)
+                    if (gate_mode == 1) {
+                        gi[0] = gate_bf16x2(gi[0], xin[0], k_one);
+                        gi[1] = gate_bf16x2(gi[1], xin[1], k_one);
+                    } else if (gate_mode == 2) {
+                        gi[0] = u16x2_mul(gi[0], (i16x2_min(xin[0], k_one) & gmul_and[T]) | gmul_or[T]);
+                        gi[1] = u16x2_mul(gi[1], (i16x2_min(xin[1], k_one) & gmul_and[T]) | gmul_or[T]);
+                    }
+                } else {
+                    gi[0] = u16x2_mul(gi[0], (i16x2_min(xin[0], k_one) & gmul_and[T]) | gmul_or[T]);
+                    gi[1] = u16x2_mul(gi[1], (i16x2_min(xin[1], k_one) & gmul_and[T]) | gmul_or[T]);
+                    gi[0] &= gkeep[T][0];
+                    gi[1] &= gkeep[T][1];
+                }
+                if constexpr (BUF) {   // one store per gradient tensor of this tile; other lanes fall out
+                    const uint32_t r0 = row0_of(grp, d);
+#pragma unroll
+                    for (int i = 0; i < IO::NS; ++i)
+                        if (IO::store[i].slot == T) {
+                            uint32_t voff, soff;
+                            buf_addr(IO::store[i], bp.store[i], v_st[i], false, sidv[d], r0, voff, soff);
+                            if (kTail && !valid[d]) voff = kBufOut;
+                            buf_store_u32x2(gi, r_st[i], voff, soff);
+                        }
+                } else {
+                    // (lanes without a chunk already point at their trash slot with stride 0)
+                    const gh_ptr dst = gptr[T] + (int64_t)srow[d][T] * gstride[T];
+                    *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(valid[d] ? dst : my_trash) = gi;
+                }
             }
         }
         {
@@ -948,10 +1239,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             }
         }
         lds_wave_sync();  // the next tile overwrites the images
+        if constexpr (!BUF) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            cur[d] = nxt[d];
-            gcur[d] = gnxt[d];
+            for (int d = 0; d < D; ++d) {
+                cur[d] = nxt[d];
+                gcur[d] = gnxt[d];
+            }
         }
     };
     const int64_t n_units = (n_tiles + D - 1) / D;
@@ -1083,9 +1376,188 @@ int grid16(int64_t n_rows, int blocks_per_cu, int waves) {
     return (int)g;
 }
 
+// ---- host: the buffer-addressed form of a backward launch (see BufPlan) ------------------------
+inline bool buf_pow2(int64_t bytes, uint8_t &shift) {
+    for (int sft = 2; sft <= 8; ++sft)
+        if (((int64_t)1 << sft) == bytes) {
+            shift = (uint8_t)sft;
+            return true;
+        }
+    return false;
+}
+inline int buf_stream(BufOpArgs *arr, int &n, const void *idx, int64_t n_rows) {
+    for (int i = 0; i < n; ++i)
+        if (arr[i].ptr == idx) return i;
+    if (n >= kBufIds) return -1;
+    arr[n].ptr = idx;
+    arr[n].bytes = (uint32_t)(n_rows * 4);
+    arr[n].shift = 2;
+    return n++;
+}
+// adds lane group g to an access of `ptr` (merging into an existing access of the same tensor / form)
+inline bool buf_add(BufOpShape *sh, BufOpArgs *ar, int &n, int cap, const void *ptr, int64_t bytes, uint8_t shift,
+                    bool w16, bool gathered, int stream, int slot, int g, int off8) {
+    if (bytes <= 0 || bytes >= (int64_t)kBufOut || off8 < 0 || off8 > 255) return false;
+    for (int i = 0; i < n; ++i) {
+        if (ar[i].ptr != ptr || sh[i].w16 != (uint8_t)w16 || sh[i].gathered != (uint8_t)gathered || sh[i].slot != slot ||
+            ((sh[i].part >> g) & 1))
+            continue;
+        bool use_b = false;
+        if (gathered && stream != sh[i].sa) {
+            if (sh[i].sb < 0)
+                sh[i].sb = (int8_t)stream;
+            else if (sh[i].sb != stream)
+                continue;
+            use_b = true;
+        }
+        sh[i].part |= (uint8_t)(1u << g);
+        if (use_b) sh[i].use_b |= (uint8_t)(1u << g);
+        ar[i].off8[g] = (uint8_t)off8;
+        return true;
+    }
+    if (n >= cap) return false;
+    sh[n] = BufOpShape{(uint8_t)w16, (uint8_t)gathered, (int8_t)(gathered ? stream : -1), -1, (uint8_t)(1u << g), 0,
+                       (uint8_t)slot, 0};
+    ar[n] = BufOpArgs{ptr, (uint32_t)bytes, shift, {0, 0, 0, 0}, {0, 0, 0}};
+    ar[n].off8[g] = (uint8_t)off8;
+    ++n;
+    return true;
+}
+
+inline void make_buf_plan(BufPlan &B, const SlotPlan &P, const gnntrk_mlp_bwd_args *a, int GT) {
+    memset(&B, 0, sizeof(B));
+    B.ones_dword = -1;
+    B.ones_group = -1;
+    if (P.KI != 1 || a->n_rows <= 0) return;
+    const int64_t M = a->n_rows;
+    // inputs: lane group g owns the chunk pair (2g, 2g + 1)
+    for (int g = 0; g < 4; ++g) {
+        B.rmin[g][0] = B.rmin[g][1] = 0x80008000u;
+        const int p0 = 2 * g, p1 = 2 * g + 1;
+        const int j0 = (p0 < P.n_chunks) ? P.seg[p0] : -1, j1 = (p1 < P.n_chunks) ? P.seg[p1] : -1;
+        for (int h = 0; h < 2; ++h) {
+            const int j = h ? j1 : j0;
+            if (j >= 0 && a->seg[j].relu) {
+                B.rmin[g][h] = 0u;
+                B.any_relu = 1;
+            }
+        }
+        auto tensor = [&](int j, int64_t &bytes, uint8_t &shift, bool &gathered, int &stream) -> bool {
+            const gnntrk_seg &sg = a->seg[j];
+            if (sg.rows <= 0 || !buf_pow2((int64_t)sg.stride * 2, shift)) return false;
+            bytes = (int64_t)sg.rows * sg.stride * 2;
+            gathered = sg.idx != nullptr;
+            stream = gathered ? buf_stream(B.ids, B.n_ids, sg.idx, M) : -1;
+            if (!gathered && sg.rows < M) return false;
+            return !gathered || stream >= 0;
+        };
+        int64_t bytes;
+        uint8_t shift;
+        bool gathered;
+        int stream;
+        const bool row16 = j0 >= 0 && j1 == j0 && P.first[p1] == P.first[p0] + 1 && (P.first[p0] & 1) == 0 &&
+                           (a->seg[j0].stride * 2) % 16 == 0 && ((uintptr_t)a->seg[j0].ptr & 15) == 0;
+        if (row16) {
+            if (!tensor(j0, bytes, shift, gathered, stream)) return;
+            if (!buf_add(B.load_s, B.load, B.n_load, kBufLoads, a->seg[j0].ptr, bytes, shift, true, gathered, stream, 0, g,
+                         8 * P.first[p0]))
+                return;
+        } else {
+            for (int h = 0; h < 2; ++h) {
+                const int j = h ? j1 : j0, p = h ? p1 : p0;
+                if (j < 0) continue;
+                if (!tensor(j, bytes, shift, gathered, stream)) return;
+                if (!buf_add(B.load_s, B.load, B.n_load, kBufLoads, a->seg[j].ptr, bytes, shift, false, gathered, stream,
+                             2 * h, g, 8 * P.first[p]))
+                    return;
+            }
+        }
+    }
+    if (B.n_load < 1) return;
+    if (P.ones_slot >= 0) {
+        const int p = P.ones_slot >> 2, r = P.ones_slot & 3;
+        B.ones_group = p >> 1;
+        B.ones_dword = 2 * (p & 1) + (r >> 1);
+        B.ones_bits = kBf16One << (16 * (r & 1));
+    }
+    // upstream gradient terms
+    const bool g32 = a->epilogue == GNNTRK_EPI_SIGMOID;
+    for (int t = 0; t < a->n_gout; ++t) {
+        const gnntrk_gterm &gt = a->gout[t];
+        uint8_t shift;
+        if (gt.rows <= 0 || !buf_pow2((int64_t)gt.stride * (g32 ? 4 : 2), shift)) return;
+        if (g32 && a->mlp.out_dim != 1) return;
+        const int64_t bytes = (int64_t)gt.rows * gt.stride * (g32 ? 4 : 2);
+        const bool gathered = gt.idx != nullptr;
+        const int stream = gathered ? buf_stream(B.ids, B.n_ids, gt.idx, M) : -1;
+        if ((gathered && stream < 0) || (!gathered && gt.rows < M)) return;
+        const int before = B.n_gout;
+        for (int g = 0; g < 4; ++g) {
+            if (4 * g >= a->mlp.out_dim) break;
+            // (one access per term: a term never merges with another one)
+            int n = (g == 0) ? B.n_gout : before;
+            if (g == 0) {
+                if (!buf_add(B.gout_s, B.gout, n, kBufGouts, gt.ptr, bytes, shift, false, gathered, stream, 0, g, 8 * g)) return;
+                B.n_gout = n;
+            } else {
+                B.gout_s[before].part |= (uint8_t)(1u << g);
+                B.gout[before].off8[g] = (uint8_t)(8 * g);
+            }
+        }
+        if (B.n_gout != before + 1) return;
+    }
+    {
+        int n_relu = 0, n_plain = 0;
+        for (int q = 0; q < P.n_gchunks; ++q) (a->seg[P.seg[P.gchunk[q]]].relu ? n_relu : n_plain)++;
+        B.gate_mode = n_relu == 0 ? 0 : n_plain == 0 ? 1 : 2;
+    }
+    // gradient slices: chunk q = 4T + g
+    for (int T = 0; T < GT; ++T)
+        for (int g = 0; g < 4; ++g) {
+            const int q = 4 * T + g;
+            if (q >= P.n_gchunks) continue;
+            const int p = P.gchunk[q], j = P.seg[p];
+            const gnntrk_gseg &gs = a->gseg[j];
+            uint8_t shift;
+            if (!buf_pow2((int64_t)gs.stride * 2, shift)) return;
+            const bool gathered = gs.idx != nullptr;
+            const int stream = gathered ? buf_stream(B.sids, B.n_sids, gs.idx, M) : -1;
+            if (gathered && stream < 0) return;
+            if (!buf_add(B.store_s, B.store, B.n_store, kBufStores, gs.ptr, M * gs.stride * 2, shift, false, gathered, stream,
+                         T, g, 8 * P.first[p]))
+                return;
+        }
+    B.ok = 1;
+}
+
+template <class IO>
+inline bool buf_plan_is(const BufPlan &B) {
+    if (!B.ok || B.n_load != IO::NL || B.n_ids != IO::NI || B.n_sids != IO::NSI || B.n_store != IO::NS ||
+        B.n_gout != IO::NG || B.ones_dword != IO::kOnesDword)
+        return false;
+    for (int i = 0; i < IO::NL; ++i)
+        if (!same_shape(B.load_s[i], IO::load[i])) return false;
+    for (int i = 0; i < IO::NG; ++i)
+        if (!same_shape(B.gout_s[i], IO::gout[i])) return false;
+    for (int i = 0; i < IO::NS; ++i)
+        if (!same_shape(B.store_s[i], IO::store[i])) return false;
+    return true;
+}
+
 constexpr int kFwd16BlocksPerCu = 5;
 constexpr int kBwd16BlocksPerCu = 2;
 
+
+// launches the backward instantiation for (plan, GT, three); G32 = fp32 upstream gradient
+// the buffer-addressed instantiation of a launch, by name ("" = the generic per-lane I/O)
+inline const char *buf_io_name(const BufPlan &B, int KI, int HT, int GT, bool three, bool g32, int debug_flags) {
+    if (!B.ok || (debug_flags & (64 | 128)) || KI != 1 || (HT != 1 && HT != 3)) return "";
+    if (g32) return (GT == 2 && three && buf_plan_is<IoHead>(B)) ? "IoHead" : "";
+    if (GT == 2 && three && buf_plan_is<IoRelational>(B)) return "IoRelational";
+    if (GT == 1 && three && buf_plan_is<IoObject>(B)) return "IoObject";
+    if (GT == 0 && !three && buf_plan_is<IoEncoder8>(B)) return "IoEncoder8";
+    return "";
+}
 
 // launches the backward instantiation for (plan, GT, three); G32 = fp32 upstream gradient
 template <bool G32>
@@ -1093,13 +1565,42 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
                  uint8_t *trash, hipStream_t stream) {
     const bool three = a->mlp.n_layers == 3;
     bool launched = false;
+    BufPlan B;
+    make_buf_plan(B, P, a, GT);
+    // the shapes of the default models go through buffer descriptors (debug_flags & 128: generic I/O)
+    {
+        const char *io = buf_io_name(B, P.KI, P.HT, GT, three, G32, a->debug_flags);
+        if (a->debug_flags & 256)   // (diagnostics: which I/O form a launch takes)
+            fprintf(stderr, "mlp_backward_bf16: KI %d HT %d GT %d three %d rows %lld plan ok %d (loads %d ids %d+%d gout %d stores %d ones %d) -> %s\n",
+                    P.KI, P.HT, GT, (int)three, (long long)a->n_rows, B.ok, B.n_load, B.n_ids, B.n_sids, B.n_gout,
+                    B.n_store, B.ones_dword, io[0] ? io : "generic");
+#define GNNTRK_BWD16_BUF(HT_, GT_, T_, IO_)                                                           \
+    if (!launched && P.HT == HT_ && strcmp(io, #IO_) == 0) {                                          \
+        auto kfn = mlp16_bwd_kernel<1, HT_, GT_, T_, G32, 2, IO_>;                                    \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash, B);             \
+        launched = true;                                                                              \
+    }
+        if constexpr (G32) {
+            GNNTRK_BWD16_BUF(3, 2, true, IoHead)
+            GNNTRK_BWD16_BUF(1, 2, true, IoHead)
+        } else {
+            GNNTRK_BWD16_BUF(3, 2, true, IoRelational)
+            GNNTRK_BWD16_BUF(1, 2, true, IoRelational)
+            GNNTRK_BWD16_BUF(3, 1, true, IoObject)
+            GNNTRK_BWD16_BUF(1, 1, true, IoObject)
+            GNNTRK_BWD16_BUF(3, 0, false, IoEncoder8)
+            GNNTRK_BWD16_BUF(1, 0, false, IoEncoder8)
+        }
+#undef GNNTRK_BWD16_BUF
+        if (launched) return check_launch("mlp_backward_bf16");
+    }
 // D = 2 (two 16-row halves per iteration, K = 32 weight-gradient contractions) wherever the
 // doubled staging images fit the workgroup's LDS budget: one k-step, up to three hidden tiles -
 // every shape of the reference's default models.  debug_flags & 64 forces D = 1 (A/B timing).
 #define GNNTRK_BWD16_LAUNCH(KI_, HT_, GT_, T_, D_)                                             \
     {                                                                                          \
         auto kfn = mlp16_bwd_kernel<KI_, HT_, GT_, T_, G32, D_>;                               \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash);         \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash, B);      \
     }
 #define GNNTRK_BWD16_CASE(KI_, HT_, GT_)                                                       \
     if (P.KI == KI_ && P.HT == HT_ && GT == GT_) {                                             \

@@ -99,6 +99,30 @@ __device__ __forceinline__ void mfma_bf16_k16_acc(u32x2 a, u32x2 b, f32x4 &acc) 
     acc = mfma_bf16_k16(a, b, acc);
 }
 __device__ __forceinline__ void drain_mfma() {}
+
+// ---- buffer addressing (wave-uniform 128-bit descriptor in SGPRs + 32-bit lane offset) ----------
+// raw buffer (stride 0): byte offset = voffset + soffset; an access whose offset is not below
+// num_records returns 0 (loads) / is dropped (stores) - per lane, soffset included (checked on an
+// MI355X: tools/probe_buf.hip).  The tile loops lean on exactly that: lanes that take no part in an
+// access carry the offset 2^31 (tensors are below 2^31 bytes), rows past the end of a tensor fall
+// out by themselves - no per-lane pointers, no masks, no store redirection.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t buf_make(const void *base, uint32_t num_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)num_bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_load_u32(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ u32x2 buf_load_u32x2(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ u32x4 buf_load_u32x4(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store_u32x2(u32x2 v, buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    typedef unsigned int v2u_hw __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_hw, v), r, (int)voff, (int)soff, 0);
+}
 #endif  // GNNTRK_BF16_PRIMITIVES
 
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }

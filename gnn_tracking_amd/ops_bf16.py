@@ -70,7 +70,7 @@ def to_rows16(x: Tensor, idx: Optional[Tensor] = None) -> Tensor:
 
 def _seg16(t: Tensor, idx, relu: bool):
     return _capi.Seg(t.data_ptr(), None if idx is None else idx.data_ptr(), t.shape[1], t.stride(0),
-                     int(relu), 0)
+                     int(relu), min(int(t.shape[0]), 0x7fffffff))
 
 
 def mlp_forward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], relu: Sequence[bool],
@@ -126,7 +126,7 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
         a.seg[j] = _seg16(s, idx[j], relu[j])
     a.n_gout = len(gout)
     for t, (rows, term_idx) in enumerate(gout):
-        a.gout[t] = _capi.GTerm(rows.data_ptr(), ops._p(term_idx), rows.stride(0), 0)
+        a.gout[t] = _capi.GTerm(rows.data_ptr(), ops._p(term_idx), rows.stride(0), min(int(rows.shape[0]), 0x7fffffff))
     dev = segs[0].device
     slices = [None] * len(segs)
     for j, s in enumerate(segs):

@@ -139,7 +139,10 @@ typedef struct gnntrk_seg {
     int32_t dim;        /* number of features taken from each row                */
     int32_t stride;     /* row stride in floats                                  */
     int32_t relu;       /* apply ReLU to the loaded values                       */
-    int32_t _pad;
+    int32_t rows;       /* rows of the tensor behind ptr, 0 = not stated.  Only read by
+                           gnntrk_mlp_backward_bf16: with the sizes of every tensor stated
+                           (and below 2 GB each) it addresses them through buffer descriptors
+                           - hardware range checks instead of per-lane address arithmetic   */
 } gnntrk_seg;
 
 typedef struct gnntrk_mlp {
@@ -219,7 +222,7 @@ typedef struct gnntrk_gterm {
     const float *ptr;
     const int32_t *idx;
     int32_t stride;
-    int32_t _pad;
+    int32_t rows; /* rows of the tensor behind ptr, 0 = not stated (see gnntrk_seg.rows) */
 } gnntrk_gterm;
 
 typedef struct gnntrk_gseg {

@@ -311,6 +311,39 @@ inline u32x2_emul lds_read_tr16(const uint16_t *p) {
     r[1] = (uint32_t)out[2] | ((uint32_t)out[3] << 16);
     return r;
 }
+// buffer addressing (tile_bf16.h): offset = voffset + soffset, out of range -> 0 / dropped, per dword
+struct buf_rsrc_t {
+    char *base;
+    uint32_t n;
+};
+inline buf_rsrc_t buf_make(const void *base, uint32_t num_bytes) { return {(char *)base, num_bytes}; }
+inline uint32_t hipemul_buf_dword(buf_rsrc_t r, uint64_t off) {
+    if (off + 4 > r.n) return 0u;
+    uint32_t v;
+    memcpy(&v, r.base + off, 4);
+    return v;
+}
+inline uint32_t buf_load_u32(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return hipemul_buf_dword(r, (uint64_t)voff + soff);
+}
+inline u32x2_emul buf_load_u32x2(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    u32x2_emul v;
+    for (int i = 0; i < 2; ++i) v[i] = hipemul_buf_dword(r, (uint64_t)voff + soff + 4 * i);
+    return v;
+}
+inline u32x4_emul buf_load_u32x4(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    u32x4_emul v;
+    for (int i = 0; i < 4; ++i) v[i] = hipemul_buf_dword(r, (uint64_t)voff + soff + 4 * i);
+    return v;
+}
+inline void buf_store_u32x2(u32x2_emul v, buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const uint64_t off = (uint64_t)voff + soff;
+    for (int i = 0; i < 2; ++i)
+        if (off + 4 * i + 4 <= r.n) {
+            const uint32_t w = v[i];
+            memcpy(r.base + off + 4 * i, &w, 4);
+        }
+}
 }  // namespace gnntrk
 
 template <class T>

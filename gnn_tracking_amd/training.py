@@ -2,7 +2,7 @@
 
 Reference: ``training/base.py:72-116`` (``TrackingModule``: ``data_preproc`` -> ``forward`` ->
 ``get_losses`` -> backward -> ``configure_optimizers``' Adam), ``training/ec.py:25-53``
-(``ECModule``) and ``training/tc.py:20-84`` (``TCModule``).  The Lightning trainer around them
+(``ECModule``), ``training/tc.py:20-84`` (``TCModule``) and ``training/ml.py:25-78`` (``MLModule``).  The Lightning trainer around them
 (logging, checkpointing, schedulers, OOM tolerance) is control plane and stays in the
 reference; what is here is the arithmetic of one step, under the reference's method names, so
 that bench.py, the parity tests and a user's own loop run the same code:
@@ -157,3 +157,34 @@ class TCModule(TrackingModule):
         data = self.data_preproc(data)
         out = self(data, _preprocessed=True)
         return self.get_losses(out, data, metrics=metrics)
+
+
+class MLModule(TrackingModule):
+    """Metric-learning training (``training/ml.py:25-78``): ``model(data) -> {"H": ...}`` (e.g.
+    ``GraphConstructionFCNN``), ``loss_fct`` a ``GraphConstructionHingeEmbeddingLoss``.  The
+    scanner of the validation step (``gc_scanner``: k-scans + figures of merit) is validation-only
+    control plane; its device part is ``graph_construction.knn_scan``."""
+
+    def __init__(self, model: nn.Module, *, loss_fct: nn.Module, **kwargs):
+        super().__init__(model, **kwargs)
+        self.loss_fct = loss_fct
+
+    def get_losses(self, out: dict[str, Any], data, *, metrics: bool = True):
+        if not hasattr(data, "true_edge_index"):
+            # (ml.py:44-47: the point-cloud data saved the true edges as edge_index)
+            data.true_edge_index = data.edge_index
+        losses = self.loss_fct(x=out["H"], particle_id=data.particle_id, batch=getattr(data, "batch", None),
+                               true_edge_index=data.true_edge_index, pt=data.pt, eta=data.eta,
+                               reconstructable=data.reconstructable)
+        if not metrics:
+            return losses.loss, {}
+        m = dict(losses.loss_dct)
+        m.update({k + "_weighted": float(v) for k, v in losses.weighted_losses.items()})
+        m.update({k: float(v) for k, v in losses.extra_metrics.items()})
+        m["total"] = float(losses.loss)
+        return losses.loss, m
+
+    def training_step(self, batch, batch_idx: int = 0, *, metrics: bool = False):
+        batch = self.data_preproc(batch)
+        out = self(batch, _preprocessed=True)
+        return self.get_losses(out, batch, metrics=metrics)

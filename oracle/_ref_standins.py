@@ -255,6 +255,9 @@ def install() -> None:
     pl.cli = sys.modules["pytorch_lightning.cli"]
     pl.loggers = sys.modules["pytorch_lightning.loggers"]
 
+    # utils/nomenclature.py:3,28 (run names; reached through training/ml.py -> k_scanner -> cluster_metrics)
+    mod("coolname", generate_slug=lambda n=3: "-".join(["standin"] * int(n)))
+
     class Metric(torch.nn.Module):
         def add_state(self, name, default, dist_reduce_fx=None):
             setattr(self, name, default)

@@ -1020,6 +1020,138 @@ def g14b_tc_step_event():
     npz("g14b_tc_step_event.npz", **arrs)
 
 
+ML_STEP_CASES = {
+    # tests/test_configs/ml.yml: GraphConstructionFCNN(in 14, out 8) + the hinge loss
+    "d3_h64": dict(model=dict(in_dim=14, hidden_dim=64, out_dim=8, depth=3), loss=dict(max_num_neighbors=256),
+                   lw_repulsive=0.5),
+    "d1_h40_nrep": dict(model=dict(in_dim=14, hidden_dim=40, out_dim=8, depth=1, alpha=0.5),
+                        loss=dict(max_num_neighbors=64, rep_normalization="n_rep_edges", r_emb=0.8), lw_repulsive=1.0),
+}
+
+
+def g15_ml_step():
+    """Row 8f-2 as a training step: the reference's own ``MLModule`` (training/ml.py:25-78) -
+    ``GraphConstructionFCNN`` -> ``GraphConstructionHingeEmbeddingLoss`` -> backward -> its own
+    ``configure_optimizers`` (Adam + the default ConstantLR) - on the 1500-hit event of G14b (two
+    events of 900 / 600 hits through ``batch``; true edges from the reference's
+    ``get_truth_edge_index``).  H, loss terms, all gradients, parameters after the step."""
+    from gnn_tracking.preprocessing.point_cloud_builder import get_truth_edge_index
+    from gnn_tracking.training.ml import MLModule
+
+    print("G15 metric-learning training step")
+    raw = tc_b_event()
+    n = raw["x"].shape[0]
+    batch = (torch.arange(n) >= 900).long()
+    te = torch.from_numpy(get_truth_edge_index(raw["particle_id"].numpy()))
+    te = te[:, batch[te[0]] == batch[te[1]]]
+    # the network sees the raw features; the embedding starts near the latent slice so that the
+    # radius graph has the density of the cfg5 event
+    arrs = dict(raw, batch=batch, true_edge_index=te)
+    for name, cfg in ML_STEP_CASES.items():
+        torch.manual_seed(41)
+        model = GraphConstructionFCNN(**cfg["model"])
+        with torch.no_grad():
+            model._latent_normalization.fill_(3.0)
+        mod = MLModule(model=model, loss_fct=GraphConstructionHingeEmbeddingLoss(lw_repulsive=cfg["lw_repulsive"], **cfg["loss"]))
+        p0 = sd(model)
+        data = Data(edge_index=te, true_edge_index=te, batch=batch, **raw)
+        out = mod(data)
+        loss, metrics = mod.get_losses(out, data)
+        loss.backward()
+        grads = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v))
+                 for k, v in model.named_parameters()}
+        conf = mod.configure_optimizers()
+        conf["optimizer"].step()
+        p1 = sd(model)
+        od = dict(raw, batch=batch, true_edge_index=te)
+        h, terms, total, og, op = O.ml_training_step(od, p0, depth=cfg["model"]["depth"], alpha=cfg["model"].get("alpha", 0.6),
+                                                     loss=cfg["loss"], lw_repulsive=cfg["lw_repulsive"])
+        worst = max(close(h, out["H"], 1e-5, name + " H"), close(total, loss, 1e-6, name + " loss"))
+        for k in ("attractive", "repulsive"):
+            worst = max(worst, close(terms[k], metrics[k], 1e-6, f"{name} {k}"))
+            arrs[f"{name}/{k}"] = metrics[k]
+        assert terms["n_edges_rep"] == int(metrics["n_edges_rep"]) and terms["n_edges_rep"] > 500
+        for k in grads:
+            worst = max(worst, close(og[k], grads[k], 1e-5, f"{name} grad {k}"), close(op[k], p1[k], 1e-6, f"{name} adam {k}"))
+            arrs[f"{name}/p0/{k}"], arrs[f"{name}/p1/{k}"], arrs[f"{name}/grad/{k}"] = p0[k], p1[k], grads[k]
+        arrs[f"{name}/H"], arrs[f"{name}/loss"] = out["H"], loss
+        arrs[f"{name}/n_edges_rep"] = np.int64(terms["n_edges_rep"])
+        arrs[f"{name}/n_edges_att"] = np.int64(terms["n_edges_att"])
+        print(f"   {name}: {terms['n_edges_att']} attractive, {terms['n_edges_rep']} repulsive edges, loss {loss.item():.6f}, "
+              f"oracle == reference (max diff {worst:.2e})")
+    npz("g15_ml_step.npz", **arrs)
+
+
+GTCN_AUTOCAST_VARIANTS = {
+    # (the threshold cut is switched off - ec_threshold 0 keeps every edge - or replaced by the truth:
+    #  a learned cut moves with bf16 noise, the networks either side of it are what is pinned here;
+    #  the edge classifier itself is pinned by G2b)
+    "default_nocut": dict(ec_threshold=0.0),
+    "ecfeed_nocut": dict(L_ec=2, L_hc=2, hidden_dim=16, mask_orphan_nodes=True, use_ec_embeddings_for_hc=True,
+                         feed_edge_weights=True, ec_threshold=0.0),
+    "latent_nocut": dict(L_ec=1, L_hc=2, hidden_dim=8, h_outdim=4, alpha_latent=0.4, n_embedding_coords=3,
+                         ec_threshold=0.0),
+    "perfect_ec": dict(_cls="PerfectECGraphTCN", L_hc=2, hidden_dim=10, mask_orphan_nodes=True, ec_threshold=0.5),
+    "mlgc": dict(_cls="GraphTCNForMLGCPipeline", L_hc=1, hidden_dim=10, ec_threshold=0.5),
+}
+
+
+def g7b_graph_tcn_autocast():
+    """The bf16 pin of the track condenser (missing 5): the reference's OWN GraphTCN
+    variants (models/track_condensation_networks.py:236-308) under
+    ``torch.autocast("cpu", dtype=torch.bfloat16)`` - what Lightning's ``precision="bf16-mixed"``
+    does to them - on the G7 graph: W / H / B (as fp32) and the fp32 parameter gradients of
+    sum(H * rH) + sum(B * rB) [+ BCE(W, y)].  Initial parameters = the variant's own seed."""
+    import gnn_tracking.models.track_condensation_networks as tcn_mod
+
+    print("G7b GraphTCN variants under CPU bf16 autocast")
+    x, ei, ea, y, pt = synth_graph(2, 300, 2000, 14, 4)
+    g = np.random.default_rng(77)
+    layer = torch.from_numpy(np.sort(g.integers(0, 45, size=x.shape[0]))).long()
+    arrs = dict(x=x, edge_index=ei, edge_attr=ea, y=y, layer=layer)
+    for name, kw in GTCN_AUTOCAST_VARIANTS.items():
+        kw = dict(kw)
+        cls = kw.pop("_cls", "GraphTCN")
+        torch.manual_seed(11)
+        model = GraphTCN(14, 4, **kw) if cls == "GraphTCN" else getattr(tcn_mod, cls)(node_indim=14, edge_indim=4, **kw)
+        p0 = sd(model)
+        data = Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=layer)
+        out32 = model(data)
+        rH = torch.from_numpy(g.normal(size=tuple(out32["H"].shape))).float()
+        rB = torch.from_numpy(g.normal(size=tuple(out32["B"].shape))).float()
+        # the same module in fp32: its gradients say how far autocast itself sits from full precision
+        loss32 = (out32["H"] * rH).sum() + (out32["B"] * rB).sum()
+        if cls == "GraphTCN":
+            loss32 = loss32 + EdgeWeightBCELoss()(w=out32["W"], y=y.float())
+        loss32.backward()
+        for k, v in model.named_parameters():
+            arrs[f"{name}/grad_fp32/{k}"] = v.grad.clone() if v.grad is not None else torch.zeros_like(v)
+        model.zero_grad()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = model(Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=layer))
+        loss = (out["H"].float() * rH).sum() + (out["B"].float() * rB).sum()
+        if cls == "GraphTCN":
+            loss = loss + EdgeWeightBCELoss()(w=out["W"].float(), y=y.float())
+        loss.backward()
+        for k in ("W", "H", "B"):
+            if out[k] is not None:
+                arrs[f"{name}/{k}"] = out[k].detach().float()
+                arrs[f"{name}/{k}_fp32"] = out32[k].detach().float()
+        for k in ("ec_hit_mask", "ec_edge_mask"):
+            if out.get(k) is not None:
+                assert torch.equal(out[k], out32[k]), f"{name}: {k} moved under autocast"
+                arrs[f"{name}/{k}"] = out[k]
+        arrs[f"{name}/rH"], arrs[f"{name}/rB"], arrs[f"{name}/loss"] = rH, rB, loss.detach()
+        for k, v in model.named_parameters():
+            arrs[f"{name}/p0/{k}"] = p0[k]
+            arrs[f"{name}/grad/{k}"] = v.grad if v.grad is not None else torch.zeros_like(v)
+        dH = (out["H"].float() - out32["H"]).abs().max().item() / max(1.0, out32["H"].abs().max().item())
+        dB = (out["B"].float() - out32["B"]).abs().max().item()
+        print(f"   {name}: |H_autocast - H_fp32| {dH:.2e} (of the largest entry), |B_autocast - B_fp32| {dB:.2e}, "
+              f"{int(out['ec_hit_mask'].sum()) if out.get('ec_hit_mask') is not None else x.shape[0]} hits kept")
+    npz("g7b_graph_tcn_bf16_autocast.npz", **arrs)
+
+
 if __name__ == "__main__":
     assert REF.is_dir(), "needs /root/reference (build container only)"
     only = set(sys.argv[1:])  # e.g. "g7 g10": regenerate just these files
@@ -1029,9 +1161,9 @@ if __name__ == "__main__":
 
     tg = g1_ec_testgraph() if (want("g1") or want("g4") or want("g6")) else None
     for tag, fn in (("g2", g2_ec_variants), ("g2b", g2b_ec_autocast), ("g3", g3_in_layer), ("g3b", g3b_resin), ("g4", lambda: g4_knn(tg)),
-                    ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g8", g8_hinge),
+                    ("g5", g5_oc), ("g6", lambda: g6_mlgc(tg)), ("g7", g7_graph_tcn), ("g7b", g7b_graph_tcn_autocast), ("g8", g8_hinge),
                     ("g9", g9_gc_fcnn), ("g10", g10_hetero_fcnn), ("g11", g11_dbscan), ("g12", g12_gc_resin), ("g13", g13_focal),
-                    ("g14", g14_tc_step), ("g14b", g14b_tc_step_event)):
+                    ("g14", g14_tc_step), ("g14b", g14b_tc_step_event), ("g15", g15_ml_step)):
         if want(tag):
             fn()
     print("goldens written; oracle pinned against the reference.")

@@ -717,6 +717,30 @@ def res_fcnn(x: Tensor, p: dict, prefix: str, depth: int, alpha: float) -> Tenso
     return torch.clamp_min(x, 0.0) @ p[f"{prefix}._decoder.weight"].t()
 
 
+def ml_training_step(data: dict, params: dict, *, depth: int, alpha: float, loss: dict, lw_repulsive: float,
+                     lr: float = 1e-3):
+    """training/ml.py:25-78 + training/base.py:94-116: ``GraphConstructionFCNN`` forward
+    (models/graph_construction.py:25-53: ``ResFCNN`` x ``_latent_normalization``),
+    ``GraphConstructionHingeEmbeddingLoss``, backward, one Adam step under the default ConstantLR
+    (factor 1/3).  ``data``: x, particle_id, pt, eta, reconstructable, batch, true_edge_index.
+    Returns (H, loss terms, total, grads, params after the step)."""
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    pp = {"." + k: v for k, v in ps.items()}
+    h = res_fcnn(data["x"], pp, "", depth, alpha) * ps["_latent_normalization"]
+    mask = good_node_mask(data["pt"], data["particle_id"], data["reconstructable"], data["eta"])
+    terms = hinge_embedding_loss(x=h, particle_id=data["particle_id"], batch=data["batch"],
+                                 true_edge_index=data["true_edge_index"], mask=mask, **loss)
+    total = terms["attractive"] + lw_repulsive * terms["repulsive"]
+    names = list(ps)
+    grads = torch.autograd.grad(total, [ps[n] for n in names], allow_unused=True)
+    for n, g in zip(names, grads):
+        ps[n].grad = g if g is not None else torch.zeros_like(ps[n])
+    opt = torch.optim.Adam([ps[n] for n in names], lr=lr)
+    torch.optim.lr_scheduler.ConstantLR(opt)
+    opt.step()
+    return h, terms, total, {n: ps[n].grad for n in names}, {n: ps[n].detach() for n in names}
+
+
 def hetero_res_fcnn(x: Tensor, layer: Tensor, p: dict, prefix: str, depth: int, alpha: float) -> Tensor:
     """models/mlp.py:123-178: pixel hits (layer 0..17) and strip hits through separate
     ``ResFCNN`` s, the two embeddings stacked pixel first."""

@@ -1026,6 +1026,76 @@ def case_graph_tcn_bf16(device):
                 assert v.grad is not None and v.grad.dtype == torch.float32 and torch.isfinite(v.grad).all(), k
 
 
+GTCN_AUTOCAST_VARIANTS = {
+    "default_nocut": dict(ec_threshold=0.0),
+    "ecfeed_nocut": dict(L_ec=2, L_hc=2, hidden_dim=16, mask_orphan_nodes=True, use_ec_embeddings_for_hc=True,
+                         feed_edge_weights=True, ec_threshold=0.0),
+    "latent_nocut": dict(L_ec=1, L_hc=2, hidden_dim=8, h_outdim=4, alpha_latent=0.4, n_embedding_coords=3,
+                         ec_threshold=0.0),
+    "perfect_ec": dict(_cls="PerfectECGraphTCN", L_hc=2, hidden_dim=10, mask_orphan_nodes=True, ec_threshold=0.5),
+    "mlgc": dict(_cls="GraphTCNForMLGCPipeline", L_hc=1, hidden_dim=10, ec_threshold=0.5),
+}
+GTCN16_PIN_H = 2.0 ** -6    # of the largest |H| entry
+GTCN16_PIN_B = 2.0 ** -7    # beta in (0, 1): two bf16 ulps on [0.5, 1)
+GTCN16_PIN_GRAD = 0.08      # relative L2 of a parameter gradient
+
+
+def case_graph_tcn_bf16_autocast(device, names=None):
+    """The bf16-storage GraphTCN PINNED AGAINST THE REFERENCE IN ITS OWN MIXED PRECISION (golden G7b:
+    the reference's GraphTCN / PerfectECGraphTCN / GraphTCNForMLGCPipeline under CPU bf16 autocast;
+    the learned threshold cut is off or replaced by the truth, so both sides see the same edges):
+    masks equal, H within 2^-6 of the largest entry, beta within 2^-7, W within one bf16 ulp, every
+    parameter gradient within 8 % relative L2 + 1.25 x the distance of the reference's autocast
+    gradient to its own fp32 gradient (on 300 hits and hidden widths of 8 - 16 a single rounding
+    moves a small gradient by tens of per cent; measured: the kernels sit at 1 - 3 % from the
+    autocast reference where autocast itself sits at 6 - 20 % from fp32) + half a per cent of the
+    whole gradient's norm.  Returns the measured distances."""
+    z = load("g7b_graph_tcn_bf16_autocast.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y, layer = tt(z["y"], device), tt(z["layer"], device)
+    report = {}
+    for name, kw in GTCN_AUTOCAST_VARIANTS.items():
+        if names is not None and name not in names:
+            continue
+        kw = dict(kw)
+        thr = kw.pop("ec_threshold")
+        model, cls = make_gtcn(kw, thr)
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        with G.bf16_storage():
+            out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y, layer=layer))
+            loss = (out["H"].float() * tt(z[f"{name}/rH"], device)).sum() + (out["B"].float() * tt(z[f"{name}/rB"], device)).sum()
+            if cls == "GraphTCN":
+                loss = loss + G.EdgeWeightBCELoss()(w=out["W"], y=y.float())
+            loss.backward()
+        rep = report.setdefault(name, {})
+        for k in ("ec_hit_mask", "ec_edge_mask"):
+            if f"{name}/{k}" in z.files:
+                assert torch.equal(out[k].cpu(), tt(z[f"{name}/{k}"])), f"{name} {k}"
+        href = tt(z[f"{name}/H"])
+        rep["H"] = ((out["H"].detach().float().cpu() - href).abs().max() / max(1.0, href.abs().max().item())).item()
+        rep["B"] = (out["B"].detach().float().cpu() - tt(z[f"{name}/B"])).abs().max().item()
+        if cls == "GraphTCN":
+            rep["W"] = (out["W"].detach().float().cpu() - tt(z[f"{name}/W"])).abs().max().item()
+            assert rep["W"] <= BF16_PIN_W, (name, rep)
+        want_all = math.sqrt(sum(float(tt(z[f"{name}/grad/{k}"]).double().pow(2).sum()) for k, _ in model.named_parameters()))
+        worst = 0.0
+        for k, v in model.named_parameters():
+            gref = tt(z[f"{name}/grad/{k}"]).double()
+            if v.grad is None:
+                assert gref.abs().max().item() == 0.0, f"{name} grad {k} missing"
+                continue
+            err = (v.grad.detach().cpu().double() - gref).norm().item()
+            own = (gref - tt(z[f"{name}/grad_fp32/{k}"]).double()).norm().item()   # autocast's own distance to fp32
+            assert err <= GTCN16_PIN_GRAD * gref.norm().item() + 1.25 * own + 0.005 * want_all, \
+                f"{name} grad {k}: {err:.3e} of {gref.norm().item():.3e} (autocast - fp32: {own:.3e})"
+            if gref.norm().item() > 0.02 * want_all:
+                worst = max(worst, err / gref.norm().item())
+        rep["grad_rel_l2"] = worst
+        assert rep["H"] <= GTCN16_PIN_H and rep["B"] <= GTCN16_PIN_B, (name, rep)
+    return report
+
+
 def case_hinge_loss(device, cases=("td1", "td4")):
     """GraphConstructionHingeEmbeddingLoss vs the reference (G8: the reference's pinned td1
     values re-run in fp32, and a two-event case), loss terms, edge counts and grad wrt x."""
@@ -1757,6 +1827,52 @@ def case_tc_step_oracle(device, n_hits=6000, loss="rg"):
     _check_after_adam(model, og, op, tag)
     return {"hits": n_hits, "edges": int(graph["edge_index"].shape[1]), "kept": int(oo["ec_edge_mask"].sum()),
             "threshold_margin": margin, "w_err": w_err}
+
+
+# ------------------------------------------------------------- ML training step (golden G15)
+ML_STEP_CASES = {
+    "d3_h64": dict(model=dict(in_dim=14, hidden_dim=64, out_dim=8, depth=3), loss=dict(max_num_neighbors=256),
+                   lw_repulsive=0.5),
+    "d1_h40_nrep": dict(model=dict(in_dim=14, hidden_dim=40, out_dim=8, depth=1, alpha=0.5),
+                        loss=dict(max_num_neighbors=64, rep_normalization="n_rep_edges", r_emb=0.8), lw_repulsive=1.0),
+}
+
+
+def case_ml_step(device, names=None):
+    """The metric-learning training step (golden G15: the reference's own ``MLModule`` on the 1500-hit
+    event, two events through ``batch``): ``GraphConstructionFCNN`` -> hinge loss (radius graph
+    inside the event, repulsion from hits of interest) -> backward -> Adam under the default
+    ConstantLR: H 1e-5, edge counts exact, loss terms 1e-5, gradients 1e-4, parameters 1e-6."""
+    from gnn_tracking_amd import training
+    from gnn_tracking_amd.losses_ml import GraphConstructionHingeEmbeddingLoss
+
+    z = load("g15_ml_step.npz")
+    raw = {k: tt(z[k], device) for k in ("x", "particle_id", "pt", "eta", "reconstructable", "batch", "true_edge_index")}
+    for name, cfg in ML_STEP_CASES.items():
+        if names is not None and name not in names:
+            continue
+        model = G.GraphConstructionFCNN(**cfg["model"])
+        load_params(model, z, f"{name}/p0/")
+        model = model.to(device)
+        mod = training.MLModule(model, loss_fct=GraphConstructionHingeEmbeddingLoss(lw_repulsive=cfg["lw_repulsive"],
+                                                                                   **cfg["loss"]))
+        data = G.Data(edge_index=raw["true_edge_index"], **raw)
+        out = mod(data)
+        assert_close(out["H"], z[f"{name}/H"], TOL_OUT, name + " H")
+        loss, metrics = mod.get_losses(out, data)
+        assert int(metrics["n_edges_rep"]) == int(z[f"{name}/n_edges_rep"]), name + " repulsive edge count"
+        assert int(metrics["n_edges_att"]) == int(z[f"{name}/n_edges_att"]), name + " attractive edge count"
+        for k in ("attractive", "repulsive"):
+            assert_close(metrics[k], z[f"{name}/{k}"], 2e-5, f"{name} {k}")
+        assert_close(loss, z[f"{name}/loss"], 2e-5, name + " loss")
+        mod.zero_grad()
+        loss.backward()
+        grads_ref = {}
+        for k, v in model.named_parameters():
+            grads_ref[k] = z[f"{name}/grad/{k}"]
+            assert_close(v.grad if v.grad is not None else torch.zeros_like(v), grads_ref[k], TOL_GRAD, f"{name} grad {k}")
+        mod.configure_optimizers().step()
+        _check_after_adam(model, grads_ref, {k: z[f"{name}/p1/{k}"] for k in model.state_dict()}, name)
 
 
 def case_oc_sampling(device):

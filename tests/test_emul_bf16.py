@@ -38,6 +38,8 @@ def test_mlp_bf16_stress_emulated():
 def test_graph_tcn_bf16_emulated():
     with emulated():
         P.case_graph_tcn_bf16("cpu")
+        for name, rep in P.case_graph_tcn_bf16_autocast("cpu").items():
+            print("GraphTCN bf16 vs reference autocast:", name, {k: float(f"{v:.3g}") for k, v in rep.items()})
 
 
 def test_bf16_reproducible_emulated():

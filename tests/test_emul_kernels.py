@@ -137,6 +137,11 @@ def test_tc_training_step_emulated():
         P.case_tc_step("cpu")
 
 
+def test_ml_training_step_emulated():
+    with emulated():
+        P.case_ml_step("cpu", names=("d1_h40_nrep",))
+
+
 def test_tc_training_step_event_scale_emulated():
     """golden G14b (1500 hits, 21 617 built edges), the Tiger / orphan-masking variant"""
     with emulated():

@@ -139,6 +139,9 @@ def test_graph_tcn(dev):
 
 def test_graph_tcn_bf16_storage(dev):
     P.case_graph_tcn_bf16(dev)
+    # the pin against the reference's own GraphTCN under bf16 autocast (golden G7b)
+    for name, rep in P.case_graph_tcn_bf16_autocast(dev).items():
+        print("GraphTCN bf16 vs reference autocast:", name, {k: float(f"{v:.3g}") for k, v in rep.items()})
 
 
 def test_hinge_embedding_loss(dev):
@@ -184,6 +187,11 @@ def test_edge_ordered_outputs(dev):
 
 def test_tc_training_step(dev):
     P.case_tc_step(dev)
+
+
+def test_ml_training_step(dev):
+    """golden G15: the reference's own MLModule (GraphConstructionFCNN + hinge loss + Adam)"""
+    P.case_ml_step(dev)
 
 
 def test_tc_training_step_event_scale(dev):

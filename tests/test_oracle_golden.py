@@ -270,3 +270,19 @@ def test_tc_training_step_oracle_at_event_scale():
         for k, v in grads.items():
             assert_close(v, z[f"{name}/grad/{k}"], 1e-5, f"{name} grad {k}")
             assert_close(after[k], z[f"{name}/p1/{k}"], 1e-6, f"{name} adam {k}")
+
+
+def test_ml_training_step_oracle():
+    """oracle.ml_training_step against the reference's own MLModule step (golden G15)."""
+    z = load("g15_ml_step.npz")
+    raw = {k: tt(z[k]) for k in ("x", "particle_id", "pt", "eta", "reconstructable", "batch", "true_edge_index")}
+    for name, cfg in P.ML_STEP_CASES.items():
+        h, terms, total, grads, after = O.ml_training_step(
+            raw, _params(z, f"{name}/p0/"), depth=cfg["model"]["depth"], alpha=cfg["model"].get("alpha", 0.6),
+            loss=cfg["loss"], lw_repulsive=cfg["lw_repulsive"])
+        assert terms["n_edges_rep"] == int(z[f"{name}/n_edges_rep"])
+        assert_close(h, z[f"{name}/H"], 1e-5, name + " H")
+        assert_close(total, z[f"{name}/loss"], 1e-6, name + " loss")
+        for k, v in grads.items():
+            assert_close(v, z[f"{name}/grad/{k}"], 1e-5, f"{name} grad {k}")
+            assert_close(after[k], z[f"{name}/p1/{k}"], 1e-6, f"{name} adam {k}")

@@ -18,11 +18,19 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--events", type=int, default=32)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--only", type=int, default=None, help="0: buffer form only, 128: generic only (for rocprofv3)")
+ap.add_argument("--seq-ids", action="store_true",
+                help="edge k joins nodes (k / 13, k / 13 + 1) and the source order is the CSR order: no random "
+                     "gather / scatter - what the kernels cost without the memory system's share")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 batch = G.collate([synthetic.make_event(100 + i, 150_000, 2_000_000, dev) for i in range(args.events)])
 gi = ops.graph_index(batch.edge_index, batch.num_nodes)
 N, E = batch.num_nodes, gi.n_edges
+if args.seq_ids:
+    k = torch.arange(E, device=dev, dtype=torch.int32)
+    gi.tgt = (k // 14).clamp_(max=N - 1).contiguous()
+    gi.src = ((k // 14) + 1).clamp_(max=N - 1).contiguous()
+    gi.spos_inv = k.clone()
 torch.manual_seed(0)
 
 

@@ -52,7 +52,7 @@ class MlpBwdArgs(C.Structure):
     _fields_ = [("mlp", Mlp), ("n_seg", C.c_int32), ("epilogue", C.c_int32),
                 ("seg", Seg * MAX_SEGS), ("n_rows", C.c_int64), ("ca", C.c_float),
                 ("cb", C.c_float), ("n_gout", C.c_int32), ("accumulate_params", C.c_int32),
-                ("gout", GTerm * 2), ("gseg", GSeg * MAX_SEGS), ("gW", C.c_void_p * 3),
+                ("gout", GTerm * 3), ("gseg", GSeg * MAX_SEGS), ("gW", C.c_void_p * 3),
                 ("gb", C.c_void_p * 3), ("debug_flags", C.c_int32), ("_pad", C.c_int32)]
 
 
@@ -98,6 +98,7 @@ _SIGNATURES = {
     "gnntrk_mlp_forward_bf16": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
     "gnntrk_mlp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
     "gnntrk_mlp_backward_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
+    "gnntrk_mlp_backward_bf16_max_terms": (C.c_int, [C.POINTER(MlpBwdArgs)]),
     "gnntrk_mlp_backward_bf16": (C.c_int, [C.POINTER(MlpBwdArgs), _P, C.c_size_t, _P]),
     "gnntrk_mlp_forward_bf16_kernel_name": (C.c_int, [C.POINTER(MlpFwdArgs), C.c_char_p, C.c_size_t]),
     "gnntrk_mlp_backward_bf16_kernel_name": (C.c_int, [C.POINTER(MlpBwdArgs), C.c_char_p, C.c_size_t]),

@@ -9,7 +9,7 @@
 static_assert(sizeof(gnntrk_seg) == 32, "gnntrk_seg layout");
 static_assert(sizeof(gnntrk_mlp) == 64, "gnntrk_mlp layout");
 static_assert(sizeof(gnntrk_mlp_fwd_args) == 448, "gnntrk_mlp_fwd_args layout");
-static_assert(sizeof(gnntrk_mlp_bwd_args) == 760, "gnntrk_mlp_bwd_args layout");
+static_assert(sizeof(gnntrk_mlp_bwd_args) == 784, "gnntrk_mlp_bwd_args layout");
 static_assert(sizeof(gnntrk_graph_index) == 72, "gnntrk_graph_index layout");
 static_assert(sizeof(gnntrk_graph_index_carry) == 40, "gnntrk_graph_index_carry layout");
 
@@ -151,6 +151,7 @@ int gnntrk_mlp_forward_bf16(const gnntrk_mlp_fwd_args *args, void *stream) {
 size_t gnntrk_mlp_backward_bf16_workspace_bytes(const gnntrk_mlp *mlp) {
     return mlp_backward_bf16_ws_bytes(mlp);
 }
+int gnntrk_mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *args) { return mlp_backward_bf16_max_terms(args); }
 int gnntrk_mlp_backward_bf16(const gnntrk_mlp_bwd_args *args, void *workspace, size_t workspace_bytes,
                              void *stream) {
     return mlp_backward_bf16_launch(args, workspace, workspace_bytes, (hipStream_t)stream);

@@ -57,6 +57,7 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len);
 int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);
 size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m);
 int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes, hipStream_t stream);
+int mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *a);
 
 
 // compact.hip

@@ -38,13 +38,34 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     return GNNTRK_OK;
 }
 
+// the number of upstream terms (2 or 3) the launch described by `a` can take: 3 where it runs
+// buffer-addressed with a further term on the tile's rows
+int mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *a) {
+    if (!a || a->epilogue == GNNTRK_EPI_SIGMOID || a->n_rows <= 0 || a->n_gout < 1 || a->n_gout > 3) return 2;
+    SlotPlan P;
+    make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
+    if (!P.ok || P.KI != 1) return 2;
+    const int GT = (P.GT == 0) ? 0 : (P.GT <= 1) ? 1 : 2;
+    gnntrk_mlp_bwd_args b = *a;
+    while (b.n_gout < 3) {   // probe with stand-in terms: rows of the tile, sized like the first term
+        b.gout[b.n_gout] = b.gout[0];
+        b.gout[b.n_gout].idx = nullptr;
+        b.gout[b.n_gout].rows = (int32_t)(a->n_rows < 0x7fffffff ? a->n_rows : 0x7fffffff);
+        b.n_gout += 1;
+    }
+    BufPlan B;
+    make_buf_plan(B, P, &b, GT);
+    const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, false, a->debug_flags);
+    return (io[0] && B.n_gout == 3) ? 3 : 2;
+}
+
 // workspace = one partial block per wave | one 8-byte trash slot per lane
 static size_t bwd16_partial_bytes(const gnntrk_mlp *m) {
-    return align_up((size_t)cu_count() * kBwd16BlocksPerCu * kWaves * (size_t)part_total(*m) * sizeof(float), 256);
+    return align_up((size_t)cu_count() * kBwd16BlocksPerCuMax * kWaves * (size_t)part_total(*m) * sizeof(float), 256);
 }
 size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m) {
     if (!m) return 0;
-    return bwd16_partial_bytes(m) + (size_t)cu_count() * kBwd16BlocksPerCu * kWaves * 64 * 8;
+    return bwd16_partial_bytes(m) + (size_t)cu_count() * kBwd16BlocksPerCuMax * kWaves * 64 * 8;
 }
 
 int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes, hipStream_t stream) {
@@ -53,8 +74,10 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     if (rc) return rc;
     if (a->epilogue < 0 || a->epilogue > 3) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad epilogue");
     const bool empty = a->n_rows == 0;  // no rows: only the parameter gradients are written (zeros)
-    if (a->n_gout < 1 || a->n_gout > 2 || (!empty && (!a->gout[0].ptr || (a->n_gout == 2 && !a->gout[1].ptr))))
+    if (a->n_gout < 1 || a->n_gout > 3)
         return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad upstream gradient terms");
+    for (int t = 0; t < a->n_gout && !empty; ++t)
+        if (!a->gout[t].ptr) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad upstream gradient terms");
     const int out_pad = (a->mlp.out_dim + 3) / 4 * 4;
     if (a->epilogue == GNNTRK_EPI_SIGMOID) {
         if (a->n_gout != 1 || a->gout[0].stride < a->mlp.out_dim)
@@ -72,6 +95,9 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
             return fail(GNNTRK_EINVAL, "mlp_backward_bf16: gradient slices must be padded bf16 rows");
     }
     if (a->n_rows < 0 || a->n_rows > 0x7fffffff) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad n_rows");
+    if (a->n_gout == 3 && a->n_rows > 0 && mlp_backward_bf16_max_terms(a) < 3)
+        return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: three upstream terms only on the buffer-addressed shapes "
+                                         "(gnntrk_mlp_backward_bf16_max_terms)");
     const bool want_dw = a->gW[0] != nullptr;
     if (want_dw)
         for (int i = 0; i < a->mlp.n_layers; ++i)
@@ -87,7 +113,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
     int grid = 0;
     if (a->n_rows > 0) {
-        grid = grid16(a->n_rows, kBwd16BlocksPerCu, kWaves);
+        grid = grid16(a->n_rows, (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu, kWaves);
         float *part = reinterpret_cast<float *>(ws);
         uint8_t *trash = reinterpret_cast<uint8_t *>(ws) + bwd16_partial_bytes(&a->mlp);
         rc = (a->epilogue == GNNTRK_EPI_SIGMOID)

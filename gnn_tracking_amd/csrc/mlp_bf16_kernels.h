@@ -551,6 +551,7 @@ __device__ __forceinline__ void pack_backward_weights(uint32_t *img, const AugWe
 // upstream gradient terms of one tile, raw (bf16: two terms x 4 features; fp32: 4 floats)
 struct RawGout {
     u32x4 v;
+    u32x2 w;   // third term (buffer form only)
 };
 
 // ---- buffer-addressed I/O of the backward tile loop ----------------------------------------
@@ -568,7 +569,7 @@ struct RawGout {
 // states its size (gnntrk_seg.rows) and stays below 2^31 bytes with power-of-two row sizes.
 // Padding elements of input rows are read as stored: every producer of padded bf16 rows in this
 // library writes them as zero (include/gnntrk.h).
-constexpr int kBufLoads = 6, kBufIds = 3, kBufStores = 6, kBufGouts = 2;
+constexpr int kBufLoads = 6, kBufIds = 3, kBufStores = 6, kBufGouts = 3;
 constexpr uint32_t kBufOut = 0x80000000u;   // lane offset of a lane that takes no part
 
 struct BufOpShape {
@@ -612,10 +613,12 @@ struct IoNone {   // the generic per-lane I/O
 // node rows, one descriptor, two id streams), e (8-byte rows of the tile); upstream gradient
 // g_e~ + g_aggr[tgt]; gradient slices g_x_i (tile rows), g_x_j (rows through the source-sort
 // permutation), g_e
+template <int NG_>   // NG_ = 3: a third upstream term on the tile's rows (the edge-weight head's share, see ops_bf16.grad_tap)
 struct IoRelational {
-    static constexpr int NL = 2, NI = 2, NSI = 1, NS = 3, NG = 2, kOnesDword = 2;
+    static constexpr int NL = 2, NI = 2, NSI = 1, NS = 3, NG = NG_, kOnesDword = 2;
     static constexpr BufOpShape load[2] = {{1, 1, 0, 1, 0b0011, 0b0010, 0, 0}, {0, 0, -1, -1, 0b0100, 0, 0, 0}};
-    static constexpr BufOpShape gout[2] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 1, 0, -1, 0b0001, 0, 0, 0}};
+    static constexpr BufOpShape gout[3] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 1, 0, -1, 0b0001, 0, 0, 0},
+                                           {0, 0, -1, -1, 0b0001, 0, 0, 0}};
     static constexpr BufOpShape store[3] = {{0, 0, -1, -1, 0b0011, 0, 0, 0}, {0, 1, 0, -1, 0b1100, 0, 0, 0},
                                             {0, 0, -1, -1, 0b0001, 0, 1, 0}};
 };
@@ -643,10 +646,11 @@ struct IoHead {
 };
 // bias-free encoder of 8-byte rows (edge_classifier.py:66-69 on the four edge features): one tensor,
 // rows of the tile, weight gradients only
+template <int NG_>
 struct IoEncoder8 {
-    static constexpr int NL = 1, NI = 0, NSI = 0, NS = 0, NG = 1, kOnesDword = -1;
+    static constexpr int NL = 1, NI = 0, NSI = 0, NS = 0, NG = NG_, kOnesDword = -1;
     static constexpr BufOpShape load[1] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}};
-    static constexpr BufOpShape gout[1] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}};
+    static constexpr BufOpShape gout[2] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 0, -1, -1, 0b0001, 0, 0, 0}};
     static constexpr BufOpShape store[1] = {};
 };
 
@@ -895,6 +899,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
         if constexpr (BUF) {
             const uint32_t r0 = row0_of(grp, d);
             r.v = u32x4{0u, 0u, 0u, 0u};
+            r.w = u32x2{0u, 0u};
 #pragma unroll
             for (int t = 0; t < IO::NG; ++t) {
                 uint32_t voff, soff;
@@ -903,8 +908,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                     r.v[0] = buf_load_u32(r_go[t], voff, soff);
                 } else {
                     const u32x2 h = buf_load_u32x2(r_go[t], voff, soff);
-                    r.v[2 * t] = h[0];
-                    r.v[2 * t + 1] = h[1];
+                    if (t < 2) {
+                        r.v[2 * (t & 1)] = h[0];
+                        r.v[2 * (t & 1) + 1] = h[1];
+                    } else {
+                        r.w = h;
+                    }
                 }
             }
         } else if (G32) {
@@ -1053,6 +1062,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
                 gy[1] = bf16_hi(gcur[d].v[0]) + bf16_hi(gcur[d].v[2]);
                 gy[2] = bf16_lo(gcur[d].v[1]) + bf16_lo(gcur[d].v[3]);
                 gy[3] = bf16_hi(gcur[d].v[1]) + bf16_hi(gcur[d].v[3]);
+                if constexpr (IO::NG > 2) {
+                    gy[0] += bf16_lo(gcur[d].w[0]);
+                    gy[1] += bf16_hi(gcur[d].w[0]);
+                    gy[2] += bf16_lo(gcur[d].w[1]);
+                    gy[3] += bf16_hi(gcur[d].w[1]);
+                }
             }
             if constexpr (BUF) {   // (lanes without output features loaded zeros)
                 if (G32) gy[1] = gy[2] = gy[3] = 0.f;
@@ -1546,16 +1561,21 @@ inline bool buf_plan_is(const BufPlan &B) {
 
 constexpr int kFwd16BlocksPerCu = 5;
 constexpr int kBwd16BlocksPerCu = 2;
+// weight-gradient-only launches (GT = 0: the encoders of raw dataset features) need 50 KB of LDS and
+// under 100 registers: three workgroups per CU are resident, and the latency-bound tile loop takes them
+constexpr int kBwd16BlocksPerCuLight = 3;
+constexpr int kBwd16BlocksPerCuMax = 3;   // (sizes the workspace)
 
 
-// launches the backward instantiation for (plan, GT, three); G32 = fp32 upstream gradient
 // the buffer-addressed instantiation of a launch, by name ("" = the generic per-lane I/O)
 inline const char *buf_io_name(const BufPlan &B, int KI, int HT, int GT, bool three, bool g32, int debug_flags) {
     if (!B.ok || (debug_flags & (64 | 128)) || KI != 1 || (HT != 1 && HT != 3)) return "";
     if (g32) return (GT == 2 && three && buf_plan_is<IoHead>(B)) ? "IoHead" : "";
-    if (GT == 2 && three && buf_plan_is<IoRelational>(B)) return "IoRelational";
+    if (GT == 2 && three && buf_plan_is<IoRelational<2>>(B)) return "IoRelational<2>";
+    if (GT == 2 && three && buf_plan_is<IoRelational<3>>(B)) return "IoRelational<3>";
     if (GT == 1 && three && buf_plan_is<IoObject>(B)) return "IoObject";
-    if (GT == 0 && !three && buf_plan_is<IoEncoder8>(B)) return "IoEncoder8";
+    if (GT == 0 && !three && buf_plan_is<IoEncoder8<1>>(B)) return "IoEncoder8<1>";
+    if (GT == 0 && !three && buf_plan_is<IoEncoder8<2>>(B)) return "IoEncoder8<2>";
     return "";
 }
 
@@ -1584,12 +1604,16 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
             GNNTRK_BWD16_BUF(3, 2, true, IoHead)
             GNNTRK_BWD16_BUF(1, 2, true, IoHead)
         } else {
-            GNNTRK_BWD16_BUF(3, 2, true, IoRelational)
-            GNNTRK_BWD16_BUF(1, 2, true, IoRelational)
+            GNNTRK_BWD16_BUF(3, 2, true, IoRelational<2>)
+            GNNTRK_BWD16_BUF(3, 2, true, IoRelational<3>)
+            GNNTRK_BWD16_BUF(1, 2, true, IoRelational<2>)
+            GNNTRK_BWD16_BUF(1, 2, true, IoRelational<3>)
             GNNTRK_BWD16_BUF(3, 1, true, IoObject)
             GNNTRK_BWD16_BUF(1, 1, true, IoObject)
-            GNNTRK_BWD16_BUF(3, 0, false, IoEncoder8)
-            GNNTRK_BWD16_BUF(1, 0, false, IoEncoder8)
+            GNNTRK_BWD16_BUF(3, 0, false, IoEncoder8<1>)
+            GNNTRK_BWD16_BUF(3, 0, false, IoEncoder8<2>)
+            GNNTRK_BWD16_BUF(1, 0, false, IoEncoder8<1>)
+            GNNTRK_BWD16_BUF(1, 0, false, IoEncoder8<2>)
         }
 #undef GNNTRK_BWD16_BUF
         if (launched) return check_launch("mlp_backward_bf16");

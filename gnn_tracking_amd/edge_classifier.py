@@ -109,7 +109,9 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         if self.hparams.use_node_embedding:
             segs += [ops.Seg(h, gi.src, False, ("src", gi)), ops.Seg(h, gi.tgt, False, ("tgt", gi))]
         if self.hparams.use_intermediate_edge_embeddings:
-            segs += [ops.Seg(t) for t in es]
+            # (every embedding but the last is also read by the next interaction network: the head's
+            #  gradient reaches its producer's backward kernel as an extra term, ops_bf16.grad_tap)
+            segs += [ops.Seg(ops_bf16.grad_tap(t) if i + 1 < len(es) else t) for i, t in enumerate(es)]
         else:
             segs.append(ops.Seg(e))
         eps = 0.001

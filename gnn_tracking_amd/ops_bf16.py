@@ -124,9 +124,6 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
     a.ca, a.cb = ca, cb
     for j, s in enumerate(segs):
         a.seg[j] = _seg16(s, idx[j], relu[j])
-    a.n_gout = len(gout)
-    for t, (rows, term_idx) in enumerate(gout):
-        a.gout[t] = _capi.GTerm(rows.data_ptr(), ops._p(term_idx), rows.stride(0), min(int(rows.shape[0]), 0x7fffffff))
     dev = segs[0].device
     slices = [None] * len(segs)
     for j, s in enumerate(segs):
@@ -134,6 +131,32 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
             slices[j] = empty_rows(n_rows, s.shape[1], dev)
             gi_j = None if gidx is None else gidx[j]
             a.gseg[j] = _capi.GSeg(slices[j].data_ptr(), ops._p(gi_j), slices[j].stride(0), 0)
+
+    def set_terms(terms):
+        a.n_gout = len(terms)
+        for t, (rows, term_idx) in enumerate(terms):
+            a.gout[t] = _capi.GTerm(rows.data_ptr(), ops._p(term_idx), rows.stride(0), min(int(rows.shape[0]), 0x7fffffff))
+
+    gout = list(gout)
+    set_terms(gout[:2])
+    a.debug_flags = _DEBUG_FLAGS
+    # more terms than this launch's kernel takes (three only on the buffer-addressed shapes): the
+    # surplus rows-of-the-tile terms are summed first, as autograd would have done
+    limit = 2 if epilogue == _capi.EPI_SIGMOID else (int(lib.gnntrk_mlp_backward_bf16_max_terms(C.byref(a))) if len(gout) > 2 else 2)
+    while len(gout) > limit:
+        (r1, i1), (r2, i2) = gout[-2], gout[-1]
+        j = len(gout) - 2
+        if i1 is not None or i2 is not None:   # fold two plain terms; a gathered one stays as it is
+            plain = [k for k, (_, ix) in enumerate(gout) if ix is None]
+            if len(plain) < 2:
+                raise RuntimeError("mlp_backward_raw: cannot fold gathered upstream terms")
+            j, k2 = plain[-2], plain[-1]
+            (r1, i1), (r2, i2) = gout[j], gout[k2]
+            del gout[k2]
+        else:
+            del gout[-1]
+        gout[j] = (rows16(r1 + r2), None)
+    set_terms(gout)
     gW = [None] * len(weights)
     gb = [None] * len(weights)
     if want_dw:
@@ -145,7 +168,7 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
     # always needed: per-wave partial blocks + the store-redirect slots of masked lanes
     ws = ops._ws(lib.gnntrk_mlp_backward_bf16_workspace_bytes(C.byref(a.mlp)), segs[0])
     a.accumulate_params = 0
-    a.debug_flags = _DEBUG_FLAGS   # (64: one 16-row tile per iteration instead of two, for A/B timing)
+    # (debug_flags: 64 one 16-row tile per iteration instead of two, 128 generic per-lane I/O - A/B timing)
     M = n_rows
     nbytes = M * (sum(2 * s.shape[1] + (4 if idx[j] is not None else 0)
                       + (2 * s.shape[1] if need_seg[j] else 0) for j, s in enumerate(segs))
@@ -243,17 +266,25 @@ class FusedMLP16(torch.autograd.Function):
         ctx.spec = spec
         ctx.save_for_backward(*segs, *weights, *[b for b in biases if b is not None])
         ctx.bias_mask = [b is not None for b in biases]
+        ctx.stash = None
+        if spec.epilogue != _capi.EPI_SIGMOID and spec.out_idx is None and spec.epilogue != _capi.EPI_RESIDUAL:
+            _attach_stash(ctx, out)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         from . import ops
         spec = ctx.spec
-        if spec.epilogue == _capi.EPI_SIGMOID:
+        extra = _stashed_terms(ctx)
+        if g_out is None:   # (every reader went through a tap)
+            if not extra:
+                raise RuntimeError("FusedMLP16.backward without upstream gradients")
+            g_rows = extra.pop(0)[0]
+        elif spec.epilogue == _capi.EPI_SIGMOID:
             g_rows = ops._as_rows(g_out.float().contiguous())
         else:
             g_rows = rows16(g_out)
-        outs, g_res = _backward_common(ctx, [(g_rows, spec.out_idx)], ctx.needs_input_grad, g_rows)
+        outs, g_res = _backward_common(ctx, [(g_rows, spec.out_idx)] + extra, ctx.needs_input_grad, g_rows)
         return (None, *outs, g_res)
 
 
@@ -336,6 +367,7 @@ class FusedINEdge16(torch.autograd.Function):
         ctx.spec, ctx.gi = spec, gi
         ctx.save_for_backward(*segs, *weights, *[b for b in biases if b is not None])
         ctx.bias_mask = [b is not None for b in biases]
+        _attach_stash(ctx, e_tilde)
         return e_tilde, aggr
 
     @staticmethod
@@ -346,11 +378,64 @@ class FusedINEdge16(torch.autograd.Function):
             gout.append((rows16(g_et), None))
         if g_aggr is not None:
             gout.append((rows16(g_aggr), gi.tgt))
+        gout += _stashed_terms(ctx)   # (a second reader's gradient of e~, handed over by grad_tap)
         if not gout:
             raise RuntimeError("FusedINEdge16.backward without upstream gradients")
         need = ctx.needs_input_grad  # [spec, gi, segs..., W..., b...]
         outs, _ = _backward_common(ctx, gout, (need[0],) + tuple(need[2:]) + (False,), None)
         return (None, None, *outs)
+
+
+# ---- gradient tap: a second reader of an edge embedding hands its gradient to the producer directly --
+class _GradStash:
+    """Filled by ``_Tap.backward`` (the reader's gradient), emptied by the producer's backward."""
+
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+
+class _Tap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, stash):
+        ctx.stash = stash
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.stash.g = g if ctx.stash.g is None else ctx.stash.g + g
+        return None, None
+
+
+#: gradient taps on / off (off: autograd sums the two gradients of a twice-read embedding itself)
+TAP = __import__("os").environ.get("GNNTRK_GRAD_TAP", "1") != "0"
+
+
+def grad_tap(t: Tensor) -> Tensor:
+    """``t`` for a SECOND reader (the edge-weight head reads every edge embedding that the next
+    interaction network also reads): the reader's gradient does not go through autograd's sum of
+    the two gradients - a 24 B/edge pass per embedding - but into a stash the backward of ``t``'s
+    producer (``FusedMLP16`` / ``FusedINEdge16``) picks up as one more upstream term of its kernel.
+    Tensors not produced by those nodes, and fp32 ones, are returned as they are."""
+    stash = getattr(t, "_gnntrk_stash", None)
+    if stash is None or not TAP or not t.requires_grad:
+        return t
+    return _Tap.apply(t, stash)
+
+
+def _attach_stash(ctx, out: Tensor) -> None:
+    ctx.stash = _GradStash()
+    out._gnntrk_stash = ctx.stash
+
+
+def _stashed_terms(ctx):
+    g = ctx.stash.take() if getattr(ctx, "stash", None) is not None else None
+    return [] if g is None else [(rows16(g), None)]
 
 
 def in_edge(segs, weights, biases, gi, n_rows: int):

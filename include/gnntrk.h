@@ -239,9 +239,9 @@ typedef struct gnntrk_mlp_bwd_args {
     gnntrk_seg seg[GNNTRK_MAX_SEGS];
     int64_t n_rows;
     float ca, cb;
-    int32_t n_gout; /* 1 or 2 */
+    int32_t n_gout; /* 1 or 2; gnntrk_mlp_backward_bf16: 3 where gnntrk_mlp_backward_bf16_max_terms says so */
     int32_t accumulate_params;
-    gnntrk_gterm gout[2];
+    gnntrk_gterm gout[3];
     gnntrk_gseg gseg[GNNTRK_MAX_SEGS];
     float *gW[3]; /* may be NULL: skip parameter gradients of that layer */
     float *gb[3];
@@ -251,6 +251,11 @@ typedef struct gnntrk_mlp_bwd_args {
     int32_t _pad;
 } gnntrk_mlp_bwd_args;
 
+/* How many upstream-gradient terms gnntrk_mlp_backward_bf16 takes for this launch (args filled as for
+ * the launch, n_gout ignored): 3 for the shapes that run on buffer descriptors (an edge embedding read by
+ * the next interaction network AND by the edge-weight head hands both gradients over without a sum pass in
+ * between), else 2. */
+int gnntrk_mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *args);
 size_t gnntrk_mlp_backward_workspace_bytes(const gnntrk_mlp *mlp);
 int gnntrk_mlp_backward(const gnntrk_mlp_bwd_args *args, void *workspace,
                         size_t workspace_bytes, void *stream);

@@ -48,7 +48,7 @@ def test_struct_layout_matches_header():
     assert _capi.MlpFwdArgs.n_rows.offset == 392
     assert ctypes.sizeof(_capi.GraphIndex) == 72
     assert ctypes.sizeof(_capi.GraphIndexCarry) == 40
-    assert ctypes.sizeof(_capi.MlpBwdArgs) == 760
+    assert ctypes.sizeof(_capi.MlpBwdArgs) == 784
 
 
 def test_product_path_refuses_cpu_tensors():

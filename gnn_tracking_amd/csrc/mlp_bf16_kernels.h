@@ -1077,13 +1077,20 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
             }
             if (need_y) {
                 const f32x4 y = contract_hidden<HT>(wimg + F::kA3, PL(d), lane, zero);
+                if (BUF && G32) {
+                    // (buffer form of the fp32-gradient launch = the one-column edge-weight head: the
+                    //  sigmoid's derivative for the one feature there is, not for four registers)
+                    const float sg = sigmoidf_(y[0]);
+                    gy[0] = gy[0] * a.cb * sg * (1.f - sg);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (epi == GNNTRK_EPI_RELU) {
-                        gy[r] = y[r] > 0.f ? gy[r] : 0.f;
-                    } else {
-                        const float sg = sigmoidf_(y[r]);
-                        gy[r] = gy[r] * a.cb * sg * (1.f - sg);
+                    for (int r = 0; r < 4; ++r) {
+                        if (epi == GNNTRK_EPI_RELU) {
+                            gy[r] = y[r] > 0.f ? gy[r] : 0.f;
+                        } else {
+                            const float sg = sigmoidf_(y[r]);
+                            gy[r] = gy[r] * a.cb * sg * (1.f - sg);
+                        }
                     }
                 }
             } else if (epi == GNNTRK_EPI_RESIDUAL) {

@@ -24,7 +24,7 @@ flat = gdist.FlatParameters(model)
 opt = torch.optim.Adam([flat.flat_param], lr=1e-4, weight_decay=1e-4)
 loss_fct = G.EdgeWeightBCELoss()
 batch = G.collate([synthetic.make_event(100 + i, 150_000, 2_000_000, dev) for i in range(args.events)])
-yf = batch.y.float()
+yf = batch.y   # (the dataset's bool labels, as bench.py passes them)
 
 
 def step():

@@ -33,8 +33,11 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     BufPlan B;
     make_buf_plan(B, P, a, GT);
     const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, g32, a->debug_flags);
-    snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s, %d, %s>", P.KI, P.HT, GT,
-             a->mlp.n_layers == 3 ? "true" : "false", g32 ? "true" : "false", D, io[0] ? io : "IoNone");
+    // (as rocprofv3 prints the instantiation: a template argument that itself ends in '>' is followed by a space)
+    const char *ion = io[0] ? io : "IoNone";
+    snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s, %d, %s%s>", P.KI, P.HT, GT,
+             a->mlp.n_layers == 3 ? "true" : "false", g32 ? "true" : "false", D, ion,
+             ion[strlen(ion) - 1] == '>' ? " " : "");
     return GNNTRK_OK;
 }
 

@@ -56,9 +56,15 @@ def init_process_group_from_env(backend: str | None = None, timeout_s: float = 1
 
 class FlatParameters:
     """Re-homes all parameters (and their gradients) of a module into two contiguous
-    fp32 buffers so that one all-reduce and one optimizer kernel cover the model."""
+    fp32 buffers so that one all-reduce and one optimizer kernel cover the model.
 
-    def __init__(self, module: nn.Module):
+    ``grad_sink`` (default on): the parameters are marked so that the fused MLP backward launches ADD
+    their weight / bias gradients into these persistent buffers themselves (``ops._param_grad_sinks``)
+    instead of returning six tensors per MLP for autograd to ``add_`` - bit-identical sums, 100 fewer
+    tiny kernels per step of the edge classifier.  The gradients are then found in ``.grad`` also after
+    ``torch.autograd.grad`` on such parameters; pass ``grad_sink=False`` where that matters."""
+
+    def __init__(self, module: nn.Module, grad_sink: bool = True):
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
             raise ValueError("module has no trainable parameters")
@@ -72,6 +78,8 @@ class FlatParameters:
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
             p.grad = self.grad[off:off + k].view_as(p)
+            if grad_sink:
+                p._gnntrk_grad_sink = True
             off += k
         self.params = params
         #: a single leaf covering every parameter, for ``torch.optim.*([flat_param])``

@@ -478,6 +478,34 @@ def _fill_mlp(weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]]):
                           out_dim)
 
 
+#: parameters marked by ``dist.FlatParameters`` own PERSISTENT fp32 gradient buffers (views of one
+#: bucket): the reduction at the end of a backward launch then adds into them directly
+#: (``gnntrk_mlp_bwd_args.accumulate_params``) and autograd gets ``None`` for those inputs, instead
+#: of six small tensors per MLP and one ``add_`` kernel each.  ``GNNTRK_GRAD_SINK=0`` turns it off;
+#: it applies to ``.backward()`` only in the sense that ``torch.autograd.grad`` on marked parameters
+#: would find the sum in ``.grad`` as well - FlatParameters documents that.
+_GRAD_SINK = os.environ.get("GNNTRK_GRAD_SINK", "1") != "0"
+
+
+def _param_grad_sinks(weights, biases, need_w, need_b):
+    """``(gW buffers, gb buffers)`` to accumulate into, or ``None``: every parameter of the launch
+    that needs a gradient must be marked and hold a matching contiguous fp32 ``.grad``."""
+    if not _GRAD_SINK:
+        return None
+    gW, gb = [], []
+    for plist, need, out in ((weights, need_w, gW), (biases, need_b, gb)):
+        for p_, nd in zip(plist, need):
+            if p_ is None:
+                out.append(None)
+                continue
+            g = getattr(p_, "grad", None)
+            if (not nd or not getattr(p_, "_gnntrk_grad_sink", False) or g is None or g.dtype != torch.float32
+                    or g.shape != p_.shape or g.device != p_.device or not g.is_contiguous()):
+                return None
+            out.append(g)
+    return gW, gb
+
+
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec: _MlpSpec, *tensors):
@@ -563,14 +591,20 @@ class _FusedMLP(torch.autograd.Function):
         gW = [None] * nl
         gb = [None] * nl
         ws = None
+        sinks = None
         if want_dw:
-            gW = [torch.empty_like(w) for w in weights]
-            gb = [None if b is None else torch.empty_like(b) for b in biases]
+            sinks = _param_grad_sinks(weights, biases, need[1 + ns:1 + ns + nl],
+                                      [need[1 + ns + nl + i] or biases[i] is None for i in range(nl)])
+            if sinks is not None:
+                gW, gb = sinks
+            else:
+                gW = [torch.empty_like(w) for w in weights]
+                gb = [None if b is None else torch.empty_like(b) for b in biases]
             for i in range(nl):
                 a.gW[i] = _p(gW[i])
                 a.gb[i] = _p(gb[i])
             ws = _ws(lib.gnntrk_mlp_backward_workspace_bytes(C.byref(a.mlp)), g_out)
-        a.accumulate_params = 0
+        a.accumulate_params = 1 if sinks is not None else 0
         a.debug_flags = int(__import__("os").environ.get("GNNTRK_DEBUG_FLAGS", "0"))
         nbytes = M * (sum(4 * s.shape[1] + (4 if spec.idx[j] is not None else 0)
                           + (4 * s.shape[1] if need[1 + j] else 0)
@@ -607,8 +641,11 @@ class _FusedMLP(torch.autograd.Function):
             g_dense = g_out if spec.out_idx is None else _permute_raw(g_out, spec.out_idx, False)
             g_res = _axpby_raw(spec.ca, g_dense.contiguous())
         outs = [None, *seg_grads]
-        outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
-        outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
+        if sinks is not None:   # (already added into the parameters' gradient buffers)
+            outs += [None] * (2 * nl)
+        else:
+            outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
+            outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
         outs.append(g_res)
         return tuple(outs)
 

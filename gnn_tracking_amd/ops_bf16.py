@@ -112,7 +112,7 @@ def mlp_forward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], rel
 def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], relu: Sequence[bool],
                      weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]], *, n_rows: int,
                      epilogue: int, ca: float, cb: float, gout: Sequence[tuple], need_seg: Sequence[bool],
-                     want_dw: bool, mlp, gidx: Optional[Sequence[Optional[Tensor]]] = None):
+                     want_dw: bool, mlp, gidx: Optional[Sequence[Optional[Tensor]]] = None, sinks=None):
     """One launch of gnntrk_mlp_backward_bf16.  ``gout``: 1-2 tuples (rows, idx) - padded
     bf16 rows, or one fp32 ``[*, out]`` tensor for EPI_SIGMOID.  Returns (row-aligned
     per-segment gradient slices ``[n_rows, dim]`` bf16 or None, gW list, gb list)."""
@@ -160,14 +160,17 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
     gW = [None] * len(weights)
     gb = [None] * len(weights)
     if want_dw:
-        gW = [torch.empty_like(w) for w in weights]
-        gb = [None if b is None else torch.empty_like(b) for b in biases]
+        if sinks is not None:   # (persistent fp32 gradient buffers of the parameters: ops._param_grad_sinks)
+            gW, gb = sinks
+        else:
+            gW = [torch.empty_like(w) for w in weights]
+            gb = [None if b is None else torch.empty_like(b) for b in biases]
         for i in range(len(weights)):
             a.gW[i] = gW[i].data_ptr()
             a.gb[i] = ops._p(gb[i])
     # always needed: per-wave partial blocks + the store-redirect slots of masked lanes
     ws = ops._ws(lib.gnntrk_mlp_backward_bf16_workspace_bytes(C.byref(a.mlp)), segs[0])
-    a.accumulate_params = 0
+    a.accumulate_params = 1 if (want_dw and sinks is not None) else 0
     # (debug_flags: 64 one 16-row tile per iteration instead of two, 128 generic per-lane I/O - A/B timing)
     M = n_rows
     nbytes = M * (sum(2 * s.shape[1] + (4 if idx[j] is not None else 0)
@@ -312,9 +315,13 @@ def _backward_common(ctx, gout, need, g_rows):
     gidx = [spec.reduce[j][1].spos_inv
             if (need_seg[j] and isinstance(spec.reduce[j], tuple) and spec.reduce[j][0] == "src")
             else None for j in range(ns)]
+    sinks = None
+    if want_dw:
+        sinks = ops._param_grad_sinks(weights, biases, need[1 + ns:1 + ns + nl],
+                                      [need[1 + ns + nl + i] or biases[i] is None for i in range(nl)])
     slices, gW, gb = mlp_backward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=M,
                                       epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb, gout=gout,
-                                      need_seg=need_seg, want_dw=want_dw, mlp=mlp, gidx=gidx)
+                                      need_seg=need_seg, want_dw=want_dw, mlp=mlp, gidx=gidx, sinks=sinks)
     seg_grads = [None] * ns
     for j, s in enumerate(segs):
         if slices[j] is None:
@@ -336,8 +343,11 @@ def _backward_common(ctx, gout, need, g_rows):
         g_dense = g_rows if spec.out_idx is None else permute_raw(g_rows, spec.out_idx, False)
         g_res = g_dense * spec.ca
     outs = list(seg_grads)
-    outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
-    outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
+    if sinks is not None:   # (already added into the parameters' gradient buffers)
+        outs += [None] * (2 * nl)
+    else:
+        outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
+        outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
     return outs, g_res
 
 

@@ -32,7 +32,7 @@ def build(asan: bool = False, verbose: bool = False) -> pathlib.Path:
     stamp = OUT / (name + ".stamp")
     if lib.exists() and stamp.exists() and stamp.read_text() == h.hexdigest():
         return lib
-    flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+    flags = ["-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
              "-Wno-attributes", "-Wno-unknown-pragmas", "-Wno-ignored-attributes",
              f"-I{HERE / 'shim'}", f"-I{REPO / 'include'}", f"-I{CSRC}"]
     if asan:

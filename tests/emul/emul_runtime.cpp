@@ -32,18 +32,94 @@ void *stack_of(unsigned t) {
     return stack_pool[t];
 }
 
+#if !HIPEMUL_UCONTEXT
+// switch(from, to): push the callee-saved registers and the floating-point control words, store the
+// stack pointer in *from, load the one in *to, pop, return - into whoever switched away from `to`
+// (or into fiber_start for a fresh lane, see prepare_fiber)
+extern "C" void hipemul_switch(FiberCtx *from, FiberCtx *to);
+asm(R"(
+    .text
+    .globl hipemul_switch
+    .type hipemul_switch,@function
+hipemul_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemul_switch,.-hipemul_switch
+)");
+#endif
+
+void switch_ctx(FiberCtx *from, FiberCtx *to) {
+#if HIPEMUL_UCONTEXT
+    swapcontext(from, to);
+#else
+    hipemul_switch(from, to);
+#endif
+}
+
 void fiber_entry() {
     Block *b = cur_block;
     (*b->fn)();
     b->fibers[b->cur].done = true;
     ++b->progress;
-    // (uc_link returns to the scheduler)
+    // (ucontext: uc_link returns to the scheduler)
+}
+
+#if !HIPEMUL_UCONTEXT
+extern "C" void hipemul_fiber_start() {
+    fiber_entry();
+    Block *b = cur_block;
+    hipemul_switch(&b->fibers[b->cur].ctx, &b->sched);   // a finished lane is never resumed
+    abort();
+}
+#endif
+
+void prepare_fiber(Block &blk, Fiber &f, unsigned t) {
+#if HIPEMUL_UCONTEXT
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = stack_of(t);
+    f.ctx.uc_stack.ss_size = kStackBytes;
+    f.ctx.uc_link = &blk.sched;
+    makecontext(&f.ctx, fiber_entry, 0);
+#else
+    (void)blk;
+    // the frame hipemul_switch pops: control words | r15 r14 r13 r12 rbx rbp | return address.  The return
+    // address sits at a 16-byte boundary, so the started function sees the stack as after a call.
+    uintptr_t top = (reinterpret_cast<uintptr_t>(stack_of(t)) + kStackBytes) & ~uintptr_t(15);
+    uint64_t *ret = reinterpret_cast<uint64_t *>(top - 32);
+    ret[0] = reinterpret_cast<uint64_t>(&hipemul_fiber_start);
+    ret[1] = 0;   // (a fake caller frame: never returned into)
+    uint64_t *sp = ret - 7;
+    for (int i = 1; i < 7; ++i) sp[i] = 0;
+    uint32_t *cw = reinterpret_cast<uint32_t *>(sp);
+    cw[0] = 0x1f80;   // MXCSR: all exceptions masked, round to nearest
+    cw[1] = 0x037f;   // x87 control word: the ABI's default
+    f.ctx.sp = sp;
+#endif
 }
 }  // namespace
 
 void fiber_yield() {
     Block *b = cur_block;
-    swapcontext(&b->fibers[b->cur].ctx, &b->sched);
+    switch_ctx(&b->fibers[b->cur].ctx, &b->sched);
 }
 void note_progress() { ++cur_block->progress; }
 const char *&fiber_waiting_at() { return cur_block->fibers[cur_block->cur].waiting_at; }
@@ -62,11 +138,7 @@ void run_block(Block &blk) {
         Fiber &f = blk.fibers[t];
         f.done = false;
         f.waiting_at = "";
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = stack_of(t);
-        f.ctx.uc_stack.ss_size = kStackBytes;
-        f.ctx.uc_link = &blk.sched;
-        makecontext(&f.ctx, fiber_entry, 0);
+        prepare_fiber(blk, f, t);
     }
     unsigned live = nt;
     while (live > 0) {
@@ -76,7 +148,7 @@ void run_block(Block &blk) {
             if (f.done) continue;
             blk.cur = t;
             threadIdx = {t, 0, 0};
-            swapcontext(&blk.sched, &f.ctx);
+            switch_ctx(&blk.sched, &f.ctx);
             if (f.done) --live;
         }
         if (live > 0 && blk.progress == before) {

@@ -141,8 +141,22 @@ struct Wave {
     uint64_t xch[64];
 };
 
+// A lane's saved context.  glibc's swapcontext() saves / restores the signal mask with two system
+// calls per switch - nine tenths of an emulated test's run time; the plain build therefore switches
+// with a dozen instructions of its own (callee-saved registers + stack pointer, emul_runtime.cpp).
+// Sanitizer builds keep ucontext, which the sanitizers know how to follow.
+#if defined(__SANITIZE_ADDRESS__) || !defined(__x86_64__)
+#define HIPEMUL_UCONTEXT 1
+typedef ucontext_t FiberCtx;
+#else
+#define HIPEMUL_UCONTEXT 0
+struct FiberCtx {
+    void *sp = nullptr;
+};
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    FiberCtx ctx;
     bool done = false;
     const char *waiting_at = "";
 };
@@ -151,7 +165,7 @@ struct Block {
     Barrier bar;
     std::vector<Wave> waves;
     std::vector<Fiber> fibers;
-    ucontext_t sched;
+    FiberCtx sched;
     unsigned cur = 0;
     unsigned long progress = 0;
     const std::function<void()> *fn = nullptr;

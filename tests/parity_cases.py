@@ -832,6 +832,40 @@ def case_ec_carry_equals_gather(device, name="skip1_L3_h40"):
         assert_close(res[True][0], z[f"{name}/loss"], 0.01, "loss vs fp32 golden") if thld == 0.9 else None
 
 
+def case_grad_sink(device, name="skip1_L3_h40"):
+    """Parameters re-homed by ``dist.FlatParameters`` receive their weight / bias gradients straight from
+    the backward launches (``accumulate_params``): BIT-IDENTICAL to the gradients autograd accumulates
+    from returned tensors, in fp32 and bf16 storage, over one backward and over two accumulated ones."""
+    from gnn_tracking_amd import dist as gdist
+    z = load("g2_ec_variants.npz")
+    x, ei, ea = tt(z["x"], device), tt(z["edge_index"], device), tt(z["edge_attr"], device)
+    y, pt = tt(z["y"], device).bool(), tt(z["pt"], device)
+    for bf16 in (False, True):
+        got = {}
+        for sink in (True, False):
+            model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_VARIANTS[name])
+            load_params(model, z, f"{name}/p0/")
+            model = model.to(device)
+            flat = gdist.FlatParameters(model, grad_sink=sink)
+            assert all(getattr(p_, "_gnntrk_grad_sink", False) == sink for p_ in flat.params)
+            snaps = []
+            for rep in range(2):   # (gradients ACCUMULATE over the two backward passes)
+                ops.clear_graph_index_cache()
+                with G.bf16_storage(bf16):
+                    out = model(G.Data(x=x, edge_index=ei, edge_attr=ea, y=y))
+                    G.EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"], y=y, pt=pt, edge_index=ei).backward()
+                snaps.append(flat.grad.clone())
+            for p_ in flat.params:   # the gradients still live in the bucket
+                assert p_.grad.data_ptr() >= flat.grad.data_ptr() and p_.grad.untyped_storage().data_ptr() == flat.grad.untyped_storage().data_ptr()
+            got[sink] = snaps
+        for rep in range(2):
+            assert torch.equal(got[True][rep], got[False][rep]), f"bf16={bf16} pass {rep}: sink != autograd accumulation"
+        assert float(got[True][0].abs().sum()) > 0 and not torch.equal(got[True][0], got[True][1])
+        if not bf16:   # (two accumulated passes = twice the reference's gradients)
+            for k, v in model.named_parameters():
+                assert_close(v.grad / 2, z[f"{name}/grad/{k}"], TOL_GRAD, f"sink grad {k} vs golden")
+
+
 BF16_PIN_W = 2.0 ** -8       # one ulp of the reference's bf16 W on [0.5, 1)
 BF16_PIN_EMB = 2.0 ** -6     # four bf16 ulps relative to the largest entry
 

@@ -28,6 +28,11 @@ def test_fused_mlp_forward_backward():
         P.case_mlp("cpu")
 
 
+def test_parameter_gradients_added_in_place_equal_autograd_accumulation():
+    with emulated():
+        P.case_grad_sink("cpu")
+
+
 def test_fused_mlp_stress_small():
     with emulated():
         P.case_mlp_stress("cpu", rounds=2, seed=11, cases_per_round=8, row_choices=(1, 16, 17, 45, 300))

@@ -28,6 +28,10 @@ def test_graph_index_carry_and_fused_bce(dev):
     P.case_ec_carry_equals_gather(dev)
 
 
+def test_parameter_gradients_added_in_place_equal_autograd_accumulation(dev):
+    P.case_grad_sink(dev)
+
+
 def test_fused_mlp_forward_backward(dev):
     P.case_mlp(dev)
     P.case_mlp(dev, shapes=((14, 40, 4, 3), (26, 40, 1, 3)), rows=40001)

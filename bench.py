@@ -66,8 +66,8 @@ CFG4_EVENTS, CFG4_SHARDS = 256, 8
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=("cfg2", "cfg3", "cfg4", "cfg5"))
     ap.add_argument("--events", type=int, default=None, help="override the event count (cfg3: per GPU; cfg4: total)")
     ap.add_argument("--dtype", default=None, choices=("bf16", "f32"),
@@ -547,12 +547,17 @@ def timed_steps(wl: Workload, world: int, dev, steps: int, warmup: int, *, kerne
     # the per-kernel / per-stage HIP-event brackets are armed during the warm-up as well (their
     # first use costs tens of milliseconds of host time inside the HIP runtime - a one-time cost
     # like the first launch of a kernel) and emptied before the timed region
-    timer = ops.KernelTimer() if kernel_timer else None
+    timer = ops.KernelTimer() if kernel_timer and not os.environ.get("GNNTRK_BENCH_NO_TIMER") else None
     ops.set_kernel_timer(timer)
     if hasattr(wl, "stage"):
         wl.stage.on = True
-    for _ in range(warmup):
+    for i in range(warmup):
         wl.step()
+        if i == warmup - 2:
+            # one synchronisation INSIDE the warm-up: on a fresh box the first step after the process's
+            # first device synchronisation costs its host thread 130 ms (measured: the runtime defers
+            # one-time work to that point); the last warm-up step now pays it, not the first timed one
+            barrier(world)
     # the timed region's events are created NOW (the warm-up has shown how many a step takes): the
     # HIP runtime grows its event storage in steps, and such a step inside the timed region costs
     # its host thread tens of milliseconds - which a 9 ms cfg5 step cannot hide
@@ -565,16 +570,23 @@ def timed_steps(wl: Workload, world: int, dev, steps: int, warmup: int, *, kerne
         wl.stage.rec.clear()
     if used and dev.type == "cuda":
         ops.reserve_timing_events((used // max(warmup, 1) + 8) * steps)
+    debug = bool(os.environ.get("GNNTRK_BENCH_DEBUG")) and dev.type == "cuda"
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if debug else None
     barrier(world)
     t0 = time.perf_counter()
     marks = []
-    for _ in range(steps):
+    if debug:
+        evs[0].record()
+    for i in range(steps):
         loss = wl.step()
         marks.append(time.perf_counter())   # (host-side enqueue times: no synchronisation)
+        if debug:
+            evs[i + 1].record()
     barrier(world)
     dt = time.perf_counter() - t0
-    if os.environ.get("GNNTRK_BENCH_DEBUG"):
+    if debug:
         print("host ms per step:", [round((b - a) * 1e3, 1) for a, b in zip([t0] + marks, marks)], file=sys.stderr)
+        print("gpu  ms per step:", [round(a.elapsed_time(b), 1) for a, b in zip(evs, evs[1:])], file=sys.stderr)
     ops.set_kernel_timer(None)
     if hasattr(wl, "stage"):
         wl.stage.on = False

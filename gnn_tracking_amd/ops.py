@@ -102,9 +102,13 @@ _EVENT_POOL: list = []
 
 
 def reserve_timing_events(n: int) -> None:
-    """Create (and record once, which is what allocates them) ``n`` timing events now."""
+    """Create ``n`` timing events now and record each TWICE: the first record is what allocates an
+    event, and recording an event that has been recorded before is a path of its own in the HIP
+    runtime - on a freshly started box its first execution cost the first timed step of bench.py
+    130 ms of host time (the code is paged in on first use)."""
     while len(_EVENT_POOL) < n:
         e = torch.cuda.Event(enable_timing=True)
+        e.record()
         e.record()
         _EVENT_POOL.append(e)
 

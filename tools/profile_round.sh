@@ -14,6 +14,7 @@ SQ="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAI
 cd /tmp
 rocprofv3 --kernel-trace -d /tmp/p_k -o k -- $B > /dev/null 2>&1
 python $ROOT/tools/rocpd_summary.py /tmp/p_k/k_results.db > $ROOT/$OUT/${TAG}_bench_cfg3_bf16_kernel_stats.md
+(cd $ROOT/tools && python rocpd_timeline.py /tmp/p_k/k_results.db > $ROOT/$OUT/${TAG}_step_timeline.md)
 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -o f -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -o w -- $B > /dev/null 2>&1
 python $ROOT/tools/make_traffic_json.py /tmp/p_f/f_results.db /tmp/p_w/w_results.db 64000000 \
@@ -27,6 +28,7 @@ python $ROOT/tools/make_pipe_json.py /tmp/p_s/s_results.db "bench.py cfg3 bf16, 
 C5="python $ROOT/bench.py --workload cfg5 --steps 4 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace -d /tmp/p_k5 -o k -- $C5 > /dev/null 2>&1
 python $ROOT/tools/rocpd_summary.py /tmp/p_k5/k_results.db > $ROOT/$OUT/${TAG}_bench_cfg5_kernel_stats.md
+(cd $ROOT/tools && python rocpd_timeline.py /tmp/p_k5/k_results.db --mark knn_bbox_partial_kernel --nth-last 2 > $ROOT/$OUT/${TAG}_cfg5_timeline.md)
 rocprofv3 --pmc $SQ -d /tmp/p_s5 -o s -- $C5 > /dev/null 2>&1
 python $ROOT/tools/make_pipe_json.py /tmp/p_s5/s_results.db "bench.py --workload cfg5 (fp32, 200 k hits), SQ counters, round 3" > $ROOT/$OUT/${TAG}_pipe_util_cfg5.json
 rocprofv3 --pmc $SQ -d /tmp/p_sd -o s -- python $ROOT/tools/bench_dbscan.py > /dev/null 2>&1

@@ -13,7 +13,8 @@ import pathlib
 import threading
 
 MAX_SEGS = 10
-MAX_IN, MAX_HIDDEN, MAX_OUT = 48, 64, 16
+MAX_IN, MAX_HIDDEN, MAX_OUT = 48, 64, 16            # fp32 kernels
+MAX_IN_BF16, MAX_HIDDEN_BF16 = 64, 95              # bf16 storage: 16 four-feature chunks, hidden + bias row <= 96
 EPI_NONE, EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID = 0, 1, 2, 3
 
 _PKG = pathlib.Path(__file__).resolve().parent

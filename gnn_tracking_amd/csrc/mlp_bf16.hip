@@ -110,13 +110,14 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
     if (!P.ok || P.KI > 2)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: more than 16 input chunks / 4 hidden tiles");
+        return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: more than 16 input chunks / 6 hidden tiles");
     const bool three = a->mlp.n_layers == 3;
     // gradient M tiles: 1 or the maximum of the k-step count (keeps the instantiation list short)
     const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
     int grid = 0;
     if (a->n_rows > 0) {
-        grid = grid16(a->n_rows, (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu, kWaves);
+        // (five / six hidden tiles: one workgroup per CU is resident - its share of the rows is simply larger)
+        grid = grid16(a->n_rows, P.HT >= 5 ? 1 : (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu, kWaves);
         float *part = reinterpret_cast<float *>(ws);
         uint8_t *trash = reinterpret_cast<uint8_t *>(ws) + bwd16_partial_bytes(&a->mlp);
         rc = (a->epilogue == GNNTRK_EPI_SIGMOID)

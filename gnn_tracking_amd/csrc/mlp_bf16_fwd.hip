@@ -28,14 +28,30 @@ namespace gnntrk {
         launched = true;                                                                \
     }
 
+// hidden widths 64 .. 95 (five / six hidden tiles): the plain forms only (own output tile per tile,
+// 8-byte loads) - four instantiations per shape instead of sixteen
+#define GNNTRK_FWD16_CASE_PLAIN(KI_, HT_)                                                   \
+    if (P.KI == KI_ && P.HT == HT_) {                                                       \
+        if (three && sig) { auto kfn = mlp16_fwd_kernel<KI_, HT_, true, true, 1, false>;    \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        else if (three) { auto kfn = mlp16_fwd_kernel<KI_, HT_, true, false, 1, false>;     \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        else if (sig) { auto kfn = mlp16_fwd_kernel<KI_, HT_, false, true, 1, false>;       \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        else { auto kfn = mlp16_fwd_kernel<KI_, HT_, false, false, 1, false>;               \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        launched = true;                                                                    \
+    }
+
 // exact forward instantiation
 int mlp16_fwd_kernel_name(const gnntrk_mlp_fwd_args *a, char *buf, size_t len) {
     if (!a || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
+    const bool plain = P.HT >= 5;
     snprintf(buf, len, "mlp16_fwd_kernel<%d, %d, %s, %s, %d, %s>", P.KI, P.HT, a->mlp.n_layers == 3 ? "true" : "false",
-             a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false", a->mlp.out_dim <= 4 ? 4 : 1,
-             wide_ok(P, a->seg, a->n_rows) ? "true" : "false");
+             a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false", (a->mlp.out_dim <= 4 && !plain) ? 4 : 1,
+             (!plain && wide_ok(P, a->seg, a->n_rows)) ? "true" : "false");
     return GNNTRK_OK;
 }
 
@@ -62,11 +78,12 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
     if (!P.ok || P.KI > 2)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: more than 16 input chunks / 4 hidden tiles");
+        return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: more than 16 input chunks / 6 hidden tiles");
     const bool three = a->mlp.n_layers == 3, sig = a->epilogue == GNNTRK_EPI_SIGMOID;
     const bool share = a->mlp.out_dim <= 4;  // four tiles share one output tile and one store
     const bool wide = wide_ok(P, a->seg, a->n_rows);  // one 16-byte load per lane and k-step
-    int grid = grid16(a->n_rows, kFwd16BlocksPerCu, kWaves);
+    // (six hidden tiles: 34 KB of fragments per workgroup - four fit a CU)
+    int grid = grid16(a->n_rows, P.HT >= 6 ? 4 : kFwd16BlocksPerCu, kWaves);
     if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
     bool launched = false;
     GNNTRK_FWD16_CASE(1, 1)
@@ -77,6 +94,10 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     GNNTRK_FWD16_CASE(2, 2)
     GNNTRK_FWD16_CASE(2, 3)
     GNNTRK_FWD16_CASE(2, 4)
+    GNNTRK_FWD16_CASE_PLAIN(1, 5)
+    GNNTRK_FWD16_CASE_PLAIN(1, 6)
+    GNNTRK_FWD16_CASE_PLAIN(2, 5)
+    GNNTRK_FWD16_CASE_PLAIN(2, 6)
     if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: no instantiation");
     return check_launch("mlp_forward_bf16");
 }

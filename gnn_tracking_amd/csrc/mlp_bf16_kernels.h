@@ -655,7 +655,7 @@ struct IoEncoder8 {
 };
 
 template <int KI, int HT, int GT, bool THREE, bool G32, int D, class IO = IoNone>
-__global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
+__global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                               uint8_t *trash, const BufPlan bp) {
     constexpr bool BUF = IO::NL > 0;
     static_assert(!BUF || KI == 1, "buffer-addressed I/O: one k-step");
@@ -1368,8 +1368,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp16_bwd_kernel(const gnntrk_mlp_b
 // n_rows == 0 is a valid no-op: row pointers may then be NULL (what an empty tensor hands over)
 int check_bf16_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, const char *who, int64_t n_rows) {
     if (m.n_layers != 2 && m.n_layers != 3) return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): n_layers must be 2 or 3");
-    if (m.in_dim < 1 || m.hidden < 1 || m.hidden > 63 || m.out_dim < 1 || m.out_dim > 16)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): hidden must be in [1,63], out in [1,16]");
+    if (m.in_dim < 1 || m.hidden < 1 || m.hidden > 16 * kMaxHiddenTiles16 - 1 || m.out_dim < 1 || m.out_dim > 16)
+        return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): hidden must be in [1,95], out in [1,16]");
     if (n_seg < 1 || n_seg > GNNTRK_MAX_SEGS) return fail(GNNTRK_EINVAL, "mlp(bf16): bad segment count");
     int tot = 0;
     for (int j = 0; j < n_seg; ++j) {
@@ -1647,7 +1647,7 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     }
 #define GNNTRK_BWD16_HT(KI_, GT_) \
     GNNTRK_BWD16_CASE(KI_, 1, GT_) GNNTRK_BWD16_CASE(KI_, 2, GT_) GNNTRK_BWD16_CASE(KI_, 3, GT_) \
-        GNNTRK_BWD16_CASE(KI_, 4, GT_)
+        GNNTRK_BWD16_CASE(KI_, 4, GT_) GNNTRK_BWD16_CASE(KI_, 5, GT_) GNNTRK_BWD16_CASE(KI_, 6, GT_)
     GNNTRK_BWD16_HT(1, 0)   // weight gradients only (the encoders of raw dataset features)
     GNNTRK_BWD16_HT(1, 1)
     GNNTRK_BWD16_HT(1, 2)

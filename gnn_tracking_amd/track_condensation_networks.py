@@ -55,9 +55,10 @@ class ResFCNN(nn.Module):
         self._reset_layer_parameters(self._decoder, var=2 / hidden_dim)
         self._alpha = alpha
         # depth 1 = a two-layer MLP; depth 2 with alpha = 0 (the heterogeneous node encoder of
-        # ModularGraphTCN) = a three-layer MLP: both are one fused launch
-        self._fusable = ((depth == 1 or (depth == 2 and alpha == 0)) and in_dim <= _capi.MAX_IN
-                         and hidden_dim <= 63 and out_dim <= _capi.MAX_OUT)
+        # ModularGraphTCN) = a three-layer MLP: both are one fused launch where the storage mode's
+        # kernels hold the widths (fp32: in <= 48, hidden <= 64; bf16: 16 input chunks, hidden <= 94)
+        self._fusable_depth = depth == 1 or (depth == 2 and alpha == 0)
+        self._dims = (in_dim, hidden_dim, out_dim)
 
     @staticmethod
     def _reset_layer_parameters(layer, var: float):
@@ -68,8 +69,12 @@ class ResFCNN(nn.Module):
     def forward(self, x: Tensor, *, epilogue: int = _capi.EPI_NONE, **ignore) -> Tensor:
         _capi.require_device(x)
         x = nn.functional.normalize(x.float(), p=2.0, dim=1, eps=1e-12)
-        if self._fusable:
-            if precision.use_bf16():  # bf16 storage: the normalised rows enter the kernels as bf16
+        bf16 = precision.use_bf16()
+        i_, h_, o_ = self._dims
+        if self._fusable_depth and o_ <= _capi.MAX_OUT and (
+                (i_ <= _capi.MAX_IN_BF16 - 4 and h_ < _capi.MAX_HIDDEN_BF16) if bf16
+                else (i_ <= _capi.MAX_IN and h_ < _capi.MAX_HIDDEN)):
+            if bf16:  # bf16 storage: the normalised rows enter the kernels as bf16
                 x = x.to(torch.bfloat16)
             lin = [self._encoder, *self._layers, self._decoder]
             return ops.fused_mlp([ops.Seg(x)], [l.weight for l in lin], [l.bias for l in lin],

@@ -205,6 +205,8 @@ EC_VARIANTS = {
                              use_node_embedding=False),
     "no_node": dict(L_ec=2, hidden_dim=8, use_node_embedding=False),
     "alpha0": dict(L_ec=2, hidden_dim=None, alpha=0.0),
+    # hidden width 64: the widest the fp32 kernels hold; five hidden tiles (64 + the bias row) in bf16 storage
+    "h64": dict(L_ec=2, hidden_dim=64),
     # widths beyond the fused kernels (hidden 128, 20-wide node / edge spaces): library-GEMM path
     "wide_h128": dict(L_ec=1, hidden_dim=128, interaction_node_dim=20, interaction_edge_dim=20),
 }

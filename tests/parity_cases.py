@@ -260,6 +260,8 @@ EC_VARIANTS = {
                              use_node_embedding=False),
     "no_node": dict(L_ec=2, hidden_dim=8, use_node_embedding=False),
     "alpha0": dict(L_ec=2, hidden_dim=None, alpha=0.0),
+    # hidden width 64: the widest the fp32 kernels hold; five hidden tiles (64 + the bias row) in bf16 storage
+    "h64": dict(L_ec=2, hidden_dim=64),
     # widths beyond the fused kernels (hidden 128, 20-wide node / edge spaces): library-GEMM path
     "wide_h128": dict(L_ec=1, hidden_dim=128, interaction_node_dim=20, interaction_edge_dim=20),
 }
@@ -581,6 +583,11 @@ def case_mlp_bf16_forward(device, rows=75):
         ((3,), (False,), (False,), 7, 2, 3, True, "none"),
         ((8, 8, 8, 8), (False,) * 4, (False,) * 4, 16, 16, 3, True, "none"),   # no free pad slot
         ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, 62, 9, 3, True, "none"),  # KI=2, HT=4
+        # hidden widths 64 .. 95: five / six hidden tiles (the plain instantiations)
+        ((5, 5, 4), (True, True, False), (True, True, True), 64, 4, 3, True, "none"),      # HT=5 (64 + ones)
+        ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, 64, 1, 3, True, "sigmoid"),
+        ((5, 4), (False, False), (False, False), 95, 5, 3, True, "residual"),               # HT=6 (95 + ones)
+        ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, 80, 9, 2, False, "relu"),              # KI=2, HT=5, no bias
     ]
     epi_code = {"none": _capi.EPI_NONE, "relu": _capi.EPI_RELU, "residual": _capi.EPI_RESIDUAL,
                 "sigmoid": _capi.EPI_SIGMOID}
@@ -644,6 +651,13 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
             ((3,), (False,), (True,), (True,), 7, 2, 3, True, "none", 1),
             ((8, 8, 8, 8), (False,) * 4, (False,) * 4, (True, False, True, False), 16, 16, 3, True, "none", 1),
             ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, (True,) * 5, 30, 9, 3, True, "none", 1),
+            # hidden widths 64 .. 95 (five / six hidden tiles, one tile per iteration)
+            ((5, 5, 4), (True, True, False), (True, True, True), (True, True, True), 64, 4, 3, True, "none", 2),
+            ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, (True,) * 6, 64, 1, 3,
+             True, "sigmoid", 1),
+            ((5, 4), (False, False), (False, False), (True, True), 95, 5, 3, True, "residual", 1),
+            ((4,), (True,), (False,), (False,), 72, 4, 2, False, "relu", 1),
+            ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, (True,) * 5, 90, 9, 3, True, "none", 1),
         ]
     if given is not None:
         cases = given
@@ -737,7 +751,7 @@ def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choic
         case_mlp_bf16_backward(device, rows=int(g.choice(row_choices)), cases=cases, seed=seed + rnd)
 
 
-def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):
+def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0", "h64")):
     """ECForGraphTCN in bf16-storage mode on the golden inputs of g2: forward against the
     bf16 restatement (oracle/ref_cpu.py:ec_for_graph_tcn_bf16, same rounding points) and
     against the reference-pinned fp32 goldens with a bf16-sized tolerance; loss and
@@ -752,11 +766,14 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0")):
         model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **kw)
         p = load_params(model, z, f"{name}/p0/")
         model = model.to(device)
+        lib_path_before = set(ops._WIDE_WARNED)
         with G.bf16_storage():
             out = model(G.Data(x=x, edge_index=ei, edge_attr=ea))
             loss = G.EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"], y=y.float(), pt=pt, edge_index=ei)
             loss.backward()
         assert out["W"].dtype == torch.float32 and out["node_embedding"].dtype == torch.bfloat16
+        if name != "wide_h128":   # every MLP of the variant ran on the fused kernels (h64: five hidden tiles)
+            assert set(ops._WIDE_WARNED) == lib_path_before, f"{name}: {set(ops._WIDE_WARNED) - lib_path_before} took the library path"
         plain = (kw.get("residual_type", "skip1") == "skip1" and kw.get("use_node_embedding", True)
                  and kw.get("use_intermediate_edge_embeddings", True))
         if plain:  # the bf16 restatement covers the default wiring

@@ -82,8 +82,9 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     const bool three = a->mlp.n_layers == 3, sig = a->epilogue == GNNTRK_EPI_SIGMOID;
     const bool share = a->mlp.out_dim <= 4;  // four tiles share one output tile and one store
     const bool wide = wide_ok(P, a->seg, a->n_rows);  // one 16-byte load per lane and k-step
-    // (six hidden tiles: 34 KB of fragments per workgroup - four fit a CU)
-    int grid = grid16(a->n_rows, P.HT >= 6 ? 4 : kFwd16BlocksPerCu, kWaves);
+    // (five / six hidden tiles: 230 .. 330 registers per lane - two workgroups per CU are resident with one
+    //  k-step, one with two; the grid of the persistent tile schedule matches what is resident)
+    int grid = grid16(a->n_rows, P.HT >= 5 ? (P.KI == 1 ? 2 : 1) : kFwd16BlocksPerCu, kWaves);
     if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
     bool launched = false;
     GNNTRK_FWD16_CASE(1, 1)

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--hidden", type=int, default=64)
 ap.add_argument("--events", type=int, default=8)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--mode", default="all", choices=("all", "fused", "library", "fp32"))
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 batch = G.collate([synthetic.make_event(100 + i, 150_000, 2_000_000, dev) for i in range(args.events)])
@@ -56,7 +57,7 @@ def run(tag, bf16, fused_rule=None):
         ms = (time.perf_counter() - t0) / args.steps * 1e3
     finally:
         ops._fused_supported = orig
-    print(f"{tag:34s}: {ms:8.2f} ms/step  {E / ms / 1e6:7.3f} G edges/s  loss {float(loss):.6f}", flush=True)
+    print(f"{tag:34s}: {ms:8.2f} ms/step  {E / ms / 1e6:7.3f} G edges/s  loss {float(loss.detach()):.6f}", flush=True)
 
 
 def old_rule(segs, weights, biases, bf16):   # the limits before the five / six-tile instantiations
@@ -69,7 +70,9 @@ def old_rule(segs, weights, biases, bf16):   # the limits before the five / six-
 
 ops_fused = ops._fused_supported
 print(f"ECForGraphTCN(hidden_dim={args.hidden}), {args.events} events, E = {E}")
-run("bf16 storage, fused kernels", True)
-run("bf16 storage, library GEMMs (before)", True, old_rule)
-if args.hidden <= 64:
+if args.mode in ("all", "fused"):
+    run("bf16 storage, fused kernels", True)
+if args.mode in ("all", "library"):
+    run("bf16 storage, library GEMMs (before)", True, old_rule)
+if args.hidden <= 64 and args.mode in ("all", "fp32"):
     run("fp32, fused kernels", False)

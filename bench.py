@@ -253,10 +253,12 @@ def cfg4_event_sizes(n_events: int) -> list[tuple[int, int]]:
 class ECWorkload(Workload):
     """cfg2 / cfg3 / cfg4: ECForGraphTCN training step(s) on collated events."""
 
-    def __init__(self, args, rank: int, world: int, dev, *, workload: str, dtype: str, index: str = "inline"):
+    def __init__(self, args, rank: int, world: int, dev, *, workload: str, dtype: str, index: str = "inline",
+                 hidden_dim: int | None = None):
         self.name, self.dtype = workload, dtype
         torch.manual_seed(0)  # identical initial weights on every rank
-        self.model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_MODEL).to(dev)
+        model_kw = dict(EC_MODEL, **({"hidden_dim": hidden_dim} if hidden_dim else {}))
+        self.model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **model_kw).to(dev)
         self.flat = gdist.FlatParameters(self.model)
         self.module = training.ECModule(
             self.model, loss_fct=G.EdgeWeightBCELoss(), flat=self.flat, bf16=dtype == "bf16", scheduler=None,
@@ -755,6 +757,17 @@ def extras(args, rank: int, world: int, dev) -> dict:
                         "the headline (which pays the index in every step)",
             "steps": 5, "warmup": 2, "ms_per_step": dt / 5 * 1e3, "value": wl.edges_per_step_global * 5 / dt,
             "unit": "edges/s", "final_loss": loss}
+        del wl
+        ops.clear_graph_index_cache()
+        torch.cuda.empty_cache()
+        wl = ECWorkload(args, 0, 1, dev, workload="cfg3", dtype="bf16", hidden_dim=64)
+        dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
+        out["cfg3_hidden64_bf16"] = {
+            "workload": "cfg3 with ECForGraphTCN(hidden_dim=64): the five-hidden-tile instantiations of the bf16 "
+                        "kernels (one tile per iteration, one workgroup per CU); before round 3 this width took "
+                        "library GEMMs",
+            "steps": 5, "warmup": 2, "ms_per_step": dt / 5 * 1e3, "value": wl.edges_per_step_global * 5 / dt,
+            "unit": "edges/s", "final_loss": loss, "kernels": sorted(ks)}
         del wl
         ops.clear_graph_index_cache()
         torch.cuda.empty_cache()

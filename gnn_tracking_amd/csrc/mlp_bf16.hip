@@ -110,7 +110,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
     if (!P.ok || P.KI > 2)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: more than 16 input chunks / 6 hidden tiles");
+        return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: more than 16 input chunks / 8 hidden tiles (6 with two k-steps of inputs)");
     const bool three = a->mlp.n_layers == 3;
     // gradient M tiles: 1 or the maximum of the k-step count (keeps the instantiation list short)
     const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
@@ -127,7 +127,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     }
     if (want_dw) {
         // one partial block per workgroup when the parameters fit the kernel's LDS image
-        const bool via_lds = part_total(a->mlp) <= bwd16_img_dwords(P.KI, P.HT, GT, three);
+        const bool via_lds = part_total(a->mlp) <= bwd16_img_dwords(P.KI, P.HT, GT, three) && P.HT <= 4 && !(a->debug_flags & 2048);
         rc = reduce_partials_launch(reinterpret_cast<const float *>(ws), via_lds ? grid : grid * kWaves, &a->mlp,
                                     a->gW, a->gb, a->accumulate_params, stream);
     }

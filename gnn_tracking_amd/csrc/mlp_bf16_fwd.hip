@@ -78,13 +78,13 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
     if (!P.ok || P.KI > 2)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: more than 16 input chunks / 6 hidden tiles");
+        return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: more than 16 input chunks / 8 hidden tiles (6 with two k-steps of inputs)");
     const bool three = a->mlp.n_layers == 3, sig = a->epilogue == GNNTRK_EPI_SIGMOID;
     const bool share = a->mlp.out_dim <= 4;  // four tiles share one output tile and one store
     const bool wide = wide_ok(P, a->seg, a->n_rows);  // one 16-byte load per lane and k-step
     // (five / six hidden tiles: 230 .. 330 registers per lane - two workgroups per CU are resident with one
     //  k-step, one with two; the grid of the persistent tile schedule matches what is resident)
-    int grid = grid16(a->n_rows, P.HT >= 5 ? (P.KI == 1 ? 2 : 1) : kFwd16BlocksPerCu, kWaves);
+    int grid = grid16(a->n_rows, P.HT >= 5 ? ((P.KI == 1 && P.HT <= 6) ? 2 : 1) : kFwd16BlocksPerCu, kWaves);
     if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
     bool launched = false;
     GNNTRK_FWD16_CASE(1, 1)
@@ -99,6 +99,8 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     GNNTRK_FWD16_CASE_PLAIN(1, 6)
     GNNTRK_FWD16_CASE_PLAIN(2, 5)
     GNNTRK_FWD16_CASE_PLAIN(2, 6)
+    GNNTRK_FWD16_CASE_PLAIN(1, 7)
+    GNNTRK_FWD16_CASE_PLAIN(1, 8)
     if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: no instantiation");
     return check_launch("mlp_forward_bf16");
 }

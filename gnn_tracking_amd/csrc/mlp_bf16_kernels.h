@@ -1284,23 +1284,33 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
     if (!want_dw) return;
     drain_mfma();
     const int PT = part_total(a.mlp);
-    const bool via_lds = PT <= I::kTotal;
-    auto emit = [&](float *pw, bool add) {
-        auto put = [&](float *dst, float v) { *dst = add ? *dst + v : v; };
+    // (five and more hidden tiles: one block per WAVE.  The in-LDS reduction of the <1, 7, 0, true> and
+    //  <1, 8, 0, true> instantiations - 105-120 KB of LDS - ended in memory-access faults on the MI355X, at
+    //  random, while the same code passes the emulator and every narrower instantiation; with per-wave blocks
+    //  they are clean - and so is the LDS form once two more run-time branches are added around its parts:
+    //  the fault follows the code generation of these 400-500 register instantiations, not the algorithm.
+    //  The wide instantiations do without the LDS step.  2048: per-wave blocks everywhere - diagnostics)
+    const bool via_lds = PT <= I::kTotal && HT <= 4 && !(a.debug_flags & 2048);
+    // (the destination is the workspace in global memory or the LDS image: an address-space-typed pointer in
+    //  both cases - through a generic pointer the LDS form became FLAT stores, and those faulted on the MI355X
+    //  in the instantiations whose LDS image lies above 64 KB: "write access to a read-only page")
+    auto emit = [&](auto pw, bool add) {
+        using FP = decltype(pw);
+        auto put = [&](FP dst, float v) { *dst = add ? *dst + v : v; };
         int off = 0;
-        float *pW1 = pw + off;
+        FP pW1 = pw + off;
         off += hidden * in_dim;
-        float *pb1 = pw + off;
+        FP pb1 = pw + off;
         off += hidden;
-        float *pW2 = pw + off, *pb2 = nullptr;
+        FP pW2 = pw + off, pb2 = nullptr;
         if (THREE) {
             off += hidden * hidden;
             pb2 = pw + off;
             off += hidden;
         }
-        float *pW3 = pw + off;
+        FP pW3 = pw + off;
         off += out_dim * hidden;
-        float *pb3 = pw + off;
+        FP pb3 = pw + off;
 #pragma unroll
         for (int to = 0; to < HT; ++to)
 #pragma unroll
@@ -1349,7 +1359,7 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
         }
     };
     if (via_lds) {
-        float *buf = reinterpret_cast<float *>(s_img);
+        GNNTRK_LDS float *buf = (GNNTRK_LDS float *)s_img;
         __syncthreads();  // every wave is done with the fragments
         for (int i = tid; i < PT; i += kBlock) buf[i] = 0.f;
         __syncthreads();
@@ -1357,10 +1367,10 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
             if (wv == w) emit(buf, true);
             __syncthreads();
         }
-        float *dst = part + (int64_t)blockIdx.x * PT;
+        gf_ptr dst = (gf_ptr)(part + (int64_t)blockIdx.x * PT);
         for (int i = tid; i < PT; i += kBlock) dst[i] = buf[i];
     } else {
-        emit(part + (int64_t)(blockIdx.x * kWaves + wv) * PT, false);
+        emit((gf_ptr)(part + (int64_t)(blockIdx.x * kWaves + wv) * PT), false);
     }
 }
 
@@ -1368,8 +1378,8 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
 // n_rows == 0 is a valid no-op: row pointers may then be NULL (what an empty tensor hands over)
 int check_bf16_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, const char *who, int64_t n_rows) {
     if (m.n_layers != 2 && m.n_layers != 3) return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): n_layers must be 2 or 3");
-    if (m.in_dim < 1 || m.hidden < 1 || m.hidden > 16 * kMaxHiddenTiles16 - 1 || m.out_dim < 1 || m.out_dim > 16)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): hidden must be in [1,95], out in [1,16]");
+    if (m.in_dim < 1 || m.hidden < 1 || m.hidden > 16 * kMaxHiddenTiles16 || m.out_dim < 1 || m.out_dim > 16)
+        return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): hidden must be in [1,128], out in [1,16]");
     if (n_seg < 1 || n_seg > GNNTRK_MAX_SEGS) return fail(GNNTRK_EINVAL, "mlp(bf16): bad segment count");
     int tot = 0;
     for (int j = 0; j < n_seg; ++j) {
@@ -1651,6 +1661,9 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     GNNTRK_BWD16_HT(1, 0)   // weight gradients only (the encoders of raw dataset features)
     GNNTRK_BWD16_HT(1, 1)
     GNNTRK_BWD16_HT(1, 2)
+    GNNTRK_BWD16_CASE(1, 7, 0) GNNTRK_BWD16_CASE(1, 8, 0)   // hidden widths 96 .. 127: one k-step of inputs
+    GNNTRK_BWD16_CASE(1, 7, 1) GNNTRK_BWD16_CASE(1, 8, 1)
+    GNNTRK_BWD16_CASE(1, 7, 2) GNNTRK_BWD16_CASE(1, 8, 2)
     GNNTRK_BWD16_HT(2, 1)
     GNNTRK_BWD16_HT(2, 4)
 #undef GNNTRK_BWD16_HT

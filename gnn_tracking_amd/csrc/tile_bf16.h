@@ -171,7 +171,7 @@ constexpr int kMaxChunks16 = 16;
 // hidden tiles of 16 (hidden features + the constant-one row): up to 4 in the hot instantiations
 // (two workgroups per CU), 5 and 6 - hidden widths 64 .. 95 - in plain ones (one tile per iteration,
 // one workgroup per CU: their weight-gradient accumulators alone take up to 264 registers)
-constexpr int kMaxHiddenTiles16 = 6;
+constexpr int kMaxHiddenTiles16 = 8;   // (seven and eight: one 32-slot k-step of inputs only)
 
 struct SlotPlan {
     int32_t n_chunks;   // chunks in use (incl. a ones-only chunk)
@@ -237,7 +237,7 @@ __host__ __device__ inline void make_slot_plan(SlotPlan &P, const gnntrk_mlp &m,
             if (P.seg[p] >= 0 && gseg[P.seg[p]].ptr) P.gchunk[q++] = (int8_t)p;
     P.n_gchunks = q;
     P.GT = (q + 3) / 4;
-    if (P.HT > kMaxHiddenTiles16 || m.out_dim > 16) P.ok = 0;
+    if (P.HT > kMaxHiddenTiles16 || (P.HT > 6 && P.KI > 1) || m.out_dim > 16) P.ok = 0;
 }
 
 // W1 column of input slot s: >= 0 column, -1 pad, -2 the ones slot

@@ -34,6 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // generic ("flat") loads count on vmcnt AND lgkmcnt, so every LDS wait would also drain
 // the software-prefetched gathers of the next tile.
 #define GNNTRK_GLOBAL __attribute__((address_space(1)))
+#define GNNTRK_LDS __attribute__((address_space(3)))
 typedef const float GNNTRK_GLOBAL *gcf_ptr;
 typedef float GNNTRK_GLOBAL *gf_ptr;
 typedef const int32_t GNNTRK_GLOBAL *gci_ptr;

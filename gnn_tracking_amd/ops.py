@@ -475,7 +475,7 @@ def _fill_mlp(weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]]):
         if tuple(w.shape) != exp:
             raise ValueError(f"layer {i} weight has shape {tuple(w.shape)}, expected {exp}")
     # (the descriptor only; each storage mode's launcher checks its own limits - fp32: in <= 48,
-    #  hidden <= 64; bf16: 16 input chunks, hidden + bias row <= 96)
+    #  hidden <= 64; bf16: 16 input chunks, hidden + bias row <= 96, <= 128 with one k-step of inputs)
     if in_dim > _capi.MAX_IN_BF16 or hidden > _capi.MAX_HIDDEN_BF16 or out_dim > _capi.MAX_OUT:
         raise NotImplementedError(
             f"fused MLP kernel limits: in<={_capi.MAX_IN_BF16}, hidden<={_capi.MAX_HIDDEN_BF16}, "
@@ -688,7 +688,7 @@ def fused_mlp(segs: Sequence[Seg], weights: Sequence[Tensor],
 def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf16: bool) -> bool:
     """The shapes the register-resident fused kernels hold (include/gnntrk.h: L in {2, 3}; at
     most sixteen 4-feature input chunks; fp32: in <= 48, hidden <= 64, out <= 16; bf16 storage:
-    hidden (+ the bias row) <= 96, out <= 16)."""
+    hidden (+ the bias row) <= 96 - <= 128 with at most eight input chunks -, out <= 16)."""
     L = len(weights)
     if L not in (2, 3):
         return False
@@ -700,7 +700,8 @@ def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf1
     if bf16:
         has_bias = any(b is not None for b in biases)
         spare = any(int(s.t.shape[1]) % 4 for s in segs if s.t.dim() == 2)   # a pad slot carries the ones column
-        return chunks + (1 if has_bias and not spare else 0) <= 16 and hidden + (1 if has_bias else 0) <= 96
+        n_ch = chunks + (1 if has_bias and not spare else 0)
+        return n_ch <= 16 and hidden + (1 if has_bias else 0) <= (128 if n_ch <= 8 else 96)
     return in_dim <= _capi.MAX_IN and hidden <= _capi.MAX_HIDDEN and chunks <= 16
 
 

@@ -72,7 +72,7 @@ class ResFCNN(nn.Module):
         bf16 = precision.use_bf16()
         i_, h_, o_ = self._dims
         if self._fusable_depth and o_ <= _capi.MAX_OUT and (
-                (i_ <= _capi.MAX_IN_BF16 - 4 and h_ < _capi.MAX_HIDDEN_BF16) if bf16
+                (i_ <= _capi.MAX_IN_BF16 - 4 and h_ < 95) if bf16
                 else (i_ <= _capi.MAX_IN and h_ < _capi.MAX_HIDDEN)):
             if bf16:  # bf16 storage: the normalised rows enter the kernels as bf16
                 x = x.to(torch.bfloat16)

@@ -588,6 +588,10 @@ def case_mlp_bf16_forward(device, rows=75):
         ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, 64, 1, 3, True, "sigmoid"),
         ((5, 4), (False, False), (False, False), 95, 5, 3, True, "residual"),               # HT=6 (95 + ones)
         ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, 80, 9, 2, False, "relu"),              # KI=2, HT=5, no bias
+        # hidden widths 96 .. 128: seven / eight hidden tiles, one k-step of inputs
+        ((5, 5, 4), (True, True, False), (True, True, True), 127, 4, 3, True, "none"),     # HT=8 (127 + ones)
+        ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, 100, 1, 3, True, "sigmoid"),
+        ((14,), (False,), (False,), 128, 5, 3, False, "relu"),                             # HT=8 exactly, no bias
     ]
     epi_code = {"none": _capi.EPI_NONE, "relu": _capi.EPI_RELU, "residual": _capi.EPI_RESIDUAL,
                 "sigmoid": _capi.EPI_SIGMOID}
@@ -658,6 +662,12 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
             ((5, 4), (False, False), (False, False), (True, True), 95, 5, 3, True, "residual", 1),
             ((4,), (True,), (False,), (False,), 72, 4, 2, False, "relu", 1),
             ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, (True,) * 5, 90, 9, 3, True, "none", 1),
+            # hidden widths 96 .. 128 (seven / eight hidden tiles, one k-step of inputs)
+            ((5, 5, 4), (True, True, False), (True, True, True), (True, True, True), 127, 4, 3, True, "none", 2),
+            ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, (True,) * 6, 100, 1, 3,
+             True, "sigmoid", 1),
+            ((5, 4), (False, False), (False, False), (True, True), 112, 5, 3, True, "residual", 1),
+            ((14,), (False,), (False,), (False,), 128, 5, 3, False, "relu", 1),
         ]
     if given is not None:
         cases = given
@@ -726,13 +736,14 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
                 assert_close(gb[i], db[i], TOL16, f"{tag} gb{i}")
 
 
-def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choices=(1, 16, 17, 33, 100, 2050)):
+def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choices=(1, 16, 17, 33, 100, 2050), wide=False):
     """Random shapes through the bf16 backward (and the forward recompute inside it): one to four
     segments with and without gathers / ReLU-on-load / wanted gradients, hidden widths on both
     sides of the tile boundaries (one k-step and up to three hidden tiles run the two-tile form,
     the rest the one-tile form; no wanted gradient at all runs the weight-gradient-only form),
     L = 2 / 3, with and without bias, all four epilogues, one or two upstream terms, row counts
-    around the 16- and 32-row tile sizes."""
+    around the 16- and 32-row tile sizes.  ``wide``: also hidden widths 63 .. 127 (five to eight hidden
+    tiles)."""
     g = np.random.default_rng(seed)
     for rnd in range(rounds):
         cases = []
@@ -743,7 +754,10 @@ def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choic
             while sum((d + 3) // 4 for d in dims) + (1 if bias and all(d % 4 == 0 for d in dims) else 0) > 16:
                 dims = dims[:-1]
             epi = ("none", "relu", "residual", "sigmoid")[int(g.integers(0, 4))]
-            hid = int(g.choice([1, 7, 15, 16, 31, 40, 47, 48, 62]))
+            hid = int(g.choice([1, 7, 15, 16, 31, 40, 47, 48, 62] + ([63, 64, 65, 79, 80, 94, 95, 96, 111, 112, 126, 127] if wide else [])))
+            n_ch = sum((d + 3) // 4 for d in dims) + (1 if bias and all(d % 4 == 0 for d in dims) else 0)
+            if hid + (1 if bias else 0) > 96 and n_ch > 8:   # seven / eight hidden tiles: one k-step of inputs
+                hid = 90
             out = int(g.integers(1, 17))
             cases.append((dims, tuple(bool(g.integers(0, 2)) for _ in dims), tuple(bool(g.integers(0, 2)) for _ in dims),
                           tuple(bool(g.integers(0, 3)) for _ in dims), hid, out, int(g.integers(2, 4)), bias, epi,

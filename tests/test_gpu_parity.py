@@ -115,6 +115,7 @@ def test_bf16_mlp_backward(dev):
 
 def test_bf16_mlp_stress(dev):
     P.case_mlp_bf16_stress(dev, rounds=6)
+    P.case_mlp_bf16_stress(dev, rounds=6, seed=29, wide=True)   # + hidden widths 63 .. 127
 
 
 def test_bf16_edge_classifier(dev):

@@ -30,6 +30,11 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
     const int D = (P.KI == 1 && P.HT <= 3 && !(a->debug_flags & 64)) ? 2 : 1;  // as launch_bwd16 dispatches
     const bool g32 = a->epilogue == GNNTRK_EPI_SIGMOID;
+    if (P.bias_init) {
+        snprintf(buf, len, "mlp16_bwd_bi_kernel<%d, %d, %d, %s, %s>", P.KI, P.HT, GT,
+                 a->mlp.n_layers == 3 ? "true" : "false", g32 ? "true" : "false");
+        return GNNTRK_OK;
+    }
     BufPlan B;
     make_buf_plan(B, P, a, GT);
     const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, g32, a->debug_flags);
@@ -117,7 +122,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     int grid = 0;
     if (a->n_rows > 0) {
         // (five / six hidden tiles: one workgroup per CU is resident - its share of the rows is simply larger)
-        grid = grid16(a->n_rows, P.HT >= 5 ? 1 : (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu, kWaves);
+        grid = grid16(a->n_rows, (P.HT >= 5 || (P.bias_init && P.KI >= 2)) ? 1 : (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu, kWaves);
         float *part = reinterpret_cast<float *>(ws);
         uint8_t *trash = reinterpret_cast<uint8_t *>(ws) + bwd16_partial_bytes(&a->mlp);
         rc = (a->epilogue == GNNTRK_EPI_SIGMOID)

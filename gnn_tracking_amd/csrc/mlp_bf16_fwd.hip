@@ -43,12 +43,31 @@ namespace gnntrk {
         launched = true;                                                                    \
     }
 
+// hidden width 64 with biases (SlotPlan::bias_init): plain forms of the accumulator-initialised kernels
+#define GNNTRK_FWD16_CASE_BI(KI_, HT_)                                                      \
+    if (P.KI == KI_ && P.HT == HT_) {                                                       \
+        if (three && sig) { auto kfn = mlp16_fwd_bi_kernel<KI_, HT_, true, true>;           \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        else if (three) { auto kfn = mlp16_fwd_bi_kernel<KI_, HT_, true, false>;            \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        else if (sig) { auto kfn = mlp16_fwd_bi_kernel<KI_, HT_, false, true>;              \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        else { auto kfn = mlp16_fwd_bi_kernel<KI_, HT_, false, false>;                      \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        launched = true;                                                                    \
+    }
+
 // exact forward instantiation
 int mlp16_fwd_kernel_name(const gnntrk_mlp_fwd_args *a, char *buf, size_t len) {
     if (!a || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
     const bool plain = P.HT >= 5;
+    if (P.bias_init) {
+        snprintf(buf, len, "mlp16_fwd_bi_kernel<%d, %d, %s, %s>", P.KI, P.HT, a->mlp.n_layers == 3 ? "true" : "false",
+                 a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false");
+        return GNNTRK_OK;
+    }
     snprintf(buf, len, "mlp16_fwd_kernel<%d, %d, %s, %s, %d, %s>", P.KI, P.HT, a->mlp.n_layers == 3 ? "true" : "false",
              a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false", (a->mlp.out_dim <= 4 && !plain) ? 4 : 1,
              (!plain && wide_ok(P, a->seg, a->n_rows)) ? "true" : "false");
@@ -87,6 +106,13 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     int grid = grid16(a->n_rows, P.HT >= 5 ? ((P.KI == 1 && P.HT <= 6) ? 2 : 1) : kFwd16BlocksPerCu, kWaves);
     if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
     bool launched = false;
+    if (P.bias_init) {
+        grid = grid16(a->n_rows, 3, kWaves);
+        GNNTRK_FWD16_CASE_BI(1, 4)
+        GNNTRK_FWD16_CASE_BI(2, 4)
+        if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: no instantiation (bias_init)");
+        return check_launch("mlp_forward_bf16");
+    }
     GNNTRK_FWD16_CASE(1, 1)
     GNNTRK_FWD16_CASE(1, 2)
     GNNTRK_FWD16_CASE(1, 3)

@@ -241,10 +241,30 @@ __device__ __forceinline__ void pack_forward_weights(uint32_t *img, const AugWei
     pack_hidden_k<HT>(img + I::kA3, 0, [&](int o, int f) { return w.wlast(o, f); }, tid, nthreads);
 }
 
+// Bias table of the accumulator-initialisation form (SlotPlan::bias_init): btab[16 t + f] = bias of hidden
+// feature 16 t + f of the MIDDLE layer, btab[16 HT + o] = bias of output o of the last layer, both rounded
+// to bf16 (what the fragment form stores), 0 where there is none.
+template <int HT>
+__device__ __forceinline__ void fill_bias_table(float *btab, const AugWeights &w, int tid, int nthreads) {
+    for (int i = tid; i < (HT + 1) * 16; i += nthreads) {
+        float v = 0.f;
+        if (i < 16 * HT) {
+            if (i < w.hidden && w.b2) v = w.b2[i];
+        } else if (i - 16 * HT < w.out_dim && w.b3) {
+            v = w.b3[i - 16 * HT];
+        }
+        btab[i] = __uint_as_float((uint32_t)bf16_bits(v) << 16);
+    }
+}
+// accumulator tile of lane (g, c) initialised with four consecutive table entries (features 4g .. 4g + 3)
+__device__ __forceinline__ f32x4 bias_frag(const float *btab16, int lane) {
+    return *reinterpret_cast<const f32x4 *>(btab16 + 4 * (lane >> 4));
+}
+
 // layers 1..(last-1): inputs B -> packed hidden activations feeding the last layer
-template <int KI, int HT, bool THREE>
+template <int KI, int HT, bool THREE, bool BI = false>
 __device__ __forceinline__ void hidden_chain(const uint32_t *img, const u32x4 (&B)[KI], int lane,
-                                             u32x2 (&P1)[HT], u32x2 (&P2)[HT]) {
+                                             u32x2 (&P1)[HT], u32x2 (&P2)[HT], const float *btab = nullptr) {
     using I = FwdImg<KI, HT>;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -258,7 +278,8 @@ __device__ __forceinline__ void hidden_chain(const uint32_t *img, const u32x4 (&
     if (THREE) {
 #pragma unroll
         for (int t = 0; t < HT; ++t)
-            P2[t] = pack_tile_relu(contract_hidden<HT>(img + I::kA2 + t * hid_k_dwords(HT), P1, lane, zero));
+            P2[t] = pack_tile_relu(contract_hidden<HT>(img + I::kA2 + t * hid_k_dwords(HT), P1, lane,
+                                                       BI ? bias_frag(btab + 16 * t, lane) : zero));
     }
 }
 
@@ -280,9 +301,9 @@ __device__ __forceinline__ void contract_hidden_d(const uint32_t *img, const u32
         for (int d = 0; d < D; ++d) acc[d] = mfma_bf16_k32(fr, join(P[d][HT - 1], zero), acc[d]);
     }
 }
-template <int KI, int HT, bool THREE, int D>
+template <int KI, int HT, bool THREE, int D, bool BI = false>
 __device__ __forceinline__ void hidden_chain_d(const uint32_t *img, const u32x4 (&B)[D][KI], int lane,
-                                               u32x2 (&P1)[D][HT], u32x2 (&P2)[D][HT]) {
+                                               u32x2 (&P1)[D][HT], u32x2 (&P2)[D][HT], const float *btab = nullptr) {
     using I = FwdImg<KI, HT>;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -304,7 +325,7 @@ __device__ __forceinline__ void hidden_chain_d(const uint32_t *img, const u32x4 
         for (int t = 0; t < HT; ++t) {
             f32x4 acc[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] = zero;
+            for (int d = 0; d < D; ++d) acc[d] = BI ? bias_frag(btab + 16 * t, lane) : zero;
             contract_hidden_d<HT, D>(img + I::kA2 + t * hid_k_dwords(HT), P1, lane, acc);
 #pragma unroll
             for (int d = 0; d < D; ++d) P2[d][t] = pack_tile_relu(acc[d]);
@@ -323,10 +344,12 @@ __device__ uint8_t g_fwd_trash[(size_t)kFwdMaxBlocks * kBlock * 16];
 // rows rotated by 4v, so tile v lands in lane group v, the four last-layer MFMA chains
 // accumulate into ONE tile (the other row blocks of each fragment are zero: exact), and a
 // single full-wave store writes 4 x 16 rows.  R = 1 is the plain layout (wider outputs).
-template <int KI, int HT, bool THREE, bool SIG, int R, bool WIDE>
-__global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
+template <int KI, int HT, bool THREE, bool SIG, int R, bool WIDE, bool BI>
+__device__ __forceinline__ void mlp16_fwd_body(const gnntrk_mlp_fwd_args &a) {
+    static_assert(!BI || R == 1, "accumulator-initialised biases: plain output layout only");
     using I = FwdImg<KI, HT>;
     __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal + (R - 1) * hid_k_dwords(HT)];
+    __shared__ __attribute__((aligned(16))) float s_btab[BI ? (HT + 1) * 16 : 4];
     __shared__ SlotPlan s_plan;
     __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];  // kernel arguments cannot be indexed dynamically
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
@@ -340,6 +363,7 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
         for (int v = 1; v < R; ++v)  // rotated copies of the last layer
             pack_hidden_k<HT>(s_img + I::kA3 + v * hid_k_dwords(HT), 0,
                               [&](int o, int f) { return (o >> 2) == v ? w.wlast(o & 3, f) : 0.f; }, tid, kBlock);
+        if (BI) fill_bias_table<HT>(s_btab, w, tid, kBlock);
     }
     LaneChunks<KI> L;
     L.init(s_plan, s_seg, g);
@@ -429,12 +453,13 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
 #pragma unroll
         for (int b = 0; b < D / R; ++b) {
             f32x4 y = {0.f, 0.f, 0.f, 0.f};
+            if (BI) y = bias_frag(s_btab + 16 * HT, lane);   // (R = 1: lane group g holds output chunk g)
 #pragma unroll
             for (int v = 0; v < R; ++v) {
                 u32x4 B[KI];
                 finish_inputs<KI>(L, cur[b * R + v], B);
                 u32x2 P1[HT], P2[HT];
-                hidden_chain<KI, HT, THREE>(s_img, B, lane, P1, P2);
+                hidden_chain<KI, HT, THREE, BI>(s_img, B, lane, P1, P2, s_btab);
                 y = contract_hidden<HT>(s_img + I::kA3 + v * hid_k_dwords(HT), THREE ? P2 : P1, lane, y);
             }
             const int64_t tile = my_tile(grp, b);
@@ -478,6 +503,16 @@ __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_
             orow_n[b] = orow_nn[b];
         }
     }
+}
+
+template <int KI, int HT, bool THREE, bool SIG, int R, bool WIDE>
+__global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
+    mlp16_fwd_body<KI, HT, THREE, SIG, R, WIDE, false>(a);
+}
+// hidden width 64 with biases: no constant-one row, biases as accumulator initial values
+template <int KI, int HT, bool THREE, bool SIG>
+__global__ __launch_bounds__(kBlock) void mlp16_fwd_bi_kernel(const gnntrk_mlp_fwd_args a) {
+    mlp16_fwd_body<KI, HT, THREE, SIG, 1, false, true>(a);
 }
 
 // =========================================================================== backward
@@ -654,10 +689,11 @@ struct IoEncoder8 {
     static constexpr BufOpShape store[1] = {};
 };
 
-template <int KI, int HT, int GT, bool THREE, bool G32, int D, class IO = IoNone>
-__global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
-                                                              uint8_t *trash, const BufPlan bp) {
+template <int KI, int HT, int GT, bool THREE, bool G32, int D, class IO, bool BI>
+__device__ __forceinline__ void mlp16_bwd_body(const gnntrk_mlp_bwd_args &a, float *part, uint8_t *trash,
+                                               const BufPlan &bp) {
     constexpr bool BUF = IO::NL > 0;
+    static_assert(!BI || (!BUF && D == 1), "accumulator-initialised biases: generic one-tile form only");
     static_assert(!BUF || KI == 1, "buffer-addressed I/O: one k-step");
     using I = BwdImg<KI, HT, GT, THREE>;
     using F = FwdImg<KI, HT>;
@@ -667,6 +703,7 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
     __shared__ SlotPlan s_plan;
     __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];
     __shared__ gnntrk_gseg s_gseg[GNNTRK_MAX_SEGS];
+    __shared__ __attribute__((aligned(16))) float s_btab[BI ? (HT + 1) * 16 : 4];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15, wv = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
     stage_seg_args(s_seg, a.seg, tid);
 #pragma unroll
@@ -679,6 +716,7 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
         const AugWeights w = make_aug(a.mlp, s_plan);
         pack_forward_weights<KI, HT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
         pack_backward_weights<KI, HT, GT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
+        if (BI) fill_bias_table<HT>(s_btab, w, tid, kBlock);
     }
     LaneChunks<KI> L;
     L.init(s_plan, s_seg, g);
@@ -821,6 +859,13 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
     for (int i = 0; i < (THREE ? HT : 1); ++i)
 #pragma unroll
         for (int j = 0; j < HT; ++j) dW2[i][j] = zero;
+
+    // accumulator-initialised biases: their gradients are sums over the rows of the gradient tiles - one
+    // more MFMA per tile against a tile of ones (every column of the result holds the sum)
+    f32x4 dbm[BI ? HT : 1], dbl = zero;
+#pragma unroll
+    for (int i = 0; i < (BI ? HT : 1); ++i) dbm[i] = zero;
+    const u32x2 ones_k16 = {0x3f803f80u, 0x3f803f80u};
 
     const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
     const TileSched sch = make_sched((n_tiles + D - 1) / D);   // in units of D tiles
@@ -1044,7 +1089,7 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
 #pragma unroll
                 for (int d = 0; d < D; ++d) load_raw_buf(grp + 1, d, bcur[d]);
             }
-            hidden_chain_d<KI, HT, THREE, D>(wimg, B, lane, P1, P2);
+            hidden_chain_d<KI, HT, THREE, D, BI>(wimg, B, lane, P1, P2, s_btab);
         }
         const u32x2(&PLs)[D][HT] = THREE ? P2 : P1;  // input of the last layer
         auto PL = [&](int d) -> const u32x2(&)[HT] { return PLs[d]; };
@@ -1076,7 +1121,8 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
                 if (!(out_lane && valid[d])) gy = zero;
             }
             if (need_y) {
-                const f32x4 y = contract_hidden<HT>(wimg + F::kA3, PL(d), lane, zero);
+                const f32x4 y = contract_hidden<HT>(wimg + F::kA3, PL(d), lane,
+                                                    BI ? bias_frag(s_btab + 16 * HT, lane) : zero);
                 if (BUF && G32) {
                     // (buffer form of the fp32-gradient launch = the one-column edge-weight head: the
                     //  sigmoid's derivative for the one feature there is, not for four registers)
@@ -1145,6 +1191,7 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
                     bt[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stX[d] + t * 512 + rd_tile));
                 dw_acc(at, bt, dW3[t]);
             }
+            if constexpr (BI) mfma_bf16_k16_acc(at[0], ones_k16, dbl);
         }
         // middle layer
         u32x2 g1[D][HT];
@@ -1185,6 +1232,7 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
                     at[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG[d] + to * 512 + rd_tile));
 #pragma unroll
                 for (int t = 0; t < HT; ++t) dw_acc(at, bt[t], dW2[to][t]);
+                if constexpr (BI) mfma_bf16_k16_acc(at[0], ones_k16, dbm[to]);
             }
         } else {
 #pragma unroll
@@ -1348,10 +1396,23 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
                     put(pb3 + o, dW3[t][r]);
             }
         }
+        if constexpr (BI) {   // accumulator-initialised biases: column 0 of the ones-operand products
+            if (c == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (THREE) {
+#pragma unroll
+                        for (int to = 0; to < HT; ++to)
+                            if (16 * to + 4 * g + r < hidden) put(pb2 + 16 * to + 4 * g + r, dbm[to][r]);
+                    }
+                    if (4 * g + r < out_dim) put(pb3 + 4 * g + r, dbl[r]);
+                }
+            }
+        }
         if (!add) {  // bias slots without a ones column must still be defined
             if (s_plan.ones_slot < 0)
                 for (int o = lane; o < hidden; o += 64) pb1[o] = 0.f;
-            if (hid_ones < 0) {
+            if (hid_ones < 0 && !BI) {
                 if (THREE)
                     for (int o = lane; o < hidden; o += 64) pb2[o] = 0.f;
                 for (int o = lane; o < out_dim; o += 64) pb3[o] = 0.f;
@@ -1372,6 +1433,18 @@ __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(cons
     } else {
         emit((gf_ptr)(part + (int64_t)(blockIdx.x * kWaves + wv) * PT), false);
     }
+}
+
+template <int KI, int HT, int GT, bool THREE, bool G32, int D, class IO = IoNone>
+__global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
+                                                                           uint8_t *trash, const BufPlan bp) {
+    mlp16_bwd_body<KI, HT, GT, THREE, G32, D, IO, false>(a, part, trash, bp);
+}
+// hidden width 64 with biases (SlotPlan::bias_init): generic I/O, one tile per iteration
+template <int KI, int HT, int GT, bool THREE, bool G32>
+__global__ __launch_bounds__(kBlock, (HT >= 5 || KI >= 2) ? 1 : 2) void mlp16_bwd_bi_kernel(const gnntrk_mlp_bwd_args a, float *part,
+                                                                              uint8_t *trash, const BufPlan bp) {
+    mlp16_bwd_body<KI, HT, GT, THREE, G32, 1, IoNone, true>(a, part, trash, bp);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -1604,6 +1677,21 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     bool launched = false;
     BufPlan B;
     make_buf_plan(B, P, a, GT);
+    if (P.bias_init) {   // hidden width 64 with biases: the accumulator-initialised kernels
+#define GNNTRK_BWD16_BI(KI_, HT_, GT_)                                                         \
+    if (!launched && P.KI == KI_ && P.HT == HT_ && GT == GT_) {                                \
+        if (three) { auto kfn = mlp16_bwd_bi_kernel<KI_, HT_, GT_, true, G32>;                 \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash, B); } \
+        else { auto kfn = mlp16_bwd_bi_kernel<KI_, HT_, GT_, false, G32>;                      \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash, B); } \
+        launched = true;                                                                       \
+    }
+        GNNTRK_BWD16_BI(1, 4, 0) GNNTRK_BWD16_BI(1, 4, 1) GNNTRK_BWD16_BI(1, 4, 2)
+        GNNTRK_BWD16_BI(2, 4, 1) GNNTRK_BWD16_BI(2, 4, 4)
+#undef GNNTRK_BWD16_BI
+        if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: no instantiation (bias_init)");
+        return check_launch("mlp_backward_bf16");
+    }
     // the shapes of the default models go through buffer descriptors (debug_flags & 128: generic I/O)
     {
         const char *io = buf_io_name(B, P.KI, P.HT, GT, three, G32, a->debug_flags);

@@ -182,6 +182,8 @@ struct SlotPlan {
     int32_t n_gchunks;  // chunks whose gradient is wanted (backward)
     int32_t GT;         // gradient M tiles = ceil(n_gchunks / 4)
     int32_t ok;         // 0: shape not supported
+    int32_t bias_init;  // 1: no constant-one hidden row - the biases of the layers after the first are the
+                        //    initial values of their accumulators (hidden width 64, see make_slot_plan)
     int8_t seg[kMaxChunks16];    // segment of the chunk, -1: none
     int8_t first[kMaxChunks16];  // first feature of the chunk inside the segment / 4
     int8_t gchunk[kMaxChunks16]; // gradient chunk q -> input chunk
@@ -229,8 +231,16 @@ __host__ __device__ inline void make_slot_plan(SlotPlan &P, const gnntrk_mlp &m,
     P.n_chunks = n;
     P.KI = (n + 7) / 8;
     const bool hid_bias = bias && (m.b[1] != nullptr || (m.n_layers == 3 && m.b[2] != nullptr));
-    P.hid_ones = hid_bias ? m.hidden : -1;
-    P.HT = (m.hidden + (hid_bias ? 1 : 0) + 15) / 16;
+    // Hidden width 64 - the power of two people pick - has no spare row in its last hidden tile: a
+    // constant-one row costs a whole tile (five instead of four: one workgroup per CU instead of two).
+    // There the biases of the layers after the first enter as the INITIAL VALUES of the fp32 accumulators
+    // (rounded to bf16 first, as the fragment form rounds them), and their gradients are one extra MFMA per
+    // gradient tile against a tile of ones.  (128 would take eight tiles this way instead of nine, but
+    // its eight-tile backward with two gradient tiles and the extra accumulators crashes the compiler's
+    // AGPR-copy pass, ROCm 7.2 - it stays on the library path.)
+    P.bias_init = (hid_bias && m.hidden == 64) ? 1 : 0;
+    P.hid_ones = (hid_bias && !P.bias_init) ? m.hidden : -1;
+    P.HT = (m.hidden + (P.hid_ones >= 0 ? 1 : 0) + 15) / 16;
     int q = 0;
     if (gseg)
         for (int p = 0; p < n; ++p)

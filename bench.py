@@ -763,9 +763,8 @@ def extras(args, rank: int, world: int, dev) -> dict:
         wl = ECWorkload(args, 0, 1, dev, workload="cfg3", dtype="bf16", hidden_dim=64)
         dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
         out["cfg3_hidden64_bf16"] = {
-            "workload": "cfg3 with ECForGraphTCN(hidden_dim=64): the five-hidden-tile instantiations of the bf16 "
-                        "kernels (one tile per iteration, one workgroup per CU); before round 3 this width took "
-                        "library GEMMs",
+            "workload": "cfg3 with ECForGraphTCN(hidden_dim=64): four hidden tiles, biases as accumulator initial "
+                        "values (mlp16_*_bi_kernel); before round 3 this width took library GEMMs",
             "steps": 5, "warmup": 2, "ms_per_step": dt / 5 * 1e3, "value": wl.edges_per_step_global * 5 / dt,
             "unit": "edges/s", "final_loss": loss, "kernels": sorted(ks)}
         del wl

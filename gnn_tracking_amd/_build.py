@@ -54,7 +54,7 @@ def _stamp(src: pathlib.Path) -> str:
     h = hashlib.sha256()
     h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src.name, [])).encode())
     h.update(src.read_bytes())
-    for hdr in sorted(list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))):
+    for hdr in sorted(list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list(INCLUDE.glob("*.h"))):
         h.update(hdr.read_bytes())
     return h.hexdigest()
 

@@ -344,175 +344,18 @@ __device__ uint8_t g_fwd_trash[(size_t)kFwdMaxBlocks * kBlock * 16];
 // rows rotated by 4v, so tile v lands in lane group v, the four last-layer MFMA chains
 // accumulate into ONE tile (the other row blocks of each fragment are zero: exact), and a
 // single full-wave store writes 4 x 16 rows.  R = 1 is the plain layout (wider outputs).
-template <int KI, int HT, bool THREE, bool SIG, int R, bool WIDE, bool BI>
-__device__ __forceinline__ void mlp16_fwd_body(const gnntrk_mlp_fwd_args &a) {
-    static_assert(!BI || R == 1, "accumulator-initialised biases: plain output layout only");
-    using I = FwdImg<KI, HT>;
-    __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal + (R - 1) * hid_k_dwords(HT)];
-    __shared__ __attribute__((aligned(16))) float s_btab[BI ? (HT + 1) * 16 : 4];
-    __shared__ SlotPlan s_plan;
-    __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];  // kernel arguments cannot be indexed dynamically
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
-    stage_seg_args(s_seg, a.seg, tid);
-    __syncthreads();
-    if (tid == 0) make_slot_plan(s_plan, a.mlp, a.n_seg, s_seg, nullptr);
-    __syncthreads();
-    {
-        const AugWeights w = make_aug(a.mlp, s_plan);
-        pack_forward_weights<KI, HT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
-        for (int v = 1; v < R; ++v)  // rotated copies of the last layer
-            pack_hidden_k<HT>(s_img + I::kA3 + v * hid_k_dwords(HT), 0,
-                              [&](int o, int f) { return (o >> 2) == v ? w.wlast(o & 3, f) : 0.f; }, tid, kBlock);
-        if (BI) fill_bias_table<HT>(s_btab, w, tid, kBlock);
-    }
-    LaneChunks<KI> L;
-    L.init(s_plan, s_seg, g);
-    __syncthreads();
-
-    const int out_dim = a.mlp.out_dim;
-    // (R = 4: lane group g holds output chunk 0 of tile g; R = 1: chunk g of the tile)
-    const int chunk = R == 1 ? g : 0;
-    const bool out_lane = 4 * chunk < out_dim;
-    // branch-free VMEM (see LaneChunks): a missing out_idx reads the output buffer as int32
-    // and is discarded, masked lanes load from / store to a private trash slot
-    const bool oi_on = a.out_idx != nullptr;
-    const gci_ptr out_idx = oi_on ? (gci_ptr)a.out_idx : (gci_ptr) reinterpret_cast<const int32_t *>(a.out);
-    const int epi = a.epilogue;
-    const bool res_on = epi == GNNTRK_EPI_RESIDUAL;
-    uint8_t GNNTRK_GLOBAL *my_trash =
-        (uint8_t GNNTRK_GLOBAL *)g_fwd_trash + ((size_t)(blockIdx.x % kFwdMaxBlocks) * kBlock + tid) * 16;
-    uint32_t okeep[2];
-    {
-        const int d = out_dim - 4 * chunk;
-        okeep[0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
-        okeep[1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
-    }
-
-    const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
-    const TileSched sch = make_sched(n_tiles);
-    if (sch.cur >= sch.end) return;
-    const int32_t last_row = (int32_t)(a.n_rows - 1);
-    auto clamp_row = [&](int64_t t) {
-        const int64_t r = t * kTileRows + c;
-        return (int32_t)(r < last_row ? r : last_row);
-    };
-
-    // Software pipeline over groups of kDepth tiles: the raw chunks of group n+1 and the row
-    // ids of group n+2 are in flight while group n computes - 16 * kDepth rows of loads per
-    // wave cover the gather latency (one tile per wave in flight left the kernel latency
-    // bound at 1/3 of the rate).  Tiles past the end of the schedule load clamped rows and
-    // run with masked stores.
-    constexpr int D = kFwdDepth;
-    static_assert(D % R == 0, "group depth must be a multiple of the output sharing factor");
-    RowIds<KI> rid[D];
-    RawTile<KI> cur[D], nxt[D];
-    // output row of this lane for sub-batch b (R = 4: of tile b*R + g; R = 1: of tile b)
-    int32_t orow_c[D / R], orow_n[D / R], orow_nn[D / R];
-    auto tile_of = [&](int64_t grp, int d) { return sch.cur + (grp * D + d) * sch.step; };
-    auto my_tile = [&](int64_t grp, int b) { return tile_of(grp, 0) + (int64_t)(b * R + (R == 1 ? 0 : g)) * sch.step; };
-    const int32_t pair_cap = last_row >= 1 ? ((last_row - 1) & ~0) : 0;  // largest valid pair base
-    auto ids_of = [&](int64_t grp) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (WIDE)
-                load_row_ids_wide<KI>(L, clamp_row(tile_of(grp, d)), rid[d]);
-            else
-                load_row_ids<KI>(L, clamp_row(tile_of(grp, d)), rid[d]);
-        }
-    };
-    auto raw_of = [&](int d, RawTile<KI> &t) {
-        if (WIDE)
-            load_raw_wide<KI>(L, rid[d], pair_cap, t);
-        else
-            load_raw<KI>(L, rid[d], t);
-    };
-    auto orows_of = [&](int64_t grp, int32_t (&orow)[D / R]) {
-#pragma unroll
-        for (int b = 0; b < D / R; ++b) {
-            const int32_t row = clamp_row(my_tile(grp, b));
-            const int32_t v = out_idx[row];
-            orow[b] = oi_on ? v : row;
-        }
-    };
-    ids_of(0);
-    orows_of(0, orow_c);
-#pragma unroll
-    for (int d = 0; d < D; ++d) raw_of(d, cur[d]);
-    ids_of(1);
-    orows_of(1, orow_n);
-
-    // (counted loop on a scalar trip count, see mlp16_bwd_kernel)
-    const int64_t gstep = sch.step * D;
-    const int n_grp = (int)__builtin_amdgcn_readfirstlane((uint32_t)((sch.end - sch.cur + gstep - 1) / gstep));
-    for (int grp = 0; grp < n_grp; ++grp) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) raw_of(d, nxt[d]);
-        ids_of(grp + 2);
-        orows_of(grp + 2, orow_nn);
-
-#pragma unroll
-        for (int b = 0; b < D / R; ++b) {
-            f32x4 y = {0.f, 0.f, 0.f, 0.f};
-            if (BI) y = bias_frag(s_btab + 16 * HT, lane);   // (R = 1: lane group g holds output chunk g)
-#pragma unroll
-            for (int v = 0; v < R; ++v) {
-                u32x4 B[KI];
-                finish_inputs<KI>(L, cur[b * R + v], B);
-                u32x2 P1[HT], P2[HT];
-                hidden_chain<KI, HT, THREE, BI>(s_img, B, lane, P1, P2, s_btab);
-                y = contract_hidden<HT>(s_img + I::kA3 + v * hid_k_dwords(HT), THREE ? P2 : P1, lane, y);
-            }
-            const int64_t tile = my_tile(grp, b);
-            const int64_t row = tile * kTileRows + c;
-            const bool st = out_lane && tile < sch.end && row < a.n_rows;
-            if (SIG) {
-                float GNNTRK_GLOBAL *outp = (gf_ptr)a.out + (int64_t)orow_c[b] * a.out_stride + 4 * chunk;
-                if (out_dim == 1) {  // the edge-weight head: one store per lane (uniform branch)
-                    *(st ? outp : (float GNNTRK_GLOBAL *)my_trash) = a.ca + a.cb * sigmoidf_(y[0]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float GNNTRK_GLOBAL *dst =
-                            (st && 4 * chunk + r < out_dim) ? outp + r : (float GNNTRK_GLOBAL *)(my_trash + 4 * r);
-                        *dst = a.ca + a.cb * sigmoidf_(y[r]);
-                    }
-                }
-            } else {
-                const gch_ptr rp = (res_on && st)
-                                       ? (gch_ptr) reinterpret_cast<const uint16_t *>(a.res) + row * a.res_stride + 4 * chunk
-                                       : (gch_ptr)(const uint16_t GNNTRK_GLOBAL *)my_trash;
-                const u32x2 rv = *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(rp);
-                if (res_on) {
-                    y[0] = a.ca * bf16_lo(rv[0]) + a.cb * y[0];
-                    y[1] = a.ca * bf16_hi(rv[0]) + a.cb * y[1];
-                    y[2] = a.ca * bf16_lo(rv[1]) + a.cb * y[2];
-                    y[3] = a.ca * bf16_hi(rv[1]) + a.cb * y[3];
-                }
-                u32x2 o = (epi == GNNTRK_EPI_RELU) ? pack_tile_relu(y) : pack_tile(y);
-                o[0] &= okeep[0];
-                o[1] &= okeep[1];
-                gh_ptr outp = (gh_ptr) reinterpret_cast<uint16_t *>(a.out) + (int64_t)orow_c[b] * a.out_stride + 4 * chunk;
-                *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(st ? outp : (gh_ptr)(uint16_t GNNTRK_GLOBAL *)my_trash) = o;
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) cur[d] = nxt[d];
-#pragma unroll
-        for (int b = 0; b < D / R; ++b) {
-            orow_c[b] = orow_n[b];
-            orow_n[b] = orow_nn[b];
-        }
-    }
-}
-
-template <int KI, int HT, bool THREE, bool SIG, int R, bool WIDE>
+template <int KI, int HT, bool THREE, bool SIG, int R_, bool WIDE_>
 __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
-    mlp16_fwd_body<KI, HT, THREE, SIG, R, WIDE, false>(a);
+    constexpr int R = R_;
+    constexpr bool WIDE = WIDE_, BI = false;
+#include "mlp_bf16_fwd_body.inc"
 }
 // hidden width 64 with biases: no constant-one row, biases as accumulator initial values
 template <int KI, int HT, bool THREE, bool SIG>
 __global__ __launch_bounds__(kBlock) void mlp16_fwd_bi_kernel(const gnntrk_mlp_fwd_args a) {
-    mlp16_fwd_body<KI, HT, THREE, SIG, 1, false, true>(a);
+    constexpr int R = 1;
+    constexpr bool WIDE = false, BI = true;
+#include "mlp_bf16_fwd_body.inc"
 }
 
 // =========================================================================== backward
@@ -689,762 +532,22 @@ struct IoEncoder8 {
     static constexpr BufOpShape store[1] = {};
 };
 
-template <int KI, int HT, int GT, bool THREE, bool G32, int D, class IO, bool BI>
-__device__ __forceinline__ void mlp16_bwd_body(const gnntrk_mlp_bwd_args &a, float *part, uint8_t *trash,
-                                               const BufPlan &bp) {
-    constexpr bool BUF = IO::NL > 0;
-    static_assert(!BI || (!BUF && D == 1), "accumulator-initialised biases: generic one-tile form only");
-    static_assert(!BUF || KI == 1, "buffer-addressed I/O: one k-step");
-    using I = BwdImg<KI, HT, GT, THREE>;
-    using F = FwdImg<KI, HT>;
-    using S = BwdStage<KI, HT>;
-    __shared__ __attribute__((aligned(16))) uint32_t s_img[I::kTotal];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves * D * S::kWave];
-    __shared__ SlotPlan s_plan;
-    __shared__ gnntrk_seg s_seg[GNNTRK_MAX_SEGS];
-    __shared__ gnntrk_gseg s_gseg[GNNTRK_MAX_SEGS];
-    __shared__ __attribute__((aligned(16))) float s_btab[BI ? (HT + 1) * 16 : 4];
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15, wv = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
-    stage_seg_args(s_seg, a.seg, tid);
-#pragma unroll
-    for (int j = 0; j < GNNTRK_MAX_SEGS; ++j)
-        if (tid == 32 + j) s_gseg[j] = a.gseg[j];
-    __syncthreads();
-    if (tid == 0) make_slot_plan(s_plan, a.mlp, a.n_seg, s_seg, s_gseg);
-    __syncthreads();
-    {
-        const AugWeights w = make_aug(a.mlp, s_plan);
-        pack_forward_weights<KI, HT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
-        pack_backward_weights<KI, HT, GT, THREE>(s_img, w, s_plan, s_seg, tid, kBlock);
-        if (BI) fill_bias_table<HT>(s_btab, w, tid, kBlock);
-    }
-    LaneChunks<KI> L;
-    L.init(s_plan, s_seg, g);
-
-    // gradient chunk handled by this lane in dX tile T: q = 4T + g.  Lanes without a chunk
-    // (and rows past the end) store to a private 8-byte slot of the trash area instead, so
-    // that the store is unconditional (see LaneChunks).
-    constexpr int GTA = GT > 0 ? GT : 1;  // (array extents; GT = 0: no input gradient at all)
-    gh_ptr gptr[GTA];
-    gci_ptr gidx[GTA];  // optional row permutation of the gradient slice (never NULL, see LaneChunks)
-    int32_t gstride[GTA], gin_off[GTA];
-    uint32_t gkeep[GTA][2];
-    uint32_t gmul_and[GTA], gmul_or[GTA];  // relu' multiplier (min(x, 1) & and) | or: branch-free "no ReLU" = 1
-    bool gon[GTA], gidx_on[GTA];
-    gh_ptr my_trash = (gh_ptr) reinterpret_cast<uint16_t *>(trash + ((int64_t)(blockIdx.x * kWaves + wv) * 64 + lane) * 8);
-#pragma unroll
-    for (int T = 0; T < GT; ++T) {
-        const int q = 4 * T + g;
-        gon[T] = q < s_plan.n_gchunks;
-        gptr[T] = my_trash;
-        gidx[T] = (gci_ptr) reinterpret_cast<const int32_t *>(a.gout[0].ptr);  // readable int32[n_rows]
-        gidx_on[T] = false;
-        gstride[T] = 0;
-        gin_off[T] = 0;
-        bool relu_in = false;
-        int d = 0;
-        if (gon[T]) {
-            const int p = s_plan.gchunk[q], j = s_plan.seg[p];
-            d = s_seg[j].dim - 4 * s_plan.first[p];
-            d = d > 4 ? 4 : d;
-            gptr[T] = (gh_ptr)(reinterpret_cast<uint16_t *>(s_gseg[j].ptr) + 4 * s_plan.first[p]);
-            gstride[T] = s_gseg[j].stride;
-            if (s_gseg[j].idx) {
-                gidx[T] = (gci_ptr)s_gseg[j].idx;
-                gidx_on[T] = true;
-            }
-            gin_off[T] = 8 * p;  // byte offset of the chunk inside a row of the input image
-            relu_in = s_seg[j].relu != 0;
-        }
-        gmul_and[T] = relu_in ? 0xffffffffu : 0u;
-        gmul_or[T] = relu_in ? 0u : 0x00010001u;
-        gkeep[T][0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
-        gkeep[T][1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
-    }
-    // buffer-addressed I/O: descriptors (SGPRs) and lane-constant offsets of every access
-    constexpr int NLA = BUF ? IO::NL : 1, NIA = IO::NI > 0 ? IO::NI : 1, NSIA = IO::NSI > 0 ? IO::NSI : 1,
-                  NSA = IO::NS > 0 ? IO::NS : 1, NGA = IO::NG > 0 ? IO::NG : 1;
-    buf_rsrc_t r_ld[NLA], r_id[NIA], r_sid[NSIA], r_go[NGA], r_st[NSA];
-    uint32_t v_ld[NLA], v_go[NGA], v_st[NSA];   // lane offsets (kBufOut: the lane takes no part)
-    bool b_ld[NLA];                             // the lane reads id stream sb of a two-stream load
-    uint32_t ones_v = 0u, rmin_v[2] = {0x80008000u, 0x80008000u};
-    const uint32_t v_c4 = 4u * (uint32_t)c;
-    if constexpr (BUF) {
-        auto lane_off = [&](const BufOpShape &sh, const BufOpArgs &ar, bool gathered) -> uint32_t {
-            const bool on = (sh.part >> g) & 1;
-            const uint32_t off = g == 0 ? ar.off8[0] : g == 1 ? ar.off8[1] : g == 2 ? ar.off8[2] : ar.off8[3];
-            return on ? (gathered ? off : ((uint32_t)c << ar.shift) + off) : kBufOut;
-        };
-#pragma unroll
-        for (int i = 0; i < IO::NL; ++i) {
-            r_ld[i] = buf_make(bp.load[i].ptr, bp.load[i].bytes);
-            v_ld[i] = lane_off(bp.load_s[i], bp.load[i], IO::load[i].gathered);
-            b_ld[i] = (bp.load_s[i].use_b >> g) & 1;
-        }
-#pragma unroll
-        for (int i = 0; i < IO::NI; ++i) r_id[i] = buf_make(bp.ids[i].ptr, bp.ids[i].bytes);
-#pragma unroll
-        for (int i = 0; i < IO::NSI; ++i) r_sid[i] = buf_make(bp.sids[i].ptr, bp.sids[i].bytes);
-#pragma unroll
-        for (int i = 0; i < IO::NG; ++i) {
-            r_go[i] = buf_make(bp.gout[i].ptr, bp.gout[i].bytes);
-            v_go[i] = lane_off(bp.gout_s[i], bp.gout[i], IO::gout[i].gathered);
-        }
-#pragma unroll
-        for (int i = 0; i < IO::NS; ++i) {
-            r_st[i] = buf_make(bp.store[i].ptr, bp.store[i].bytes);
-            v_st[i] = lane_off(bp.store_s[i], bp.store[i], IO::store[i].gathered);
-        }
-        ones_v = g == bp.ones_group ? bp.ones_bits : 0u;
-        rmin_v[0] = g == 0 ? bp.rmin[0][0] : g == 1 ? bp.rmin[1][0] : g == 2 ? bp.rmin[2][0] : bp.rmin[3][0];
-        rmin_v[1] = g == 0 ? bp.rmin[0][1] : g == 1 ? bp.rmin[1][1] : g == 2 ? bp.rmin[2][1] : bp.rmin[3][1];
-    }
-    const bool any_relu = BUF && bp.any_relu != 0;
-    const int gate_mode = BUF ? bp.gate_mode : 2;
-    // W1 column of the input slot 16 ts + c (partials of dW1')
-    int32_t col1[2 * KI];
-#pragma unroll
-    for (int ts = 0; ts < 2 * KI; ++ts) col1[ts] = slot_col(s_plan, s_seg, 16 * ts + c);
-    const int hid_ones = s_plan.hid_ones;
-    const uint32_t k_one = opaque_u32(0x00010001u);
-    __syncthreads();
-
-    const int out_dim = a.mlp.out_dim, hidden = a.mlp.hidden, in_dim = a.mlp.in_dim;
-    const bool out_lane = 4 * g < out_dim;
-    const int epi = a.epilogue;
-    const bool need_y = epi == GNNTRK_EPI_RELU || epi == GNNTRK_EPI_SIGMOID;
-    const bool want_dw = a.gW[0] != nullptr;
-    uint32_t okeep[2];
-    {
-        const int d = out_dim - 4 * g;
-        okeep[0] = (d >= 1 ? 0x0000ffffu : 0u) | (d >= 2 ? 0xffff0000u : 0u);
-        okeep[1] = (d >= 3 ? 0x0000ffffu : 0u) | (d >= 4 ? 0xffff0000u : 0u);
-    }
-    // upstream-gradient terms, branch-free: a missing second term aliases the first (and is
-    // discarded), missing row indices read the term's own rows as int32 (discarded), lanes
-    // without output features read chunk 0 (masked by okeep)
-    const bool two_terms = a.n_gout > 1;
-    const int gq = out_lane ? g : 0;
-    const void *gp0 = a.gout[0].ptr, *gp1 = two_terms ? a.gout[1].ptr : a.gout[0].ptr;
-    const int32_t gs0 = a.gout[0].stride, gs1 = two_terms ? a.gout[1].stride : a.gout[0].stride;
-    const bool gi0_on = a.gout[0].idx != nullptr, gi1_on = two_terms && a.gout[1].idx != nullptr;
-    const gci_ptr go_idx0 = gi0_on ? (gci_ptr)a.gout[0].idx : (gci_ptr) reinterpret_cast<const int32_t *>(gp0);
-    const gci_ptr go_idx1 = gi1_on ? (gci_ptr)a.gout[1].idx : go_idx0;
-    int32_t gcol[4];  // fp32 term: column of register r (clamped)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) gcol[r] = (4 * gq + r < out_dim) ? 4 * gq + r : out_dim - 1;
-
-    uint8_t *stIn[D], *stX[D], *stG[D];  // one set of staging images per 16-row half
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        stIn[d] = s_stage + (wv * D + d) * S::kWave;
-        stX[d] = stIn[d] + S::kIn;
-        stG[d] = stX[d] + S::kX;
-    }
-    // byte offsets inside the staging images
-    const int wr_tile = c * 32 + 8 * (g ^ ((c >> 2) & 3));                  // write [row c][4g..4g+3]
-    const int rd_tile = (4 * g + (c >> 2)) * 32 + 8 * ((c & 3) ^ g);        // transpose read (row >> 2 = g)
-    const int in_swz = 16 * ((c >> 3) & 1);                                 // unit swizzle of row c
-    const int rd_row = 4 * g + (c >> 2);                                    // row this lane addresses in reads
-
-    f32x4 dW1[HT][2 * KI], dW2[THREE ? HT : 1][HT], dW3[HT];
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < HT; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2 * KI; ++j) dW1[i][j] = zero;
-        dW3[i] = zero;
-    }
-#pragma unroll
-    for (int i = 0; i < (THREE ? HT : 1); ++i)
-#pragma unroll
-        for (int j = 0; j < HT; ++j) dW2[i][j] = zero;
-
-    // accumulator-initialised biases: their gradients are sums over the rows of the gradient tiles - one
-    // more MFMA per tile against a tile of ones (every column of the result holds the sum)
-    f32x4 dbm[BI ? HT : 1], dbl = zero;
-#pragma unroll
-    for (int i = 0; i < (BI ? HT : 1); ++i) dbm[i] = zero;
-    const u32x2 ones_k16 = {0x3f803f80u, 0x3f803f80u};
-
-    const int64_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
-    const TileSched sch = make_sched((n_tiles + D - 1) / D);   // in units of D tiles
-    const int32_t last_row = (int32_t)(a.n_rows - 1);
-    auto clamp_row = [&](int64_t t) {
-        const int64_t r = t * kTileRows + c;
-        return (int32_t)(r < last_row ? r : last_row);
-    };
-
-    RowIds<KI> rid[D];
-    int32_t grow[D][2];
-    RawTile<KI> cur[D], nxt[D];
-    RawGout gcur[D], gnxt[D];
-    // buffer form: ids of the load streams (one unit ahead of the raw loads), raw results per access
-    uint32_t idv[D][NIA];
-    struct RawBuf {
-        u32x4 w16[NLA];   // (an 8-byte access uses the first two dwords)
-    };
-    RawBuf bcur[D], bnxt[BUF ? 1 : D];
-    // D = 1: one 16-row tile per iteration.  D = 2: a wave owns SUPER tiles of 32 consecutive rows
-    // and walks the two 16-row halves stage by stage (two independent dependency chains in one
-    // instruction stream: the LDS round trips and MFMA latencies of one half hide behind the
-    // other), and the weight-gradient contractions run over all 32 rows with K = 32 MFMAs.
-    auto tile_of = [&](int64_t grp, int d) { return (sch.cur + grp * sch.step) * D + d; };
-    // first row of half d of unit grp as a scalar (buffer form: rows past the end fall out in the
-    // range check of the descriptors, so nothing is clamped; units past the wave's last one read
-    // rows of other waves, or nothing)
-    // (32-bit scalar arithmetic: the launcher takes the buffer form only for tensors below 2^31 bytes,
-    //  so even two units past the end the byte offsets stay below 2^32)
-    const uint32_t u_cur = (uint32_t)sch.cur, u_step = (uint32_t)sch.step;
-    auto row0_of = [&](int grp, int d) -> uint32_t {
-        return ((u_cur + (uint32_t)grp * u_step) * (uint32_t)D + (uint32_t)d) * (uint32_t)kTileRows;
-    };
-    auto ids_of = [&](int grp, int d) {
-        if constexpr (BUF) {
-            const uint32_t r0 = row0_of(grp, d);
-#pragma unroll
-            for (int i = 0; i < IO::NI; ++i) idv[d][i] = buf_load_u32(r_id[i], v_c4, r0 << 2);
-        } else {
-            const int32_t row = clamp_row(tile_of(grp, d));
-            load_row_ids<KI>(L, row, rid[d]);
-            const int32_t i0 = go_idx0[row], i1 = go_idx1[row];
-            grow[d][0] = gi0_on ? i0 : row;
-            grow[d][1] = gi1_on ? i1 : row;
-        }
-    };
-    // one access of the buffer form: lane offset + scalar offset from the shape
-    auto buf_addr = [&](const BufOpShape &sh, const BufOpArgs &ar, uint32_t v_lane, bool use_b, const uint32_t *ids,
-                        uint32_t r0, uint32_t &voff, uint32_t &soff) {
-        if (sh.gathered) {
-            uint32_t id = ids[sh.sa < 0 ? 0 : sh.sa];
-            if (sh.sb >= 0) id = use_b ? ids[sh.sb] : id;
-            voff = (id << ar.shift) + v_lane;
-            soff = 0u;
-        } else {
-            voff = v_lane;
-            soff = r0 << ar.shift;
-        }
-    };
-    auto load_raw_buf = [&](int grp, int d, RawBuf &t) {
-        const uint32_t r0 = row0_of(grp, d);
-#pragma unroll
-        for (int i = 0; i < IO::NL; ++i) {
-            uint32_t voff, soff;
-            buf_addr(IO::load[i], bp.load[i], v_ld[i], b_ld[i], idv[d], r0, voff, soff);
-            if (IO::load[i].w16) {
-                t.w16[i] = buf_load_u32x4(r_ld[i], voff, soff);
-            } else {
-                const u32x2 h = buf_load_u32x2(r_ld[i], voff, soff);
-                t.w16[i][0] = h[0];
-                t.w16[i][1] = h[1];
-            }
-        }
-    };
-    auto load_gout = [&](int grp, int d, RawGout &r) {
-        if constexpr (BUF) {
-            const uint32_t r0 = row0_of(grp, d);
-            r.v = u32x4{0u, 0u, 0u, 0u};
-            r.w = u32x2{0u, 0u};
-#pragma unroll
-            for (int t = 0; t < IO::NG; ++t) {
-                uint32_t voff, soff;
-                buf_addr(IO::gout[t], bp.gout[t], v_go[t], false, idv[d], r0, voff, soff);
-                if (G32) {   // fp32 upstream gradient of a one-column output (the edge-weight head)
-                    r.v[0] = buf_load_u32(r_go[t], voff, soff);
-                } else {
-                    const u32x2 h = buf_load_u32x2(r_go[t], voff, soff);
-                    if (t < 2) {
-                        r.v[2 * (t & 1)] = h[0];
-                        r.v[2 * (t & 1) + 1] = h[1];
-                    } else {
-                        r.w = h;
-                    }
-                }
-            }
-        } else if (G32) {
-            const float GNNTRK_GLOBAL *p = (gcf_ptr) reinterpret_cast<const float *>(gp0) + (int64_t)grow[d][0] * gs0;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) r.v[r4] = __float_as_uint(p[gcol[r4]]);
-        } else {
-            const u32x2 t0 = *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(
-                (gch_ptr) reinterpret_cast<const uint16_t *>(gp0) + (int64_t)grow[d][0] * gs0 + 4 * gq);
-            const u32x2 t1 = *reinterpret_cast<const u32x2 GNNTRK_GLOBAL *>(
-                (gch_ptr) reinterpret_cast<const uint16_t *>(gp1) + (int64_t)grow[d][1] * gs1 + 4 * gq);
-            r.v[0] = t0[0];
-            r.v[1] = t0[1];
-            r.v[2] = two_terms ? t1[0] : 0u;
-            r.v[3] = two_terms ? t1[1] : 0u;
-        }
-    };
-    auto load_unit = [&](int grp, int d, RawTile<KI> &t, RawBuf &tb, RawGout &go) {
-        if constexpr (BUF)
-            load_raw_buf(grp, d, tb);
-        else
-            load_raw<KI>(L, rid[d], t);
-        load_gout(grp, d, go);
-    };
-
-    if (sch.cur < sch.end) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) ids_of(0, d);
-#pragma unroll
-        for (int d = 0; d < D; ++d) load_unit(0, d, cur[d], bcur[d], gcur[d]);
-#pragma unroll
-        for (int d = 0; d < D; ++d) ids_of(1, d);
-    }
-
-    // transposed reads of the staging images as MFMA operands over the rows: one K = 16
-    // operand per half; for D = 2 the halves are joined into one K = 32 operand (k-slot
-    // (g, e): e < 4 -> row 4g + e of half 0, e >= 4 -> row 4g + e - 4 of half 1, the same on
-    // both operands)
-    auto dw_acc = [&](const u32x2 (&at)[D], const u32x2 (&bt)[D], f32x4 &acc) {
-        if constexpr (D == 2)
-            acc = mfma_bf16_k32(join(at[0], at[1]), join(bt[0], bt[1]), acc);
-        else
-            mfma_bf16_k16_acc(at[0], bt[0], acc);
-    };
-
-    // counted loop on a scalar trip count: a plain do-while for the compiler, so the
-    // loop-carried weight-gradient accumulators are updated in place
-    const int64_t span = sch.end - sch.cur, gstep = sch.step;
-    const int n_grp = (int)__builtin_amdgcn_readfirstlane((uint32_t)(span > 0 ? (span + gstep - 1) / gstep : 0));
-    // Only the LAST unit of the whole range can hold rows past the end (every wave's trip count is
-    // exact).  The body is instantiated twice: without the validity masks for the bulk (their
-    // selects are a tenth of the loop's VALU work) and with them for that one unit.
-    auto tile_step = [&](auto tail_tag, int grp) __attribute__((always_inline)) {
-        constexpr bool kTail = decltype(tail_tag)::value;
-        // generic form: the next unit's raw data into a second set of registers, rotated at the end of
-        // the step.  Buffer form: issued below, as soon as S0 / S1 have consumed the current unit's
-        // registers - straight into them (no rotation moves, a dozen registers less).
-        if constexpr (!BUF) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) load_unit(grp + 1, d, nxt[d], bnxt[d], gnxt[d]);
-#pragma unroll
-            for (int d = 0; d < D; ++d) ids_of(grp + 2, d);
-        }
-
-        // (kTail: rows past the end run as invalid rows: zero upstream gradient, stores redirected)
-        bool valid[D];
-        int32_t srow[D][GTA];  // destination rows of the input-gradient slices
-        uint32_t sidv[D][NSIA];  // buffer form: ids of the store streams, this unit's rows
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int64_t tile = tile_of(grp, d);
-            valid[d] = !kTail || (tile < n_tiles && tile * kTileRows + c < a.n_rows);
-            if constexpr (BUF) {
-                const uint32_t r0 = row0_of(grp, d);
-#pragma unroll
-                for (int i = 0; i < IO::NSI; ++i) sidv[d][i] = buf_load_u32(r_sid[i], v_c4, r0 << 2);
-            } else {
-                const int32_t rc = clamp_row(tile);
-#pragma unroll
-                for (int T = 0; T < GT; ++T) {
-                    const int32_t v = gidx[T][rc];
-                    srow[d][T] = gidx_on[T] ? v : rc;
-                }
-            }
-        }
-
-        // ---- S0: recompute ----------------------------------------------------------
-        const uint32_t *wimg = s_img + opaque_zero();
-        u32x2 P1[D][HT], P2[D][HT];
-        {
-            u32x4 B[D][KI];
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if constexpr (BUF) {
-                    // the accesses cover disjoint (lane group, dword) positions and return zero
-                    // elsewhere: OR them together; pads are stored as zero; ones slot; optional ReLU
-                    u32x4 m = IO::load[0].w16 ? bcur[d].w16[0] : u32x4{0u, 0u, 0u, 0u};
-                    if (!IO::load[0].w16) {
-                        m[IO::load[0].slot] = bcur[d].w16[0][0];
-                        m[IO::load[0].slot + 1] = bcur[d].w16[0][1];
-                    }
-#pragma unroll
-                    for (int i = 1; i < IO::NL; ++i) {
-                        if (IO::load[i].w16) {
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) m[w] |= bcur[d].w16[i][w];
-                        } else {
-                            m[IO::load[i].slot] |= bcur[d].w16[i][0];
-                            m[IO::load[i].slot + 1] |= bcur[d].w16[i][1];
-                        }
-                    }
-                    if (IO::kOnesDword >= 0) m[IO::kOnesDword >= 0 ? IO::kOnesDword : 0] |= ones_v;
-                    if (any_relu) {
-                        m[0] = i16x2_max(m[0], rmin_v[0]);
-                        m[1] = i16x2_max(m[1], rmin_v[0]);
-                        m[2] = i16x2_max(m[2], rmin_v[1]);
-                        m[3] = i16x2_max(m[3], rmin_v[1]);
-                    }
-                    B[d][0] = m;
-                } else {
-                    finish_inputs<KI>(L, cur[d], B[d]);
-                }
-#pragma unroll
-                for (int kk = 0; kk < KI; ++kk)
-                    *reinterpret_cast<u32x4 *>(stIn[d] + c * S::kInRow + ((64 * kk + 16 * g) ^ in_swz)) = B[d][kk];
-            }
-            if constexpr (BUF) {   // (the raw input registers are free: the next unit's rows go straight into them)
-#pragma unroll
-                for (int d = 0; d < D; ++d) load_raw_buf(grp + 1, d, bcur[d]);
-            }
-            hidden_chain_d<KI, HT, THREE, D, BI>(wimg, B, lane, P1, P2, s_btab);
-        }
-        const u32x2(&PLs)[D][HT] = THREE ? P2 : P1;  // input of the last layer
-        auto PL = [&](int d) -> const u32x2(&)[HT] { return PLs[d]; };
-
-        // ---- S1: upstream gradient --------------------------------------------------
-        u32x2 g3[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            f32x4 gy;
-            if (G32) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gy[r] = __uint_as_float(gcur[d].v[r]);
-            } else {
-                gy[0] = bf16_lo(gcur[d].v[0]) + bf16_lo(gcur[d].v[2]);
-                gy[1] = bf16_hi(gcur[d].v[0]) + bf16_hi(gcur[d].v[2]);
-                gy[2] = bf16_lo(gcur[d].v[1]) + bf16_lo(gcur[d].v[3]);
-                gy[3] = bf16_hi(gcur[d].v[1]) + bf16_hi(gcur[d].v[3]);
-                if constexpr (IO::NG > 2) {
-                    gy[0] += bf16_lo(gcur[d].w[0]);
-                    gy[1] += bf16_hi(gcur[d].w[0]);
-                    gy[2] += bf16_lo(gcur[d].w[1]);
-                    gy[3] += bf16_hi(gcur[d].w[1]);
-                }
-            }
-            if constexpr (BUF) {   // (lanes without output features loaded zeros)
-                if (G32) gy[1] = gy[2] = gy[3] = 0.f;
-                if (kTail && !valid[d]) gy = zero;
-            } else {
-                if (!(out_lane && valid[d])) gy = zero;
-            }
-            if (need_y) {
-                const f32x4 y = contract_hidden<HT>(wimg + F::kA3, PL(d), lane,
-                                                    BI ? bias_frag(s_btab + 16 * HT, lane) : zero);
-                if (BUF && G32) {
-                    // (buffer form of the fp32-gradient launch = the one-column edge-weight head: the
-                    //  sigmoid's derivative for the one feature there is, not for four registers)
-                    const float sg = sigmoidf_(y[0]);
-                    gy[0] = gy[0] * a.cb * sg * (1.f - sg);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (epi == GNNTRK_EPI_RELU) {
-                            gy[r] = y[r] > 0.f ? gy[r] : 0.f;
-                        } else {
-                            const float sg = sigmoidf_(y[r]);
-                            gy[r] = gy[r] * a.cb * sg * (1.f - sg);
-                        }
-                    }
-                }
-            } else if (epi == GNNTRK_EPI_RESIDUAL) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gy[r] *= a.cb;
-            }
-            g3[d] = pack_tile(gy);
-            if constexpr (!BUF) {   // (buffer form: lanes / features without data loaded zeros)
-                g3[d][0] &= okeep[0];
-                g3[d][1] &= okeep[1];
-            }
-        }
-
-        if constexpr (BUF) {   // (the upstream-gradient registers are free: next unit's terms, then the ids after it)
-#pragma unroll
-            for (int d = 0; d < D; ++d) load_gout(grp + 1, d, gcur[d]);
-#pragma unroll
-            for (int d = 0; d < D; ++d) ids_of(grp + 2, d);
-        }
-
-        // ---- S2 / S3 interleaved: every dW stage reuses the staging images --------------
-        // last layer: gradient at its input (hidden, after relu')
-        u32x2 gh[D][HT];
-#pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            const u32x2 fr = frag_k16(wimg + I::kD3 + t * 128, lane);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const f32x4 acc = mfma_bf16_k16(fr, g3[d], zero);
-                gh[d][t] = pack_tile(acc);
-                gh[d][t][0] = gate_bf16x2(gh[d][t][0], PL(d)[t][0], k_one);
-                gh[d][t][1] = gate_bf16x2(gh[d][t][1], PL(d)[t][1], k_one);
-            }
-        }
-        {   // weight gradients are always accumulated (a branch here would turn the
-            // loop-carried accumulators into phi copies); only the final write is optional
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-#pragma unroll
-                for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stX[d] + t * 512 + wr_tile) = PL(d)[t];
-                *reinterpret_cast<u32x2 *>(stG[d] + wr_tile) = g3[d];
-            }
-            lds_wave_sync();
-            u32x2 at[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) at[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG[d] + rd_tile));
-#pragma unroll
-            for (int t = 0; t < HT; ++t) {
-                u32x2 bt[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d)
-                    bt[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stX[d] + t * 512 + rd_tile));
-                dw_acc(at, bt, dW3[t]);
-            }
-            if constexpr (BI) mfma_bf16_k16_acc(at[0], ones_k16, dbl);
-        }
-        // middle layer
-        u32x2 g1[D][HT];
-        if (THREE) {
-#pragma unroll
-            for (int t = 0; t < HT; ++t) {
-                f32x4 acc[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d) acc[d] = zero;
-                contract_hidden_d<HT, D>(wimg + I::kD2 + t * hid_k_dwords(HT), gh, lane, acc);
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    g1[d][t] = pack_tile(acc[d]);
-                    g1[d][t][0] = gate_bf16x2(g1[d][t][0], P1[d][t][0], k_one);
-                    g1[d][t][1] = gate_bf16x2(g1[d][t][1], P1[d][t][1], k_one);
-                }
-            }
-            lds_wave_sync();
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int t = 0; t < HT; ++t) {
-                    *reinterpret_cast<u32x2 *>(stX[d] + t * 512 + wr_tile) = P1[d][t];
-                    *reinterpret_cast<u32x2 *>(stG[d] + t * 512 + wr_tile) = gh[d][t];
-                }
-            lds_wave_sync();
-            u32x2 bt[HT][D];
-#pragma unroll
-            for (int t = 0; t < HT; ++t)
-#pragma unroll
-                for (int d = 0; d < D; ++d)
-                    bt[t][d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stX[d] + t * 512 + rd_tile));
-#pragma unroll
-            for (int to = 0; to < HT; ++to) {
-                u32x2 at[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d)
-                    at[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG[d] + to * 512 + rd_tile));
-#pragma unroll
-                for (int t = 0; t < HT; ++t) dw_acc(at, bt[t], dW2[to][t]);
-                if constexpr (BI) mfma_bf16_k16_acc(at[0], ones_k16, dbm[to]);
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int t = 0; t < HT; ++t) g1[d][t] = gh[d][t];
-        }
-        // first layer: stage g1, input gradients, dW1
-        lds_wave_sync();
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int t = 0; t < HT; ++t) *reinterpret_cast<u32x2 *>(stG[d] + t * 512 + wr_tile) = g1[d][t];
-        lds_wave_sync();
-#pragma unroll
-        for (int T = 0; T < GT; ++T) {
-            f32x4 accs[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) accs[d] = zero;
-            contract_hidden_d<HT, D>(wimg + I::kD1 + T * hid_k_dwords(HT), g1, lane, accs);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                u32x2 gi = pack_tile(accs[d]);
-                const u32x2 xin = *reinterpret_cast<const u32x2 *>(stIn[d] + c * S::kInRow + (gin_off[T] ^ in_swz));
-                if constexpr (BUF) {
-                    // relu' of the inputs: none / all of the segments (a uniform branch) or mixed; the pad
-                    // slots of a gradient row come out as +0 by themselves (zero columns of W1'^T)
-                    if (gate_mode == 1) {
-                        gi[0] = gate_bf16x2(gi[0], xin[0], k_one);
-                        gi[1] = gate_bf16x2(gi[1], xin[1], k_one);
-                    } else if (gate_mode == 2) {
-                        gi[0] = u16x2_mul(gi[0], (i16x2_min(xin[0], k_one) & gmul_and[T]) | gmul_or[T]);
-                        gi[1] = u16x2_mul(gi[1], (i16x2_min(xin[1], k_one) & gmul_and[T]) | gmul_or[T]);
-                    }
-                } else {
-                    gi[0] = u16x2_mul(gi[0], (i16x2_min(xin[0], k_one) & gmul_and[T]) | gmul_or[T]);
-                    gi[1] = u16x2_mul(gi[1], (i16x2_min(xin[1], k_one) & gmul_and[T]) | gmul_or[T]);
-                    gi[0] &= gkeep[T][0];
-                    gi[1] &= gkeep[T][1];
-                }
-                if constexpr (BUF) {   // one store per gradient tensor of this tile; other lanes fall out
-                    const uint32_t r0 = row0_of(grp, d);
-#pragma unroll
-                    for (int i = 0; i < IO::NS; ++i)
-                        if (IO::store[i].slot == T) {
-                            uint32_t voff, soff;
-                            buf_addr(IO::store[i], bp.store[i], v_st[i], false, sidv[d], r0, voff, soff);
-                            if (kTail && !valid[d]) voff = kBufOut;
-                            buf_store_u32x2(gi, r_st[i], voff, soff);
-                        }
-                } else {
-                    // (lanes without a chunk already point at their trash slot with stride 0)
-                    const gh_ptr dst = gptr[T] + (int64_t)srow[d][T] * gstride[T];
-                    *reinterpret_cast<u32x2 GNNTRK_GLOBAL *>(valid[d] ? dst : my_trash) = gi;
-                }
-            }
-        }
-        {
-            u32x2 bt[2 * KI][D];
-#pragma unroll
-            for (int ts = 0; ts < 2 * KI; ++ts)
-#pragma unroll
-                for (int d = 0; d < D; ++d)
-                    bt[ts][d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(
-                        stIn[d] + rd_row * S::kInRow + ((32 * ts + 8 * (c & 3)) ^ (16 * (g >> 1)))));
-#pragma unroll
-            for (int to = 0; to < HT; ++to) {
-                u32x2 at[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d)
-                    at[d] = lds_read_tr16(reinterpret_cast<const uint16_t *>(stG[d] + to * 512 + rd_tile));
-#pragma unroll
-                for (int ts = 0; ts < 2 * KI; ++ts) dw_acc(at, bt[ts], dW1[to][ts]);
-            }
-        }
-        lds_wave_sync();  // the next tile overwrites the images
-        if constexpr (!BUF) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                cur[d] = nxt[d];
-                gcur[d] = gnxt[d];
-            }
-        }
-    };
-    const int64_t n_units = (n_tiles + D - 1) / D;
-    const bool last_is_partial = n_units * D * kTileRows != a.n_rows;
-    const int has_tail = (int)__builtin_amdgcn_readfirstlane(
-        (uint32_t)((n_grp > 0 && last_is_partial && sch.cur + (int64_t)(n_grp - 1) * sch.step == n_units - 1) ? 1 : 0));
-    const int n_main = n_grp - has_tail;
-    for (int grp = 0; grp < n_main; ++grp) tile_step(std::false_type{}, grp);
-    if (has_tail) tile_step(std::true_type{}, n_main);
-
-    // ---- partial block (parameter layout: W1, b1, [W2, b2,] W3, b3) ------------------------
-    // The four waves of the workgroup are summed in wave order through LDS (the weight-fragment
-    // image is free by now) and ONE block per workgroup goes to the workspace; shapes whose
-    // parameter count exceeds the image fall back to one block per wave.
-    if (!want_dw) return;
-    drain_mfma();
-    const int PT = part_total(a.mlp);
-    // (five and more hidden tiles: one block per WAVE.  The in-LDS reduction of the <1, 7, 0, true> and
-    //  <1, 8, 0, true> instantiations - 105-120 KB of LDS - ended in memory-access faults on the MI355X, at
-    //  random, while the same code passes the emulator and every narrower instantiation; with per-wave blocks
-    //  they are clean - and so is the LDS form once two more run-time branches are added around its parts:
-    //  the fault follows the code generation of these 400-500 register instantiations, not the algorithm.
-    //  The wide instantiations do without the LDS step.  2048: per-wave blocks everywhere - diagnostics)
-    const bool via_lds = PT <= I::kTotal && HT <= 4 && !(a.debug_flags & 2048);
-    // (the destination is the workspace in global memory or the LDS image: an address-space-typed pointer in
-    //  both cases - through a generic pointer the LDS form became FLAT stores, and those faulted on the MI355X
-    //  in the instantiations whose LDS image lies above 64 KB: "write access to a read-only page")
-    auto emit = [&](auto pw, bool add) {
-        using FP = decltype(pw);
-        auto put = [&](FP dst, float v) { *dst = add ? *dst + v : v; };
-        int off = 0;
-        FP pW1 = pw + off;
-        off += hidden * in_dim;
-        FP pb1 = pw + off;
-        off += hidden;
-        FP pW2 = pw + off, pb2 = nullptr;
-        if (THREE) {
-            off += hidden * hidden;
-            pb2 = pw + off;
-            off += hidden;
-        }
-        FP pW3 = pw + off;
-        off += out_dim * hidden;
-        FP pb3 = pw + off;
-#pragma unroll
-        for (int to = 0; to < HT; ++to)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * to + 4 * g + r;
-                if (o >= hidden) continue;
-#pragma unroll
-                for (int ts = 0; ts < 2 * KI; ++ts) {
-                    if (col1[ts] >= 0)
-                        put(pW1 + o * in_dim + col1[ts], dW1[to][ts][r]);
-                    else if (col1[ts] == -2)
-                        put(pb1 + o, dW1[to][ts][r]);
-                }
-                if (THREE) {
-#pragma unroll
-                    for (int t = 0; t < HT; ++t) {
-                        const int f = 16 * t + c;
-                        if (f < hidden)
-                            put(pW2 + o * hidden + f, dW2[THREE ? to : 0][t][r]);
-                        else if (f == hid_ones)
-                            put(pb2 + o, dW2[THREE ? to : 0][t][r]);
-                    }
-                }
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 4 * g + r;
-            if (o >= out_dim) continue;
-#pragma unroll
-            for (int t = 0; t < HT; ++t) {
-                const int f = 16 * t + c;
-                if (f < hidden)
-                    put(pW3 + o * hidden + f, dW3[t][r]);
-                else if (f == hid_ones)
-                    put(pb3 + o, dW3[t][r]);
-            }
-        }
-        if constexpr (BI) {   // accumulator-initialised biases: column 0 of the ones-operand products
-            if (c == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (THREE) {
-#pragma unroll
-                        for (int to = 0; to < HT; ++to)
-                            if (16 * to + 4 * g + r < hidden) put(pb2 + 16 * to + 4 * g + r, dbm[to][r]);
-                    }
-                    if (4 * g + r < out_dim) put(pb3 + 4 * g + r, dbl[r]);
-                }
-            }
-        }
-        if (!add) {  // bias slots without a ones column must still be defined
-            if (s_plan.ones_slot < 0)
-                for (int o = lane; o < hidden; o += 64) pb1[o] = 0.f;
-            if (hid_ones < 0 && !BI) {
-                if (THREE)
-                    for (int o = lane; o < hidden; o += 64) pb2[o] = 0.f;
-                for (int o = lane; o < out_dim; o += 64) pb3[o] = 0.f;
-            }
-        }
-    };
-    if (via_lds) {
-        GNNTRK_LDS float *buf = (GNNTRK_LDS float *)s_img;
-        __syncthreads();  // every wave is done with the fragments
-        for (int i = tid; i < PT; i += kBlock) buf[i] = 0.f;
-        __syncthreads();
-        for (int w = 0; w < kWaves; ++w) {
-            if (wv == w) emit(buf, true);
-            __syncthreads();
-        }
-        gf_ptr dst = (gf_ptr)(part + (int64_t)blockIdx.x * PT);
-        for (int i = tid; i < PT; i += kBlock) dst[i] = buf[i];
-    } else {
-        emit((gf_ptr)(part + (int64_t)(blockIdx.x * kWaves + wv) * PT), false);
-    }
-}
-
-template <int KI, int HT, int GT, bool THREE, bool G32, int D, class IO = IoNone>
+template <int KI, int HT, int GT, bool THREE, bool G32, int D_, class IO_ = IoNone>
 __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                                            uint8_t *trash, const BufPlan bp) {
-    mlp16_bwd_body<KI, HT, GT, THREE, G32, D, IO, false>(a, part, trash, bp);
+    constexpr int D = D_;
+    using IO = IO_;
+    constexpr bool BI = false;
+#include "mlp_bf16_bwd_body.inc"
 }
 // hidden width 64 with biases (SlotPlan::bias_init): generic I/O, one tile per iteration
 template <int KI, int HT, int GT, bool THREE, bool G32>
 __global__ __launch_bounds__(kBlock, (HT >= 5 || KI >= 2) ? 1 : 2) void mlp16_bwd_bi_kernel(const gnntrk_mlp_bwd_args a, float *part,
-                                                                              uint8_t *trash, const BufPlan bp) {
-    mlp16_bwd_body<KI, HT, GT, THREE, G32, 1, IoNone, true>(a, part, trash, bp);
+                                                                                          uint8_t *trash, const BufPlan bp) {
+    constexpr int D = 1;
+    using IO = IoNone;
+    constexpr bool BI = true;
+#include "mlp_bf16_bwd_body.inc"
 }
 
 // ------------------------------------------------------------------ launchers

@@ -24,7 +24,7 @@ def build(asan: bool = False, verbose: bool = False) -> pathlib.Path:
     name = "libgnntrk_emul_asan.so" if asan else "libgnntrk_emul.so"
     lib = OUT / name
     srcs = [s for s in sorted(CSRC.glob("*.hip")) if s.name not in SKIP]
-    deps = srcs + sorted(CSRC.glob("*.h")) + sorted((REPO / "include").glob("*.h")) + [
+    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + sorted((REPO / "include").glob("*.h")) + [
         HERE / "shim/hip/hip_runtime.h", HERE / "emul_runtime.cpp"]
     h = hashlib.sha256()
     for d in deps:

@@ -55,6 +55,11 @@ int mlp16_kernel_name(const gnntrk_mlp *m, int n_seg, const gnntrk_seg *seg, int
 int mlp16_fwd_kernel_name(const gnntrk_mlp_fwd_args *a, char *buf, size_t len);
 int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len);
 int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream);
+// hidden width 128 with biases (eight hidden tiles, accumulator-initialised biases): mlp_bf16_bi8.hip
+struct SlotPlan;
+int launch_fwd16_bi8(const gnntrk_mlp_fwd_args *a, const SlotPlan &P, int grid, hipStream_t stream);
+int launch_bwd16_bi8(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int g32, int grid, float *part,
+                     uint8_t *trash, hipStream_t stream);
 size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m);
 int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes, hipStream_t stream);
 int mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *a);

@@ -106,6 +106,7 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     int grid = grid16(a->n_rows, P.HT >= 5 ? ((P.KI == 1 && P.HT <= 6) ? 2 : 1) : kFwd16BlocksPerCu, kWaves);
     if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
     bool launched = false;
+    if (P.bias_init && P.HT == 8) return launch_fwd16_bi8(a, P, grid16(a->n_rows, 1, kWaves), stream);
     if (P.bias_init) {
         grid = grid16(a->n_rows, 3, kWaves);
         GNNTRK_FWD16_CASE_BI(1, 4)

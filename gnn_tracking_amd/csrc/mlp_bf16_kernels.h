@@ -780,6 +780,8 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     bool launched = false;
     BufPlan B;
     make_buf_plan(B, P, a, GT);
+    if (P.bias_init && P.HT == 8)   // hidden width 128: own translation unit (mlp_bf16_bi8.hip says why)
+        return launch_bwd16_bi8(a, P, GT, G32 ? 1 : 0, grid, part, trash, stream);
     if (P.bias_init) {   // hidden width 64 with biases: the accumulator-initialised kernels
 #define GNNTRK_BWD16_BI(KI_, HT_, GT_)                                                         \
     if (!launched && P.KI == KI_ && P.HT == HT_ && GT == GT_) {                                \

@@ -183,7 +183,7 @@ struct SlotPlan {
     int32_t GT;         // gradient M tiles = ceil(n_gchunks / 4)
     int32_t ok;         // 0: shape not supported
     int32_t bias_init;  // 1: no constant-one hidden row - the biases of the layers after the first are the
-                        //    initial values of their accumulators (hidden width 64, see make_slot_plan)
+                        //    initial values of their accumulators (hidden widths 64 / 128, see make_slot_plan)
     int8_t seg[kMaxChunks16];    // segment of the chunk, -1: none
     int8_t first[kMaxChunks16];  // first feature of the chunk inside the segment / 4
     int8_t gchunk[kMaxChunks16]; // gradient chunk q -> input chunk
@@ -235,10 +235,9 @@ __host__ __device__ inline void make_slot_plan(SlotPlan &P, const gnntrk_mlp &m,
     // constant-one row costs a whole tile (five instead of four: one workgroup per CU instead of two).
     // There the biases of the layers after the first enter as the INITIAL VALUES of the fp32 accumulators
     // (rounded to bf16 first, as the fragment form rounds them), and their gradients are one extra MFMA per
-    // gradient tile against a tile of ones.  (128 would take eight tiles this way instead of nine, but
-    // its eight-tile backward with two gradient tiles and the extra accumulators crashes the compiler's
-    // AGPR-copy pass, ROCm 7.2 - it stays on the library path.)
-    P.bias_init = (hid_bias && m.hidden == 64) ? 1 : 0;
+    // gradient tile against a tile of ones.  128 takes eight tiles this way instead of nine (which no wave
+    // has the registers for) where the inputs fit one k-step; its kernels live in mlp_bf16_bi8.hip.
+    P.bias_init = (hid_bias && (m.hidden == 64 || (m.hidden == 128 && P.KI == 1))) ? 1 : 0;
     P.hid_ones = (hid_bias && !P.bias_init) ? m.hidden : -1;
     P.HT = (m.hidden + (P.hid_ones >= 0 ? 1 : 0) + 15) / 16;
     int q = 0;

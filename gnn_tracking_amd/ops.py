@@ -701,7 +701,10 @@ def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf1
         has_bias = any(b is not None for b in biases)
         spare = any(int(s.t.shape[1]) % 4 for s in segs if s.t.dim() == 2)   # a pad slot carries the ones column
         n_ch = chunks + (1 if has_bias and not spare else 0)
-        return n_ch <= 16 and hidden + (1 if has_bias else 0) <= (128 if n_ch <= 8 else 96)
+        hid_bias = any(b is not None for b in list(biases)[1:])   # a bias after the first layer
+        # (the constant-one hidden row; 64 and - with one k-step of inputs - 128 do without it: tile_bf16.h)
+        rows = hidden + (1 if hid_bias and not (hidden == 64 or (hidden == 128 and n_ch <= 8)) else 0)
+        return n_ch <= 16 and rows <= (128 if n_ch <= 8 else 96)
     return in_dim <= _capi.MAX_IN and hidden <= _capi.MAX_HIDDEN and chunks <= 16
 
 

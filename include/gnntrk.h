@@ -193,8 +193,9 @@ int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream);
  *   - GNNTRK_EPI_SIGMOID writes an fp32 output [*, out_stride floats] (the edge weights
  *     feed the fp32 loss); GNNTRK_EPI_RESIDUAL reads bf16 res rows;
  *   - limits: <= 16 four-feature input chunks; hidden + the bias row (present when a layer after the
- *     first has a bias) <= 96, or <= 128 when the inputs fit eight chunks; above 64 one 16-row tile
- *     per iteration and one workgroup per CU; out <= 16, n_rows < 2^31. */
+ *     first has a bias; hidden 64 and - with at most eight input chunks - 128 do without it) <= 96, or
+ *     <= 128 when the inputs fit eight chunks; above 64 one 16-row tile per iteration and one
+ *     workgroup per CU; out <= 16, n_rows < 2^31. */
 int gnntrk_mlp_forward_bf16(const gnntrk_mlp_fwd_args *args, void *stream);
 
 /* Backward of the same fused op with full recompute (nothing but the op inputs is

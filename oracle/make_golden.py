@@ -207,6 +207,8 @@ EC_VARIANTS = {
     "alpha0": dict(L_ec=2, hidden_dim=None, alpha=0.0),
     # hidden width 64: the widest the fp32 kernels hold; five hidden tiles (64 + the bias row) in bf16 storage
     "h64": dict(L_ec=2, hidden_dim=64),
+    # hidden width 128: eight hidden tiles in bf16 storage (biases as accumulator initial values); library GEMMs in fp32
+    "h128": dict(L_ec=1, hidden_dim=128),
     # widths beyond the fused kernels (hidden 128, 20-wide node / edge spaces): library-GEMM path
     "wide_h128": dict(L_ec=1, hidden_dim=128, interaction_node_dim=20, interaction_edge_dim=20),
 }

@@ -262,6 +262,8 @@ EC_VARIANTS = {
     "alpha0": dict(L_ec=2, hidden_dim=None, alpha=0.0),
     # hidden width 64: the widest the fp32 kernels hold; five hidden tiles (64 + the bias row) in bf16 storage
     "h64": dict(L_ec=2, hidden_dim=64),
+    # hidden width 128: eight hidden tiles in bf16 storage (biases as accumulator initial values); library GEMMs in fp32
+    "h128": dict(L_ec=1, hidden_dim=128),
     # widths beyond the fused kernels (hidden 128, 20-wide node / edge spaces): library-GEMM path
     "wide_h128": dict(L_ec=1, hidden_dim=128, interaction_node_dim=20, interaction_edge_dim=20),
 }
@@ -592,6 +594,11 @@ def case_mlp_bf16_forward(device, rows=75):
         ((5, 5, 4), (True, True, False), (True, True, True), 127, 4, 3, True, "none"),     # HT=8 (127 + ones)
         ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, 100, 1, 3, True, "sigmoid"),
         ((14,), (False,), (False,), 128, 5, 3, False, "relu"),                             # HT=8 exactly, no bias
+        # hidden 64 / 128 WITH biases: no constant-one row, biases as accumulator initial values
+        ((5, 5, 4), (True, True, False), (True, True, True), 128, 4, 3, True, "none"),
+        ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, 128, 1, 3, True, "sigmoid"),
+        ((5, 4), (False, False), (False, False), 128, 5, 2, True, "residual"),
+        ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, 64, 9, 3, True, "relu"),              # KI=2, hidden 64
     ]
     epi_code = {"none": _capi.EPI_NONE, "relu": _capi.EPI_RELU, "residual": _capi.EPI_RESIDUAL,
                 "sigmoid": _capi.EPI_SIGMOID}
@@ -668,6 +675,13 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
              True, "sigmoid", 1),
             ((5, 4), (False, False), (False, False), (True, True), 112, 5, 3, True, "residual", 1),
             ((14,), (False,), (False,), (False,), 128, 5, 3, False, "relu", 1),
+            # hidden 64 / 128 WITH biases: biases as accumulator initial values, bias gradients through ones tiles
+            ((5, 5, 4), (True, True, False), (True, True, True), (True, True, True), 128, 4, 3, True, "none", 2),
+            ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, (True,) * 6, 128, 1, 3,
+             True, "sigmoid", 1),
+            ((5, 4), (False, False), (False, False), (True, True), 128, 5, 3, True, "residual", 1),
+            ((14,), (False,), (False,), (False,), 128, 5, 2, True, "relu", 1),
+            ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, (True,) * 5, 64, 9, 3, True, "none", 1),
         ]
     if given is not None:
         cases = given
@@ -754,9 +768,9 @@ def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choic
             while sum((d + 3) // 4 for d in dims) + (1 if bias and all(d % 4 == 0 for d in dims) else 0) > 16:
                 dims = dims[:-1]
             epi = ("none", "relu", "residual", "sigmoid")[int(g.integers(0, 4))]
-            hid = int(g.choice([1, 7, 15, 16, 31, 40, 47, 48, 62] + ([63, 64, 65, 79, 80, 94, 95, 96, 111, 112, 126, 127] if wide else [])))
+            hid = int(g.choice([1, 7, 15, 16, 31, 40, 47, 48, 62] + ([63, 64, 65, 79, 80, 94, 95, 96, 111, 112, 126, 127, 128] if wide else [])))
             n_ch = sum((d + 3) // 4 for d in dims) + (1 if bias and all(d % 4 == 0 for d in dims) else 0)
-            if hid + (1 if bias else 0) > 96 and n_ch > 8:   # seven / eight hidden tiles: one k-step of inputs
+            if hid + (1 if bias and hid != 128 else 0) > 96 and n_ch > 8:   # seven / eight hidden tiles: one k-step of inputs
                 hid = 90
             out = int(g.integers(1, 17))
             cases.append((dims, tuple(bool(g.integers(0, 2)) for _ in dims), tuple(bool(g.integers(0, 2)) for _ in dims),
@@ -765,7 +779,7 @@ def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choic
         case_mlp_bf16_backward(device, rows=int(g.choice(row_choices)), cases=cases, seed=seed + rnd)
 
 
-def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0", "h64")):
+def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0", "h64", "h128")):
     """ECForGraphTCN in bf16-storage mode on the golden inputs of g2: forward against the
     bf16 restatement (oracle/ref_cpu.py:ec_for_graph_tcn_bf16, same rounding points) and
     against the reference-pinned fp32 goldens with a bf16-sized tolerance; loss and

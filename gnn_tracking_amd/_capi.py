@@ -14,7 +14,8 @@ import threading
 
 MAX_SEGS = 10
 MAX_IN, MAX_HIDDEN, MAX_OUT = 48, 64, 16            # fp32 kernels
-MAX_IN_BF16, MAX_HIDDEN_BF16 = 64, 128             # bf16 storage: 16 four-feature chunks; hidden + bias row <= 96
+MAX_OUT_BF16 = 48                                  # bf16 storage, three hidden tiles: up to three output tiles
+MAX_IN_BF16, MAX_HIDDEN_BF16 = 128, 128             # bf16 storage: 16 four-feature chunks; hidden + bias row <= 96
 #                                                    (<= 128 where the inputs fit one k-step of 32 slots)
 EPI_NONE, EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID = 0, 1, 2, 3
 

@@ -30,6 +30,11 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
     const int D = (P.KI == 1 && P.HT <= 3 && !(a->debug_flags & 64)) ? 2 : 1;  // as launch_bwd16 dispatches
     const bool g32 = a->epilogue == GNNTRK_EPI_SIGMOID;
+    if (a->mlp.out_dim > 16 || P.KI > 2) {
+        snprintf(buf, len, "mlp16_bwd_ot_kernel<%d, %d, %d, %s>", P.KI, P.HT, (a->mlp.out_dim + 15) / 16,
+                 a->mlp.n_layers == 3 ? "true" : "false");
+        return GNNTRK_OK;
+    }
     if (P.bias_init) {
         snprintf(buf, len, "mlp16_bwd_bi_kernel<%d, %d, %d, %s, %s>", P.KI, P.HT, GT,
                  a->mlp.n_layers == 3 ? "true" : "false", g32 ? "true" : "false");
@@ -114,15 +119,16 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
         return fail(GNNTRK_EINVAL, "mlp_backward_bf16: workspace too small (always required)");
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
-    if (!P.ok || P.KI > 2)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: more than 16 input chunks / 8 hidden tiles (6 with two k-steps of inputs)");
+    if (!P.ok || P.KI > kMaxChunks16 / 8)
+        return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: shape outside the instantiations (include/gnntrk.h)");
     const bool three = a->mlp.n_layers == 3;
     // gradient M tiles: 1 or the maximum of the k-step count (keeps the instantiation list short)
-    const int GT = (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
+    const bool wide_io = a->mlp.out_dim > 16 || P.KI > 2;   // output tiles / wide inputs: every gradient tile
+    const int GT = wide_io ? 2 * P.KI : (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
     int grid = 0;
     if (a->n_rows > 0) {
         // (five / six hidden tiles: one workgroup per CU is resident - its share of the rows is simply larger)
-        grid = grid16(a->n_rows, (P.HT >= 5 || (P.bias_init && P.KI >= 2)) ? 1 : (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu, kWaves);
+        grid = grid16(a->n_rows, (P.HT >= 5 || wide_io || (P.bias_init && P.KI >= 2)) ? 1 : (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu, kWaves);
         float *part = reinterpret_cast<float *>(ws);
         uint8_t *trash = reinterpret_cast<uint8_t *>(ws) + bwd16_partial_bytes(&a->mlp);
         rc = (a->epilogue == GNNTRK_EPI_SIGMOID)

@@ -57,12 +57,27 @@ namespace gnntrk {
         launched = true;                                                                    \
     }
 
+// outputs of 17 .. 48 features / inputs of 65 .. 128 slots (three hidden tiles): the plain output-tile kernels
+#define GNNTRK_FWD16_CASE_OT(KI_, OT_)                                                      \
+    if (P.KI == KI_ && ot == OT_) {                                                         \
+        if (three) { auto kfn = mlp16_fwd_ot_kernel<KI_, 3, OT_, true>;                     \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        else { auto kfn = mlp16_fwd_ot_kernel<KI_, 3, OT_, false>;                          \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a); }             \
+        launched = true;                                                                    \
+    }
+
 // exact forward instantiation
 int mlp16_fwd_kernel_name(const gnntrk_mlp_fwd_args *a, char *buf, size_t len) {
     if (!a || !buf || len == 0) return fail(GNNTRK_EINVAL, "mlp_kernel_name: bad argument");
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
     const bool plain = P.HT >= 5;
+    if (a->mlp.out_dim > 16 || P.KI > 2) {
+        snprintf(buf, len, "mlp16_fwd_ot_kernel<%d, %d, %d, %s>", P.KI, P.HT, (a->mlp.out_dim + 15) / 16,
+                 a->mlp.n_layers == 3 ? "true" : "false");
+        return GNNTRK_OK;
+    }
     if (P.bias_init) {
         snprintf(buf, len, "mlp16_fwd_bi_kernel<%d, %d, %s, %s>", P.KI, P.HT, a->mlp.n_layers == 3 ? "true" : "false",
                  a->epilogue == GNNTRK_EPI_SIGMOID ? "true" : "false");
@@ -96,8 +111,8 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     if (a->n_rows == 0) return GNNTRK_OK;
     SlotPlan P;
     make_slot_plan(P, a->mlp, a->n_seg, a->seg, nullptr);
-    if (!P.ok || P.KI > 2)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: more than 16 input chunks / 8 hidden tiles (6 with two k-steps of inputs)");
+    if (!P.ok || P.KI > kMaxChunks16 / 8)
+        return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: shape outside the instantiations (include/gnntrk.h)");
     const bool three = a->mlp.n_layers == 3, sig = a->epilogue == GNNTRK_EPI_SIGMOID;
     const bool share = a->mlp.out_dim <= 4;  // four tiles share one output tile and one store
     const bool wide = wide_ok(P, a->seg, a->n_rows);  // one 16-byte load per lane and k-step
@@ -106,6 +121,17 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     int grid = grid16(a->n_rows, P.HT >= 5 ? ((P.KI == 1 && P.HT <= 6) ? 2 : 1) : kFwd16BlocksPerCu, kWaves);
     if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;
     bool launched = false;
+    if (a->mlp.out_dim > 16 || P.KI > 2) {
+        if (sig) return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: SIGMOID epilogue with a wide input / output");
+        const int ot = (a->mlp.out_dim + 15) / 16;
+        grid = grid16(a->n_rows, P.KI > 2 ? 1 : 2, kWaves);
+        GNNTRK_FWD16_CASE_OT(1, 2) GNNTRK_FWD16_CASE_OT(1, 3)
+        GNNTRK_FWD16_CASE_OT(2, 2) GNNTRK_FWD16_CASE_OT(2, 3)
+        GNNTRK_FWD16_CASE_OT(3, 1) GNNTRK_FWD16_CASE_OT(3, 2) GNNTRK_FWD16_CASE_OT(3, 3)
+        GNNTRK_FWD16_CASE_OT(4, 1) GNNTRK_FWD16_CASE_OT(4, 2) GNNTRK_FWD16_CASE_OT(4, 3)
+        if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: no instantiation (output tiles)");
+        return check_launch("mlp_forward_bf16");
+    }
     if (P.bias_init && P.HT == 8) return launch_fwd16_bi8(a, P, grid16(a->n_rows, 1, kWaves), stream);
     if (P.bias_init) {
         grid = grid16(a->n_rows, 3, kWaves);

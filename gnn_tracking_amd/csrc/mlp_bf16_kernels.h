@@ -346,14 +346,21 @@ __device__ uint8_t g_fwd_trash[(size_t)kFwdMaxBlocks * kBlock * 16];
 // single full-wave store writes 4 x 16 rows.  R = 1 is the plain layout (wider outputs).
 template <int KI, int HT, bool THREE, bool SIG, int R_, bool WIDE_>
 __global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
-    constexpr int R = R_;
+    constexpr int R = R_, OT = 1;
     constexpr bool WIDE = WIDE_, BI = false;
+#include "mlp_bf16_fwd_body.inc"
+}
+// outputs of 17 .. 48 features (OT output tiles), up to four k-steps of inputs: plain form
+template <int KI, int HT, int OT_, bool THREE>
+__global__ __launch_bounds__(kBlock) void mlp16_fwd_ot_kernel(const gnntrk_mlp_fwd_args a) {
+    constexpr int R = 1, OT = OT_;
+    constexpr bool WIDE = false, BI = false, SIG = false;
 #include "mlp_bf16_fwd_body.inc"
 }
 // hidden width 64 with biases: no constant-one row, biases as accumulator initial values
 template <int KI, int HT, bool THREE, bool SIG>
 __global__ __launch_bounds__(kBlock) void mlp16_fwd_bi_kernel(const gnntrk_mlp_fwd_args a) {
-    constexpr int R = 1;
+    constexpr int R = 1, OT = 1;
     constexpr bool WIDE = false, BI = true;
 #include "mlp_bf16_fwd_body.inc"
 }
@@ -535,16 +542,26 @@ struct IoEncoder8 {
 template <int KI, int HT, int GT, bool THREE, bool G32, int D_, class IO_ = IoNone>
 __global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                                            uint8_t *trash, const BufPlan bp) {
-    constexpr int D = D_;
+    constexpr int D = D_, OT = 1;
     using IO = IO_;
     constexpr bool BI = false;
+#include "mlp_bf16_bwd_body.inc"
+}
+// outputs of 17 .. 48 features (OT output tiles) / up to four k-steps of inputs: generic I/O, one tile per
+// iteration, one workgroup per CU, all 2 KI input-gradient tiles (unwanted ones go to the trash slots)
+template <int KI, int HT, int OT_, bool THREE>
+__global__ __launch_bounds__(kBlock, 1) void mlp16_bwd_ot_kernel(const gnntrk_mlp_bwd_args a, float *part, uint8_t *trash,
+                                                                const BufPlan bp) {
+    constexpr int D = 1, OT = OT_, GT = 2 * KI;
+    using IO = IoNone;
+    constexpr bool BI = false, G32 = false;
 #include "mlp_bf16_bwd_body.inc"
 }
 // hidden width 64 with biases (SlotPlan::bias_init): generic I/O, one tile per iteration
 template <int KI, int HT, int GT, bool THREE, bool G32>
 __global__ __launch_bounds__(kBlock, (HT >= 5 || KI >= 2) ? 1 : 2) void mlp16_bwd_bi_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                                                           uint8_t *trash, const BufPlan bp) {
-    constexpr int D = 1;
+    constexpr int D = 1, OT = 1;
     using IO = IoNone;
     constexpr bool BI = true;
 #include "mlp_bf16_bwd_body.inc"
@@ -554,8 +571,8 @@ __global__ __launch_bounds__(kBlock, (HT >= 5 || KI >= 2) ? 1 : 2) void mlp16_bw
 // n_rows == 0 is a valid no-op: row pointers may then be NULL (what an empty tensor hands over)
 int check_bf16_mlp(const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, const char *who, int64_t n_rows) {
     if (m.n_layers != 2 && m.n_layers != 3) return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): n_layers must be 2 or 3");
-    if (m.in_dim < 1 || m.hidden < 1 || m.hidden > 16 * kMaxHiddenTiles16 || m.out_dim < 1 || m.out_dim > 16)
-        return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): hidden must be in [1,128], out in [1,16]");
+    if (m.in_dim < 1 || m.hidden < 1 || m.hidden > 16 * kMaxHiddenTiles16 || m.out_dim < 1 || m.out_dim > kMaxOut16)
+        return fail(GNNTRK_EUNSUPPORTED, "mlp(bf16): hidden must be in [1,128], out in [1,48]");
     if (n_seg < 1 || n_seg > GNNTRK_MAX_SEGS) return fail(GNNTRK_EINVAL, "mlp(bf16): bad segment count");
     int tot = 0;
     for (int j = 0; j < n_seg; ++j) {
@@ -780,6 +797,27 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     bool launched = false;
     BufPlan B;
     make_buf_plan(B, P, a, GT);
+    if (a->mlp.out_dim > 16 || P.KI > 2) {   // output tiles / wide inputs (three hidden tiles; GT = 2 KI)
+        if (G32 || a->epilogue == GNNTRK_EPI_RELU || a->epilogue == GNNTRK_EPI_SIGMOID)
+            return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: outputs over 16 / inputs over 64 slots take the NONE and RESIDUAL epilogues");
+        const int ot = (a->mlp.out_dim + 15) / 16;
+#define GNNTRK_BWD16_OT(KI_, OT_)                                                              \
+    if (!launched && P.KI == KI_ && ot == OT_ && P.HT == 3 && GT == 2 * KI_) {                 \
+        if (three) { auto kfn = mlp16_bwd_ot_kernel<KI_, 3, OT_, true>;                        \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash, B); } \
+        else { auto kfn = mlp16_bwd_ot_kernel<KI_, 3, OT_, false>;                             \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash, B); } \
+        launched = true;                                                                       \
+    }
+        if constexpr (!G32) {
+            GNNTRK_BWD16_OT(1, 2) GNNTRK_BWD16_OT(1, 3) GNNTRK_BWD16_OT(2, 2) GNNTRK_BWD16_OT(2, 3)
+            GNNTRK_BWD16_OT(3, 1) GNNTRK_BWD16_OT(3, 2) GNNTRK_BWD16_OT(3, 3)
+            GNNTRK_BWD16_OT(4, 1) GNNTRK_BWD16_OT(4, 2) GNNTRK_BWD16_OT(4, 3)
+        }
+#undef GNNTRK_BWD16_OT
+        if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: no instantiation (output tiles)");
+        return check_launch("mlp_backward_bf16");
+    }
     if (P.bias_init && P.HT == 8)   // hidden width 128: own translation unit (mlp_bf16_bi8.hip says why)
         return launch_bwd16_bi8(a, P, GT, G32 ? 1 : 0, grid, part, trash, stream);
     if (P.bias_init) {   // hidden width 64 with biases: the accumulator-initialised kernels

@@ -237,8 +237,17 @@ int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const
     // rows may be NULL when there are no rows at all (every segment empty)
     if (!rowptr || n_seg < 0 || (rows && !rows_ok(rows, dim, row_stride)) || !rows_ok(out, dim, out_stride))
         return fail(GNNTRK_EINVAL, "segment_sum_bf16: bad argument");
+    if (dim > 16) {
+        // rows wider than 16 features (the 40-wide edge embeddings of GraphConstructionResIN): one pass per
+        // block of 16 columns - same strides, shifted base pointers (32 bytes: the alignment classes stay)
+        for (int c0 = 0; c0 < dim; c0 += 16) {
+            const int rc = segment_sum_bf16_launch(rows ? rows + c0 : rows, dim - c0 < 16 ? dim - c0 : 16, row_stride, rowptr,
+                                                   pos, n_seg, out + c0, out_stride, stream);
+            if (rc) return rc;
+        }
+        return GNNTRK_OK;
+    }
     const int nch = (dim + 3) / 4;
-    if (nch > 4) return fail(GNNTRK_EUNSUPPORTED, "segment_sum_bf16: dim > 16");
     const int grid = grid_for_threads(n_seg * 4);
     if (nch == 1 && row_stride == 4 && !pos && rows && ((uintptr_t)rows & 15) == 0) {
         // contiguous 8-byte rows in CSR order (the message aggregation): aligned 16-byte pair loads

@@ -167,10 +167,11 @@ __device__ __forceinline__ uint16_t bf16_bits(float x) {  // RNE (weight packing
 // forced to 1.0 when any layer has a bias: the biases ride in the weight fragments
 // (column `ones_slot` of W1', column `hid_ones` of W2'/W3'; row `hid_ones` of W1'/W2'
 // regenerates the constant), rounded to bf16 like autocast rounds them.
-constexpr int kMaxChunks16 = 16;
+constexpr int kMaxChunks16 = 32;   // four k-steps of 32 slots (more than two: the output-tile kernels, three hidden tiles)
 // hidden tiles of 16 (hidden features + the constant-one row): up to 4 in the hot instantiations
 // (two workgroups per CU), 5 and 6 - hidden widths 64 .. 95 - in plain ones (one tile per iteration,
 // one workgroup per CU: their weight-gradient accumulators alone take up to 264 registers)
+constexpr int kMaxOut16 = 48;          // output features: up to three output tiles (with three hidden tiles)
 constexpr int kMaxHiddenTiles16 = 8;   // (seven and eight: one 32-slot k-step of inputs only)
 
 struct SlotPlan {
@@ -246,7 +247,10 @@ __host__ __device__ inline void make_slot_plan(SlotPlan &P, const gnntrk_mlp &m,
             if (P.seg[p] >= 0 && gseg[P.seg[p]].ptr) P.gchunk[q++] = (int8_t)p;
     P.n_gchunks = q;
     P.GT = (q + 3) / 4;
-    if (P.HT > kMaxHiddenTiles16 || (P.HT > 6 && P.KI > 1) || m.out_dim > 16) P.ok = 0;
+    if (P.HT > kMaxHiddenTiles16 || (P.HT > 6 && P.KI > 1) || m.out_dim > kMaxOut16) P.ok = 0;
+    // outputs over 16 features (two / three output tiles) and inputs over 64 slots: three hidden tiles, ones-row
+    // biases, bf16 output - the shapes of GraphConstructionResIN(hidden_dim=40)
+    if ((m.out_dim > 16 || P.KI > 2) && (P.HT != 3 || P.bias_init)) P.ok = 0;
 }
 
 // W1 column of input slot s: >= 0 column, -1 pad, -2 the ones slot

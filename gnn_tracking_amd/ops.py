@@ -476,10 +476,10 @@ def _fill_mlp(weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]]):
             raise ValueError(f"layer {i} weight has shape {tuple(w.shape)}, expected {exp}")
     # (the descriptor only; each storage mode's launcher checks its own limits - fp32: in <= 48,
     #  hidden <= 64; bf16: 16 input chunks, hidden + bias row <= 96, <= 128 with one k-step of inputs)
-    if in_dim > _capi.MAX_IN_BF16 or hidden > _capi.MAX_HIDDEN_BF16 or out_dim > _capi.MAX_OUT:
+    if in_dim > _capi.MAX_IN_BF16 or hidden > _capi.MAX_HIDDEN_BF16 or out_dim > _capi.MAX_OUT_BF16:
         raise NotImplementedError(
             f"fused MLP kernel limits: in<={_capi.MAX_IN_BF16}, hidden<={_capi.MAX_HIDDEN_BF16}, "
-            f"out<={_capi.MAX_OUT}; got in={in_dim}, hidden={hidden}, out={out_dim}")
+            f"out<={_capi.MAX_OUT_BF16}; got in={in_dim}, hidden={hidden}, out={out_dim}")
     return _capi.make_mlp([_p(w) for w in weights], [_p(b) for b in biases], in_dim, hidden,
                           out_dim)
 
@@ -671,7 +671,7 @@ def fused_mlp(segs: Sequence[Seg], weights: Sequence[Tensor],
         if s.t.dim() == 1:
             raise ValueError("fused_mlp segments must be 2-D [rows, dim]")
     bf16 = segs[0].t.dtype == torch.bfloat16
-    if not _fused_supported(segs, weights, biases, bf16):
+    if not _fused_supported(segs, weights, biases, bf16, epilogue):
         return _wide_mlp(segs, weights, biases, n_rows=int(n_rows), epilogue=epilogue, ca=float(ca), cb=float(cb),
                          res=res, out_idx=out_idx, out_rows=int(out_rows if out_rows is not None else n_rows))
     spec = _MlpSpec(len(segs), len(weights), any(b is not None for b in biases),
@@ -685,7 +685,11 @@ def fused_mlp(segs: Sequence[Seg], weights: Sequence[Tensor],
 
 
 # ------------------------------------------------ MLPs beyond the fused kernels' shapes
-def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf16: bool) -> bool:
+#: four-feature input chunks the bf16 kernels take (wide inputs: with three hidden tiles only)
+_BF16_MAX_CHUNKS = 32
+
+
+def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf16: bool, epilogue=None) -> bool:
     """The shapes the register-resident fused kernels hold (include/gnntrk.h: L in {2, 3}; at
     most sixteen 4-feature input chunks; fp32: in <= 48, hidden <= 64, out <= 16; bf16 storage:
     hidden (+ the bias row) <= 96 - <= 128 with at most eight input chunks -, out <= 16)."""
@@ -695,7 +699,7 @@ def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf1
     hidden, out_dim = int(weights[0].shape[0]), int(weights[-1].shape[0])
     in_dim = sum(int(s.t.shape[1]) if s.t.dim() == 2 else 1 for s in segs)
     chunks = sum((int(s.t.shape[1]) + 3) // 4 for s in segs if s.t.dim() == 2)
-    if out_dim > _capi.MAX_OUT:
+    if out_dim > (_capi.MAX_OUT_BF16 if bf16 else _capi.MAX_OUT):
         return False
     if bf16:
         has_bias = any(b is not None for b in biases)
@@ -704,6 +708,8 @@ def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf1
         hid_bias = any(b is not None for b in list(biases)[1:])   # a bias after the first layer
         # (the constant-one hidden row; 64 and - with one k-step of inputs - 128 do without it: tile_bf16.h)
         rows = hidden + (1 if hid_bias and not (hidden == 64 or (hidden == 128 and n_ch <= 8)) else 0)
+        if out_dim > 16 or n_ch > 16:   # output tiles / wide inputs: the three-hidden-tile instantiations only
+            return n_ch <= _BF16_MAX_CHUNKS and 33 <= rows <= 48 and epilogue != _capi.EPI_SIGMOID
         return n_ch <= 16 and rows <= (128 if n_ch <= 8 else 96)
     return in_dim <= _capi.MAX_IN and hidden <= _capi.MAX_HIDDEN and chunks <= 16
 

@@ -168,9 +168,10 @@ class GraphConstructionResIN(nn.Module, HyperparametersMixin):
         networks (models/graph_construction.py:136-219): encoders to ``hidden_dim``, ``ResIN``
         with node and edge width ``hidden_dim``, decoder to ``h_outdim``, mixed with the first
         ``h_outdim`` input features.  Where ``3 * hidden_dim`` fits the fused kernels' input width
-        (48 features in fp32, 64 in bf16 storage) the interaction networks are the fused kernels;
-        wider stacks - the reference's default ``hidden_dim=40`` included - run the same operator
-        as library GEMMs (``ops._wide_mlp``)."""
+        (48 features in fp32; 128 slots in bf16 storage, with outputs up to 48 wide where the hidden
+        width is 33 .. 47: the reference's default ``hidden_dim=40``) the interaction networks are the
+        fused kernels; other stacks - the default in fp32 included - run the same operator as library
+        GEMMs (``ops._wide_mlp``)."""
         super().__init__()
         self.save_hyperparameters()
         self._node_encoder = MLP(node_indim, hidden_dim, hidden_dim=hidden_dim, L=2, bias=False)
@@ -184,8 +185,12 @@ class GraphConstructionResIN(nn.Module, HyperparametersMixin):
         x_fcnn = data.x[:, :self.hparams.h_outdim]
         assert_feat_dim(data.x, self.hparams.node_indim)
         assert_feat_dim(data.edge_attr, self.hparams.edge_indim)
-        x = self._node_encoder(data.x)
-        edge_attr = self._edge_encoder(data.edge_attr)
+        x_in, ea_in = data.x, data.edge_attr
+        if precision.use_bf16():   # bf16 storage: the dataset's fp32 features are converted once
+            from . import ops_bf16
+            x_in, ea_in = ops_bf16.to_rows16(x_in), ops_bf16.to_rows16(ea_in)
+        x = self._node_encoder(x_in)
+        edge_attr = self._edge_encoder(ea_in)
         x, _, _ = self._resin(x, data.edge_index, edge_attr)
         assert_feat_dim(x, self.hparams.hidden_dim)
         delta = self._decoder(x).float()

@@ -599,6 +599,15 @@ def case_mlp_bf16_forward(device, rows=75):
         ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, 128, 1, 3, True, "sigmoid"),
         ((5, 4), (False, False), (False, False), 128, 5, 2, True, "residual"),
         ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, 64, 9, 3, True, "relu"),              # KI=2, hidden 64
+        # outputs over 16 features: two / three output tiles (three hidden tiles)
+        ((5, 5, 4), (True, True, False), (True, True, True), 40, 40, 3, True, "none"),
+        ((14,), (False,), (False,), 40, 40, 2, False, "relu"),
+        ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, 40, 33, 3, True, "residual"),         # KI=2, OT=3
+        ((9, 4), (False, True), (False, False), 36, 17, 3, True, "none"),                  # OT=2, ragged
+        # inputs over 64 slots: three / four k-steps (GraphConstructionResIN(hidden_dim=40): 120 -> 40 -> 40 -> 40)
+        ((40, 40, 40), (True, True, False), (True, True, True), 40, 40, 3, True, "none"),  # KI=4, OT=3
+        ((40, 40), (False, False), (True, False), 40, 40, 3, True, "residual"),            # KI=3 (20 chunks + ones)
+        ((40, 31, 30), (True, False, True), (False, False, False), 37, 5, 2, False, "relu"),  # KI=4, OT=1, ragged
     ]
     epi_code = {"none": _capi.EPI_NONE, "relu": _capi.EPI_RELU, "residual": _capi.EPI_RESIDUAL,
                 "sigmoid": _capi.EPI_SIGMOID}
@@ -682,6 +691,15 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
             ((5, 4), (False, False), (False, False), (True, True), 128, 5, 3, True, "residual", 1),
             ((14,), (False,), (False,), (False,), 128, 5, 2, True, "relu", 1),
             ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, (True,) * 5, 64, 9, 3, True, "none", 1),
+            # outputs over 16 features: two / three output tiles (three hidden tiles; NONE / RESIDUAL epilogues)
+            ((5, 5, 4), (True, True, False), (True, True, True), (True, True, True), 40, 40, 3, True, "none", 2),
+            ((14,), (False,), (False,), (False,), 40, 40, 2, False, "none", 1),
+            ((8, 8, 8, 8, 3), (False,) * 5, (True,) * 5, (True, False, True, False, True), 40, 33, 3, True, "residual", 1),
+            ((9, 4), (False, True), (False, False), (True, True), 36, 17, 3, True, "none", 2),
+            # inputs over 64 slots: three / four k-steps
+            ((40, 40, 40), (True, True, False), (True, True, True), (True, True, True), 40, 40, 3, True, "none", 2),
+            ((40, 40), (False, False), (True, False), (True, True), 40, 40, 3, True, "residual", 1),
+            ((40, 31, 30), (True, False, True), (False, False, False), (True, False, True), 37, 5, 2, False, "none", 1),
         ]
     if given is not None:
         cases = given
@@ -939,7 +957,8 @@ def case_rows_bf16(device):
     not multiples of 4), row permutations - against torch on the same bf16 values."""
     from gnn_tracking_amd import ops_bf16 as B
     g = np.random.default_rng(4)
-    for N, E, D in ((1, 0, 4), (7, 20, 5), (300, 4000, 4), (1000, 9000, 9), (50, 333, 4), (5, 1, 3), (9, 2, 2)):
+    for N, E, D in ((1, 0, 4), (7, 20, 5), (300, 4000, 4), (1000, 9000, 9), (50, 333, 4), (5, 1, 3), (9, 2, 2),
+                    (300, 4000, 40), (50, 333, 33)):   # (rows wider than 16 features: 16-column passes)
         ei = tt(g.integers(0, N, size=(2, E)), device).long()
         gi = ops.graph_index(ei, N, cache=False)
         x32 = tt(g.normal(size=(E, D)).astype(np.float32), device)
@@ -1483,17 +1502,30 @@ def case_gc_resin(device, names=None):
         (out * tt(z[f"{name}/r"], device)).sum().backward()
         for k, v in model.named_parameters():
             assert_close(v.grad, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
-    # bf16 storage through the library-GEMM path (the default width): runs, finite, close to fp32
+    # bf16 storage at the reference's default width: the 120 -> 40 -> 40 -> 40 relational model, the 80-wide object
+    # model and the 40-wide encoder outputs run on the fused kernels (output tiles, three / four k-steps of inputs),
+    # not on library GEMMs; H and the parameter gradients against the fp32 goldens with bf16-sized bounds
     kw = GC_RESIN_CASES["default_h40"]
     if names is None or "default_h40" in names:
         model = G.GraphConstructionResIN(node_indim=14, edge_indim=4, **kw)
         load_params(model, z, "default_h40/p0/")
         model = model.to(device)
+        ops._WIDE_WARNED.clear()   # (the fp32 run above took the library path for the same shapes)
         with G.bf16_storage():
             out16 = model(G.Data(x=x, edge_index=ei, edge_attr=ea))["H"]
             (out16.float() * tt(z["default_h40/r"], device)).sum().backward()
-        assert_close(out16.float(), z["default_h40/H"], 0.05, "default_h40 H (bf16 storage)")
-        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        assert not ops._WIDE_WARNED, f"library path taken: {ops._WIDE_WARNED}"
+        assert float((out16.float() - tt(z["default_h40/H"], device)).abs().max()) > 0, "bf16 storage was not engaged"
+        assert_close(out16.float(), z["default_h40/H"], 0.02, "default_h40 H (bf16 storage)")
+        tot = math.sqrt(sum(float(tt(z[f"default_h40/grad/{k}"]).double().pow(2).sum()) for k, _ in model.named_parameters()))
+        err2 = 0.0
+        for k, v in model.named_parameters():
+            assert v.grad is not None and torch.isfinite(v.grad).all(), k
+            gref = tt(z[f"default_h40/grad/{k}"]).double()
+            d = float((v.grad.detach().cpu().double() - gref).norm())
+            err2 += d * d
+            assert d <= 0.10 * float(gref.norm()) + 0.01 * tot, f"default_h40 bf16 grad {k}: {d:.3e} vs |g| {float(gref.norm()):.3e}"
+        assert math.sqrt(err2) <= 0.05 * tot, f"default_h40 bf16 gradients: relative L2 {math.sqrt(err2) / tot:.3f}"
 
 
 FOCAL_CASES = {"ew_default": ("EdgeWeightFocalLoss", dict()),

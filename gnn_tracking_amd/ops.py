@@ -709,7 +709,9 @@ def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf1
         # (the constant-one hidden row; 64 and - with one k-step of inputs - 128 do without it: tile_bf16.h)
         rows = hidden + (1 if hid_bias and not (hidden == 64 or (hidden == 128 and n_ch <= 8)) else 0)
         if out_dim > 16 or n_ch > 16:   # output tiles / wide inputs: the three-hidden-tile instantiations only
-            return n_ch <= _BF16_MAX_CHUNKS and 33 <= rows <= 48 and epilogue != _capi.EPI_SIGMOID
+            # (their backward takes the NONE / RESIDUAL epilogues)
+            return (n_ch <= _BF16_MAX_CHUNKS and 33 <= rows <= 48
+                    and epilogue in (None, _capi.EPI_NONE, _capi.EPI_RESIDUAL))
         return n_ch <= 16 and rows <= (128 if n_ch <= 8 else 96)
     return in_dim <= _capi.MAX_IN and hidden <= _capi.MAX_HIDDEN and chunks <= 16
 

@@ -196,7 +196,7 @@ int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream);
  *     first has a bias; hidden 64 and - with at most eight input chunks - 128 do without it) <= 96, or
  *     <= 128 when the inputs fit eight chunks; above 64 one 16-row tile per iteration and one
  *     workgroup per CU; out <= 16; with hidden + bias row in 33 .. 48 (three hidden tiles) also up to
- *     32 input chunks and out <= 48 (epilogues NONE / RESIDUAL, and RELU in the forward); n_rows < 2^31. */
+ *     32 input chunks and out <= 48 (epilogues NONE / RESIDUAL; the forward alone also RELU); n_rows < 2^31. */
 int gnntrk_mlp_forward_bf16(const gnntrk_mlp_fwd_args *args, void *stream);
 
 /* Backward of the same fused op with full recompute (nothing but the op inputs is

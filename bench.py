@@ -728,6 +728,32 @@ def dbscan_short(dev) -> dict:
     return out
 
 
+def gc_resin_short(dev, hits: int = 200_000, edges: int = 3_000_000, steps: int = 10) -> dict:
+    """GraphConstructionResIN at the reference's default hidden_dim = 40 (120 -> 40 -> 40 -> 40 relational model) in
+    bf16 storage: forward + backward on one 200 k-hit / 3 M-edge graph (the output-tile / wide-input kernels)."""
+    ev = synthetic.make_event(7, hits, edges, dev)
+    data = G.Data(x=ev.x, edge_index=ev.edge_index, edge_attr=ev.edge_attr)
+    torch.manual_seed(0)
+    model = G.GraphConstructionResIN(node_indim=14, edge_indim=4, n_layers=1).to(dev)
+
+    def step():
+        model.zero_grad()
+        with G.bf16_storage(True):
+            model(data)["H"].float().square().mean().backward()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"workload": f"GraphConstructionResIN(hidden_dim=40), {hits} hits, {edges} edges, forward + backward, bf16 storage",
+            "steps": steps, "ms_per_step": ms, "value": edges / ms * 1e3, "unit": "edges/s",
+            "library_path_taken": sorted(map(str, ops._WIDE_WARNED))}
+
+
 def extras(args, rank: int, world: int, dev) -> dict:
     """Short driver-timed runs of the configurations the headline does not cover: cfg4 at
     every rank count; at N = 1 also cfg3 in fp32 and cfg2 as a HIP graph."""
@@ -770,6 +796,7 @@ def extras(args, rank: int, world: int, dev) -> dict:
         del wl
         ops.clear_graph_index_cache()
         torch.cuda.empty_cache()
+        out["gc_resin_default_bf16"] = gc_resin_short(dev)
         out["cfg2_hipgraph_bf16"] = hipgraph_cfg2(dev, "bf16", 100)
         out["cfg2_hipgraph_f32"] = hipgraph_cfg2(dev, "f32", 100)
         torch.cuda.empty_cache()

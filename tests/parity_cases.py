@@ -768,18 +768,19 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
                 assert_close(gb[i], db[i], TOL16, f"{tag} gb{i}")
 
 
-def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choices=(1, 16, 17, 33, 100, 2050), wide=False):
+def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choices=(1, 16, 17, 33, 100, 2050), wide=False,
+                         wide_io=False):
     """Random shapes through the bf16 backward (and the forward recompute inside it): one to four
     segments with and without gathers / ReLU-on-load / wanted gradients, hidden widths on both
     sides of the tile boundaries (one k-step and up to three hidden tiles run the two-tile form,
     the rest the one-tile form; no wanted gradient at all runs the weight-gradient-only form),
     L = 2 / 3, with and without bias, all four epilogues, one or two upstream terms, row counts
     around the 16- and 32-row tile sizes.  ``wide``: also hidden widths 63 .. 127 (five to eight hidden
-    tiles)."""
+    tiles).  ``wide_io``: three hidden tiles with up to 32 input chunks and up to 48 outputs (NONE / RESIDUAL)."""
     g = np.random.default_rng(seed)
     for rnd in range(rounds):
         cases = []
-        for _ in range(cases_per_round):
+        for _ in range(cases_per_round if not wide_io else 0):
             n_seg = int(g.integers(1, 5))
             dims = tuple(int(g.integers(1, 13)) for _ in range(n_seg))
             bias = bool(g.integers(0, 2))
@@ -794,6 +795,19 @@ def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choic
             cases.append((dims, tuple(bool(g.integers(0, 2)) for _ in dims), tuple(bool(g.integers(0, 2)) for _ in dims),
                           tuple(bool(g.integers(0, 3)) for _ in dims), hid, out, int(g.integers(2, 4)), bias, epi,
                           1 if epi == "sigmoid" else int(g.integers(1, 3))))
+        for _ in range(cases_per_round if wide_io else 0):
+            n_seg = int(g.integers(1, 5))
+            dims = tuple(int(g.integers(1, 41)) for _ in range(n_seg))
+            bias = bool(g.integers(0, 2))
+            while sum((d + 3) // 4 for d in dims) + (1 if bias and all(d % 4 == 0 for d in dims) else 0) > 32:
+                dims = dims[:-1]
+            n_ch = sum((d + 3) // 4 for d in dims) + (1 if bias and all(d % 4 == 0 for d in dims) else 0)
+            out = int(g.integers(17, 49)) if (n_ch <= 16 or g.integers(0, 2)) else int(g.integers(1, 17))
+            hid = int(g.integers(33, 48 if not bias else 47))   # (hidden + bias row in 33 .. 48: three hidden tiles)
+            epi = ("none", "residual")[int(g.integers(0, 2))]
+            cases.append((dims, tuple(bool(g.integers(0, 2)) for _ in dims), tuple(bool(g.integers(0, 2)) for _ in dims),
+                          tuple(bool(g.integers(0, 3)) for _ in dims), hid, out, int(g.integers(2, 4)), bias, epi,
+                          int(g.integers(1, 3))))
         case_mlp_bf16_backward(device, rows=int(g.choice(row_choices)), cases=cases, seed=seed + rnd)
 
 

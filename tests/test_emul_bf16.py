@@ -34,6 +34,7 @@ def test_mlp_bf16_stress_emulated():
     with emulated():
         P.case_mlp_bf16_stress("cpu", rounds=2, cases_per_round=6, row_choices=(1, 17, 33, 100))
         P.case_mlp_bf16_stress("cpu", rounds=1, cases_per_round=6, row_choices=(17, 33), seed=29, wide=True)
+        P.case_mlp_bf16_stress("cpu", rounds=1, cases_per_round=6, row_choices=(17, 33), seed=31, wide_io=True)
 
 
 def test_graph_tcn_bf16_emulated():

@@ -115,7 +115,8 @@ def test_bf16_mlp_backward(dev):
 
 def test_bf16_mlp_stress(dev):
     P.case_mlp_bf16_stress(dev, rounds=6)
-    P.case_mlp_bf16_stress(dev, rounds=6, seed=29, wide=True)   # + hidden widths 63 .. 127
+    P.case_mlp_bf16_stress(dev, rounds=6, seed=29, wide=True)   # + hidden widths 63 .. 128
+    P.case_mlp_bf16_stress(dev, rounds=4, seed=31, wide_io=True)   # output tiles / three - four k-steps of inputs
 
 
 def test_bf16_edge_classifier(dev):

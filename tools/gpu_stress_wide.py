@@ -15,6 +15,7 @@ for r in range(args.rounds):
     code = ("import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'oracle'); sys.path.insert(0,'.');"
             "import torch, parity_cases as P;"
             f"P.case_mlp_bf16_stress(torch.device('cuda',0), rounds=3, seed={1000 + r}, cases_per_round=8, wide=True);"
+            f"P.case_mlp_bf16_stress(torch.device('cuda',0), rounds=2, seed={5000 + r}, cases_per_round=8, wide_io=True);"
             "torch.cuda.synchronize(); print('ok')")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     ok = p.returncode == 0 and p.stdout.strip().endswith("ok")

@@ -692,7 +692,8 @@ _BF16_MAX_CHUNKS = 32
 def _fused_supported(segs: Sequence[Seg], weights: Sequence[Tensor], biases, bf16: bool, epilogue=None) -> bool:
     """The shapes the register-resident fused kernels hold (include/gnntrk.h: L in {2, 3}; at
     most sixteen 4-feature input chunks; fp32: in <= 48, hidden <= 64, out <= 16; bf16 storage:
-    hidden (+ the bias row) <= 96 - <= 128 with at most eight input chunks -, out <= 16)."""
+    hidden (+ the bias row, which 64 and 128 do without) <= 96 - <= 128 with at most eight input chunks -,
+    out <= 16; with hidden + bias row in 33 .. 48 also 32 input chunks and out <= 48, NONE / RESIDUAL)."""
     L = len(weights)
     if L not in (2, 3):
         return False

@@ -70,15 +70,15 @@ class ResFCNN(nn.Module):
         _capi.require_device(x)
         x = nn.functional.normalize(x.float(), p=2.0, dim=1, eps=1e-12)
         bf16 = precision.use_bf16()
-        i_, h_, o_ = self._dims
-        if self._fusable_depth and o_ <= _capi.MAX_OUT and (
-                (i_ <= _capi.MAX_IN_BF16 - 4 and h_ < 95) if bf16
-                else (i_ <= _capi.MAX_IN and h_ < _capi.MAX_HIDDEN)):
-            if bf16:  # bf16 storage: the normalised rows enter the kernels as bf16
-                x = x.to(torch.bfloat16)
+        if self._fusable_depth:
+            # one MLP: the fused kernels where the storage mode's instantiations hold the widths, the same
+            # operator as library GEMMs otherwise (ops.fused_mlp decides) - in bf16 storage the rows stay bf16
+            # either way, so that what follows keeps running in that mode
             lin = [self._encoder, *self._layers, self._decoder]
-            return ops.fused_mlp([ops.Seg(x)], [l.weight for l in lin], [l.bias for l in lin],
-                                 epilogue=epilogue)
+            ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+            xs = x.to(torch.bfloat16) if bf16 else x
+            if bf16 or ops._fused_supported([ops.Seg(xs)], ws, bs, False, epilogue):
+                return ops.fused_mlp([ops.Seg(xs)], ws, bs, epilogue=epilogue)
         x = self._encoder(x)
         for layer in self._layers:
             x = math.sqrt(self._alpha) * x + math.sqrt(1 - self._alpha) * layer(torch.relu(x))

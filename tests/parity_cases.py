@@ -1500,6 +1500,32 @@ GC_RESIN_CASES = {"h12_l2": dict(h_outdim=6, hidden_dim=12, n_layers=2, alpha=0.
                   "default_h40": dict(h_outdim=8, hidden_dim=40, n_layers=1, alpha=0.5, alpha_fcnn=0.5)}
 
 
+def case_graph_tcn_wide_hidden_bf16(device, hiddens=(64, 100, 128), n_hits=400, n_edges=3000):
+    """GraphTCN (edge classifier + track condenser + heads) with hidden widths beyond four hidden tiles in bf16
+    storage: every MLP runs on the fused kernels (no library launch), H and the parameter gradients sit at a
+    bf16-sized distance from the fp32 run of the same model (which takes library GEMMs above hidden 64)."""
+    from gnn_tracking_amd import synthetic
+    ev = synthetic.make_event(3, n_hits, n_edges, device)
+    for hd in hiddens:
+        torch.manual_seed(0)
+        model = G.GraphTCN(node_indim=14, edge_indim=4, h_dim=5, e_dim=4, h_outdim=4, hidden_dim=hd, L_ec=2, L_hc=2).to(device)
+        res = {}
+        for bf16 in (False, True):
+            model.zero_grad()
+            ops._WIDE_WARNED.clear()
+            ops.clear_graph_index_cache()
+            with G.bf16_storage(bf16):
+                out = model(G.Data(x=ev.x, edge_index=ev.edge_index, edge_attr=ev.edge_attr, y=ev.y))
+                (out["H"].float().square().mean() + out["B"].float().mean()).backward()
+            if bf16:
+                assert not ops._WIDE_WARNED, f"hidden {hd}: library path taken for {sorted(ops._WIDE_WARNED)}"
+            res[bf16] = (out["H"].float().detach().clone(),
+                         torch.cat([p_.grad.reshape(-1).float() for p_ in model.parameters() if p_.grad is not None]).clone())
+        dh = float((res[True][0] - res[False][0]).abs().max()) / max(float(res[False][0].abs().max()), 1e-6)
+        dg = float((res[True][1] - res[False][1]).norm()) / max(float(res[False][1].norm()), 1e-12)
+        assert 0 < dh < 0.05 and dg < 0.05, f"hidden {hd}: bf16 vs fp32 H {dh:.3e} gradients {dg:.3e}"
+
+
 def case_gc_resin(device, names=None):
     """GraphConstructionResIN vs the reference (G12): encoders, ResIN with node = edge width =
     hidden_dim (relational input 3 x hidden_dim), decoder, latent mix."""

@@ -47,3 +47,8 @@ def test_graph_tcn_bf16_emulated():
 def test_bf16_reproducible_emulated():
     with emulated():
         P.case_bf16_reproducible("cpu")
+
+
+def test_graph_tcn_wide_hidden_bf16_emulated():
+    with emulated():
+        P.case_graph_tcn_wide_hidden_bf16("cpu", hiddens=(64, 128), n_hits=200, n_edges=1200)

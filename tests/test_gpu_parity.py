@@ -113,6 +113,11 @@ def test_bf16_mlp_backward(dev):
     P.case_mlp_bf16_backward(dev, rows=100_000, full=False)
 
 
+def test_graph_tcn_wide_hidden_bf16(dev):
+    P.case_graph_tcn_wide_hidden_bf16(dev)
+    P.case_graph_tcn_wide_hidden_bf16(dev, hiddens=(64, 127), n_hits=20_000, n_edges=200_000)
+
+
 def test_bf16_mlp_stress(dev):
     P.case_mlp_bf16_stress(dev, rounds=6)
     P.case_mlp_bf16_stress(dev, rounds=6, seed=29, wide=True)   # + hidden widths 63 .. 128

@@ -768,6 +768,42 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
                 assert_close(gb[i], db[i], TOL16, f"{tag} gb{i}")
 
 
+def case_bf16_shape_rules_agree(device):
+    """What ``ops._fused_supported`` accepts in bf16 storage, the C launchers run - forward and backward - over a
+    grid of widths around every tile boundary: a drift between the Python rule and ``make_slot_plan`` /
+    the instantiation lists would otherwise surface as ``GNNTRK_EUNSUPPORTED`` in the middle of a training step."""
+    from gnn_tracking_amd import _capi, ops_bf16 as B
+    gen = torch.Generator().manual_seed(5)
+    rows = 3
+    dim_sets = ((5, 5, 4), (14,), (8, 8, 8, 8, 3), (40, 40, 40), (40, 40), (12, 12, 12, 12, 12, 4))
+    ran = 0
+    for dims in dim_sets:
+        for hid in (1, 16, 31, 32, 33, 40, 47, 48, 63, 64, 65, 95, 96, 97, 112, 127, 128, 129):
+            for out in (1, 4, 16, 17, 40, 48, 49):
+                for bias in (True, False):
+                    for L, epi in ((3, _capi.EPI_NONE), (2, _capi.EPI_RESIDUAL), (3, _capi.EPI_RELU)):
+                        segs = [B.rows16(_rand_rows16(rows, d, device, gen)) for d in dims]
+                        m = G.MLP(sum(dims), out, hid, L=L, bias=bias)
+                        W = [l.weight.detach().to(device).contiguous() for l in m.linears()]
+                        b = [l.bias.detach().to(device).contiguous() if bias else None for l in m.linears()]
+                        if not ops._fused_supported([ops.Seg(t) for t in segs], W, b, True, epi):
+                            continue
+                        tag = f"dims {dims} hidden {hid} out {out} bias {bias} L {L} epilogue {epi}"
+                        mlp = ops._fill_mlp(W, b)
+                        res = B.rows16(_rand_rows16(rows, out, device, gen)) if epi == _capi.EPI_RESIDUAL else None
+                        try:
+                            B.mlp_forward_raw(segs, [None] * len(dims), [False] * len(dims), W, b, n_rows=rows, epilogue=epi,
+                                              ca=0.6, cb=0.8, res=res, out_idx=None, out_rows=rows, mlp=mlp)
+                            g = B.rows16(_rand_rows16(rows, out, device, gen))
+                            B.mlp_backward_raw(segs, [None] * len(dims), [False] * len(dims), W, b, n_rows=rows, epilogue=epi,
+                                               ca=0.6, cb=0.8, gout=[(g, None)], need_seg=[True] * len(dims), want_dw=True,
+                                               mlp=mlp)
+                        except NotImplementedError as e:
+                            raise AssertionError(f"Python accepts what the library refuses: {tag}: {e}") from e
+                        ran += 1
+    assert ran > 300, ran
+
+
 def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choices=(1, 16, 17, 33, 100, 2050), wide=False,
                          wide_io=False):
     """Random shapes through the bf16 backward (and the forward recompute inside it): one to four

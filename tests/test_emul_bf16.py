@@ -52,3 +52,8 @@ def test_bf16_reproducible_emulated():
 def test_graph_tcn_wide_hidden_bf16_emulated():
     with emulated():
         P.case_graph_tcn_wide_hidden_bf16("cpu", hiddens=(64, 128), n_hits=200, n_edges=1200)
+
+
+def test_python_shape_rule_and_library_agree_emulated():
+    with emulated():
+        P.case_bf16_shape_rules_agree("cpu")

@@ -768,7 +768,8 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
                 assert_close(gb[i], db[i], TOL16, f"{tag} gb{i}")
 
 
-def case_bf16_shape_rules_agree(device):
+def case_bf16_shape_rules_agree(device, hiddens=(1, 16, 31, 32, 33, 40, 47, 48, 63, 64, 65, 95, 96, 97, 112, 127, 128, 129),
+                                outs=(1, 4, 16, 17, 40, 48, 49), min_ran=300):
     """What ``ops._fused_supported`` accepts in bf16 storage, the C launchers run - forward and backward - over a
     grid of widths around every tile boundary: a drift between the Python rule and ``make_slot_plan`` /
     the instantiation lists would otherwise surface as ``GNNTRK_EUNSUPPORTED`` in the middle of a training step."""
@@ -778,8 +779,8 @@ def case_bf16_shape_rules_agree(device):
     dim_sets = ((5, 5, 4), (14,), (8, 8, 8, 8, 3), (40, 40, 40), (40, 40), (12, 12, 12, 12, 12, 4))
     ran = 0
     for dims in dim_sets:
-        for hid in (1, 16, 31, 32, 33, 40, 47, 48, 63, 64, 65, 95, 96, 97, 112, 127, 128, 129):
-            for out in (1, 4, 16, 17, 40, 48, 49):
+        for hid in hiddens:
+            for out in outs:
                 for bias in (True, False):
                     for L, epi in ((3, _capi.EPI_NONE), (2, _capi.EPI_RESIDUAL), (3, _capi.EPI_RELU)):
                         segs = [B.rows16(_rand_rows16(rows, d, device, gen)) for d in dims]
@@ -801,7 +802,7 @@ def case_bf16_shape_rules_agree(device):
                         except NotImplementedError as e:
                             raise AssertionError(f"Python accepts what the library refuses: {tag}: {e}") from e
                         ran += 1
-    assert ran > 300, ran
+    assert ran > min_ran, ran
 
 
 def case_mlp_bf16_stress(device, rounds=3, seed=17, cases_per_round=8, row_choices=(1, 16, 17, 33, 100, 2050), wide=False,

@@ -113,11 +113,6 @@ def test_bf16_mlp_backward(dev):
     P.case_mlp_bf16_backward(dev, rows=100_000, full=False)
 
 
-def test_python_shape_rule_and_library_agree(dev):
-    # (also launches every accepted instantiation once on the device)
-    P.case_bf16_shape_rules_agree(dev)
-
-
 def test_graph_tcn_wide_hidden_bf16(dev):
     P.case_graph_tcn_wide_hidden_bf16(dev)
     P.case_graph_tcn_wide_hidden_bf16(dev, hiddens=(64, 127), n_hits=20_000, n_edges=200_000)

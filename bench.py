@@ -217,7 +217,9 @@ def measured_pipe(which: str, kernel_prefix: str):
         ks = json.load(f)["kernels"]
     for name, rec in ks.items():
         if name.startswith(kernel_prefix) and "valu_busy" in rec:
-            return {"bound": "valu", "achieved": rec["valu_busy"], "peak": 1.0,
+            return {"source": "committed_profile",   # (NOT measured in this run: a constant read from profiles/)
+                    "profile": PIPE_PROFILES[which],
+                    "bound": "valu", "achieved": rec["valu_busy"], "peak": 1.0,
                     "unit": "share of the chip's vector-issue cycles (SQ_INSTS_VALU x 4 / (1024 SIMDs x cycles); "
                             f"rocprofv3 --pmc, profiles/{PIPE_PROFILES[which]})",
                     "frac": rec["valu_busy"], "kernel": name, "kernel_us_under_pmc": rec["avg_us_under_pmc"],
@@ -592,11 +594,70 @@ def timed_steps(wl: Workload, world: int, dev, steps: int, warmup: int, *, kerne
     ops.set_kernel_timer(None)
     if hasattr(wl, "stage"):
         wl.stage.on = False
+    global PER_RANK_MS
+    PER_RANK_MS = [dt / steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own wall time between the two barriers (they differ by how long a rank waited in the
+        # closing barrier: the spread shows load imbalance); the job's time is the maximum
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[torch.distributed.get_rank()] = dt
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        PER_RANK_MS = [float(v) / steps * 1e3 for v in t.tolist()]
+        dt = float(t.max().item())
     return dt, float(loss.item()), (timer.summary() if timer else {})
+
+
+PER_RANK_MS: list = []
+
+
+def collective_info(dist_backend: str) -> dict:
+    """What the first multi-GPU line should say about itself (rank 0, N > 1): the collective library's version
+    and how the GPUs of the node are linked (``rocm-smi --showtopo``: link type and hop count per pair), so
+    that a scaling curve can be read against the xGMI topology without a second run.  Best effort: anything
+    that cannot be probed is null."""
+    import shutil
+    import subprocess
+
+    info: dict = {"rccl_version": None, "link_type": None, "hops": None}
+    if dist_backend == "nccl":
+        try:
+            v = torch.cuda.nccl.version()
+            info["rccl_version"] = ".".join(map(str, v)) if isinstance(v, tuple) else str(v)
+        except Exception:  # noqa: BLE001
+            pass
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([smi, "--showtopo"], capture_output=True, text=True, timeout=30).stdout
+    except Exception:  # noqa: BLE001
+        return info
+    info.update(parse_showtopo(out))
+    return info
+
+
+def parse_showtopo(text: str) -> dict:
+    """``rocm-smi --showtopo`` -> {"link_type": [[...]], "hops": [[...]]} (matrices over the GPUs in the tool's
+    order; null where a block is missing)."""
+    def block(title: str):
+        rows, on = [], False
+        for ln in text.splitlines():
+            if title in ln:
+                on = True
+                continue
+            if on:
+                if ln.startswith("=") and rows:
+                    break
+                parts = ln.split()
+                if parts and parts[0].startswith("GPU") and len(parts) > 1 and not parts[1].startswith("GPU"):
+                    rows.append(parts[1:])
+        return rows or None
+
+    hops = block("Hops between two GPUs")
+    if hops is not None:
+        try:
+            hops = [[int(v) for v in r] for r in hops]
+        except ValueError:
+            pass
+    return {"link_type": block("Link Type between two GPUs"), "hops": hops}
 
 
 def roofline_of(ks: dict, dtype: str):
@@ -886,6 +947,7 @@ def main(argv=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            **({"ms_per_step_per_rank": PER_RANK_MS, "collective": collective_info(dist_backend)} if world > 1 else {}),
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,

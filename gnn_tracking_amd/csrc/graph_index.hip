@@ -23,7 +23,7 @@
 //
 //   What makes steps 1 / 3 stream: a collated batch is a list of events with disjoint id ranges and
 //   contiguous edge ranges, so a chunk only touches the few hundred buckets of its own event: the
-//   counters of a chunk live in an LDS window of 8192 buckets around the chunk's first id and the
+//   counters of a chunk live in an LDS window of 4096 buckets (kWin) placed a third below the chunk's first id and the
 //   runs it writes are hundreds of bytes long.  Ids outside the window (one giant unsorted graph)
 //   take global atomics on the table itself - slower, same result.  A bucket beyond the LDS
 //   capacity (hub nodes) is ranked from global memory in tiles - slower, same result.

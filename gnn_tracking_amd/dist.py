@@ -58,11 +58,14 @@ class FlatParameters:
     """Re-homes all parameters (and their gradients) of a module into two contiguous
     fp32 buffers so that one all-reduce and one optimizer kernel cover the model.
 
-    ``grad_sink`` (default on): the parameters are marked so that the fused MLP backward launches ADD
+    ``grad_sink`` (default on): the parameters are marked so that the fused MLP backward launches MAY add
     their weight / bias gradients into these persistent buffers themselves (``ops._param_grad_sinks``)
     instead of returning six tensors per MLP for autograd to ``add_`` - bit-identical sums, 100 fewer
-    tiny kernels per step of the edge classifier.  The gradients are then found in ``.grad`` also after
-    ``torch.autograd.grad`` on such parameters; pass ``grad_sink=False`` where that matters."""
+    tiny kernels per step of the edge classifier.  The shortcut bypasses ``AccumulateGrad`` (tensor hooks,
+    post-accumulate-grad hooks and DDP's reducer hooks would not fire), so it is only taken inside
+    ``ops.grad_sinks_armed()`` - which ``training.TrackingModule.backward_step`` puts around its own plain
+    ``loss.backward()`` - and only for parameters without hooks.  Any other ``backward()`` /
+    ``torch.autograd.grad`` on these parameters takes the ordinary autograd path."""
 
     def __init__(self, module: nn.Module, grad_sink: bool = True):
         params = [p for p in module.parameters() if p.requires_grad]

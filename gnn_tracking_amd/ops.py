@@ -25,6 +25,7 @@ from __future__ import annotations
 import os
 
 import ctypes as C
+import contextlib
 import dataclasses
 import weakref
 from typing import Optional, Sequence
@@ -229,11 +230,11 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
                          _p(gi.rowptr_s), _p(gi.spos), _p(gi.spos_inv))
     cy = _capi.GraphIndexCarry()
     lab = rows = None
-    if CARRY and carry_label is not None and E > 0 and _carry_label_ok(carry_label, E):
+    if CARRY and carry_label is not None and E > 0 and _carry_label_ok(carry_label, E, dev):
         lab = carry_label.detach().view(torch.uint8).contiguous().view(-1)
         lab_csr = torch.empty(E, dtype=torch.uint8, device=dev)
         cy.edge_label, cy.label_csr = _p(lab), _p(lab_csr)
-    if CARRY and carry_rows is not None and E > 0 and _carry_rows_ok(carry_rows, E):
+    if CARRY and carry_rows is not None and E > 0 and _carry_rows_ok(carry_rows, E, dev):
         from . import ops_bf16
         rows = carry_rows.detach()
         rows_csr = ops_bf16.empty_rows(E, 4, dev)
@@ -256,12 +257,12 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     return gi
 
 
-def _carry_label_ok(y: Tensor, E: int) -> bool:
-    return y.dtype in (torch.bool, torch.uint8) and y.numel() == E and y.device.type != "meta"
+def _carry_label_ok(y: Tensor, E: int, dev) -> bool:
+    return y.dtype in (torch.bool, torch.uint8) and y.numel() == E and y.device == dev
 
 
-def _carry_rows_ok(r: Tensor, E: int) -> bool:
-    return (r.dtype == torch.float32 and r.dim() == 2 and tuple(r.shape) == (E, 4) and r.stride(1) == 1
+def _carry_rows_ok(r: Tensor, E: int, dev) -> bool:
+    return (r.device == dev and r.dtype == torch.float32 and r.dim() == 2 and tuple(r.shape) == (E, 4) and r.stride(1) == 1
             and r.stride(0) >= 4 and r.stride(0) % 4 == 0 and r.data_ptr() % 16 == 0)
 
 
@@ -487,16 +488,35 @@ def _fill_mlp(weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]]):
 #: parameters marked by ``dist.FlatParameters`` own PERSISTENT fp32 gradient buffers (views of one
 #: bucket): the reduction at the end of a backward launch then adds into them directly
 #: (``gnntrk_mlp_bwd_args.accumulate_params``) and autograd gets ``None`` for those inputs, instead
-#: of six small tensors per MLP and one ``add_`` kernel each.  ``GNNTRK_GRAD_SINK=0`` turns it off;
-#: it applies to ``.backward()`` only in the sense that ``torch.autograd.grad`` on marked parameters
-#: would find the sum in ``.grad`` as well - FlatParameters documents that.
+#: of six small tensors per MLP and one ``add_`` kernel each.  Because ``AccumulateGrad`` then never
+#: runs for such a parameter, the shortcut is only taken where that is known to be harmless:
+#: INSIDE ``grad_sinks_armed()`` - which this package's own optimisation step puts around its plain
+#: ``loss.backward()`` (``training.TrackingModule.backward_step``) - and for parameters without tensor
+#: hooks / post-accumulate-grad hooks.  A ``loss.backward()`` or ``torch.autograd.grad`` issued by
+#: anyone else (a Lightning loop, DDP's reducer hooks on the accumulators, a user's own hooks) gets
+#: the ordinary autograd path: gradients are returned, hooks fire.  ``GNNTRK_GRAD_SINK=0`` turns the
+#: shortcut off altogether.
 _GRAD_SINK = os.environ.get("GNNTRK_GRAD_SINK", "1") != "0"
+_SINKS_ARMED = 0
+
+
+@contextlib.contextmanager
+def grad_sinks_armed():
+    """Around a plain ``tensor.backward()`` whose marked parameters (``dist.FlatParameters(grad_sink=True)``)
+    may receive their gradients in place from the backward launches."""
+    global _SINKS_ARMED
+    _SINKS_ARMED += 1
+    try:
+        yield
+    finally:
+        _SINKS_ARMED -= 1
 
 
 def _param_grad_sinks(weights, biases, need_w, need_b):
-    """``(gW buffers, gb buffers)`` to accumulate into, or ``None``: every parameter of the launch
-    that needs a gradient must be marked and hold a matching contiguous fp32 ``.grad``."""
-    if not _GRAD_SINK:
+    """``(gW buffers, gb buffers)`` to accumulate into, or ``None``: only inside ``grad_sinks_armed()``, and
+    every parameter of the launch that needs a gradient must be marked, free of hooks and hold a matching
+    contiguous fp32 ``.grad``."""
+    if not _GRAD_SINK or _SINKS_ARMED <= 0:
         return None
     gW, gb = [], []
     for plist, need, out in ((weights, need_w, gW), (biases, need_b, gb)):
@@ -506,7 +526,8 @@ def _param_grad_sinks(weights, biases, need_w, need_b):
                 continue
             g = getattr(p_, "grad", None)
             if (not nd or not getattr(p_, "_gnntrk_grad_sink", False) or g is None or g.dtype != torch.float32
-                    or g.shape != p_.shape or g.device != p_.device or not g.is_contiguous()):
+                    or g.shape != p_.shape or g.device != p_.device or not g.is_contiguous()
+                    or getattr(p_, "_backward_hooks", None) or getattr(p_, "_post_accumulate_grad_hooks", None)):
                 return None
             out.append(g)
     return gW, gb
@@ -990,12 +1011,14 @@ class _BCECsr(torch.autograd.Function):
         ws = _ws(lib.gnntrk_bce_workspace_bytes(n), w)
         _capi.check(lib.gnntrk_bce_csr(_p(w), _p(label_csr), _p(src_csr), _p(pt), pt_thld, n, _p(loss), _p(gw),
                                        _p(ws), ws.numel(), _stream(w)), lib)
-        ctx.gw = gw
+        # (saved, not kept as an attribute: the E-sized buffer is released with the graph)
+        ctx.save_for_backward(*([gw] if gw is not None else []))
         return loss.view(())
 
     @staticmethod
     def backward(ctx, g):
-        return ctx.gw * g.to(torch.float32), None, None, None, None
+        (gw,) = ctx.saved_tensors
+        return gw * g.to(torch.float32), None, None, None, None
 
 
 class _Focal(torch.autograd.Function):
@@ -1114,9 +1137,13 @@ def bce_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None,
         w_csr, gi = fast
         lab = carried_label(gi, y)
         if lab is not None:  # ... and the labels came along with the graph-index build: one fused pass
-            ptf = pt.detach().to(torch.float32).contiguous() if pt_thld > 0.0 else None
+            ptf = None
             if pt_thld > 0.0:
                 assert pt is not None
+                ptf = pt.detach().to(torch.float32).contiguous()
+                if ptf.device != w_csr.device or ptf.numel() < gi.n_nodes:
+                    raise ValueError(f"bce_loss: pt must hold one value per node ({gi.n_nodes}) on {w_csr.device}, "
+                                     f"got {ptf.numel()} on {ptf.device}")
             return _BCECsr.apply(w_csr, lab, gi.src if pt_thld > 0.0 else None, ptf, float(pt_thld))
         return _BCE.apply(w_csr, edge_targets_csr(y, gi, pt, float(pt_thld)), None, None, 0.0)
     y = y.to(torch.float32)

@@ -22,6 +22,7 @@ from typing import Any, Callable, Optional
 import torch
 from torch import Tensor, nn
 
+from . import ops
 from .precision import bf16_storage
 
 
@@ -98,7 +99,10 @@ class TrackingModule:
         """forward + loss + backward of one (micro-)batch; gradients ACCUMULATE."""
         with bf16_storage(self.bf16):
             loss = self._loss(data)
-            (loss if scale == 1.0 else loss * scale).backward()
+            # (a plain backward of this module's own loss: parameters re-homed by dist.FlatParameters may
+            #  take their gradients in place from the backward launches, see ops.grad_sinks_armed)
+            with ops.grad_sinks_armed():
+                (loss if scale == 1.0 else loss * scale).backward()
         return loss.detach()
 
     def optimisation_step(self, data) -> Tensor:

@@ -46,6 +46,39 @@ def test_self_launch_eight_ranks_dry_run():
     d = _line(r.stdout)
     assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["backend"] == "gloo" and d["self_launched"] is True
     assert d["config"]["global_edges_per_step"] == 64 * 8
+    # the N > 1 line explains itself: every rank's own time (the job's time is their maximum), the
+    # collective library's version (RCCL only) and the GPU link matrix where rocm-smi can be asked
+    assert len(d["ms_per_step_per_rank"]) == 8 and abs(max(d["ms_per_step_per_rank"]) - d["ms_per_step"]) < 1e-9
+    assert set(d["collective"]) == {"rccl_version", "link_type", "hops"} and d["collective"]["rccl_version"] is None
+
+
+def test_showtopo_parser():
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    text = """
+============================ ROCm System Management Interface ============================
+================================ Weight between two GPUs =================================
+       GPU0         GPU1
+GPU0   0            15
+GPU1   15           0
+
+================================= Hops between two GPUs ==================================
+       GPU0         GPU1
+GPU0   0            1
+GPU1   1            0
+
+=============================== Link Type between two GPUs ===============================
+       GPU0         GPU1
+GPU0   0            XGMI
+GPU1   XGMI         0
+
+======================================= Numa Nodes =======================================
+GPU[0]          : (Topology) Numa Node: 0
+"""
+    t = bench.parse_showtopo(text)
+    assert t["hops"] == [[0, 1], [1, 0]] and t["link_type"] == [["0", "XGMI"], ["XGMI", "0"]]
+    assert bench.parse_showtopo("no such tool") == {"link_type": None, "hops": None}
 
 
 def test_a_rank_that_cannot_join_fails_loudly_not_for_ever():

@@ -57,3 +57,10 @@ def test_graph_tcn_wide_hidden_bf16_emulated():
 def test_python_shape_rule_and_library_agree_emulated():
     with emulated():
         P.case_bf16_shape_rules_agree("cpu")
+
+
+def test_batch_gradient_is_sum_of_event_gradients_emulated():
+    """The full-size cfg3 backward property test (test_gpu_parity.py) at emulator scale: 4 events x 300
+    hits x 2 400 edges, fp32 and bf16 storage."""
+    with emulated():
+        print(P.case_full_size_backward("cpu", n_events=4, n_nodes=300, n_edges=2400))

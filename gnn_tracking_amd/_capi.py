@@ -79,6 +79,29 @@ class OcArgs(C.Structure):
                 ("rep_seed", C.c_uint64), ("cap_nbr", C.c_void_p)]
 
 
+RESFCNN_MAX_HIDDEN, RESFCNN_MAX_IN, RESFCNN_MAX_WIDTH, RESFCNN_MAX_OUT = 16, 64, 128, 32
+
+
+class ResFcnn(C.Structure):
+    _fields_ = [("W_enc", C.c_void_p), ("b_enc", C.c_void_p), ("W_hid", C.c_void_p * RESFCNN_MAX_HIDDEN),
+                ("b_hid", C.c_void_p * RESFCNN_MAX_HIDDEN), ("W_dec", C.c_void_p), ("b_dec", C.c_void_p),
+                ("out_scale", C.c_void_p), ("in_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32),
+                ("n_hidden", C.c_int32), ("alpha", C.c_float), ("normalize", C.c_int32), ("out_relu", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class ResFcnnGrads(C.Structure):
+    _fields_ = [("W_enc", C.c_void_p), ("b_enc", C.c_void_p), ("W_hid", C.c_void_p * RESFCNN_MAX_HIDDEN),
+                ("b_hid", C.c_void_p * RESFCNN_MAX_HIDDEN), ("W_dec", C.c_void_p), ("b_dec", C.c_void_p),
+                ("out_scale", C.c_void_p)]
+
+
+class HingeArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dim", C.c_int32), ("x_stride", C.c_int32), ("n_nodes", C.c_int64),
+                ("node_mask", C.c_void_p), ("particle_id", C.c_void_p), ("r_emb", C.c_float), ("p", C.c_float),
+                ("repulsive", C.c_int32), ("_pad", C.c_int32)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -159,12 +182,24 @@ _SIGNATURES = {
     "gnntrk_oc_backward_spatial": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
     "gnntrk_oc_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "gnntrk_oc_backward": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
+    "gnntrk_resfcnn_hidden_pad": (C.c_int32, [C.c_int32]),
+    "gnntrk_resfcnn_forward_workspace_bytes": (C.c_size_t, [C.POINTER(ResFcnn)]),
+    "gnntrk_resfcnn_forward": (C.c_int, [C.POINTER(ResFcnn), _P, C.c_int32, C.c_int64, _P, C.c_int32, _P, _P,
+                                         C.c_size_t, _P]),
+    "gnntrk_resfcnn_backward_workspace_bytes": (C.c_size_t, [C.POINTER(ResFcnn), C.c_int64]),
+    "gnntrk_resfcnn_backward": (C.c_int, [C.POINTER(ResFcnn), _P, C.c_int32, C.c_int64, _P, _P, C.c_int32, _P,
+                                          C.c_int32, _P, C.c_int32, C.POINTER(ResFcnnGrads), C.c_int32, _P,
+                                          C.c_size_t, _P]),
+    "gnntrk_hinge_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnntrk_hinge_forward": (C.c_int, [C.POINTER(HingeArgs), _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
+    "gnntrk_hinge_backward": (C.c_int, [C.POINTER(HingeArgs), C.POINTER(GraphIndex), _P, _P, _P, C.c_int32,
+                                        C.c_int32, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 300   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
+ABI_VERSION = 400   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

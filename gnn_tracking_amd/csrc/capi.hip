@@ -12,6 +12,9 @@ static_assert(sizeof(gnntrk_mlp_fwd_args) == 448, "gnntrk_mlp_fwd_args layout");
 static_assert(sizeof(gnntrk_mlp_bwd_args) == 784, "gnntrk_mlp_bwd_args layout");
 static_assert(sizeof(gnntrk_graph_index) == 72, "gnntrk_graph_index layout");
 static_assert(sizeof(gnntrk_graph_index_carry) == 40, "gnntrk_graph_index_carry layout");
+static_assert(sizeof(gnntrk_resfcnn) == 8 * (5 + 2 * GNNTRK_RESFCNN_MAX_HIDDEN) + 32, "gnntrk_resfcnn layout");
+static_assert(sizeof(gnntrk_resfcnn_grads) == 8 * (5 + 2 * GNNTRK_RESFCNN_MAX_HIDDEN), "gnntrk_resfcnn_grads layout");
+static_assert(sizeof(gnntrk_hinge_args) == 56, "gnntrk_hinge_args layout");
 
 namespace gnntrk {
 

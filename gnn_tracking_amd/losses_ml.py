@@ -9,8 +9,11 @@ The neighbour search - the O(N^2 D) part - is the HIP kNN kernel with a radius c
 torch_cluster's ``radius_graph`` whenever the cap is not reached; with the cap reached
 torch_cluster keeps an implementation-defined subset), run per event of ``batch``; the
 hit-of-interest mask is ``gnntrk_good_node_mask``.  The two edge-list reductions that follow
-(gather, norm, power, hinge) are torch device ops under autograd; the repulsive edges' endpoint
-gathers go through the graph index, so that their backward is a pair of deterministic segment sums.
+(gather, norm, power, hinge, sum, normalisation) are one fused kernel each
+(``ops_ml.hinge_terms`` -> ``gnntrk_hinge_forward``), with the reference's edge selection - hits of
+interest at the first endpoint, different particles at the two ends - applied inside the kernel
+instead of compacting the edge lists; their backward is ONE node-centric pass over the graph index
+of the edge list (``gnntrk_hinge_backward``: no per-edge intermediate, no atomics).
 """
 
 from __future__ import annotations
@@ -81,21 +84,15 @@ class GraphConstructionHingeEmbeddingLoss(nn.Module, HyperparametersMixin):
         mask = get_good_node_mask_tensors(pt=pt, particle_id=particle_id, reconstructable=reconstructable,
                                           eta=eta, pt_thld=hp.pt_thld, max_eta=hp.max_eta)
         n_hits_oi = mask.sum()
+        if x.dtype == torch.float32:   # (other dtypes - the reference's float64 known-answer tests - below)
+            return self._forward_kernels(x=x, particle_id=particle_id, batch=batch, true_edge_index=true_edge_index,
+                                         mask=mask, n_hits_oi=n_hits_oi)
         att_edges, rep_edges = self._get_edges(x=x, batch=batch, true_edge_index=true_edge_index,
                                                mask=mask, particle_id=particle_id)
         eps = 1e-9
         dists_att = torch.linalg.norm(x[att_edges[0]] - x[att_edges[1]], dim=-1)
         v_att = torch.sum(torch.pow(dists_att, hp.p_attr)) / (att_edges.shape[1] + eps)
-        if rep_edges.shape[1] > 0 and x.is_cuda and x.dtype == torch.float32:
-            # the two endpoint gathers through the graph index of the repulsive edges: their backward
-            # is then a pair of deterministic segment sums instead of two sorted index_put passes
-            # (3.7 -> 0.4 ms at 2.6 M edges); the sum below does not depend on the edge order
-            gi = ops.graph_index(rep_edges, int(x.shape[0]), validate=False)
-            x_src = ops._GatherRows.apply(x, gi.src, ("src", gi))
-            x_tgt = ops._GatherRows.apply(x, gi.tgt, ("tgt", gi))
-            dists_rep = torch.linalg.norm(x_src - x_tgt, dim=-1)
-        else:
-            dists_rep = torch.linalg.norm(x[rep_edges[0]] - x[rep_edges[1]], dim=-1)
+        dists_rep = torch.linalg.norm(x[rep_edges[0]] - x[rep_edges[1]], dim=-1)
         if hp.rep_normalization == "n_rep_edges":
             norm_rep = rep_edges.shape[1] + eps
         elif hp.rep_normalization == "n_hits_oi":
@@ -110,3 +107,21 @@ class GraphConstructionHingeEmbeddingLoss(nn.Module, HyperparametersMixin):
             weight_dct={"attractive": 1.0, "repulsive": hp.lw_repulsive},
             extra_metrics={"n_hits_oi": n_hits_oi, "n_edges_att": att_edges.shape[1],
                            "n_edges_rep": rep_edges.shape[1]})
+
+    def _forward_kernels(self, *, x: T, particle_id: T, batch: T, true_edge_index: T, mask: T, n_hits_oi: T):
+        """fp32 embedding on the device: the kernels of csrc/hinge.hip.  The edge counts stay on the device
+        (one-element tensors in ``extra_metrics``): nothing in the loss waits for the host."""
+        from . import ops_ml
+        hp = self.hparams
+        if hp.rep_normalization not in ("n_rep_edges", "n_hits_oi", "n_att_edges"):
+            raise ValueError(f"Normalization {hp.rep_normalization} not recognized.")
+        near_edges = radius_graph(x, r=hp.r_emb, batch=batch, max_num_neighbors=hp.max_num_neighbors)
+        v_att, n_att, _ = ops_ml.hinge_terms(x, true_edge_index, node_mask=mask, p=hp.p_attr, repulsive=False)
+        norm = {"n_rep_edges": None, "n_hits_oi": n_hits_oi, "n_att_edges": n_att}[hp.rep_normalization]
+        v_rep, n_rep, _ = ops_ml.hinge_terms(x, near_edges, node_mask=mask if hp.rep_oi_only else None,
+                                             particle_id=particle_id, norm=norm, r_emb=hp.r_emb, p=hp.p_rep,
+                                             repulsive=True)
+        return MultiLossFctReturn(
+            loss_dct={"attractive": v_att, "repulsive": v_rep},
+            weight_dct={"attractive": 1.0, "repulsive": hp.lw_repulsive},
+            extra_metrics={"n_hits_oi": n_hits_oi, "n_edges_att": n_att, "n_edges_rep": n_rep})

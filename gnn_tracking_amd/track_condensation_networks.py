@@ -23,7 +23,7 @@ import os
 import torch
 from torch import Tensor, nn
 
-from . import _capi, edge_order, graph_cut, ops, precision
+from . import _capi, edge_order, graph_cut, ops, ops_ml, precision
 from .edge_classifier import ECForGraphTCN, PerfectEdgeClassification
 from .hparams import HyperparametersMixin, assert_feat_dim, obj_from_or_to_hparams
 from .mlp import MLP
@@ -37,11 +37,13 @@ class ResFCNN(nn.Module):
         L2-normalised input -> encoder -> ``depth-1`` residual hidden layers
         ``x = sqrt(a) x + sqrt(1-a) W relu(x)`` -> decoder on ``relu(x)``.
 
-        ``depth == 1`` with a hidden width the fused kernels cover (the node encoder of
-        ``ModularGraphTCN``) is ONE fused gather-MLP launch.  Deeper / wider stacks (the
-        metric-learning embedding network: hidden 256-512, depth 6) are plain GEMM-shaped
-        work on [N, hidden] x [hidden, hidden] and go to the library GEMM (hipBLASLt through
-        ``torch.nn.functional.linear``), with the residual mix as torch device ops.
+        Up to ``in_dim`` 64, ``hidden_dim`` 128, ``out_dim`` 32 and any depth the whole network - input
+        normalisation, encoder, residual layers, decoder, output scale - is ONE forward and ONE backward
+        launch (``ops_ml.res_fcnn``: csrc/resfcnn.hip, fp32 MFMA, activations in registers, one layer's
+        weights at a time in LDS).  In bf16 storage ``depth == 1`` (the node encoder of ``ModularGraphTCN``)
+        stays on the fused bf16 gather-MLP kernels so that its rows stay bf16.  Wider stacks (hidden
+        256-512) are GEMM-shaped work on [N, hidden] x [hidden, hidden] and go to the library GEMM
+        (hipBLASLt through ``torch.nn.functional.linear``), with the residual mix as torch device ops.
         """
         super().__init__()
         if depth < 1:
@@ -66,24 +68,36 @@ class ResFCNN(nn.Module):
         for p in layer.parameters():
             nn.init.normal_(p.data, mean=0, std=math.sqrt(var))
 
-    def forward(self, x: Tensor, *, epilogue: int = _capi.EPI_NONE, **ignore) -> Tensor:
+    def forward(self, x: Tensor, *, epilogue: int = _capi.EPI_NONE, scale: Tensor | None = None, **ignore) -> Tensor:
+        """``scale``: one-element parameter multiplied onto the output (the embedding networks'
+        ``_latent_normalization``) - inside the kernel where the residual-FCNN kernel runs."""
         _capi.require_device(x)
-        x = nn.functional.normalize(x.float(), p=2.0, dim=1, eps=1e-12)
         bf16 = precision.use_bf16()
+        lin = [self._encoder, *self._layers, self._decoder]
+        ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+        in_dim, hidden, out_dim = self._dims
+        if not (bf16 and self._fusable_depth) and epilogue in (_capi.EPI_NONE, _capi.EPI_RELU) \
+                and ops_ml.res_fcnn_supported(in_dim, hidden, out_dim, len(lin) - 1):
+            # ONE launch for the whole network, any depth (gnntrk_resfcnn_forward: L2 normalisation, encoder,
+            # residual layers, decoder, output scale / ReLU; fp32, activations in registers)
+            return ops_ml.res_fcnn(x.float(), ws, bs, alpha=self._alpha, normalize=True,
+                                   out_relu=epilogue == _capi.EPI_RELU, scale=scale)
+        x = nn.functional.normalize(x.float(), p=2.0, dim=1, eps=1e-12)
         if self._fusable_depth:
-            # one MLP: the fused kernels where the storage mode's instantiations hold the widths, the same
-            # operator as library GEMMs otherwise (ops.fused_mlp decides) - in bf16 storage the rows stay bf16
-            # either way, so that what follows keeps running in that mode
-            lin = [self._encoder, *self._layers, self._decoder]
-            ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+            # bf16 storage: one fused MLP launch where the instantiations hold the widths, the same operator as
+            # library GEMMs otherwise (ops.fused_mlp decides) - the rows stay bf16 either way, so that what
+            # follows keeps running in that mode
             xs = x.to(torch.bfloat16) if bf16 else x
             if bf16 or ops._fused_supported([ops.Seg(xs)], ws, bs, False, epilogue):
-                return ops.fused_mlp([ops.Seg(xs)], ws, bs, epilogue=epilogue)
+                y = ops.fused_mlp([ops.Seg(xs)], ws, bs, epilogue=epilogue)
+                return y if scale is None else y.float() * scale
+        # wider than the kernels' limits (hidden > 128, in > 64, out > 32): library GEMMs
         x = self._encoder(x)
         for layer in self._layers:
             x = math.sqrt(self._alpha) * x + math.sqrt(1 - self._alpha) * layer(torch.relu(x))
         x = self._decoder(torch.relu(x))
-        return torch.relu(x) if epilogue == _capi.EPI_RELU else x
+        x = torch.relu(x) if epilogue == _capi.EPI_RELU else x
+        return x if scale is None else x * scale
 
 
 class GraphConstructionFCNN(ResFCNN, HyperparametersMixin):
@@ -97,8 +111,7 @@ class GraphConstructionFCNN(ResFCNN, HyperparametersMixin):
         self.save_hyperparameters()
 
     def forward(self, data) -> dict[str, Tensor]:
-        out = ResFCNN.forward(self, data.x).float() * self._latent_normalization
-        return {"H": out}
+        return {"H": ResFCNN.forward(self, data.x, scale=self._latent_normalization).float()}
 
 
 def get_pixel_mask(layer: Tensor) -> Tensor:
@@ -117,12 +130,12 @@ class HeterogeneousResFCNN(nn.Module):
         self.pixel_fcnn = ResFCNN(**kw)
         self.strip_fcnn = ResFCNN(**kw)
 
-    def forward(self, x: Tensor, layer: Tensor, *, epilogue: int = _capi.EPI_NONE) -> Tensor:
+    def forward(self, x: Tensor, layer: Tensor, *, epilogue: int = _capi.EPI_NONE, scale: Tensor | None = None) -> Tensor:
         pixel_mask = get_pixel_mask(layer)
         if "PYTEST_CURRENT_TEST" not in os.environ and (pixel_mask.all() or not pixel_mask.any()):
             raise ValueError("All or no pixel data found; this doesn't make sense with heterogeneous model")
-        embed_pixel = self.pixel_fcnn(x[pixel_mask], epilogue=epilogue)
-        embed_strip = self.strip_fcnn(x[~pixel_mask], epilogue=epilogue)
+        embed_pixel = self.pixel_fcnn(x[pixel_mask], epilogue=epilogue, scale=scale)
+        embed_strip = self.strip_fcnn(x[~pixel_mask], epilogue=epilogue, scale=scale)
         return torch.vstack([embed_pixel, embed_strip])
 
 
@@ -135,7 +148,7 @@ class GraphConstructionHeteroResFCNN(HeterogeneousResFCNN, HyperparametersMixin)
         self.save_hyperparameters()
 
     def forward(self, data) -> dict[str, Tensor]:
-        out = HeterogeneousResFCNN.forward(self, data.x, layer=data.layer).float() * self._latent_normalization
+        out = HeterogeneousResFCNN.forward(self, data.x, layer=data.layer, scale=self._latent_normalization).float()
         return {"H": out}
 
 
@@ -156,9 +169,9 @@ class GraphConstructionHeteroEncResFCNN(nn.Module, HyperparametersMixin):
         assert_feat_dim(data.x, self.hparams.in_dim)
         enc = self.encoder(data.x, layer=data.layer, epilogue=_capi.EPI_RELU)
         assert_feat_dim(enc, self.hparams.hidden_dim)
-        out = self.fcnn(enc).float()
+        out = self.fcnn(enc, scale=self._latent_normalization).float()
         assert_feat_dim(out, self.hparams.out_dim)
-        return {"H": out * self._latent_normalization}
+        return {"H": out}
 
 
 class GraphConstructionResIN(nn.Module, HyperparametersMixin):

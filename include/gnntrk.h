@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNNTRK_VERSION 300 /* 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
+#define GNNTRK_VERSION 400 /* 0.4.0: + resfcnn_*, hinge_* (metric-learning stage); 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
 #define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
 #define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
 #define GNNTRK_MAX_HIDDEN 64
@@ -577,6 +577,106 @@ int gnntrk_oc_forward_spatial(const gnntrk_oc_args *args, float *out /*[9]*/, vo
 int gnntrk_oc_backward_spatial(const gnntrk_oc_args *args, const float *g /*[4]*/, const float *fwd /*[9]*/,
                                float *gx, float *gbeta, int64_t max_cps, void *spatial, size_t spatial_bytes,
                                void *stream);
+
+/* ------------------------------------------------------------------ residual FCNN
+ * ResFCNN (models/mlp.py:65-120) and the embedding networks built on it
+ * (models/graph_construction.py:25-132) as ONE forward and ONE backward launch:
+ *
+ *   x  <- x / max(||x||_2, 1e-12)                      (normalize != 0; mlp.py:116)
+ *   h  <- W_enc x + b_enc                              (mlp.py:117)
+ *   h  <- sqrt(alpha) h + sqrt(1 - alpha) (W_l relu(h) + b_l),  l = 1 .. n_hidden   (mlp.py:118-119)
+ *   y  <- W_dec relu(h) + b_dec                        (mlp.py:120)
+ *   y  <- y * out_scale[0]   (out_scale != NULL: GraphConstructionFCNN._latent_normalization,
+ *                             graph_construction.py:52)
+ *   y  <- relu(y)            (out_relu != 0: the caller's relu(encoder(x)), graph_construction.py:123)
+ *
+ * fp32 throughout (v_mfma_f32_16x16x4_f32, bit-exact fmaf chains).  A wave keeps the activations
+ * of its rows in registers through all layers; the weights of one layer at a time are staged in LDS
+ * as MFMA A-operand fragments (packed once per call into the workspace).  Limits: in_dim <= 64,
+ * hidden <= 128, out_dim <= 32, n_hidden <= GNNTRK_RESFCNN_MAX_HIDDEN.
+ *
+ * Backward: the forward optionally leaves the pre-activation residual stream of every layer in
+ * `acts` ([n_hidden + 1][n_rows][gnntrk_resfcnn_hidden_pad(hidden)] floats); the backward walks the
+ * layers from the decoder down, every wave over its own rows, with the weight gradients of ONE
+ * layer at a time in registers (hidden 128: 256 accumulator registers), the gradient of the residual
+ * stream in a workspace buffer between layers, per-block partial sums reduced in a fixed order
+ * (deterministic, no atomics).  Weight / bias pointers of gnntrk_resfcnn_grads may be NULL (no
+ * gradient wanted); accumulate != 0 adds into them.
+ */
+#define GNNTRK_RESFCNN_MAX_HIDDEN 16 /* hidden (residual) layers = depth - 1 */
+#define GNNTRK_RESFCNN_MAX_IN 64
+#define GNNTRK_RESFCNN_MAX_WIDTH 128
+#define GNNTRK_RESFCNN_MAX_OUT 32
+
+typedef struct gnntrk_resfcnn {
+    const float *W_enc, *b_enc;                        /* [hidden, in_dim], [hidden] or NULL     */
+    const float *W_hid[GNNTRK_RESFCNN_MAX_HIDDEN];     /* [hidden, hidden]                       */
+    const float *b_hid[GNNTRK_RESFCNN_MAX_HIDDEN];     /* [hidden] or NULL                       */
+    const float *W_dec, *b_dec;                        /* [out_dim, hidden], [out_dim] or NULL   */
+    const float *out_scale;                            /* device scalar or NULL                  */
+    int32_t in_dim, hidden, out_dim, n_hidden;
+    float alpha;
+    int32_t normalize, out_relu, _pad;
+} gnntrk_resfcnn;
+
+typedef struct gnntrk_resfcnn_grads {
+    float *W_enc, *b_enc;
+    float *W_hid[GNNTRK_RESFCNN_MAX_HIDDEN];
+    float *b_hid[GNNTRK_RESFCNN_MAX_HIDDEN];
+    float *W_dec, *b_dec;
+    float *out_scale;
+} gnntrk_resfcnn_grads;
+
+int32_t gnntrk_resfcnn_hidden_pad(int32_t hidden); /* floats per row of `acts` (multiple of 16) */
+size_t gnntrk_resfcnn_forward_workspace_bytes(const gnntrk_resfcnn *m);
+int gnntrk_resfcnn_forward(const gnntrk_resfcnn *m, const float *x, int32_t x_stride, int64_t n_rows, float *out,
+                           int32_t out_stride, float *acts /* or NULL */, void *workspace, size_t workspace_bytes,
+                           void *stream);
+size_t gnntrk_resfcnn_backward_workspace_bytes(const gnntrk_resfcnn *m, int64_t n_rows);
+/* `out` is the forward's output (read for out_relu only), `gx` ([n_rows, gx_stride], NULL: not wanted)
+ * the gradient w.r.t. the un-normalised input rows */
+int gnntrk_resfcnn_backward(const gnntrk_resfcnn *m, const float *x, int32_t x_stride, int64_t n_rows,
+                            const float *acts, const float *out, int32_t out_stride, const float *gout,
+                            int32_t gout_stride, float *gx, int32_t gx_stride, const gnntrk_resfcnn_grads *grads,
+                            int32_t accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ hinge embedding loss
+ * The two edge-list reductions of GraphConstructionHingeEmbeddingLoss
+ * (metrics/losses/metric_learning.py:14-55, `_hinge_loss_components`; edge selection :88-110):
+ * per edge (a, b) = (edges[0][e], edges[1][e]) with d = ||x[a] - x[b]||_2
+ *     attractive (repulsive = 0):  d^p                    (:30-32)
+ *     repulsive  (repulsive = 1):  relu(r_emb - d^p)      (:50-53)
+ * summed over the edges that pass the reference's selection, applied INSIDE the kernels instead of
+ * compacting the edge list first (boolean indexing = a host round trip per mask):
+ *     node_mask   != NULL: only edges with node_mask[a] != 0      (`mask[edges[0]]`, :104-106, :109)
+ *     particle_id != NULL: only edges with pid[a] != pid[b]       (:107)
+ * out[0] = sum / denom, out[1] = number of selected edges, out[2] = denom, with
+ * denom = (norm ? norm[0] : out[1]) + 1e-9 (the reference's three normalisations: its own edge count, the
+ * hits of interest, the attractive edge count - the latter two handed in as device scalars).
+ * Deterministic two-stage sums (fp64 partials).
+ *
+ * Backward: node-centric, no per-edge intermediate and no atomics.  With the graph index of the SAME
+ * edge list (gnntrk_graph_index_build: CSR by edges[1], source-sorted view of edges[0]) one thread owns a
+ * node and walks both of its segments, recomputing every incident edge's term:
+ *     gx[n] (+)= g[0] / denom * ( sum_{e: a = n} c_e (x[a] - x[b])  -  sum_{e: b = n} c_e (x[a] - x[b]) ),
+ *     c_e = s p d^(p-2)  (s = 1 attractive; s = -1 where r_emb - d^p > 0, else 0; c_e = 0 at d = 0, as
+ *     torch's norm backward)
+ */
+typedef struct gnntrk_hinge_args {
+    const float *x;             /* [n_nodes, x_stride] embedding, dim <= 32                        */
+    int32_t dim, x_stride;
+    int64_t n_nodes;
+    const uint8_t *node_mask;   /* [n_nodes] or NULL                                               */
+    const int64_t *particle_id; /* [n_nodes] or NULL                                               */
+    float r_emb, p;
+    int32_t repulsive, _pad;
+} gnntrk_hinge_args;
+size_t gnntrk_hinge_workspace_bytes(int64_t n_edges);
+int gnntrk_hinge_forward(const gnntrk_hinge_args *args, const int64_t *edges /* [2, n_edges], rows edge_stride apart */,
+                         int64_t n_edges, int64_t edge_stride, const float *norm /* device scalar or NULL */,
+                         float *out /* [3] */, void *workspace, size_t workspace_bytes, void *stream);
+int gnntrk_hinge_backward(const gnntrk_hinge_args *args, const gnntrk_graph_index *index, const float *g,
+                          const float *denom, float *gx, int32_t gx_stride, int32_t accumulate, void *stream);
 
 #ifdef __cplusplus
 }

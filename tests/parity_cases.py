@@ -1317,6 +1317,122 @@ def case_gc_fcnn(device, names=("d1_h40", "d4_h96")):
             assert_close(v.grad, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
 
 
+def case_res_fcnn(device, shapes=None, rows=(1, 16, 45, 130)):
+    """``ops_ml.res_fcnn`` (gnntrk_resfcnn_forward / _backward: the whole residual FCNN of models/mlp.py:65-120
+    in one launch each) against the reference's formula in float64, over depths 1 .. 6, hidden widths on both
+    sides of every tile count (10 .. 128), with and without biases, the output scale, the ReLU epilogue, row
+    counts off the tile size, and the gradient w.r.t. the (normalised) input."""
+    from gnn_tracking_amd import ops_ml
+    gen = torch.Generator().manual_seed(7)
+    shapes = shapes or [(14, 10, 8, 2, 0.6, False), (14, 40, 8, 1, 0.6, True), (7, 64, 12, 3, 0.3, True),
+                        (30, 33, 5, 2, 0.0, False), (14, 96, 8, 4, 0.6, False), (64, 128, 32, 6, 0.5, True),
+                        (3, 17, 1, 2, 1.0, True), (20, 80, 24, 3, 0.7, False)]
+    worst = 0.0
+    for (din, hid, dout, depth, alpha, bias) in shapes:
+        for n in rows:
+            for out_relu, use_scale in ((False, True), (True, False)):
+                ws = [torch.randn(hid, din, generator=gen) / din ** 0.5] + \
+                     [torch.randn(hid, hid, generator=gen) * (2 / hid) ** 0.5 for _ in range(depth - 1)] + \
+                     [torch.randn(dout, hid, generator=gen) * (2 / hid) ** 0.5]
+                bs = [torch.randn(w.shape[0], generator=gen) * 0.3 if bias else None for w in ws]
+                x = torch.randn(n, din, generator=gen) * 2
+                if n > 2:
+                    x[1] = 0   # a zero row: the eps branch of the normalisation
+                scale = torch.tensor([1.7]) if use_scale else None
+                r = torch.randn(n, dout, generator=gen)
+
+                def ref():
+                    xs = x.double().requires_grad_(True)
+                    W = [w.double().requires_grad_(True) for w in ws]
+                    B = [None if b is None else b.double().requires_grad_(True) for b in bs]
+                    sc = None if scale is None else scale.double().requires_grad_(True)
+                    lin = lambda h, i: h @ W[i].t() + (0 if B[i] is None else B[i])  # noqa: E731
+                    h = lin(torch.nn.functional.normalize(xs, p=2.0, dim=1, eps=1e-12), 0)
+                    for i in range(1, depth):
+                        h = math.sqrt(alpha) * h + math.sqrt(1 - alpha) * lin(torch.relu(h), i)
+                    y = lin(torch.relu(h), depth)
+                    if sc is not None:
+                        y = y * sc
+                    if out_relu:
+                        y = torch.relu(y)
+                    (y * r.double()).sum().backward()
+                    return y, xs.grad, [w.grad for w in W], [None if b is None else b.grad for b in B], None if sc is None else sc.grad
+
+                xd = x.clone().to(device).requires_grad_(True)
+                Wd = [w.clone().to(device).requires_grad_(True) for w in ws]
+                Bd = [None if b is None else b.clone().to(device).requires_grad_(True) for b in bs]
+                sd = None if scale is None else scale.clone().to(device).requires_grad_(True)
+                y = ops_ml.res_fcnn(xd, Wd, Bd, alpha=alpha, normalize=True, out_relu=out_relu, scale=sd)
+                (y * r.to(device)).sum().backward()
+                yr, gxr, gWr, gBr, gsr = ref()
+                tag = f"res_fcnn in {din} hidden {hid} out {dout} depth {depth} alpha {alpha} bias {bias} rows {n} relu {out_relu}"
+                assert_close(y, yr, TOL_OUT, tag + " y")
+                assert_close(xd.grad, gxr, TOL_GRAD, tag + " grad x")
+                for i, (a, b) in enumerate(zip(Wd, gWr)):
+                    assert_close(a.grad, b, TOL_GRAD, tag + f" grad W{i}")
+                    worst = max(worst, float((a.grad.cpu().double() - b).abs().max() / max(1.0, float(b.abs().max()))))
+                for i, (a, b) in enumerate(zip(Bd, gBr)):
+                    if a is not None:
+                        assert_close(a.grad, b, TOL_GRAD, tag + f" grad b{i}")
+                if sd is not None:
+                    assert_close(sd.grad, gsr, TOL_GRAD, tag + " grad scale")
+    # two runs are bit-identical (fixed-order partial sums)
+    y2 = ops_ml.res_fcnn(xd.detach().requires_grad_(True), Wd, Bd, alpha=alpha, normalize=True, out_relu=out_relu, scale=sd)
+    assert torch.equal(y2, y)
+    return worst
+
+
+def case_hinge_terms(device, n=400, dim=8, n_edges=3000):
+    """``ops_ml.hinge_terms`` (gnntrk_hinge_forward / _backward) against the reference's expressions
+    (metric_learning.py:14-55 with the edge selection of :88-110) in torch: every selection mode, powers 1 / 2 /
+    0.5 / 3, the three normalisations, an empty selection, duplicate and self edges."""
+    from gnn_tracking_amd import ops_ml
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.randn(n, dim, generator=gen) * 0.4)
+    pid = torch.randint(0, 40, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) > 0.3
+    edges = torch.randint(0, n, (2, n_edges), generator=gen)
+    edges[:, :5] = edges[:, 5:10]          # duplicates
+    edges[1, 10:14] = edges[0, 10:14]      # self edges: d = 0
+    norm_t = torch.tensor(123.0)
+    for rep in (False, True):
+        for p in (1.0, 2.0, 0.5, 3.0):
+            for use_mask, use_pid, norm in ((True, False, None), (False, True, norm_t), (True, True, None), (False, False, None)):
+                xr = x.double().requires_grad_(True)
+                keep = torch.ones(n_edges, dtype=torch.bool)
+                if use_mask:
+                    keep &= mask[edges[0]]
+                if use_pid:
+                    keep &= pid[edges[0]] != pid[edges[1]]
+                e = edges[:, keep]
+                d = torch.linalg.norm(xr[e[0]] - xr[e[1]], dim=-1)
+                terms = torch.relu(0.9 - torch.pow(d, p)) if rep else torch.pow(d, p)
+                den = (float(norm) if norm is not None else e.shape[1]) + 1e-9
+                lr = terms.sum() / den
+                lr.backward()
+                xd = x.clone().to(device).requires_grad_(True)
+                l, cnt, dn = ops_ml.hinge_terms(xd, edges.to(device), node_mask=mask.to(device) if use_mask else None,
+                                                particle_id=pid.to(device) if use_pid else None,
+                                                norm=None if norm is None else norm.to(device), r_emb=0.9, p=p, repulsive=rep)
+                tag = f"hinge rep {rep} p {p} mask {use_mask} pid {use_pid}"
+                assert int(cnt) == e.shape[1], tag
+                assert_close(l, lr, TOL_OUT, tag + " loss")
+                (l * 1.5).backward()
+                g_ref = xr.grad * 1.5
+                if p < 1.0:   # (d^(p-1) is unbounded near d = 0: compare where the reference itself is finite)
+                    ok = torch.isfinite(g_ref).all(dim=1)
+                    assert_close(xd.grad.cpu()[ok], g_ref[ok], TOL_GRAD, tag + " grad")
+                else:
+                    assert_close(xd.grad, g_ref, TOL_GRAD, tag + " grad")
+    # nothing selected: 0 / 1e-9 = 0, zero gradient
+    xd = x.clone().to(device).requires_grad_(True)
+    l, cnt, _ = ops_ml.hinge_terms(xd, edges.to(device), node_mask=torch.zeros(n, dtype=torch.bool, device=device))
+    l.backward()
+    assert float(l) == 0.0 and int(cnt) == 0 and float(xd.grad.abs().max()) == 0.0
+    l, cnt, _ = ops_ml.hinge_terms(xd, edges[:, :0].to(device))
+    assert float(l) == 0.0 and int(cnt) == 0
+
+
 HETERO_CASES = {
     "hetero_d2": ("GraphConstructionHeteroResFCNN", dict(hidden_dim=40, depth=2, out_dim=8, alpha=0.0)),
     "hetero_d3": ("GraphConstructionHeteroResFCNN", dict(hidden_dim=48, depth=3, out_dim=6, alpha=0.6)),

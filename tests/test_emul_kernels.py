@@ -100,6 +100,12 @@ def test_gc_fcnn_emulated():
         P.case_pc_transformer("cpu")
 
 
+def test_res_fcnn_and_hinge_kernels_emulated():
+    with emulated():
+        print("res_fcnn worst weight-gradient error:", P.case_res_fcnn("cpu", rows=(1, 45)))
+        P.case_hinge_terms("cpu")
+
+
 def test_hetero_fcnn_emulated():
     with emulated():
         P.case_hetero_fcnn("cpu")

@@ -163,6 +163,12 @@ def test_graph_construction_fcnn(dev):
     P.case_gc_fcnn(dev)
 
 
+def test_res_fcnn_and_hinge_kernels(dev):
+    print("res_fcnn worst weight-gradient error:", P.case_res_fcnn(dev))
+    P.case_hinge_terms(dev)
+    P.case_hinge_terms(dev, n=20_000, dim=12, n_edges=300_000)
+
+
 def test_hetero_fcnn(dev):
     P.case_hetero_fcnn(dev)
 

@@ -5,7 +5,7 @@
 // Forward: thread = edge; selection (node mask of the first endpoint, different particle ids) applied in
 // place; per-block fp64 partial sums of (term, count) in a fixed tree, one finishing block adds the
 // partials in block order and forms sum / denom: deterministic.
-// Backward: thread = node, over the graph index of the same edge list (CSR by edges[1], source-sorted view
+// Backward: eight lanes = node, over the graph index of the same edge list (CSR by edges[1], source-sorted view
 // of edges[0]): every incident edge's term is recomputed from x and added in list order - no per-edge
 // intermediate, no atomics, bit-reproducible.
 #include "host_util.h"
@@ -123,20 +123,27 @@ __global__ __launch_bounds__(kHingeTpb) void hinge_finish_kernel(const double *p
     }
 }
 
+// kHingeLpn lanes share a node: lane j takes the edges j, j + kHingeLpn, ... of both of the node's lists (the
+// radius graph's degrees range from 0 to max_num_neighbors = 256: one thread per node left most of a wave
+// waiting for its longest list), the lanes' sums are added in a fixed shuffle tree.
+constexpr int kHingeLpn = 8;
+
 template <int DP>   // padded dim (registers)
 __global__ __launch_bounds__(kHingeTpb) void hinge_bwd_kernel(const gnntrk_hinge_args h, const gnntrk_graph_index gi, const float *g,
                                                            const float *denom, float *gx, int gx_stride, int accumulate) {
-    const int64_t n = (int64_t)blockIdx.x * kHingeTpb + threadIdx.x;
-    if (n >= h.n_nodes) return;
+    const int64_t n = ((int64_t)blockIdx.x * kHingeTpb + threadIdx.x) / kHingeLpn;
+    const int j = threadIdx.x % kHingeLpn;
+    const bool live = n < h.n_nodes;
+    const int64_t nn = live ? n : 0;   // (idle lanes of the last block walk node 0's lists and discard the result)
     const float scale = g[0] / denom[0];
     float acc[DP];
 #pragma unroll
     for (int f = 0; f < DP; ++f) acc[f] = 0.f;
-    const float *xn = h.x + n * h.x_stride;
+    const float *xn = h.x + nn * h.x_stride;
     // edges whose second endpoint (edges[1], the CSR target) is n: gradient -coef * (x[a] - x[n])
-    for (int k = gi.rowptr_t[n]; k < gi.rowptr_t[n + 1]; ++k) {
+    for (int k = gi.rowptr_t[nn] + j; k < gi.rowptr_t[nn + 1]; k += kHingeLpn) {
         const int64_t a = gi.src[k];
-        const HingeTerm t = hinge_term(h, a, n);
+        const HingeTerm t = hinge_term(h, a, nn);
         if (t.on && t.coef != 0.f) {
             const float *xa = h.x + a * h.x_stride;
 #pragma unroll
@@ -145,9 +152,9 @@ __global__ __launch_bounds__(kHingeTpb) void hinge_bwd_kernel(const gnntrk_hinge
         }
     }
     // edges whose first endpoint is n (source-sorted view): gradient +coef * (x[n] - x[b])
-    for (int m = gi.rowptr_s[n]; m < gi.rowptr_s[n + 1]; ++m) {
+    for (int m = gi.rowptr_s[nn] + j; m < gi.rowptr_s[nn + 1]; m += kHingeLpn) {
         const int64_t b = gi.tgt[gi.spos[m]];
-        const HingeTerm t = hinge_term(h, n, b);
+        const HingeTerm t = hinge_term(h, nn, b);
         if (t.on && t.coef != 0.f) {
             const float *xb = h.x + b * h.x_stride;
 #pragma unroll
@@ -155,10 +162,18 @@ __global__ __launch_bounds__(kHingeTpb) void hinge_bwd_kernel(const gnntrk_hinge
                 if (f < h.dim) acc[f] += t.coef * (xn[f] - xb[f]);
         }
     }
-    float *o = gx + n * gx_stride;
 #pragma unroll
-    for (int f = 0; f < DP; ++f)
-        if (f < h.dim) o[f] = (accumulate ? o[f] : 0.f) + scale * acc[f];
+    for (int f = 0; f < DP; ++f) {
+        float v = acc[f];
+        for (int m = 1; m < kHingeLpn; m <<= 1) v += __shfl_xor(v, m);
+        acc[f] = v;
+    }
+    if (live && j == 0) {
+        float *o = gx + n * gx_stride;
+#pragma unroll
+        for (int f = 0; f < DP; ++f)
+            if (f < h.dim) o[f] = (accumulate ? o[f] : 0.f) + scale * acc[f];
+    }
 }
 
 int hinge_check(const gnntrk_hinge_args *a, const char *who) {
@@ -216,7 +231,7 @@ int gnntrk_hinge_backward(const gnntrk_hinge_args *args, const gnntrk_graph_inde
     if (!index || !g || !denom || !gx || gx_stride < args->dim) return fail(GNNTRK_EINVAL, "hinge_backward: bad argument");
     if (index->n_nodes != args->n_nodes) return fail(GNNTRK_EINVAL, "hinge_backward: the index is over another node set");
     if (args->n_nodes == 0) return GNNTRK_OK;
-    const int nb = (int)((args->n_nodes + kHingeTpb - 1) / kHingeTpb);
+    const int nb = (int)((args->n_nodes * kHingeLpn + kHingeTpb - 1) / kHingeTpb);
 #define GNNTRK_HINGE_BWD(DP_)                                                                                  \
     hipLaunchKernelGGL((hinge_bwd_kernel<DP_>), dim3(nb), dim3(kHingeTpb), 0, stream, *args, *index, g, denom, gx, \
                        (int)gx_stride, (int)accumulate)

@@ -42,7 +42,7 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     }
     BufPlan B;
     make_buf_plan(B, P, a, GT);
-    const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, g32, a->debug_flags);
+    const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, g32, a->debug_flags, a->epilogue);
     // (as rocprofv3 prints the instantiation: a template argument that itself ends in '>' is followed by a space)
     const char *ion = io[0] ? io : "IoNone";
     snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s, %d, %s%s>", P.KI, P.HT, GT,
@@ -68,7 +68,7 @@ int mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *a) {
     }
     BufPlan B;
     make_buf_plan(B, P, &b, GT);
-    const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, false, a->debug_flags);
+    const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, false, a->debug_flags, a->epilogue);
     return (io[0] && B.n_gout == 3) ? 3 : 2;
 }
 

@@ -494,7 +494,16 @@ struct BufPlan {
     BufOpArgs ids[kBufIds], sids[kBufIds];   // int32 id streams of the loads (one unit ahead) / of the stores
 };
 
+#ifndef GNNTRK_BWD_REG_FRAGS
+#define GNNTRK_BWD_REG_FRAGS 0   // (1: first- / last-layer weight fragments of the two-tile buffer shapes in registers)
+#endif
+#ifndef GNNTRK_BWD_STATIC_EPI
+#define GNNTRK_BWD_STATIC_EPI 1   // (0: the epilogue of the buffer-addressed shapes stays a run-time value - A/B builds)
+#endif
+constexpr int kEpiOf(int e) { return GNNTRK_BWD_STATIC_EPI ? e : -1; }
+
 struct IoNone {   // the generic per-lane I/O
+    static constexpr int kEpi = -1;
     static constexpr int NL = 0, NI = 0, NSI = 0, NS = 0, NG = 0, kOnesDword = -1;
     static constexpr BufOpShape load[1] = {}, gout[1] = {}, store[1] = {};
 };
@@ -504,6 +513,7 @@ struct IoNone {   // the generic per-lane I/O
 // permutation), g_e
 template <int NG_>   // NG_ = 3: a third upstream term on the tile's rows (the edge-weight head's share, see ops_bf16.grad_tap)
 struct IoRelational {
+    static constexpr int kEpi = kEpiOf(GNNTRK_EPI_NONE);
     static constexpr int NL = 2, NI = 2, NSI = 1, NS = 3, NG = NG_, kOnesDword = 2;
     static constexpr BufOpShape load[2] = {{1, 1, 0, 1, 0b0011, 0b0010, 0, 0}, {0, 0, -1, -1, 0b0100, 0, 0, 0}};
     static constexpr BufOpShape gout[3] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 1, 0, -1, 0b0001, 0, 0, 0},
@@ -514,6 +524,7 @@ struct IoRelational {
 // object model (interaction_network.py:92-103): x (16-byte rows) | aggr (8-byte rows), all rows of
 // the tile; one upstream term; gradient slices g_x, g_aggr
 struct IoObject {
+    static constexpr int kEpi = kEpiOf(GNNTRK_EPI_RESIDUAL);
     static constexpr int NL = 2, NI = 0, NSI = 0, NS = 2, NG = 1, kOnesDword = 2;
     static constexpr BufOpShape load[2] = {{1, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 0, -1, -1, 0b0010, 0, 0, 0}};
     static constexpr BufOpShape gout[1] = {{0, 0, -1, -1, 0b0011, 0, 0, 0}};
@@ -524,6 +535,7 @@ struct IoObject {
 // weight per edge; gradient slices g_h[src] (rows through the source-sort permutation), g_h[tgt],
 // g_e0 .. g_e3
 struct IoHead {
+    static constexpr int kEpi = kEpiOf(GNNTRK_EPI_SIGMOID);
     static constexpr int NL = 5, NI = 2, NSI = 1, NS = 6, NG = 1, kOnesDword = 2;
     static constexpr BufOpShape load[5] = {{1, 1, 0, 1, 0b0011, 0b0010, 0, 0}, {0, 0, -1, -1, 0b0100, 0, 0, 0},
                                            {0, 0, -1, -1, 0b0100, 0, 2, 0}, {0, 0, -1, -1, 0b1000, 0, 0, 0},
@@ -537,6 +549,7 @@ struct IoHead {
 // rows of the tile, weight gradients only
 template <int NG_>
 struct IoEncoder8 {
+    static constexpr int kEpi = kEpiOf(GNNTRK_EPI_RELU);
     static constexpr int NL = 1, NI = 0, NSI = 0, NS = 0, NG = NG_, kOnesDword = -1;
     static constexpr BufOpShape load[1] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}};
     static constexpr BufOpShape gout[2] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 0, -1, -1, 0b0001, 0, 0, 0}};
@@ -782,14 +795,16 @@ constexpr int kBwd16BlocksPerCuMax = 3;   // (sizes the workspace)
 
 
 // the buffer-addressed instantiation of a launch, by name ("" = the generic per-lane I/O)
-inline const char *buf_io_name(const BufPlan &B, int KI, int HT, int GT, bool three, bool g32, int debug_flags) {
+inline const char *buf_io_name(const BufPlan &B, int KI, int HT, int GT, bool three, bool g32, int debug_flags,
+                               int epilogue) {
     if (!B.ok || (debug_flags & (64 | 128)) || KI != 1 || (HT != 1 && HT != 3)) return "";
-    if (g32) return (GT == 2 && three && buf_plan_is<IoHead>(B)) ? "IoHead" : "";
-    if (GT == 2 && three && buf_plan_is<IoRelational<2>>(B)) return "IoRelational<2>";
-    if (GT == 2 && three && buf_plan_is<IoRelational<3>>(B)) return "IoRelational<3>";
-    if (GT == 1 && three && buf_plan_is<IoObject>(B)) return "IoObject";
-    if (GT == 0 && !three && buf_plan_is<IoEncoder8<1>>(B)) return "IoEncoder8<1>";
-    if (GT == 0 && !three && buf_plan_is<IoEncoder8<2>>(B)) return "IoEncoder8<2>";
+    auto epi_ok = [&](int k) { return k < 0 || k == epilogue; };   // (a class with a static epilogue only takes that one)
+    if (g32) return (GT == 2 && three && epi_ok(IoHead::kEpi) && buf_plan_is<IoHead>(B)) ? "IoHead" : "";
+    if (GT == 2 && three && epi_ok(IoRelational<2>::kEpi) && buf_plan_is<IoRelational<2>>(B)) return "IoRelational<2>";
+    if (GT == 2 && three && epi_ok(IoRelational<3>::kEpi) && buf_plan_is<IoRelational<3>>(B)) return "IoRelational<3>";
+    if (GT == 1 && three && epi_ok(IoObject::kEpi) && buf_plan_is<IoObject>(B)) return "IoObject";
+    if (GT == 0 && !three && epi_ok(IoEncoder8<1>::kEpi) && buf_plan_is<IoEncoder8<1>>(B)) return "IoEncoder8<1>";
+    if (GT == 0 && !three && epi_ok(IoEncoder8<2>::kEpi) && buf_plan_is<IoEncoder8<2>>(B)) return "IoEncoder8<2>";
     return "";
 }
 
@@ -841,7 +856,7 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     }
     // the shapes of the default models go through buffer descriptors (debug_flags & 128: generic I/O)
     {
-        const char *io = buf_io_name(B, P.KI, P.HT, GT, three, G32, a->debug_flags);
+        const char *io = buf_io_name(B, P.KI, P.HT, GT, three, G32, a->debug_flags, a->epilogue);
         if (a->debug_flags & 256)   // (diagnostics: which I/O form a launch takes)
             fprintf(stderr, "mlp_backward_bf16: KI %d HT %d GT %d three %d rows %lld plan ok %d (loads %d ids %d+%d gout %d stores %d ones %d) -> %s\n",
                     P.KI, P.HT, GT, (int)three, (long long)a->n_rows, B.ok, B.n_load, B.n_ids, B.n_sids, B.n_gout,

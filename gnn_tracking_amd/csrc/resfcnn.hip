@@ -615,6 +615,8 @@ struct RfReduceArgs {
     float *dst[2 * kRfMaxL];        // destination or NULL
     int32_t scaled[2 * kRfMaxL];    // segment is multiplied by out_scale (decoder W / b)
     const float *out_scale;
+    float *raw;                     // [n_raw] unscaled sums of the first n_raw entries (decoder W, b), or NULL
+    int32_t n_raw, _pad;
 };
 
 __global__ __launch_bounds__(256) void resfcnn_reduce_kernel(const RfReduceArgs a) {
@@ -622,6 +624,7 @@ __global__ __launch_bounds__(256) void resfcnn_reduce_kernel(const RfReduceArgs 
     if (i >= a.part_total) return;
     float s = 0.f;
     for (int b = 0; b < a.n_part; ++b) s += a.part[(int64_t)b * a.part_total + i];
+    if (a.raw != nullptr && i < a.n_raw) a.raw[i] = s;
     int j = 0;
     while (j + 1 < a.n_seg && i >= a.off[j + 1]) ++j;
     if (a.dst[j] == nullptr) return;
@@ -632,15 +635,14 @@ __global__ __launch_bounds__(256) void resfcnn_reduce_kernel(const RfReduceArgs 
 
 // gradient of the output scale: sum over the decoder's parameters of  value * (unscaled gradient)
 //   d/ds sum_rows g . (s (W p + b)) = sum_{o,i} W[o][i] dWraw[o][i] + sum_o b[o] dbraw[o]
-__global__ __launch_bounds__(256) void resfcnn_scale_grad_kernel(const float *part, int n_part, int part_total, const float *W,
-                                                                const float *b, int nW, int nb, float *dst, int accumulate) {
+// (`raw`: the reduced unscaled sums the reduction kernel left behind)
+__global__ __launch_bounds__(256) void resfcnn_scale_grad_kernel(const float *raw, const float *W, const float *b, int nW, int nb,
+                                                                float *dst, int accumulate) {
     __shared__ double s_sum[256];
     double acc = 0.0;
     for (int i = threadIdx.x; i < nW + nb; i += 256) {
-        float s = 0.f;
-        for (int k = 0; k < n_part; ++k) s += part[(int64_t)k * part_total + i];
         const float v = i < nW ? W[i] : (b != nullptr ? b[i - nW] : 0.f);
-        acc += (double)v * (double)s;
+        acc += (double)v * (double)raw[i];
     }
     s_sum[threadIdx.x] = acc;
     __syncthreads();
@@ -813,7 +815,8 @@ size_t gnntrk_resfcnn_backward_workspace_bytes(const gnntrk_resfcnn *m, int64_t 
     const size_t frag = rf_layout(m, true).total * sizeof(float);
     const size_t gs = align_up((size_t)n_rows * 16 * rf_ht(m->hidden) * sizeof(float), 256);
     const size_t part = (size_t)rf_bwd_grid(n_rows) * rf_part_total(m) * sizeof(float);
-    return align_up(frag, 256) + gs + align_up(part, 256);
+    const size_t raw = (size_t)(m->out_dim * m->hidden + m->out_dim) * sizeof(float);
+    return align_up(frag, 256) + gs + align_up(part, 256) + align_up(raw, 256);
 }
 
 int gnntrk_resfcnn_backward(const gnntrk_resfcnn *m, const float *x, int32_t x_stride, int64_t n_rows, const float *acts,
@@ -840,6 +843,8 @@ int gnntrk_resfcnn_backward(const gnntrk_resfcnn *m, const float *x, int32_t x_s
     float *part = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(gstream) +
                                             align_up((size_t)n_rows * 16 * HT * sizeof(float), 256));
     const int PT = rf_part_total(m);
+    float *raw = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(part) +
+                                           align_up((size_t)rf_bwd_grid(n_rows) * PT * sizeof(float), 256));
     int grid = 0;
     if (n_rows > 0) {
         rc = rf_pack(m, frag, L, true, stream);
@@ -894,11 +899,14 @@ int gnntrk_resfcnn_backward(const gnntrk_resfcnn *m, const float *x, int32_t x_s
     seg(m->b_enc ? grads->b_enc : nullptr, m->hidden, 0);
     ra.off[n] = off;
     ra.n_seg = n;
+    const bool want_scale = m->out_scale && grads->out_scale;
+    ra.raw = want_scale ? raw : nullptr;
+    ra.n_raw = m->out_dim * m->hidden + m->out_dim;
     hipLaunchKernelGGL(resfcnn_reduce_kernel, dim3((PT + 255) / 256), dim3(256), 0, stream, ra);
     rc = check_launch("resfcnn_reduce");
     if (rc) return rc;
-    if (m->out_scale && grads->out_scale) {
-        hipLaunchKernelGGL(resfcnn_scale_grad_kernel, dim3(1), dim3(256), 0, stream, part, grid, PT, m->W_dec, m->b_dec,
+    if (want_scale) {
+        hipLaunchKernelGGL(resfcnn_scale_grad_kernel, dim3(1), dim3(256), 0, stream, raw, m->W_dec, m->b_dec,
                            m->out_dim * m->hidden, m->out_dim, grads->out_scale, accumulate);
         rc = check_launch("resfcnn_scale_grad");
     }

@@ -131,6 +131,25 @@ __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// The same ordering WITHOUT the drain.  The DS instructions of one wave are executed by the LDS in the
+// order they were issued, so a read (transposed reads included) issued after a write of the same wave sees
+// the written data - whichever lane wrote it - and a write issued after a read cannot overtake it.  What is
+// left to enforce is that the COMPILER keeps the DS instructions in program order; the fences above do
+// that too, but they also emit s_waitcnt lgkmcnt(0) (an empty LDS queue before the first dependent read is
+// even issued: five drains of 100-200 cycles per pair of tiles in the bf16 backward) and stop every other
+// instruction from being scheduled across.  sched_barrier mask 0x7f: ALU, VALU, SALU, MFMA and VMEM
+// instructions may cross, DS instructions may not.  (The wave64 emulator runs lanes as fibers: there the
+// barrier is real.)
+#ifndef GNNTRK_LDS_INORDER
+#define GNNTRK_LDS_INORDER 1
+#endif
+__device__ __forceinline__ void lds_wave_order() {
+#if defined(GNNTRK_BF16_PRIMITIVES) || !GNNTRK_LDS_INORDER
+    lds_wave_sync();
+#else
+    __builtin_amdgcn_sched_barrier(0x7f);
+#endif
+}
 
 // A-operand fragments of a matrix Mat[rowfeat][kfeat] held in nn.Linear storage
 // W[out][in] (ld = in_dim):  forward layer: Mat = W  (rows = out, k = in);

@@ -15,7 +15,7 @@ def dev():
     from gnn_tracking_amd import _capi
 
     lib = _capi.load()  # fails loudly if the extension is missing
-    assert lib.gnntrk_version() == 300
+    assert lib.gnntrk_version() == 400
     return "cuda"
 
 

@@ -80,6 +80,7 @@ class OcArgs(C.Structure):
 
 
 RESFCNN_MAX_HIDDEN, RESFCNN_MAX_IN, RESFCNN_MAX_WIDTH, RESFCNN_MAX_OUT = 16, 64, 128, 32
+WIDE_MAX_IN, WIDE_MAX_HIDDEN, WIDE_MAX_OUT = 128, 128, 48   # gnntrk_mlp_*_wide (fp32)
 
 
 class ResFcnn(C.Structure):
@@ -182,6 +183,11 @@ _SIGNATURES = {
     "gnntrk_oc_backward_spatial": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
     "gnntrk_oc_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "gnntrk_oc_backward": (C.c_int, [C.POINTER(OcArgs), _P, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
+    "gnntrk_mlp_wide_hidden_pad": (C.c_int32, [C.c_int32]),
+    "gnntrk_mlp_wide_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
+    "gnntrk_mlp_forward_wide": (C.c_int, [C.POINTER(MlpFwdArgs), _P, _P, C.c_size_t, _P]),
+    "gnntrk_mlp_wide_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp), C.c_int64]),
+    "gnntrk_mlp_backward_wide": (C.c_int, [C.POINTER(MlpBwdArgs), _P, _P, C.c_int32, _P, C.c_size_t, _P]),
     "gnntrk_resfcnn_hidden_pad": (C.c_int32, [C.c_int32]),
     "gnntrk_resfcnn_forward_workspace_bytes": (C.c_size_t, [C.POINTER(ResFcnn)]),
     "gnntrk_resfcnn_forward": (C.c_int, [C.POINTER(ResFcnn), _P, C.c_int32, C.c_int64, _P, C.c_int32, _P, _P,

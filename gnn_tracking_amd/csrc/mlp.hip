@@ -148,10 +148,10 @@ __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(const gnntrk_mlp_fwd_ar
         int64_t orow = row;
         if (valid && out_idx) orow = out_idx[row];
 
-        lds_wave_sync();
+        lds_wave_order();
         f32x4 bin[KT];
         read_operand<KT>(sc, boff, nti, bin);
-        lds_wave_sync();  // all lanes hold their operands: the buffer may be restaged
+        lds_wave_order();  // all lanes hold their operands: the buffer may be restaged
         f32x4 a1[HT], a2[HT];
         mlp_layer1<KT, HT>(dm, w1, b1, lane, bin, a1);
         mlp_layer2<HT>(dm, w2, b2, lane, a1, a2);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
             item_row_ids<NI>(it, clamp_row(t2), rid_n);
             gout_rows(clamp_row(t2), gr0_n, gr1_n);
         }
-        lds_wave_sync();  // staged inputs of this tile are visible
+        lds_wave_order();  // staged inputs of this tile are visible
         f32x4 bin[KT], gyv[1];
         read_operand<KT>(sc, boff, nti, bin);
         read_operand<1>(gc, ooff, 1, gyv);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
 #pragma unroll
         for (int t = 0; t < HT; ++t) a1T[t] = a1[t];
         if (want_dw && tr_on) {
-            lds_wave_sync();
+            lds_wave_order();
             tr_read<KT>(sc, nti, g, c, mT);  // the staging buffer IS m^T
             tr_read<HT>(tb1, nth, g, c, a1T);
         }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
             for (int t = 0; t < HT; ++t) a2T[t] = a2[t];
             gyT[0] = gy;
             if (tr_on) {
-                lds_wave_sync();
+                lds_wave_order();
                 tr_read<HT>(tb2, nth, g, c, a2T);
                 tr_read<1>(tb0, 1, g, c, gyT);
                 tr_write<HT>(tb1, off_h, nth, dm.hid_ks(), dl);  // a1T was read a stage ago
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
 #pragma unroll
                 for (int t = 0; t < HT; ++t) dlT[t] = dl[t];
                 if (tr_on) {
-                    lds_wave_sync();
+                    lds_wave_order();
                     tr_read<HT>(tb1, nth, g, c, dlT);
                     tr_write<HT>(tb2, off_h, nth, dm.hid_ks(), d1);  // a2T was read a stage ago
                 }
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
 #pragma unroll
             for (int t = 0; t < HT; ++t) d1T[t] = d1[t];
             if (tr_on) {
-                lds_wave_sync();
+                lds_wave_order();
                 // three layers: d1 went to tb2 in S3; two layers: d1 == dl sits in tb1
                 tr_read<HT>(dm.three() ? tb2 : tb1, nth, g, c, d1T);
             }
@@ -608,9 +608,9 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(const gnntrk_mlp_bwd_
                     }
         }
         // ---- output: input-gradient slices leave through tb0, row-wise per item ------
-        lds_wave_sync();  // tb0 (gy^T) reads are done
+        lds_wave_order();  // tb0 (gy^T) reads are done
         tr_write<KT>(tb0, off_i, nti, dm.in_ks(), gin);
-        lds_wave_sync();
+        lds_wave_order();
         if (!((a.debug_flags & 1) && gin[0][0] != 12345.678f)) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {

@@ -494,6 +494,9 @@ struct BufPlan {
     BufOpArgs ids[kBufIds], sids[kBufIds];   // int32 id streams of the loads (one unit ahead) / of the stores
 };
 
+#ifndef GNNTRK_ABLATE
+#define GNNTRK_ABLATE 0   // (timing-only ablation builds of the backward tile loop, see mlp_bf16_bwd_body.inc)
+#endif
 #ifndef GNNTRK_BWD_REG_FRAGS
 #define GNNTRK_BWD_REG_FRAGS 0   // (1: first- / last-layer weight fragments of the two-tile buffer shapes in registers)
 #endif

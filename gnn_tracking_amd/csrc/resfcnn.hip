@@ -345,7 +345,9 @@ template <int HT>
 __global__ __launch_bounds__(kBlock, HT > 4 ? 1 : 2) void resfcnn_bwd_kernel(const RfArgs a) {
     constexpr int KSH = 4 * HT;
     constexpr int kFragFloats = HT * (KSH > 4 * kRfMaxKTI ? KSH : 4 * kRfMaxKTI) * 64;   // >= hidden^2, hidden * in, out * hidden
-    constexpr int kImg = 16 * HT * kRfLd;
+    // (an image holds hidden, input or output tiles: as many rows as the widest of the three can have)
+    constexpr int kImgTiles = HT > kRfMaxKTI ? HT : kRfMaxKTI;
+    constexpr int kImg = 16 * kImgTiles * kRfLd;
     __shared__ __attribute__((aligned(16))) float s_frag[kFragFloats];
     __shared__ __attribute__((aligned(16))) float s_img[kWaves][2][kImg];
     __shared__ __attribute__((aligned(16))) float s_redb[16 * (HT > kRfMaxOT ? HT : kRfMaxOT)];
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(kBlock, HT > 4 ? 1 : 2) void resfcnn_bwd_kernel(con
             // scale's own gradient from these sums), db_dec
             rf_stage_tiles<kRfMaxOT>(imgG, go, ot, g, c);
             rf_stage_tiles<HT>(imgP, p, HT, g, c);
-            lds_wave_sync();
+            lds_wave_order();
 #pragma unroll
             for (int ti = 0; ti < HT; ++ti) {
                 const f32x4 b4 = rf_read_k(imgP, ti, g, c);
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(kBlock, HT > 4 ? 1 : 2) void resfcnn_bwd_kernel(con
             for (int to = 0; to < kRfMaxOT; ++to)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dbacc[to][r] += go[to][r];
-            lds_wave_sync();
+            lds_wave_order();
         }
         rf_emit_dw<kRfMaxOT, HT>(s_frag, part + poff, dW, ot, HT, a.out_dim, H, wv, tid, g, c);
         poff += a.out_dim * H;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(kBlock, HT > 4 ? 1 : 2) void resfcnn_bwd_kernel(con
             f32x4 gp[HT];
 #pragma unroll
             for (int t = 0; t < HT; ++t) gp[t] = zero;
-            lds_wave_sync();
+            lds_wave_order();
             // W^T gz: the B operand of k-step ks is read back from the staged image (a run-time loop: fully
             // unrolled, the scheduler hoists all 4 HT^2 fragment reads and spills at eight tiles)
 #pragma unroll 4
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(kBlock, HT > 4 ? 1 : 2) void resfcnn_bwd_kernel(con
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (keeps the operand reads of the next column tile from being hoisted)
             }
-            lds_wave_sync();
+            lds_wave_order();
         }
         rf_emit_dw<HT, HT>(s_frag, part + poff, dW, HT, HT, H, H, wv, tid, g, c);
         poff += H * H;
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(kBlock, HT > 4 ? 1 : 2) void resfcnn_bwd_kernel(con
             }
             rf_stage_tiles<HT>(imgG, gy, HT, g, c);
             rf_stage_tiles<kRfMaxKTI>(imgP, xin, kti, g, c);
-            lds_wave_sync();
+            lds_wave_order();
 #pragma unroll
             for (int ti = 0; ti < kRfMaxKTI; ++ti)
                 if (ti < kti) {
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(kBlock, HT > 4 ? 1 : 2) void resfcnn_bwd_kernel(con
             for (int to = 0; to < HT; ++to)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dbacc[to][r] += gy[to][r];
-            lds_wave_sync();
+            lds_wave_order();
         }
         rf_emit_dw<HT, kRfMaxKTI>(s_frag, part + poff, dW, HT, kti, H, a.in_dim, wv, tid, g, c);
         poff += H * a.in_dim;

@@ -137,8 +137,10 @@ __device__ __forceinline__ void lds_wave_sync() {
 // left to enforce is that the COMPILER keeps the DS instructions in program order; the fences above do
 // that too, but they also emit s_waitcnt lgkmcnt(0) (an empty LDS queue before the first dependent read is
 // even issued: five drains of 100-200 cycles per pair of tiles in the bf16 backward) and stop every other
-// instruction from being scheduled across.  sched_barrier mask 0x7f: ALU, VALU, SALU, MFMA and VMEM
-// instructions may cross, DS instructions may not.  (The wave64 emulator runs lanes as fibers: there the
+// instruction from being scheduled across.  A fence at WAVEFRONT scope is exactly that: the memory model
+// orders the wave's own accesses on both sides of it - other lanes' included, the compiler may not move a
+// read above the write whatever it can prove about one lane's addresses - and, a wave's memory operations
+// being in order already, it costs no instruction.  (The wave64 emulator runs lanes as fibers: there the
 // barrier is real.)
 #ifndef GNNTRK_LDS_INORDER
 #define GNNTRK_LDS_INORDER 1
@@ -147,7 +149,7 @@ __device__ __forceinline__ void lds_wave_order() {
 #if defined(GNNTRK_BF16_PRIMITIVES) || !GNNTRK_LDS_INORDER
     lds_wave_sync();
 #else
-    __builtin_amdgcn_sched_barrier(0x7f);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #endif
 }
 

@@ -30,6 +30,11 @@ from .mlp import MLP
 from .resin import ResIN
 
 
+#: the residual-FCNN kernel on / off (off: the fused two- / three-layer MLP kernels where they apply, library
+#: GEMMs otherwise - A/B measurements and bisecting)
+_RESFCNN_KERNEL = os.environ.get("GNNTRK_RESFCNN", "1") != "0"
+
+
 class ResFCNN(nn.Module):
     def __init__(self, *, in_dim: int, hidden_dim: int, out_dim: int, depth: int, alpha: float = 0.6,
                  bias: bool = True):
@@ -76,7 +81,7 @@ class ResFCNN(nn.Module):
         lin = [self._encoder, *self._layers, self._decoder]
         ws, bs = [l.weight for l in lin], [l.bias for l in lin]
         in_dim, hidden, out_dim = self._dims
-        if not (bf16 and self._fusable_depth) and epilogue in (_capi.EPI_NONE, _capi.EPI_RELU) \
+        if _RESFCNN_KERNEL and not (bf16 and self._fusable_depth) and epilogue in (_capi.EPI_NONE, _capi.EPI_RELU) \
                 and ops_ml.res_fcnn_supported(in_dim, hidden, out_dim, len(lin) - 1):
             # ONE launch for the whole network, any depth (gnntrk_resfcnn_forward: L2 normalisation, encoder,
             # residual layers, decoder, output scale / ReLU; fp32, activations in registers)

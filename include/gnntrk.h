@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNNTRK_VERSION 400 /* 0.4.0: + resfcnn_*, hinge_* (metric-learning stage); 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
+#define GNNTRK_VERSION 400 /* 0.4.0: + resfcnn_*, hinge_* (metric-learning stage), mlp_*_wide (fp32 in <= 128 / hidden <= 128 / out <= 48); 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
 #define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
 #define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
 #define GNNTRK_MAX_HIDDEN 64
@@ -577,6 +577,27 @@ int gnntrk_oc_forward_spatial(const gnntrk_oc_args *args, float *out /*[9]*/, vo
 int gnntrk_oc_backward_spatial(const gnntrk_oc_args *args, const float *g /*[4]*/, const float *fwd /*[9]*/,
                                float *gx, float *gbeta, int64_t max_cps, void *spatial, size_t spatial_bytes,
                                void *stream);
+
+/* ------------------------------------------------------------------ wide fp32 fused MLP
+ * The operator of gnntrk_mlp_forward / gnntrk_mlp_backward (same argument structs, same semantics of
+ * segments, epilogues NONE / RELU / RESIDUAL, upstream terms, gradient slices, accumulate_params) for the
+ * shapes beyond the register-resident fp32 kernels: in_dim <= 128, hidden <= 128, out_dim <= 48 - e.g. the
+ * reference-default GraphConstructionResIN(hidden_dim=40), models/graph_construction.py:136-219, whose
+ * relational model is 120 -> 40 -> 40 -> 40, in the reference's own precision.  One forward and one
+ * backward launch (+ a fragment-packing and a reduction launch); one layer's weights at a time in LDS,
+ * activations in registers (csrc/mlp_wide.hip).  The forward leaves the hidden layers' pre-activations in
+ * `acts` ([n_layers - 1][n_rows][gnntrk_mlp_wide_hidden_pad(hidden)] floats, 16-byte aligned; NULL when no
+ * backward follows) - the backward walks the layers last to first with one layer's weight-gradient tiles
+ * in registers at a time.  out_idx and gseg.idx are not supported (plain per-row slices).
+ */
+int32_t gnntrk_mlp_wide_hidden_pad(int32_t hidden);
+size_t gnntrk_mlp_wide_forward_workspace_bytes(const gnntrk_mlp *mlp);
+int gnntrk_mlp_forward_wide(const gnntrk_mlp_fwd_args *args, float *acts, void *workspace, size_t workspace_bytes,
+                            void *stream);
+size_t gnntrk_mlp_wide_backward_workspace_bytes(const gnntrk_mlp *mlp, int64_t n_rows);
+/* `out`: the forward's output (read for EPI_RELU only) */
+int gnntrk_mlp_backward_wide(const gnntrk_mlp_bwd_args *args, const float *acts, const float *out, int32_t out_stride,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ residual FCNN
  * ResFCNN (models/mlp.py:65-120) and the embedding networks built on it

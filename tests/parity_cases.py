@@ -1326,7 +1326,8 @@ def case_res_fcnn(device, shapes=None, rows=(1, 16, 45, 130)):
     gen = torch.Generator().manual_seed(7)
     shapes = shapes or [(14, 10, 8, 2, 0.6, False), (14, 40, 8, 1, 0.6, True), (7, 64, 12, 3, 0.3, True),
                         (30, 33, 5, 2, 0.0, False), (14, 96, 8, 4, 0.6, False), (64, 128, 32, 6, 0.5, True),
-                        (3, 17, 1, 2, 1.0, True), (20, 80, 24, 3, 0.7, False)]
+                        (3, 17, 1, 2, 1.0, True), (20, 80, 24, 3, 0.7, False),
+                        (19, 16, 5, 1, 0.6, True), (64, 12, 32, 2, 0.5, False), (40, 30, 20, 3, 0.4, True)]
     worst = 0.0
     for (din, hid, dout, depth, alpha, bias) in shapes:
         for n in rows:
@@ -2087,13 +2088,14 @@ def case_tc_step(device, names=None):
         for k, v in model.state_dict().items():
             # Adam's first step is lr * g / (|g| + 1e-8): where a gradient ELEMENT vanishes (dead
             # ReLU units; the bias of the last cluster layer - the potentials are translation
-            # invariant) rounding noise of 1e-9 becomes a step of a tenth of lr.  Those elements
-            # are only required to stay within one step (lr / 3 under the default ConstantLR).
+            # invariant) rounding noise of 1e-9 becomes a step of up to lr in EITHER direction, in the
+            # reference's run and in ours.  Those elements are only required to stay within two steps of
+            # each other (a step is lr / 3 under the default ConstantLR).
             ref1 = tt(z[f"{name}/p1/{k}"]).double()
             got = v.detach().cpu().double()
             tol = torch.full_like(ref1, 1e-6)
             if f"{name}/grad/{k}" in z.files:
-                tol[tt(z[f"{name}/grad/{k}"]).abs() < 1e-6] = 3.4e-4
+                tol[tt(z[f"{name}/grad/{k}"]).abs() < 1e-6] = 2 * 3.4e-4
             bad = (got - ref1).abs() > tol * torch.clamp_min(ref1.abs(), 1.0)
             assert not bool(bad.any()), f"{name} after Adam {k}: max|diff| {(got - ref1).abs().max().item():.3e}"
         # and the same through the one-call form (a second step from the updated parameters)
@@ -2117,13 +2119,14 @@ TC_B_MLGC = dict(embedding_slice=(0, 8), max_radius=1.0, max_num_neighbors=16)
 def _check_after_adam(model, grads_ref: dict, p1_ref: dict, tag: str, lr_step: float = 3.4e-4):
     """Parameters after the step within 1e-6; where a gradient ELEMENT vanishes analytically (dead
     ReLU units, the translation-invariant last cluster bias) Adam turns rounding noise into a step
-    of a tenth of lr: those elements only have to stay within one step."""
+    of up to lr in EITHER direction - the sign of the noise is arbitrary in the reference's run and in ours -
+    so those elements only have to stay within two steps of each other."""
     for k, v in model.state_dict().items():
         ref1 = tt(p1_ref[k]).double()
         got = v.detach().cpu().double()
         tol = torch.full_like(ref1, 1e-6)
         if k in grads_ref:
-            tol[tt(grads_ref[k]).abs() < 1e-6] = lr_step
+            tol[tt(grads_ref[k]).abs() < 1e-6] = 2 * lr_step
         bad = (got - ref1).abs() > tol * torch.clamp_min(ref1.abs(), 1.0)
         assert not bool(bad.any()), f"{tag} after Adam {k}: max|diff| {(got - ref1).abs().max().item():.3e}"
 

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 import gnn_tracking_amd as G
-from gnn_tracking_amd import ops
+from gnn_tracking_amd import _capi, ops
 import ref_cpu as O
 
 GOLD = pathlib.Path(__file__).resolve().parent / "golden"
@@ -1383,6 +1383,89 @@ def case_res_fcnn(device, shapes=None, rows=(1, 16, 45, 130)):
     return worst
 
 
+def case_mlp_wide(device, rows=(1, 16, 45, 130), shapes=None):
+    """``ops.fused_mlp`` on the wide fp32 kernels (gnntrk_mlp_forward_wide / _backward_wide: in <= 128, hidden <= 128,
+    out <= 48) against the reference's MLP (models/mlp.py:18-62) on the gathered concatenation in float64: gathered
+    and identity segments, ReLU on load, two and three layers, with and without biases, the three epilogues,
+    every tile count on both sides of the limits."""
+    gen = torch.Generator().manual_seed(13)
+    shapes = shapes or [((40, 40, 40), 40, 40, 3, True), ((40, 40), 40, 40, 3, True), ((14,), 40, 40, 2, False),
+                        ((20, 20, 9), 64, 17, 3, True), ((50, 50, 28), 128, 48, 3, True), ((5, 5, 4), 100, 4, 3, False),
+                        ((64, 64), 16, 33, 2, True), ((30,), 96, 1, 3, True)]
+    for dims, hid, dout, L, bias in shapes:
+        din = sum(dims)
+        for n in rows:
+            for epi in (_capi.EPI_NONE, _capi.EPI_RELU, _capi.EPI_RESIDUAL):
+                n_src = max(7, n // 3)
+                srcs = [torch.randn(n_src if j < len(dims) - 1 else n, d, generator=gen) for j, d in enumerate(dims)]
+                idxs = [torch.randint(0, n_src, (n,), generator=gen).int() if j < len(dims) - 1 else None
+                        for j in range(len(dims))]
+                relu = [bool((j + n) % 2) for j in range(len(dims))]
+                sizes = [din] + [hid] * (L - 1) + [dout]
+                ws = [torch.randn(sizes[i + 1], sizes[i], generator=gen) / sizes[i] ** 0.5 for i in range(L)]
+                bs = [torch.randn(sizes[i + 1], generator=gen) * 0.3 if bias else None for i in range(L)]
+                res = torch.randn(n, dout, generator=gen)
+                r = torch.randn(n, dout, generator=gen)
+                ca, cb = 0.6, 0.8
+
+                def run(dev, dt):
+                    S = [t.clone().to(dev, dt).requires_grad_(True) for t in srcs]
+                    W = [w.clone().to(dev, dt).requires_grad_(True) for w in ws]
+                    B = [None if b is None else b.clone().to(dev, dt).requires_grad_(True) for b in bs]
+                    R = res.clone().to(dev, dt).requires_grad_(True)
+                    if dt == torch.float64:
+                        cols = []
+                        for t, ix, rl in zip(S, idxs, relu):
+                            t2 = torch.relu(t) if rl else t
+                            cols.append(t2 if ix is None else t2[ix.long()])
+                        h = torch.cat(cols, dim=1)
+                        for i in range(L):
+                            h = h @ W[i].t() + (0 if B[i] is None else B[i])
+                            if i < L - 1:
+                                h = torch.relu(h)
+                        y = torch.relu(h) if epi == _capi.EPI_RELU else (ca * R + cb * h if epi == _capi.EPI_RESIDUAL else h)
+                    else:
+                        segs = [ops.Seg(t, None if ix is None else ix.to(dev), rl,
+                                        None if ix is None else _IndexReduce(ix.to(dev), int(t.shape[0])))
+                                for t, ix, rl in zip(S, idxs, relu)]
+                        y = ops.fused_mlp(segs, W, B, n_rows=n, epilogue=epi, ca=ca, cb=cb,
+                                          res=R if epi == _capi.EPI_RESIDUAL else None)
+                    (y * r.to(dev, dt)).sum().backward()
+                    return y, S, W, B, R
+
+                ops._WIDE_WARNED.clear()
+                y, S, W, B, R = run(device, torch.float32)
+                assert not ops._WIDE_WARNED, f"library path taken: {ops._WIDE_WARNED}"
+                yr, Sr, Wr, Br, Rr = run("cpu", torch.float64)
+                tag = f"mlp_wide in {dims} hidden {hid} out {dout} L {L} bias {bias} rows {n} epilogue {epi}"
+                assert_close(y, yr, TOL_OUT, tag + " y")
+                for j, (a, b) in enumerate(zip(S, Sr)):
+                    assert_close(a.grad, b.grad, TOL_GRAD, tag + f" grad seg {j}")
+                for i, (a, b) in enumerate(zip(W, Wr)):
+                    assert_close(a.grad, b.grad, TOL_GRAD, tag + f" grad W{i}")
+                for i, (a, b) in enumerate(zip(B, Br)):
+                    if a is not None:
+                        assert_close(a.grad, b.grad, TOL_GRAD, tag + f" grad b{i}")
+                if epi == _capi.EPI_RESIDUAL:
+                    assert_close(R.grad, Rr.grad, TOL_GRAD, tag + " grad res")
+
+
+class _IndexReduce(tuple):
+    """A ``("tgt", index)`` reduce rule for a plain row gather (test helper): row pointers of the stable sort of
+    ``idx`` stand in for a graph index, so that the fold is the package's own segment sum."""
+
+    def __new__(cls, idx, n_src):
+        order = torch.argsort(idx.long(), stable=True)
+        rowptr = torch.zeros(n_src + 1, dtype=torch.int32, device=idx.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(idx.long(), minlength=n_src), 0).int()
+
+        class _GI:
+            pass
+        gi = _GI()
+        gi.rowptr_s, gi.spos, gi.rowptr_t = rowptr, order.int().contiguous(), None
+        return super().__new__(cls, ("src", gi))
+
+
 def case_hinge_terms(device, n=400, dim=8, n_edges=3000):
     """``ops_ml.hinge_terms`` (gnntrk_hinge_forward / _backward) against the reference's expressions
     (metric_learning.py:14-55 with the edge selection of :88-110) in torch: every selection mode, powers 1 / 2 /
@@ -1802,11 +1885,15 @@ def case_gc_resin(device, names=None):
         model = G.GraphConstructionResIN(node_indim=14, edge_indim=4, **kw)
         load_params(model, z, f"{name}/p0/")
         model = model.to(device)
+        ops._WIDE_WARNED.clear()
         out = model(G.Data(x=x, edge_index=ei, edge_attr=ea))["H"]
         assert_close(out, z[f"{name}/H"], TOL_OUT, name + " H")
         (out * tt(z[f"{name}/r"], device)).sum().backward()
         for k, v in model.named_parameters():
             assert_close(v.grad, z[f"{name}/grad/{k}"], TOL_GRAD, f"{name} grad {k}")
+        # (fp32 - the reference's own precision - at the reference's default width runs on the wide fused kernels,
+        #  csrc/mlp_wide.hip: no library GEMM)
+        assert not ops._WIDE_WARNED, f"{name}: library path taken in fp32: {ops._WIDE_WARNED}"
     # bf16 storage at the reference's default width: the 120 -> 40 -> 40 -> 40 relational model, the 80-wide object
     # model and the 40-wide encoder outputs run on the fused kernels (output tiles, three / four k-steps of inputs),
     # not on library GEMMs; H and the parameter gradients against the fp32 goldens with bf16-sized bounds
@@ -1815,7 +1902,7 @@ def case_gc_resin(device, names=None):
         model = G.GraphConstructionResIN(node_indim=14, edge_indim=4, **kw)
         load_params(model, z, "default_h40/p0/")
         model = model.to(device)
-        ops._WIDE_WARNED.clear()   # (the fp32 run above took the library path for the same shapes)
+        ops._WIDE_WARNED.clear()
         with G.bf16_storage():
             out16 = model(G.Data(x=x, edge_index=ei, edge_attr=ea))["H"]
             (out16.float() * tt(z["default_h40/r"], device)).sum().backward()

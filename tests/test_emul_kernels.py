@@ -106,6 +106,11 @@ def test_res_fcnn_and_hinge_kernels_emulated():
         P.case_hinge_terms("cpu")
 
 
+def test_mlp_wide_emulated():
+    with emulated():
+        P.case_mlp_wide("cpu", rows=(1, 45))
+
+
 def test_hetero_fcnn_emulated():
     with emulated():
         P.case_hetero_fcnn("cpu")

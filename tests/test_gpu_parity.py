@@ -169,6 +169,10 @@ def test_res_fcnn_and_hinge_kernels(dev):
     P.case_hinge_terms(dev, n=20_000, dim=12, n_edges=300_000)
 
 
+def test_mlp_wide(dev):
+    P.case_mlp_wide(dev)
+
+
 def test_hetero_fcnn(dev):
     P.case_hetero_fcnn(dev)
 

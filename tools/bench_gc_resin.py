@@ -64,4 +64,9 @@ if args.mode in ("all", "fused"):
 if args.mode in ("all", "library"):
     run("bf16 storage, library GEMMs (before)", True, old_rule)
 if args.mode in ("all", "fp32"):
-    run("fp32 (library GEMMs)", False)
+    run("fp32, wide fused kernels (mlp_wide)", False)
+    ops._WIDE_KERNEL = False
+    try:
+        run("fp32, library GEMMs (before round 4)", False)
+    finally:
+        ops._WIDE_KERNEL = True

@@ -71,6 +71,7 @@ struct WArgs {
     int32_t n_seg, n_layers, epilogue, n_gout;
     int32_t in_dim, hidden, out_dim;
     int32_t res_stride, out_stride, part_total, want_dx;
+    int32_t vec4, _pad;   // every 4-feature group of the input lies in one segment, 16-byte aligned: float4 I/O
     float ca, cb;
 };
 
@@ -123,6 +124,25 @@ __device__ __forceinline__ void w_load_input(const WArgs &a, const WFeatTab &tb,
         }
     }
     lds_wave_order();
+    if (a.vec4) {   // one 16-byte load per tile and lane (the four features 16 t + 4 g .. + 3 of row c)
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < kti) {
+                const int f = 16 * t + 4 * g;
+                const float *p = tb.ptr[f];
+                if (valid && p != nullptr) {
+                    v = *reinterpret_cast<const f32x4 *>(p + (int64_t)s_rid[tb.seg[f] * 16 + c] * tb.stride[f]);
+                    if (tb.relu[f]) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                }
+            }
+            xin[t] = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -338,14 +358,19 @@ __device__ __forceinline__ void w_emit_db(float *s_redb, float *dst, const f32x4
 }
 
 template <int HT, int KT>
-__global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_kernel(const WArgs a) {
-    constexpr int KSH = 4 * HT, KSI = 4 * KT;
-    constexpr int kKsMax = KSH > KSI ? KSH : KSI;
-    constexpr int kRtMax = HT > KT ? HT : KT;    // rows of the largest fragment set / reduction buffer (hidden x in)
-    constexpr int kImgTiles = kRtMax > kWMaxOT ? kRtMax : kWMaxOT;
-    constexpr int kImg = 16 * kImgTiles * kWLd;
-    __shared__ __attribute__((aligned(16))) float s_frag[kRtMax * kKsMax * 64];
-    __shared__ __attribute__((aligned(16))) float s_img[kWaves][2][kImg];
+__global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) void mlpw_bwd_kernel(const WArgs a) {
+    constexpr int KSH = 4 * HT;
+    // W^T fragment sets: last layer HT x (4 OT), middle HT x KSH, first KT x KSH; the same buffer takes the
+    // block's weight-gradient sums (at most 16 HT x 16 KT floats = KT x KSH x 64)
+    constexpr int kKsLast = 4 * kWMaxOT;
+    constexpr int kFragSteps = HT * (KSH > kKsLast ? KSH : kKsLast) > KT * KSH ? HT * (KSH > kKsLast ? KSH : kKsLast) : KT * KSH;
+    constexpr int kRtMax = HT > KT ? HT : KT;
+    constexpr int kImgGTiles = HT > kWMaxOT ? HT : kWMaxOT;   // gradient side: hidden or output tiles
+    constexpr int kImgPTiles = kRtMax;                        // activation side: hidden or input tiles
+    constexpr int kImgG = 16 * kImgGTiles * kWLd, kImgP = 16 * kImgPTiles * kWLd;
+    __shared__ __attribute__((aligned(16))) float s_frag[kFragSteps * 64];
+    __shared__ __attribute__((aligned(16))) float s_imgG[kWaves][kImgG];
+    __shared__ __attribute__((aligned(16))) float s_imgP[kWaves][kImgP];
     __shared__ __attribute__((aligned(16))) float s_redb[16 * (HT > kWMaxOT ? HT : kWMaxOT)];
     __shared__ WFeatTab s_tab;
     __shared__ int32_t s_rid[kWaves][GNNTRK_MAX_SEGS * 16];
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_k
     const int64_t n_tiles = (a.n_rows + 15) / 16;
     const int64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
     const int64_t tb0 = per * blockIdx.x, tb1 = (tb0 + per < n_tiles) ? tb0 + per : n_tiles;
-    float *imgG = s_img[wv][0], *imgP = s_img[wv][1];
+    float *imgG = s_imgG[wv], *imgP = s_imgP[wv];
     float *part = a.part + (int64_t)blockIdx.x * a.part_total;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int poff = 0;   // partial block: last layer (W, b), middle layer (W, b), first layer (W, b)
@@ -374,14 +399,15 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_k
 #pragma unroll
             for (int ti = 0; ti < HT; ++ti) dW[to][ti] = zero;
         }
-        for (int64_t tile = tb0 + wv; tile < tb1; tile += kWaves) {
+        // (one wave per SIMD at the wide shapes: nobody covers a tile's load latency, so the next tile's rows are
+        //  requested before the current one is worked on)
+        auto load_last = [&](int64_t tile, f32x4 (&go)[kWMaxOT], f32x4 (&xv)[HT]) {
             const int64_t r0 = tile * 16 + c;
             const bool valid = r0 < a.n_rows;
             const int64_t row = valid ? r0 : a.n_rows - 1;
             int64_t grow[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) grow[t] = (t < a.n_gout && a.gout[t].idx != nullptr) ? a.gout[t].idx[row] : row;
-            f32x4 go[kWMaxOT], p[HT];
 #pragma unroll
             for (int to = 0; to < kWMaxOT; ++to) {
                 go[to] = zero;
@@ -402,11 +428,23 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_k
                 }
             }
 #pragma unroll
-            for (int t = 0; t < HT; ++t) {
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xl + row * HP + 16 * t + 4 * g);
+            for (int t = 0; t < HT; ++t) xv[t] = *reinterpret_cast<const f32x4 *>(xl + row * HP + 16 * t + 4 * g);
+        };
+        f32x4 goN[kWMaxOT], xvN[HT];
+        if (tb0 + wv < tb1) load_last(tb0 + wv, goN, xvN);
+        for (int64_t tile = tb0 + wv; tile < tb1; tile += kWaves) {
+            const int64_t r0 = tile * 16 + c;
+            const bool valid = r0 < a.n_rows;
+            const int64_t row = valid ? r0 : a.n_rows - 1;
+            f32x4 go[kWMaxOT], p[HT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[t][r] = fmaxf(xv[r], 0.f);
+            for (int to = 0; to < kWMaxOT; ++to) go[to] = goN[to];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[t][r] = fmaxf(xvN[t][r], 0.f);
             }
+            if (tile + kWaves < tb1) load_last(tile + kWaves, goN, xvN);
             f32x4 gh[HT];
 #pragma unroll
             for (int t = 0; t < HT; ++t) gh[t] = zero;
@@ -465,15 +503,32 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_k
 #pragma unroll
             for (int ti = 0; ti < HT; ++ti) dW[to][ti] = zero;
         }
+        auto load_mid = [&](int64_t tile, f32x4 (&gy)[HT], f32x4 (&xv)[HT]) {
+            const int64_t r0 = tile * 16 + c;
+            const bool valid = r0 < a.n_rows;
+            const int64_t row = valid ? r0 : a.n_rows - 1;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                gy[t] = valid ? *reinterpret_cast<const f32x4 *>(a.gstream + row * HP + 16 * t + 4 * g) : zero;
+                xv[t] = *reinterpret_cast<const f32x4 *>(xl + row * HP + 16 * t + 4 * g);
+            }
+        };
+        f32x4 gyN[HT], xvN[HT];
+        if (tb0 + wv < tb1) load_mid(tb0 + wv, gyN, xvN);
         for (int64_t tile = tb0 + wv; tile < tb1; tile += kWaves) {
             const int64_t r0 = tile * 16 + c;
             const bool valid = r0 < a.n_rows;
             const int64_t row = valid ? r0 : a.n_rows - 1;
             f32x4 gy[HT], p[HT];
 #pragma unroll
+            for (int t = 0; t < HT; ++t) gy[t] = gyN[t];
+            f32x4 xvC[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) xvC[t] = xvN[t];
+            if (tile + kWaves < tb1) load_mid(tile + kWaves, gyN, xvN);
+#pragma unroll
             for (int t = 0; t < HT; ++t) {
-                gy[t] = valid ? *reinterpret_cast<const f32x4 *>(a.gstream + row * HP + 16 * t + 4 * g) : zero;
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xl + row * HP + 16 * t + 4 * g);
+                const f32x4 xv = xvC[t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     p[t][r] = fmaxf(xv[r], 0.f);
@@ -504,16 +559,31 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_k
             for (int to = 0; to < HT; ++to)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dbacc[to][r] += gy[to][r];
+            if constexpr (HT <= 4) {
+                // gradient-side operands read once; consecutive MFMAs go to different accumulators
+                f32x4 aG[HT];
 #pragma unroll
-            for (int ti = 0; ti < HT; ++ti) {
-                const f32x4 b4 = w_read_k(imgP, ti, g, c);
+                for (int to = 0; to < HT; ++to) aG[to] = w_read_k(imgG, to, g, c);
 #pragma unroll
-                for (int to = 0; to < HT; ++to) {
-                    const f32x4 a4 = w_read_k(imgG, to, g, c);
+                for (int ti = 0; ti < HT; ++ti) {
+                    const f32x4 b4 = w_read_k(imgP, ti, g, c);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) dW[to][ti] = mfma4(a4[s], b4[s], dW[to][ti]);
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int to = 0; to < HT; ++to) dW[to][ti] = mfma4(aG[to][s], b4[s], dW[to][ti]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < HT; ++ti) {
+                    const f32x4 b4 = w_read_k(imgP, ti, g, c);
+#pragma unroll
+                    for (int to = 0; to < HT; ++to) {
+                        const f32x4 a4 = w_read_k(imgG, to, g, c);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) dW[to][ti] = mfma4(a4[s], b4[s], dW[to][ti]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             lds_wave_order();
         }
@@ -533,14 +603,24 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_k
 #pragma unroll
             for (int ti = 0; ti < KT; ++ti) dW[to][ti] = zero;
         }
+        auto load_gy = [&](int64_t tile, f32x4 (&gy)[HT]) {
+            const int64_t r0 = tile * 16 + c;
+            const bool valid = r0 < a.n_rows;
+            const int64_t row = valid ? r0 : a.n_rows - 1;
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+                gy[t] = valid ? *reinterpret_cast<const f32x4 *>(a.gstream + row * HP + 16 * t + 4 * g) : zero;
+        };
+        f32x4 gyN[HT];
+        if (tb0 + wv < tb1) load_gy(tb0 + wv, gyN);
         for (int64_t tile = tb0 + wv; tile < tb1; tile += kWaves) {
             const int64_t r0 = tile * 16 + c;
             const bool valid = r0 < a.n_rows;
             const int64_t row = valid ? r0 : a.n_rows - 1;
             f32x4 gy[HT], xin[KT];
 #pragma unroll
-            for (int t = 0; t < HT; ++t)
-                gy[t] = valid ? *reinterpret_cast<const f32x4 *>(a.gstream + row * HP + 16 * t + 4 * g) : zero;
+            for (int t = 0; t < HT; ++t) gy[t] = gyN[t];
+            if (tile + kWaves < tb1) load_gy(tile + kWaves, gyN);
             w_load_input<KT>(a, s_tab, s_rid[wv], row, valid, g, c, kti, xin);
             w_stage_tiles<HT>(imgG, gy, HT, g, c);
             w_stage_tiles<KT>(imgP, xin, kti, g, c);
@@ -558,7 +638,21 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_k
                     for (int ti = 0; ti < KT; ++ti)
                         if (ti < kti) gx[ti] = mfma4(s_frag[(ti * KSH + ks) * 64 + lane], gv, gx[ti]);
                 }
-                if (valid) {
+                if (valid && a.vec4) {
+#pragma unroll
+                    for (int ti = 0; ti < KT; ++ti) {
+                        const int f = 16 * ti + 4 * g;
+                        float *gp = (ti < kti && f < a.in_dim) ? s_tab.gptr[f] : nullptr;
+                        if (gp != nullptr) {
+                            f32x4 v = gx[ti];
+                            if (s_tab.relu[f]) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = xin[ti][r] > 0.f ? v[r] : 0.f;
+                            }
+                            *reinterpret_cast<f32x4 *>(gp + r0 * s_tab.gstride[f]) = v;
+                        }
+                    }
+                } else if (valid) {
 #pragma unroll
                     for (int ti = 0; ti < KT; ++ti)
 #pragma unroll
@@ -575,18 +669,33 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || KT > 4) ? 1 : 2) void mlpw_bwd_k
                         }
                 }
             }
+            if constexpr (HT <= 4) {
+                f32x4 aG[HT];
 #pragma unroll
-            for (int ti = 0; ti < KT; ++ti)
-                if (ti < kti) {
-                    const f32x4 b4 = w_read_k(imgP, ti, g, c);
+                for (int to = 0; to < HT; ++to) aG[to] = w_read_k(imgG, to, g, c);
 #pragma unroll
-                    for (int to = 0; to < HT; ++to) {
-                        const f32x4 a4 = w_read_k(imgG, to, g, c);
+                for (int ti = 0; ti < KT; ++ti)
+                    if (ti < kti) {
+                        const f32x4 b4 = w_read_k(imgP, ti, g, c);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) dW[to][ti] = mfma4(a4[s], b4[s], dW[to][ti]);
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int to = 0; to < HT; ++to) dW[to][ti] = mfma4(aG[to][s], b4[s], dW[to][ti]);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < KT; ++ti)
+                    if (ti < kti) {
+                        const f32x4 b4 = w_read_k(imgP, ti, g, c);
+#pragma unroll
+                        for (int to = 0; to < HT; ++to) {
+                            const f32x4 a4 = w_read_k(imgG, to, g, c);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) dW[to][ti] = mfma4(a4[s], b4[s], dW[to][ti]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
 #pragma unroll
             for (int to = 0; to < HT; ++to)
 #pragma unroll
@@ -722,6 +831,10 @@ void w_common(WArgs &w, const gnntrk_mlp &m, int n_seg, const gnntrk_seg *seg, i
     w.ca = ca;
     w.cb = cb;
     w.n_rows = n_rows;
+    bool v4 = true;
+    for (int j = 0; j < n_seg; ++j)
+        if (seg[j].dim % 4 != 0 || seg[j].stride % 4 != 0 || ((uintptr_t)seg[j].ptr & 15) != 0) v4 = false;
+    w.vec4 = v4 ? 1 : 0;
 }
 
 }  // namespace
@@ -830,7 +943,10 @@ int gnntrk_mlp_backward_wide(const gnntrk_mlp_bwd_args *a, const float *acts, co
         if (rc) return rc;
         WArgs w;
         w_common(w, m, a->n_seg, a->seg, a->epilogue, a->ca, a->cb, a->n_rows, base, L, true);
-        for (int j = 0; j < a->n_seg; ++j) w.gseg[j] = a->gseg[j];
+        for (int j = 0; j < a->n_seg; ++j) {
+            w.gseg[j] = a->gseg[j];
+            if (a->gseg[j].ptr && (a->gseg[j].stride % 4 != 0 || ((uintptr_t)a->gseg[j].ptr & 15) != 0)) w.vec4 = 0;
+        }
         for (int t = 0; t < a->n_gout; ++t) w.gout[t] = a->gout[t];
         w.n_gout = a->n_gout;
         w.acts = const_cast<float *>(acts);

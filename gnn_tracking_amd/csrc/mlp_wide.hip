@@ -71,7 +71,8 @@ struct WArgs {
     int32_t n_seg, n_layers, epilogue, n_gout;
     int32_t in_dim, hidden, out_dim;
     int32_t res_stride, out_stride, part_total, want_dx;
-    int32_t vec4, _pad;   // every 4-feature group of the input lies in one segment, 16-byte aligned: float4 I/O
+    int32_t vec4;    // every 4-feature group of the input lies in one segment, 16-byte aligned: float4 I/O
+    int32_t vec4o;   // output side likewise (out / res / upstream terms: widths and strides multiples of 4, aligned)
     float ca, cb;
 };
 
@@ -278,18 +279,38 @@ __global__ __launch_bounds__(kBlock) void mlpw_fwd_kernel(const WArgs a) {
 #pragma unroll
         for (int t = 0; t < T; ++t)
             if (valid[t]) {
+                if (a.vec4o) {   // 16 bytes per lane and output tile
 #pragma unroll
-                for (int to = 0; to < kWMaxOT; ++to)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = 16 * to + 4 * g + r;
+                    for (int to = 0; to < kWMaxOT; ++to) {
+                        const int f = 16 * to + 4 * g;
                         if (to < ot && f < a.out_dim) {
-                            float v = y[t][to][r];
-                            if (a.epilogue == GNNTRK_EPI_RELU) v = fmaxf(v, 0.f);
-                            if (a.epilogue == GNNTRK_EPI_RESIDUAL) v = a.ca * a.res[row[t] * a.res_stride + f] + a.cb * v;
-                            a.out[row[t] * a.out_stride + f] = v;
+                            f32x4 v = y[t][to];
+                            if (a.epilogue == GNNTRK_EPI_RELU) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                            }
+                            if (a.epilogue == GNNTRK_EPI_RESIDUAL) {
+                                const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.res + row[t] * a.res_stride + f);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = a.ca * rv[r] + a.cb * v[r];
+                            }
+                            *reinterpret_cast<f32x4 *>(a.out + row[t] * a.out_stride + f) = v;
                         }
                     }
+                } else {
+#pragma unroll
+                    for (int to = 0; to < kWMaxOT; ++to)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = 16 * to + 4 * g + r;
+                            if (to < ot && f < a.out_dim) {
+                                float v = y[t][to][r];
+                                if (a.epilogue == GNNTRK_EPI_RELU) v = fmaxf(v, 0.f);
+                                if (a.epilogue == GNNTRK_EPI_RESIDUAL) v = a.ca * a.res[row[t] * a.res_stride + f] + a.cb * v;
+                                a.out[row[t] * a.out_stride + f] = v;
+                            }
+                        }
+                }
             }
     }
 }
@@ -411,10 +432,32 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) voi
 #pragma unroll
             for (int to = 0; to < kWMaxOT; ++to) {
                 go[to] = zero;
-                if (to < ot) {
+                const int f0 = 16 * to + 4 * g;
+                if (to < ot && a.vec4o) {
+                    if (valid && f0 < a.out_dim) {
+                        f32x4 v = zero;
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            if (t < a.n_gout) {
+                                const f32x4 u = *reinterpret_cast<const f32x4 *>(a.gout[t].ptr + grow[t] * a.gout[t].stride + f0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += u[r];
+                            }
+                        if (a.epilogue == GNNTRK_EPI_RELU) {
+                            const f32x4 o = *reinterpret_cast<const f32x4 *>(a.fwd_out + row * a.out_stride + f0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = o[r] > 0.f ? v[r] : 0.f;
+                        }
+                        if (a.epilogue == GNNTRK_EPI_RESIDUAL) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] *= a.cb;
+                        }
+                        go[to] = v;
+                    }
+                } else if (to < ot) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int f = 16 * to + 4 * g + r;
+                        const int f = f0 + r;
                         if (valid && f < a.out_dim) {
                             float v = 0.f;
 #pragma unroll
@@ -876,6 +919,9 @@ int gnntrk_mlp_forward_wide(const gnntrk_mlp_fwd_args *a, float *acts, void *wor
     w.out = a->out;
     w.out_stride = a->out_stride;
     w.acts = acts;
+    w.vec4o = (a->mlp.out_dim % 4 == 0 && a->out_stride % 4 == 0 && ((uintptr_t)a->out & 15) == 0 &&
+               (a->epilogue != GNNTRK_EPI_RESIDUAL || (a->res_stride % 4 == 0 && ((uintptr_t)a->res & 15) == 0)))
+                  ? 1 : 0;
     const int HT = w_ht(a->mlp.hidden), KT = w_kt(a->mlp.in_dim);
     const int64_t tiles = (a->n_rows + 15) / 16;
     bool launched = false;
@@ -949,6 +995,11 @@ int gnntrk_mlp_backward_wide(const gnntrk_mlp_bwd_args *a, const float *acts, co
         }
         for (int t = 0; t < a->n_gout; ++t) w.gout[t] = a->gout[t];
         w.n_gout = a->n_gout;
+        bool vo = m.out_dim % 4 == 0;
+        for (int t = 0; t < a->n_gout; ++t)
+            if (a->gout[t].stride % 4 != 0 || ((uintptr_t)a->gout[t].ptr & 15) != 0) vo = false;
+        if (a->epilogue == GNNTRK_EPI_RELU && (out_stride % 4 != 0 || ((uintptr_t)out & 15) != 0)) vo = false;
+        w.vec4o = vo ? 1 : 0;
         w.acts = const_cast<float *>(acts);
         w.fwd_out = out;
         w.out_stride = out_stride;

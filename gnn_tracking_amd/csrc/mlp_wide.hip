@@ -116,7 +116,7 @@ __device__ __forceinline__ void w_stage(float *s_frag, const float *src, int n_f
 // wave's [segment][16] row-id scratch.
 template <int KT>
 __device__ __forceinline__ void w_load_input(const WArgs &a, const WFeatTab &tb, int32_t *s_rid, int64_t row, bool valid,
-                                             int g, int c, int kti, f32x4 (&xin)[KT]) {
+                                             int g, int c, int kti, f32x4 (&xin)[KT], int t0 = 0) {   // tiles t0 .. t0 + kti - 1
     lds_wave_order();   // (the previous tile's readers are done with the ids)
     if (g == 0) {
         for (int j = 0; j < a.n_seg; ++j) {
@@ -130,7 +130,7 @@ __device__ __forceinline__ void w_load_input(const WArgs &a, const WFeatTab &tb,
         for (int t = 0; t < KT; ++t) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (t < kti) {
-                const int f = 16 * t + 4 * g;
+                const int f = 16 * (t0 + t) + 4 * g;
                 const float *p = tb.ptr[f];
                 if (valid && p != nullptr) {
                     v = *reinterpret_cast<const f32x4 *>(p + (int64_t)s_rid[tb.seg[f] * 16 + c] * tb.stride[f]);
@@ -150,7 +150,7 @@ __device__ __forceinline__ void w_load_input(const WArgs &a, const WFeatTab &tb,
         if (t < kti) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int f = 16 * t + 4 * g + r;
+                const int f = 16 * (t0 + t) + 4 * g + r;
                 const float *p = tb.ptr[f];
                 if (valid && p != nullptr) {
                     const float x = p[(int64_t)s_rid[tb.seg[f] * 16 + c] * tb.stride[f]];
@@ -328,9 +328,11 @@ __device__ __forceinline__ void w_stage_tiles(float *img, const f32x4 (&v)[NT], 
 __device__ __forceinline__ f32x4 w_read_k(const float *img, int t, int g, int c) {
     return *reinterpret_cast<const f32x4 *>(img + (16 * t + c) * kWLd + 4 * g);
 }
+// (`K` columns of the accumulator tiles go to columns i0 .. i0 + K - 1 of a destination with leading dimension ldk)
 template <int NO, int NI>
 __device__ __forceinline__ void w_emit_dw(float *s_red, float *dst, const f32x4 (&acc)[NO][NI], int no, int ni, int O, int K,
-                                          int wv, int tid, int g, int c) {
+                                          int wv, int tid, int g, int c, int ldk = -1, int i0 = 0) {
+    if (ldk < 0) ldk = K;
     __syncthreads();
     for (int w = 0; w < kWaves; ++w) {
         if (wv == w) {
@@ -351,7 +353,7 @@ __device__ __forceinline__ void w_emit_dw(float *s_red, float *dst, const f32x4 
         }
         __syncthreads();
     }
-    for (int i = tid; i < O * K; i += kBlock) dst[i] = s_red[i];
+    for (int i = tid; i < O * K; i += kBlock) dst[(i / K) * ldk + i0 + (i % K)] = s_red[i];
 }
 template <int NO>
 __device__ __forceinline__ void w_emit_db(float *s_redb, float *dst, const f32x4 (&dbacc)[NO], int no, int O, int wv, int tid,
@@ -378,11 +380,14 @@ __device__ __forceinline__ void w_emit_db(float *s_redb, float *dst, const f32x4
     for (int i = tid; i < O; i += kBlock) dst[i] = s_redb[i];
 }
 
-template <int HT, int KT>
-__global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) void mlpw_bwd_kernel(const WArgs a) {
-    constexpr int KSH = 4 * HT;
-    // W^T fragment sets: last layer HT x (4 OT), middle HT x KSH, first KT x KSH; the same buffer takes the
-    // block's weight-gradient sums (at most 16 HT x 16 KT floats = KT x KSH x 64)
+// KT = 4: the first-layer stage takes the input tiles FOUR at a time (one pass over the wave's rows per group of 64
+// input features: at 128 inputs the 24 + 8 + 8 tiles of dW1 / gx / xin of a single pass cost the second wave
+// per SIMD - 369 registers - and with it the cover for every load).
+template <int HT>
+__global__ __launch_bounds__(kBlock, HT > 3 ? 1 : 2) void mlpw_bwd_kernel(const WArgs a) {
+    constexpr int KSH = 4 * HT, KT = 4;
+    // W^T fragment sets: last layer HT x (4 OT), middle HT x KSH, first (per pass) KT x KSH; the same buffer takes
+    // the block's weight-gradient sums (at most 16 HT x 16 KT floats per pass = KT x KSH x 64)
     constexpr int kKsLast = 4 * kWMaxOT;
     constexpr int kFragSteps = HT * (KSH > kKsLast ? KSH : kKsLast) > KT * KSH ? HT * (KSH > kKsLast ? KSH : kKsLast) : KT * KSH;
     constexpr int kRtMax = HT > KT ? HT : KT;
@@ -636,8 +641,10 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) voi
         poff += H;
     }
 
-    {   // ---------------------------------------------------------------- first layer
-        if (a.want_dx) w_stage(s_frag, a.fragT[0], kti * KSH * 64, s_redb, nullptr, 0, 0, tid);
+    const int npass = (kti + KT - 1) / KT;
+    for (int pass = 0; pass < npass; ++pass) {   // ------------------------------------------------ first layer
+        const int t0 = KT * pass, ktp = kti - t0 < KT ? kti - t0 : KT;
+        if (a.want_dx) w_stage(s_frag, a.fragT[0] + (size_t)t0 * KSH * 64, ktp * KSH * 64, s_redb, nullptr, 0, 0, tid);
         else __syncthreads();
         f32x4 dW[HT][KT], dbacc[HT];
 #pragma unroll
@@ -664,9 +671,9 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) voi
 #pragma unroll
             for (int t = 0; t < HT; ++t) gy[t] = gyN[t];
             if (tile + kWaves < tb1) load_gy(tile + kWaves, gyN);
-            w_load_input<KT>(a, s_tab, s_rid[wv], row, valid, g, c, kti, xin);
+            w_load_input<KT>(a, s_tab, s_rid[wv], row, valid, g, c, ktp, xin, t0);
             w_stage_tiles<HT>(imgG, gy, HT, g, c);
-            w_stage_tiles<KT>(imgP, xin, kti, g, c);
+            w_stage_tiles<KT>(imgP, xin, ktp, g, c);
             lds_wave_order();
             if (a.want_dx) {
                 // gradient at the concatenated input (through the ReLU on load where a segment has one),
@@ -679,13 +686,13 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) voi
                     const float gv = imgG[(16 * (ks >> 2) + 4 * g + (ks & 3)) * kWLd + c];
 #pragma unroll
                     for (int ti = 0; ti < KT; ++ti)
-                        if (ti < kti) gx[ti] = mfma4(s_frag[(ti * KSH + ks) * 64 + lane], gv, gx[ti]);
+                        if (ti < ktp) gx[ti] = mfma4(s_frag[(ti * KSH + ks) * 64 + lane], gv, gx[ti]);
                 }
                 if (valid && a.vec4) {
 #pragma unroll
                     for (int ti = 0; ti < KT; ++ti) {
-                        const int f = 16 * ti + 4 * g;
-                        float *gp = (ti < kti && f < a.in_dim) ? s_tab.gptr[f] : nullptr;
+                        const int f = 16 * (t0 + ti) + 4 * g;
+                        float *gp = (ti < ktp && f < a.in_dim) ? s_tab.gptr[f] : nullptr;
                         if (gp != nullptr) {
                             f32x4 v = gx[ti];
                             if (s_tab.relu[f]) {
@@ -700,8 +707,8 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) voi
                     for (int ti = 0; ti < KT; ++ti)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int f = 16 * ti + 4 * g + r;
-                            if (ti < kti && f < a.in_dim) {
+                            const int f = 16 * (t0 + ti) + 4 * g + r;
+                            if (ti < ktp && f < a.in_dim) {
                                 float *gp = s_tab.gptr[f];
                                 if (gp != nullptr) {
                                     float v = gx[ti][r];
@@ -718,7 +725,7 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) voi
                 for (int to = 0; to < HT; ++to) aG[to] = w_read_k(imgG, to, g, c);
 #pragma unroll
                 for (int ti = 0; ti < KT; ++ti)
-                    if (ti < kti) {
+                    if (ti < ktp) {
                         const f32x4 b4 = w_read_k(imgP, ti, g, c);
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) voi
             } else {
 #pragma unroll
                 for (int ti = 0; ti < KT; ++ti)
-                    if (ti < kti) {
+                    if (ti < ktp) {
                         const f32x4 b4 = w_read_k(imgP, ti, g, c);
 #pragma unroll
                         for (int to = 0; to < HT; ++to) {
@@ -739,15 +746,18 @@ __global__ __launch_bounds__(kBlock, (HT > 4 || (HT > 3 && KT > 4)) ? 1 : 2) voi
                         __builtin_amdgcn_sched_barrier(0);
                     }
             }
+            if (pass == 0) {
 #pragma unroll
-            for (int to = 0; to < HT; ++to)
+                for (int to = 0; to < HT; ++to)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dbacc[to][r] += gy[to][r];
+                    for (int r = 0; r < 4; ++r) dbacc[to][r] += gy[to][r];
+            }
             lds_wave_order();
         }
-        w_emit_dw<HT, KT>(s_frag, part + poff, dW, HT, kti, H, a.in_dim, wv, tid, g, c);
-        poff += H * a.in_dim;
-        w_emit_db<HT>(s_redb, part + poff, dbacc, HT, H, wv, tid, g, c);
+        // this pass's columns 16 t0 .. of dW1 (leading dimension in_dim)
+        const int kcols = a.in_dim - 16 * t0 < 16 * KT ? a.in_dim - 16 * t0 : 16 * KT;
+        w_emit_dw<HT, KT>(s_frag, part + poff, dW, HT, ktp, H, kcols, wv, tid, g, c, a.in_dim, 16 * t0);
+        if (pass == 0) w_emit_db<HT>(s_redb, part + poff + H * a.in_dim, dbacc, HT, H, wv, tid, g, c);
     }
 }
 
@@ -758,11 +768,23 @@ struct WReduceArgs {
     int32_t off[7];
     float *dst[6];
 };
+// 32 parameters x 8 slices of the partial blocks per workgroup: a slice adds its blocks in order, the eight slice
+// sums are added in slice order - a fixed association, and 256 instead of 32 workgroups in flight (the one-thread-
+// per-parameter walk over 256 blocks was a 90 us latency chain for 32 KB of sums)
 __global__ __launch_bounds__(256) void mlpw_reduce_kernel(const WReduceArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.part_total) return;
+    __shared__ float s_part[8][32];
+    const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + pl;
+    const int per = (a.n_part + 7) / 8, b0 = sl * per, b1 = b0 + per < a.n_part ? b0 + per : a.n_part;
+    float acc = 0.f;
+    if (i < a.part_total)
+        for (int b = b0; b < b1; ++b) acc += a.part[(int64_t)b * a.part_total + i];
+    s_part[sl][pl] = acc;
+    __syncthreads();
+    if (sl != 0 || i >= a.part_total) return;
     float s = 0.f;
-    for (int b = 0; b < a.n_part; ++b) s += a.part[(int64_t)b * a.part_total + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += s_part[q][pl];
     int j = 0;
     while (j + 1 < a.n_seg && i >= a.off[j + 1]) ++j;
     if (a.dst[j] == nullptr) return;
@@ -828,10 +850,11 @@ int w_part_total(const gnntrk_mlp &m) {
     return m.out_dim * m.hidden + m.out_dim + (m.n_layers == 3 ? m.hidden * m.hidden + m.hidden : 0) + m.hidden * m.in_dim +
            m.hidden;
 }
-int w_bwd_grid(int64_t n_rows) {
+int w_bwd_grid(int64_t n_rows, int hidden) {
     const int64_t tiles = (n_rows + 15) / 16;
     int64_t g = (tiles + kWaves - 1) / kWaves;
-    if (g > cu_count()) g = cu_count();
+    const int64_t cap = (int64_t)cu_count() * (w_ht(hidden) > 3 ? 1 : 2);   // (resident workgroups per CU)
+    if (g > cap) g = cap;
     return (int)(g < 1 ? 1 : g);
 }
 int w_pack(const gnntrk_mlp &m, float *base, const WLayout &L, bool with_bwd, hipStream_t stream) {
@@ -944,7 +967,7 @@ size_t gnntrk_mlp_wide_backward_workspace_bytes(const gnntrk_mlp *m, int64_t n_r
     if (!m || m->n_layers < 2 || m->n_layers > 3 || n_rows < 0) return 0;
     const size_t frag = w_layout(*m, true).total * sizeof(float);
     const size_t gs = align_up((size_t)n_rows * 16 * w_ht(m->hidden) * sizeof(float), 256);
-    const size_t part = (size_t)w_bwd_grid(n_rows) * w_part_total(*m) * sizeof(float);
+    const size_t part = (size_t)w_bwd_grid(n_rows, m->hidden) * w_part_total(*m) * sizeof(float);
     return align_up(frag, 256) + gs + align_up(part, 256);
 }
 
@@ -979,7 +1002,7 @@ int gnntrk_mlp_backward_wide(const gnntrk_mlp_bwd_args *a, const float *acts, co
     float *base = reinterpret_cast<float *>(workspace);
     uint8_t *bytes = reinterpret_cast<uint8_t *>(workspace);
     float *gstream = reinterpret_cast<float *>(bytes + align_up(L.total * sizeof(float), 256));
-    const int HT = w_ht(m.hidden), KT = w_kt(m.in_dim);
+    const int HT = w_ht(m.hidden);
     float *part = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(gstream) +
                                             align_up((size_t)a->n_rows * 16 * HT * sizeof(float), 256));
     const int PT = w_part_total(m);
@@ -1007,15 +1030,14 @@ int gnntrk_mlp_backward_wide(const gnntrk_mlp_bwd_args *a, const float *acts, co
         w.part = part;
         w.part_total = PT;
         w.want_dx = want_dx ? 1 : 0;
-        grid = w_bwd_grid(a->n_rows);
+        grid = w_bwd_grid(a->n_rows, m.hidden);
         bool launched = false;
-#define GNNTRK_MW_BWD(HT_, KT_)                                                                          \
-    if (!launched && HT == HT_ && KT == KT_) {                                                           \
-        hipLaunchKernelGGL((mlpw_bwd_kernel<HT_, KT_>), dim3(grid), dim3(kBlock), 0, stream, w);         \
-        launched = true;                                                                                 \
+#define GNNTRK_MW_BWD(HT_)                                                                               \
+    if (!launched && HT == HT_) {                                                                         \
+        hipLaunchKernelGGL((mlpw_bwd_kernel<HT_>), dim3(grid), dim3(kBlock), 0, stream, w);               \
+        launched = true;                                                                                  \
     }
-        GNNTRK_MW_BWD(1, 4) GNNTRK_MW_BWD(2, 4) GNNTRK_MW_BWD(3, 4) GNNTRK_MW_BWD(4, 4) GNNTRK_MW_BWD(6, 4) GNNTRK_MW_BWD(8, 4)
-        GNNTRK_MW_BWD(1, 8) GNNTRK_MW_BWD(2, 8) GNNTRK_MW_BWD(3, 8) GNNTRK_MW_BWD(4, 8) GNNTRK_MW_BWD(6, 8) GNNTRK_MW_BWD(8, 8)
+        GNNTRK_MW_BWD(1) GNNTRK_MW_BWD(2) GNNTRK_MW_BWD(3) GNNTRK_MW_BWD(4) GNNTRK_MW_BWD(6) GNNTRK_MW_BWD(8)
 #undef GNNTRK_MW_BWD
         rc = check_launch("mlp_backward_wide");
         if (rc) return rc;
@@ -1045,7 +1067,7 @@ int gnntrk_mlp_backward_wide(const gnntrk_mlp_bwd_args *a, const float *acts, co
     seg(m.b[0] ? a->gb[0] : nullptr, m.hidden);
     ra.off[n] = off;
     ra.n_seg = n;
-    hipLaunchKernelGGL(mlpw_reduce_kernel, dim3((PT + 255) / 256), dim3(256), 0, stream, ra);
+    hipLaunchKernelGGL(mlpw_reduce_kernel, dim3((PT + 31) / 32), dim3(256), 0, stream, ra);
     return check_launch("mlp_wide_reduce");
 }
 

@@ -621,11 +621,23 @@ struct RfReduceArgs {
     int32_t n_raw, _pad;
 };
 
+// 32 parameters x 8 slices of the partial blocks per workgroup: a slice adds its blocks in order, the eight slice
+// sums are added in slice order - a fixed association, and 256 instead of 32 workgroups in flight (the one-thread-
+// per-parameter walk over 256 blocks was a 90 us latency chain for 32 KB of sums)
 __global__ __launch_bounds__(256) void resfcnn_reduce_kernel(const RfReduceArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.part_total) return;
+    __shared__ float s_part[8][32];
+    const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + pl;
+    const int per = (a.n_part + 7) / 8, b0 = sl * per, b1 = b0 + per < a.n_part ? b0 + per : a.n_part;
+    float acc = 0.f;
+    if (i < a.part_total)
+        for (int b = b0; b < b1; ++b) acc += a.part[(int64_t)b * a.part_total + i];
+    s_part[sl][pl] = acc;
+    __syncthreads();
+    if (sl != 0 || i >= a.part_total) return;
     float s = 0.f;
-    for (int b = 0; b < a.n_part; ++b) s += a.part[(int64_t)b * a.part_total + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += s_part[q][pl];
     if (a.raw != nullptr && i < a.n_raw) a.raw[i] = s;
     int j = 0;
     while (j + 1 < a.n_seg && i >= a.off[j + 1]) ++j;
@@ -904,7 +916,7 @@ int gnntrk_resfcnn_backward(const gnntrk_resfcnn *m, const float *x, int32_t x_s
     const bool want_scale = m->out_scale && grads->out_scale;
     ra.raw = want_scale ? raw : nullptr;
     ra.n_raw = m->out_dim * m->hidden + m->out_dim;
-    hipLaunchKernelGGL(resfcnn_reduce_kernel, dim3((PT + 255) / 256), dim3(256), 0, stream, ra);
+    hipLaunchKernelGGL(resfcnn_reduce_kernel, dim3((PT + 31) / 32), dim3(256), 0, stream, ra);
     rc = check_launch("resfcnn_reduce");
     if (rc) return rc;
     if (want_scale) {

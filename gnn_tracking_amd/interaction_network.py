@@ -65,6 +65,13 @@ class InteractionNetwork(nn.Module, HyperparametersMixin):
             # backward kernel takes "direct" and "through aggr" gradients as two terms
             e_tilde, aggr = ops_bf16.in_edge(rel_segs, [m.weight for m in lin], [m.bias for m in lin],
                                              gi, gi.n_edges)
+        elif (x.dtype == torch.float32 and e_csr.dtype == torch.float32 and gi.n_edges > 0
+              and not ops._fused_supported(rel_segs, [m.weight for m in lin], [m.bias for m in lin], False)
+              and ops._wide_kernel_supported(rel_segs, [m.weight for m in lin], None)):
+            # fp32 at widths of the wide kernels: the same single node (the aggregation's gradient reaches the
+            # backward kernel as a gathered term instead of an edge-sized tensor)
+            e_tilde, aggr = ops.in_edge_wide(rel_segs, [m.weight for m in lin], [m.bias for m in lin],
+                                             gi, gi.n_edges)
         else:
             e_tilde = self.relational_model.fused(rel_segs, n_rows=gi.n_edges)
             aggr = ops.segment_sum(e_tilde, gi, "tgt")

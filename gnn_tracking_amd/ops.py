@@ -761,127 +761,186 @@ def _wide_kernel_supported(segs: Sequence[Seg], weights: Sequence[Tensor], epilo
             and epilogue in (None, _capi.EPI_NONE, _capi.EPI_RELU, _capi.EPI_RESIDUAL))
 
 
+def _wide_forward(ctx, spec: "_MlpSpec", tensors, needs_grad: bool):
+    """Forward launch of the wide fp32 kernels for ``_FusedMLPWide`` / ``_FusedINEdgeWide``: fills ``ctx`` for
+    ``_wide_backward`` and returns the output rows."""
+    ns, nl = spec.n_seg, spec.n_layers
+    segs = [_as_rows(t) for t in tensors[:ns]]
+    weights = [w.contiguous() for w in tensors[ns:ns + nl]]
+    biases = [None if b is None else b.contiguous() for b in tensors[ns + nl:ns + 2 * nl]]
+    res = tensors[ns + 2 * nl] if len(tensors) > ns + 2 * nl else None
+    _capi.require_device(*segs, *weights)
+    lib = _capi.load()
+    a = _capi.MlpFwdArgs()
+    a.mlp = _fill_mlp(weights, biases)
+    if sum(s.shape[1] for s in segs) != a.mlp.in_dim:
+        raise AssertionError(
+            f"Expected feature dimension {a.mlp.in_dim}, got {sum(s.shape[1] for s in segs)}")
+    a.n_seg, a.epilogue, a.n_rows = ns, spec.epilogue, spec.n_rows
+    for j, s in enumerate(segs):
+        a.seg[j] = _capi.Seg(_p(s), _p(spec.idx[j]), s.shape[1], _row_stride(s), int(spec.relu[j]), 0)
+    a.ca, a.cb = spec.ca, spec.cb
+    if spec.epilogue == _capi.EPI_RESIDUAL:
+        res = _as_rows(res)
+        a.res, a.res_stride = _p(res), _row_stride(res)
+    M = spec.n_rows
+    dev = segs[0].device
+    out = torch.empty(M, a.mlp.out_dim, dtype=torch.float32, device=dev)
+    a.out, a.out_stride = _p(out), _row_stride(out)
+    acts = None
+    if needs_grad and M > 0:
+        hp = int(lib.gnntrk_mlp_wide_hidden_pad(a.mlp.hidden))
+        acts = torch.empty(nl - 1, M, hp, dtype=torch.float32, device=dev)
+    ws = _ws(lib.gnntrk_mlp_wide_forward_workspace_bytes(C.byref(a.mlp)), out)
+    _capi.check(lib.gnntrk_mlp_forward_wide(C.byref(a), _p(acts), _p(ws), ws.numel(), _stream(out)), lib)
+    ctx.spec = spec
+    ctx.save_for_backward(acts, out if spec.epilogue == _capi.EPI_RELU else None, *segs, *weights,
+                          *[b for b in biases if b is not None])
+    ctx.bias_mask = [b is not None for b in biases]
+    return out
+
+
+def _wide_backward(ctx, gterms, need):
+    """Backward launch of the wide fp32 kernels.  ``gterms``: up to three ``(rows, index or None)`` upstream
+    gradient terms, summed per row inside the kernel (include/gnntrk.h: gout); ``need``:
+    ``[spec, segs..., W..., b..., res]``.  Returns the gradients in that order."""
+    spec: _MlpSpec = ctx.spec
+    ns, nl = spec.n_seg, spec.n_layers
+    saved = ctx.saved_tensors
+    acts, out = saved[0], saved[1]
+    segs, weights = list(saved[2:2 + ns]), list(saved[2 + ns:2 + ns + nl])
+    bl = list(saved[2 + ns + nl:])
+    biases = [bl.pop(0) if m else None for m in ctx.bias_mask]
+    lib = _capi.load()
+    gterms = [(_as_rows(g.contiguous()), idx) for g, idx in gterms]
+    dev = gterms[0][0].device
+    a = _capi.MlpBwdArgs()
+    a.mlp = _fill_mlp(weights, biases)
+    a.n_seg, a.epilogue, a.n_rows = ns, spec.epilogue, spec.n_rows
+    a.ca, a.cb = spec.ca, spec.cb
+    for j, s in enumerate(segs):
+        a.seg[j] = _capi.Seg(_p(s), _p(spec.idx[j]), s.shape[1], _row_stride(s), int(spec.relu[j]), 0)
+    a.n_gout = len(gterms)
+    for t, (g, idx) in enumerate(gterms):
+        a.gout[t] = _capi.GTerm(_p(g), _p(idx), _row_stride(g), 0)
+    M = spec.n_rows
+    seg_grads: list[Optional[Tensor]] = [None] * ns
+    row_tmp: list[Optional[Tensor]] = [None] * ns
+    for j, s in enumerate(segs):
+        if not need[1 + j]:
+            continue
+        if spec.idx[j] is None:
+            if s.shape[0] != M:
+                raise RuntimeError("identity segments must have n_rows rows")
+            gj = torch.empty(M, s.shape[1], dtype=torch.float32, device=dev)
+            seg_grads[j] = gj
+            a.gseg[j] = _capi.GSeg(_p(gj), None, _row_stride(gj), 0)
+        else:
+            if spec.reduce[j] is None:
+                raise RuntimeError("gathered segment requires a `reduce` rule for backward")
+            tmp = torch.empty(M, s.shape[1], dtype=torch.float32, device=dev)
+            row_tmp[j] = tmp
+            a.gseg[j] = _capi.GSeg(_p(tmp), None, _row_stride(tmp), 0)
+    want_dw = any(need[1 + ns:1 + ns + 2 * nl])
+    gW, gb = [None] * nl, [None] * nl
+    sinks = None
+    if want_dw:
+        sinks = _param_grad_sinks(weights, biases, need[1 + ns:1 + ns + nl],
+                                  [need[1 + ns + nl + i] or biases[i] is None for i in range(nl)])
+        if sinks is not None:
+            gW, gb = sinks
+        else:
+            gW = [torch.empty_like(w) for w in weights]
+            gb = [None if b is None else torch.empty_like(b) for b in biases]
+        for i in range(nl):
+            a.gW[i] = _p(gW[i])
+            a.gb[i] = _p(gb[i])
+    a.accumulate_params = 1 if sinks is not None else 0
+    g0 = gterms[0][0]
+    ws = _ws(lib.gnntrk_mlp_wide_backward_workspace_bytes(C.byref(a.mlp), M), g0)
+    _capi.check(lib.gnntrk_mlp_backward_wide(C.byref(a), _p(acts), _p(out),
+                                             0 if out is None else _row_stride(out), _p(ws), ws.numel(),
+                                             _stream(g0)), lib)
+    for j, s in enumerate(segs):
+        if row_tmp[j] is None:
+            continue
+        if spec.reduce[j] == "perm":
+            if s.shape[0] != M:
+                raise RuntimeError("'perm' segments must cover all source rows")
+            seg_grads[j] = _permute_raw(row_tmp[j], spec.idx[j], scatter=True)
+            continue
+        by, gi = spec.reduce[j]
+        rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
+        seg_grads[j] = _segment_sum_raw(row_tmp[j], rowptr, pos, s.shape[0])
+    g_res = None
+    if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
+        g_res = _axpby_raw(spec.ca, sum_terms(gterms))
+    outs = [None, *seg_grads]
+    if sinks is not None:
+        outs += [None] * (2 * nl)
+    else:
+        outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
+        outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
+    outs.append(g_res)
+    return tuple(outs)
+
+
+def sum_terms(gterms) -> Tensor:
+    """The upstream gradient the kernel sums per row, materialised (only the residual epilogue's pass-through
+    gradient needs it, and that one has a single un-gathered term)."""
+    total = None
+    for g, idx in gterms:
+        rows = g if idx is None else g.index_select(0, idx.long())
+        total = rows if total is None else total + rows
+    return total.contiguous()
+
+
 class _FusedMLPWide(torch.autograd.Function):
     """``_FusedMLP`` on the wide fp32 kernels (csrc/mlp_wide.hip): same spec, same fold rules for gathered
     segments; the forward keeps the hidden layers' pre-activations for the backward."""
 
     @staticmethod
     def forward(ctx, spec: _MlpSpec, *tensors):
-        ns, nl = spec.n_seg, spec.n_layers
-        segs = [_as_rows(t) for t in tensors[:ns]]
-        weights = [w.contiguous() for w in tensors[ns:ns + nl]]
-        biases = [None if b is None else b.contiguous() for b in tensors[ns + nl:ns + 2 * nl]]
-        res = tensors[ns + 2 * nl]
-        _capi.require_device(*segs, *weights)
-        lib = _capi.load()
-        a = _capi.MlpFwdArgs()
-        a.mlp = _fill_mlp(weights, biases)
-        if sum(s.shape[1] for s in segs) != a.mlp.in_dim:
-            raise AssertionError(
-                f"Expected feature dimension {a.mlp.in_dim}, got {sum(s.shape[1] for s in segs)}")
-        a.n_seg, a.epilogue, a.n_rows = ns, spec.epilogue, spec.n_rows
-        for j, s in enumerate(segs):
-            a.seg[j] = _capi.Seg(_p(s), _p(spec.idx[j]), s.shape[1], _row_stride(s), int(spec.relu[j]), 0)
-        a.ca, a.cb = spec.ca, spec.cb
-        if spec.epilogue == _capi.EPI_RESIDUAL:
-            res = _as_rows(res)
-            a.res, a.res_stride = _p(res), _row_stride(res)
-        M = spec.n_rows
-        dev = segs[0].device
-        out = torch.empty(M, a.mlp.out_dim, dtype=torch.float32, device=dev)
-        a.out, a.out_stride = _p(out), _row_stride(out)
-        acts = None
-        if any(ctx.needs_input_grad) and M > 0:
-            hp = int(lib.gnntrk_mlp_wide_hidden_pad(a.mlp.hidden))
-            acts = torch.empty(nl - 1, M, hp, dtype=torch.float32, device=dev)
-        ws = _ws(lib.gnntrk_mlp_wide_forward_workspace_bytes(C.byref(a.mlp)), out)
-        _capi.check(lib.gnntrk_mlp_forward_wide(C.byref(a), _p(acts), _p(ws), ws.numel(), _stream(out)), lib)
-        ctx.spec = spec
-        ctx.save_for_backward(acts, out if spec.epilogue == _capi.EPI_RELU else None, *segs, *weights,
-                              *[b for b in biases if b is not None])
-        ctx.bias_mask = [b is not None for b in biases]
-        return out
+        return _wide_forward(ctx, spec, tensors, any(ctx.needs_input_grad))
 
     @staticmethod
     def backward(ctx, g_out):
-        spec: _MlpSpec = ctx.spec
-        ns, nl = spec.n_seg, spec.n_layers
-        saved = ctx.saved_tensors
-        acts, out = saved[0], saved[1]
-        segs, weights = list(saved[2:2 + ns]), list(saved[2 + ns:2 + ns + nl])
-        bl = list(saved[2 + ns + nl:])
-        biases = [bl.pop(0) if m else None for m in ctx.bias_mask]
-        lib = _capi.load()
-        g_out = _as_rows(g_out.contiguous())
-        dev = g_out.device
-        a = _capi.MlpBwdArgs()
-        a.mlp = _fill_mlp(weights, biases)
-        a.n_seg, a.epilogue, a.n_rows = ns, spec.epilogue, spec.n_rows
-        a.ca, a.cb = spec.ca, spec.cb
-        for j, s in enumerate(segs):
-            a.seg[j] = _capi.Seg(_p(s), _p(spec.idx[j]), s.shape[1], _row_stride(s), int(spec.relu[j]), 0)
-        a.n_gout = 1
-        a.gout[0] = _capi.GTerm(_p(g_out), None, _row_stride(g_out), 0)
-        need = ctx.needs_input_grad  # [spec, segs..., W..., b..., res]
-        M = spec.n_rows
-        seg_grads: list[Optional[Tensor]] = [None] * ns
-        row_tmp: list[Optional[Tensor]] = [None] * ns
-        for j, s in enumerate(segs):
-            if not need[1 + j]:
-                continue
-            if spec.idx[j] is None:
-                if s.shape[0] != M:
-                    raise RuntimeError("identity segments must have n_rows rows")
-                gj = torch.empty(M, s.shape[1], dtype=torch.float32, device=dev)
-                seg_grads[j] = gj
-                a.gseg[j] = _capi.GSeg(_p(gj), None, _row_stride(gj), 0)
-            else:
-                if spec.reduce[j] is None:
-                    raise RuntimeError("gathered segment requires a `reduce` rule for backward")
-                tmp = torch.empty(M, s.shape[1], dtype=torch.float32, device=dev)
-                row_tmp[j] = tmp
-                a.gseg[j] = _capi.GSeg(_p(tmp), None, _row_stride(tmp), 0)
-        want_dw = any(need[1 + ns:1 + ns + 2 * nl])
-        gW, gb = [None] * nl, [None] * nl
-        sinks = None
-        if want_dw:
-            sinks = _param_grad_sinks(weights, biases, need[1 + ns:1 + ns + nl],
-                                      [need[1 + ns + nl + i] or biases[i] is None for i in range(nl)])
-            if sinks is not None:
-                gW, gb = sinks
-            else:
-                gW = [torch.empty_like(w) for w in weights]
-                gb = [None if b is None else torch.empty_like(b) for b in biases]
-            for i in range(nl):
-                a.gW[i] = _p(gW[i])
-                a.gb[i] = _p(gb[i])
-        a.accumulate_params = 1 if sinks is not None else 0
-        ws = _ws(lib.gnntrk_mlp_wide_backward_workspace_bytes(C.byref(a.mlp), M), g_out)
-        _capi.check(lib.gnntrk_mlp_backward_wide(C.byref(a), _p(acts), _p(out),
-                                                 0 if out is None else _row_stride(out), _p(ws), ws.numel(),
-                                                 _stream(g_out)), lib)
-        for j, s in enumerate(segs):
-            if row_tmp[j] is None:
-                continue
-            if spec.reduce[j] == "perm":
-                if s.shape[0] != M:
-                    raise RuntimeError("'perm' segments must cover all source rows")
-                seg_grads[j] = _permute_raw(row_tmp[j], spec.idx[j], scatter=True)
-                continue
-            by, gi = spec.reduce[j]
-            rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
-            seg_grads[j] = _segment_sum_raw(row_tmp[j], rowptr, pos, s.shape[0])
-        g_res = None
-        if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
-            g_res = _axpby_raw(spec.ca, g_out.contiguous())
-        outs = [None, *seg_grads]
-        if sinks is not None:
-            outs += [None] * (2 * nl)
-        else:
-            outs += [gW[i] if need[1 + ns + i] else None for i in range(nl)]
-            outs += [gb[i] if need[1 + ns + nl + i] else None for i in range(nl)]
-        outs.append(g_res)
-        return tuple(outs)
+        return _wide_backward(ctx, [(g_out, None)], ctx.needs_input_grad)
+
+
+class _FusedINEdgeWide(torch.autograd.Function):
+    """Relational model + sum aggregation of one interaction-network layer (interaction_network.py:67-89) as
+    ONE autograd node on the wide fp32 kernels: ``(e~, aggr) = f(segments, params)``.  The backward hands the
+    kernel both upstream terms - ``g_e~[k] + g_aggr[tgt[k]]`` - so the aggregation's gradient is never
+    gathered into an edge-sized tensor (the fp32 twin of ``ops_bf16.FusedINEdge16``)."""
+
+    @staticmethod
+    def forward(ctx, spec: _MlpSpec, gi: GraphIndex, *tensors):
+        e_tilde = _wide_forward(ctx, spec, tensors, any(ctx.needs_input_grad))
+        ctx.gi = gi
+        ctx.set_materialize_grads(False)
+        return e_tilde, _segment_sum_raw(e_tilde, gi.rowptr_t, None, gi.n_nodes)
+
+    @staticmethod
+    def backward(ctx, g_et, g_aggr):
+        gterms = []
+        if g_et is not None:
+            gterms.append((g_et, None))
+        if g_aggr is not None:
+            gterms.append((g_aggr, ctx.gi.tgt))
+        need = ctx.needs_input_grad  # [spec, gi, segs..., W..., b...]
+        if not gterms:
+            return (None,) * len(need)
+        outs = _wide_backward(ctx, gterms, (need[0],) + tuple(need[2:]) + (False,))
+        return (None, None, *outs[1:-1])
+
+
+def in_edge_wide(segs, weights, biases, gi: GraphIndex, n_rows: int):
+    """``(e~, aggr)`` of one interaction-network layer in fp32 on the wide kernels (see _FusedINEdgeWide)."""
+    spec = _MlpSpec(len(segs), len(weights), any(b is not None for b in biases),
+                    [s.idx for s in segs], [s.relu for s in segs], [s.reduce for s in segs],
+                    _capi.EPI_NONE, 0.0, 1.0, None, int(n_rows), int(n_rows))
+    return _FusedINEdgeWide.apply(spec, gi, *[s.t for s in segs], *weights, *biases)
 
 
 class _GatherRows(torch.autograd.Function):

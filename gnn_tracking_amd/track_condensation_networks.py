@@ -185,11 +185,10 @@ class GraphConstructionResIN(nn.Module, HyperparametersMixin):
         """Refinement of a metric-learning latent space with a residual stack of interaction
         networks (models/graph_construction.py:136-219): encoders to ``hidden_dim``, ``ResIN``
         with node and edge width ``hidden_dim``, decoder to ``h_outdim``, mixed with the first
-        ``h_outdim`` input features.  Where ``3 * hidden_dim`` fits the fused kernels' input width
-        (48 features in fp32; 128 slots in bf16 storage, with outputs up to 48 wide where the hidden
-        width is 33 .. 47: the reference's default ``hidden_dim=40``) the interaction networks are the
-        fused kernels; other stacks - the default in fp32 included - run the same operator as library
-        GEMMs (``ops._wide_mlp``)."""
+        ``h_outdim`` input features.  The interaction networks are fused kernels where ``3 * hidden_dim``
+        fits their input width: 128 features in fp32 (csrc/mlp_wide.hip above 48) and 128 slots in bf16
+        storage (outputs up to 48 wide where the hidden width is 33 .. 47) - the reference's default
+        ``hidden_dim=40`` in both; wider stacks run the same operator as library GEMMs (``ops._wide_mlp``)."""
         super().__init__()
         self.save_hyperparameters()
         self._node_encoder = MLP(node_indim, hidden_dim, hidden_dim=hidden_dim, L=2, bias=False)

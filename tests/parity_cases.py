@@ -1064,6 +1064,36 @@ def case_rows_bf16(device):
             assert_close(out.float(), ref.to(torch.bfloat16).float(), TOL16, f"segment_sum16 {by} N={N} D={D}")
 
 
+def case_segment_sum_f32(device):
+    """fp32 CSR segment sums (PyG ``aggr="add"``, interaction_network.py:36): every row-width class of the
+    kernels (scalar, the 4-wide edge rows, 16-byte rows for widths that are multiples of four) against
+    index_add in fp64, both orders, with and without accumulation; the 16-byte kernel and the scalar kernel -
+    reached through a row stride that is not a multiple of four - agree bit for bit."""
+    g = np.random.default_rng(14)
+    for N, E, D in ((1, 0, 4), (7, 20, 5), (300, 4000, 4), (300, 4000, 40), (1000, 9000, 8), (50, 333, 12),
+                    (5, 1, 3), (9, 2, 1), (64, 5000, 48)):
+        ei = tt(g.integers(0, N, size=(2, E)), device).long()
+        gi = ops.graph_index(ei, N, cache=False)
+        wide = tt(g.normal(size=(E, D + 1)).astype(np.float32), device)
+        rows_strided = wide[:, :D]                     # row stride D + 1
+        rows = rows_strided.contiguous()
+        for by in ("tgt", "src"):
+            out = ops.segment_sum(rows, gi, by)
+            node = (gi.tgt if by == "tgt" else gi.src).cpu().long()
+            ref = torch.zeros(N, D, dtype=torch.float64)
+            if E:
+                ref.index_add_(0, node, rows.cpu().double())
+            assert_close(out, ref.float(), TOL_OUT, f"segment_sum {by} N={N} D={D}")
+            rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
+            if E:
+                out_s = ops._segment_sum_raw(rows_strided, rowptr, pos, N)
+                assert torch.equal(out.cpu(), out_s.cpu()), f"row-width classes differ: {by} N={N} D={D}"
+            base = tt(g.normal(size=(N, D)).astype(np.float32), device)
+            acc = base.clone()
+            ops._segment_sum_raw(rows, rowptr, pos, N, out=acc, accumulate=True)
+            assert_close(acc, (base.cpu().double() + ref).float(), TOL_OUT, f"segment_sum accumulate {by} D={D}")
+
+
 def case_hipgraph_capture(device):
     """The training step is capturable as a HIP graph (every gnntrk_* call is stream
     ordered, allocation- and sync-free); a replay reproduces the eager gradients bit for bit."""
@@ -1448,6 +1478,78 @@ def case_mlp_wide(device, rows=(1, 16, 45, 130), shapes=None):
                         assert_close(a.grad, b.grad, TOL_GRAD, tag + f" grad b{i}")
                 if epi == _capi.EPI_RESIDUAL:
                     assert_close(R.grad, Rr.grad, TOL_GRAD, tag + " grad res")
+
+
+def case_in_edge_wide(device, sizes=((60, 700), (9, 1), (300, 4000))):
+    """One interaction-network layer (interaction_network.py:67-89) at the widths of the wide fp32 kernels - the
+    relational model and its sum aggregation as one autograd node (ops.in_edge_wide) - against the same layer
+    in float64 torch: node and edge outputs, and all gradients with the edge embedding read by a second
+    consumer, by the aggregation only, and by neither the aggregation's consumer (upstream terms: both / the
+    gathered one / the direct one)."""
+    from gnn_tracking_amd.interaction_network import InteractionNetwork
+    gen = torch.Generator().manual_seed(21)
+    calls, inner = [], ops.in_edge_wide
+
+    def counted(*a, **k):
+        calls.append(1)
+        return inner(*a, **k)
+    ops.in_edge_wide = counted
+    try:
+        _in_edge_wide_body(device, sizes, gen)
+    finally:
+        ops.in_edge_wide = inner
+    assert len(calls) == 6 * len(sizes), "the fused relational + aggregation node was not the path taken"
+
+
+def _in_edge_wide_body(device, sizes, gen):
+    from gnn_tracking_amd.interaction_network import InteractionNetwork
+    for (N, E), (dn, de, eo, no) in [(sz, w) for sz in sizes for w in ((40, 40, 40, 40), (24, 17, 33, 8))]:
+        net = InteractionNetwork(node_indim=dn, edge_indim=de, node_outdim=no, edge_outdim=eo)
+        ref = InteractionNetwork(node_indim=dn, edge_indim=de, node_outdim=no, edge_outdim=eo).double()
+        ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        net = net.to(device)
+        ei = torch.randint(0, N, (2, E), generator=gen)
+        x0, e0 = torch.randn(N, dn, generator=gen), torch.randn(E, de, generator=gen)
+        rx, re = torch.randn(N, no, generator=gen), torch.randn(E, eo, generator=gen)
+        for use_x, use_e in ((True, True), (True, False), (False, True)):
+            net.zero_grad()
+            ref.zero_grad()
+            x = x0.clone().to(device).requires_grad_(True)
+            e = e0.clone().to(device).requires_grad_(True)
+            ops._WIDE_WARNED.clear()
+            xo, eo_ = net(x, ei.to(device), e)
+            assert not ops._WIDE_WARNED, f"library path taken: {ops._WIDE_WARNED}"
+            xr_in, er_in = x0.clone().double().requires_grad_(True), e0.clone().double().requires_grad_(True)
+            src, tgt = ei[0], ei[1]
+
+            def chain(m, h):   # models/mlp.py:18-62 as torch ops
+                lin = m.linears()
+                for i, l in enumerate(lin):
+                    h = torch.nn.functional.linear(h, l.weight, l.bias)
+                    if i < len(lin) - 1:
+                        h = torch.relu(h)
+                return h
+
+            er = chain(ref.relational_model, torch.cat([xr_in[tgt], xr_in[src], er_in], dim=1))
+            aggr = torch.zeros(N, eo, dtype=torch.float64).index_add(0, tgt, er)
+            xr = chain(ref.object_model, torch.cat([xr_in, aggr], dim=1))
+            tag = f"in_edge_wide N={N} E={E} widths {(dn, de, eo, no)} x {use_x} e {use_e}"
+            assert_close(xo, xr, TOL_OUT, tag + " x~")
+            assert_close(eo_, er, TOL_OUT, tag + " e~")
+            loss = 0
+            loss_r = 0
+            if use_x:
+                loss, loss_r = loss + (xo * rx.to(device)).sum(), loss_r + (xr * rx.double()).sum()
+            if use_e:
+                loss, loss_r = loss + (eo_ * re.to(device)).sum(), loss_r + (er * re.double()).sum()
+            loss.backward()
+            loss_r.backward()
+            assert_close(x.grad, xr_in.grad, TOL_GRAD, tag + " grad x")
+            assert_close(e.grad, er_in.grad, TOL_GRAD, tag + " grad e")
+            pr = dict(ref.named_parameters())
+            for k, v in net.named_parameters():
+                if use_x or k.startswith("relational_model"):
+                    assert_close(v.grad, pr[k].grad, TOL_GRAD, tag + f" grad {k}")
 
 
 class _IndexReduce(tuple):

@@ -111,6 +111,16 @@ def test_mlp_wide_emulated():
         P.case_mlp_wide("cpu", rows=(1, 45))
 
 
+def test_in_edge_wide_emulated():
+    with emulated():
+        P.case_in_edge_wide("cpu", sizes=((60, 700), (9, 1)))
+
+
+def test_segment_sum_f32_emulated():
+    with emulated():
+        P.case_segment_sum_f32("cpu")
+
+
 def test_hetero_fcnn_emulated():
     with emulated():
         P.case_hetero_fcnn("cpu")

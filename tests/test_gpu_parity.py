@@ -173,6 +173,14 @@ def test_mlp_wide(dev):
     P.case_mlp_wide(dev)
 
 
+def test_segment_sum_f32(dev):
+    P.case_segment_sum_f32(dev)
+
+
+def test_in_edge_wide(dev):
+    P.case_in_edge_wide(dev)
+
+
 def test_hetero_fcnn(dev):
     P.case_hetero_fcnn(dev)
 

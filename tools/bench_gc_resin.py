@@ -19,7 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--hits", type=int, default=200_000)
 ap.add_argument("--edges", type=int, default=3_000_000)
 ap.add_argument("--steps", type=int, default=5)
-ap.add_argument("--mode", default="all", choices=("all", "fused", "library", "fp32"))
+ap.add_argument("--mode", default="all", choices=("all", "fused", "library", "fp32", "fp32w"))
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 ev = synthetic.make_event(7, args.hits, args.edges, dev)
@@ -63,8 +63,9 @@ if args.mode in ("all", "fused"):
     run("bf16 storage, fused kernels", True)
 if args.mode in ("all", "library"):
     run("bf16 storage, library GEMMs (before)", True, old_rule)
-if args.mode in ("all", "fp32"):
+if args.mode in ("all", "fp32", "fp32w"):
     run("fp32, wide fused kernels (mlp_wide)", False)
+if args.mode in ("all", "fp32"):
     ops._WIDE_KERNEL = False
     try:
         run("fp32, library GEMMs (before round 4)", False)

@@ -44,7 +44,18 @@ constexpr int kSortTpb = 512;
 constexpr int kSortR = 10;              // records a thread of the bucket sort holds in registers
 constexpr int kCap = kSortTpb * kSortR; // records of a bucket the bucket sort holds in LDS (5120)
 constexpr int kWin = 4096;              // bucket counters a chunk holds in LDS
-constexpr int kSplitTpb = 1024;
+// One split workgroup of 1024 lanes per CU.  Two resident workgroups (768 lanes at <= 85 registers) measured
+// SLOWER (split by target 1.18 against 1.12 ms, by source 0.38 against 0.33): the open (bucket, chunk) runs of
+// the resident chunks - about 600 partially written lines per chunk and output array - then no longer fit an
+// XCD's 4 MB L2, and the runs leave it in pieces.
+#ifndef GNNTRK_GI_SPLIT_TPB
+#define GNNTRK_GI_SPLIT_TPB 1024
+#endif
+#ifndef GNNTRK_GI_SPLIT_WG
+#define GNNTRK_GI_SPLIT_WG 1
+#endif
+constexpr int kSplitTpb = GNNTRK_GI_SPLIT_TPB;
+constexpr int kCountTpb = 1024;
 constexpr int kSplitR = 4;              // edges per thread and tile of the split
 constexpr int kSplitTile = kSplitTpb * kSplitR;
 constexpr int kMaxChunks = 512;
@@ -64,7 +75,7 @@ struct KeysCoo {
     __device__ __forceinline__ uint32_t key(int64_t e, int *bad) const {
         int64_t v = tgt[e];
         if (v < 0 || v >= N) {
-            atomicAdd(bad, 1);
+            if (bad) atomicAdd(bad, 1);
             v = v < 0 ? 0 : N - 1;
         }
         return (uint32_t)v;
@@ -72,7 +83,7 @@ struct KeysCoo {
     __device__ __forceinline__ uint32_t payload(int64_t e, int *bad) const {
         int64_t v = src[e];
         if (v < 0 || v >= N) {
-            atomicAdd(bad, 1);
+            if (bad) atomicAdd(bad, 1);
             v = v < 0 ? 0 : N - 1;
         }
         return (uint32_t)v;
@@ -84,6 +95,75 @@ struct KeysCoo {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(rows + e * rows_stride);
         return uint2{bf16x2_pack(v[0], v[1]), bf16x2_pack(v[2], v[3])};
     }
+    // four consecutive edges e .. e + 3 of one lane (e a multiple of four): with `vec` (16-byte aligned id rows,
+    // 4-byte aligned labels) the ids come as 16-byte loads - 8-byte-per-lane streams top out near 3 TB/s here
+    int vec;
+    __device__ __forceinline__ uint32_t checked(int64_t v, int *bad) const {
+        if (v < 0 || v >= N) {
+            if (bad) atomicAdd(bad, 1);
+            v = v < 0 ? 0 : N - 1;
+        }
+        return (uint32_t)v;
+    }
+    __device__ __forceinline__ void keys4(int64_t e, int64_t e1, uint32_t k[4], int *bad) const {
+        if (vec && e + 4 <= e1) {
+            const longlong2 a = *reinterpret_cast<const longlong2 *>(tgt + e);
+            const longlong2 b = *reinterpret_cast<const longlong2 *>(tgt + e + 2);
+            k[0] = checked(a.x, bad);
+            k[1] = checked(a.y, bad);
+            k[2] = checked(b.x, bad);
+            k[3] = checked(b.y, bad);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) k[q] = e + q < e1 ? key(e + q, bad) : 0u;
+        }
+    }
+    // the split holds the NEXT tile's ids as loaded (converted only when their tile starts: a conversion at the
+    // load would wait for it on the spot)
+    struct Raw {
+        longlong2 ta, tb, sa, sb;
+        uint32_t l4;
+    };
+    __device__ __forceinline__ void load_raw(int64_t e, int64_t e1, Raw &r) const {
+        if (vec && e + 4 <= e1) {
+            r.ta = *reinterpret_cast<const longlong2 *>(tgt + e);
+            r.tb = *reinterpret_cast<const longlong2 *>(tgt + e + 2);
+            r.sa = *reinterpret_cast<const longlong2 *>(src + e);
+            r.sb = *reinterpret_cast<const longlong2 *>(src + e + 2);
+            r.l4 = label ? *reinterpret_cast<const uint32_t *>(label + e) : 0u;
+        } else {
+            long long t[4], u[4];
+            r.l4 = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = e + q < e1;
+                t[q] = in ? tgt[e + q] : 0;
+                u[q] = in ? src[e + q] : 0;
+                if (in && label && label[e + q]) r.l4 |= 1u << (8 * q);
+            }
+            r.ta = longlong2{t[0], t[1]};
+            r.tb = longlong2{t[2], t[3]};
+            r.sa = longlong2{u[0], u[1]};
+            r.sb = longlong2{u[2], u[3]};
+        }
+    }
+    // (ids out of range: the targets were counted by step 1, the sources are counted here)
+    __device__ __forceinline__ void decode(const Raw &r, int64_t e, uint32_t k[4], uint32_t p[4], uint32_t v[4],
+                                           int *bad) const {
+        k[0] = checked(r.ta.x, nullptr);
+        k[1] = checked(r.ta.y, nullptr);
+        k[2] = checked(r.tb.x, nullptr);
+        k[3] = checked(r.tb.y, nullptr);
+        p[0] = checked(r.sa.x, bad);
+        p[1] = checked(r.sa.y, bad);
+        p[2] = checked(r.sb.x, bad);
+        p[3] = checked(r.sb.y, bad);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (uint32_t)(e + q) | (((r.l4 >> (8 * q)) & 0xffu) ? 0x80000000u : 0u);
+    }
+    __device__ __forceinline__ f32x4 row_raw(int64_t e) const {
+        return *reinterpret_cast<const f32x4 *>(rows + e * rows_stride);
+    }
 };
 // second sort: key = source of the CSR-ordered list (already validated), value = CSR position
 struct KeysCsr {
@@ -92,6 +172,41 @@ struct KeysCsr {
     __device__ __forceinline__ uint32_t payload(int64_t, int *) const { return 0u; }
     __device__ __forceinline__ uint32_t value(int64_t e) const { return (uint32_t)e; }
     __device__ __forceinline__ uint2 row(int64_t) const { return uint2{0u, 0u}; }
+    __device__ __forceinline__ void keys4(int64_t e, int64_t e1, uint32_t k[4], int *) const {
+        if (e + 4 <= e1) {   // (the CSR list is an own 16-byte aligned array; e is a multiple of four)
+            const int4 a = *reinterpret_cast<const int4 *>(src + e);
+            k[0] = (uint32_t)a.x;
+            k[1] = (uint32_t)a.y;
+            k[2] = (uint32_t)a.z;
+            k[3] = (uint32_t)a.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) k[q] = e + q < e1 ? (uint32_t)src[e + q] : 0u;
+        }
+    }
+    struct Raw {
+        int4 a;
+    };
+    __device__ __forceinline__ void load_raw(int64_t e, int64_t e1, Raw &r) const {
+        if (e + 4 <= e1) {
+            r.a = *reinterpret_cast<const int4 *>(src + e);
+        } else {
+            r.a = int4{e < e1 ? src[e] : 0, e + 1 < e1 ? src[e + 1] : 0, e + 2 < e1 ? src[e + 2] : 0, 0};
+        }
+    }
+    __device__ __forceinline__ void decode(const Raw &r, int64_t e, uint32_t k[4], uint32_t p[4], uint32_t v[4],
+                                           int *) const {
+        k[0] = (uint32_t)r.a.x;
+        k[1] = (uint32_t)r.a.y;
+        k[2] = (uint32_t)r.a.z;
+        k[3] = (uint32_t)r.a.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p[q] = 0u;
+            v[q] = (uint32_t)(e + q);
+        }
+    }
+    __device__ __forceinline__ f32x4 row_raw(int64_t) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 };
 
 // The LDS window of a chunk starts a third of its width below the bucket of the chunk's first id: a
@@ -104,32 +219,37 @@ __device__ __forceinline__ int gi_window_start(uint32_t first_key) {
 // step 1.  tbl[bucket * n_chunks + chunk] = edges of the chunk in the bucket (tbl zeroed before);
 // range[chunk] = (first, last) touched window slot
 template <class K>
-__global__ __launch_bounds__(kSplitTpb) void gi_count_kernel(K keys, int64_t E, int chunk, int n_chunks, int NB,
+__global__ __launch_bounds__(kCountTpb) void gi_count_kernel(K keys, int64_t E, int chunk, int n_chunks, int NB,
                                                              uint32_t *__restrict__ tbl, int2 *__restrict__ range,
                                                              int *__restrict__ bad) {
     __shared__ uint32_t s_cnt[kWin];
     __shared__ int s_lo, s_hi;
     const int tid = threadIdx.x, c = blockIdx.x;
     const int64_t e0 = (int64_t)c * chunk, e1 = e0 + chunk < E ? e0 + chunk : E;
-    for (int d = tid; d < kWin; d += kSplitTpb) s_cnt[d] = 0;
+    for (int d = tid; d < kWin; d += kCountTpb) s_cnt[d] = 0;
     if (tid == 0) {
         s_lo = kWin;
         s_hi = -1;
     }
     __syncthreads();
-    int nobad = 0;
-    const int w0 = gi_window_start(keys.key(e0, &nobad));   // (e0 is counted below)
-    for (int64_t e = e0 + tid; e < e1; e += kSplitTpb) {
-        const uint32_t b = keys.key(e, bad) >> kSH;
-        const uint32_t d = b - (uint32_t)w0;
-        if (d < (uint32_t)kWin)
-            atomicAdd(&s_cnt[d], 1u);
-        else
-            atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u);
+    const int w0 = gi_window_start(keys.key(e0, nullptr));   // (e0 is counted below)
+    for (int64_t e = e0 + 4 * tid; e < e1; e += 4 * kCountTpb) {
+        uint32_t k4[4];
+        keys.keys4(e, e1, k4, bad);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (e + q >= e1) break;
+            const uint32_t b = k4[q] >> kSH;
+            const uint32_t d = b - (uint32_t)w0;
+            if (d < (uint32_t)kWin)
+                atomicAdd(&s_cnt[d], 1u);
+            else
+                atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u);
+        }
     }
     __syncthreads();
     int lo = kWin, hi = -1;
-    for (int d = tid; d < kWin; d += kSplitTpb) {
+    for (int d = tid; d < kWin; d += kCountTpb) {
         const uint32_t v = s_cnt[d];
         if (v) {
             tbl[(size_t)(w0 + d) * n_chunks + c] = v;
@@ -280,7 +400,7 @@ __device__ __forceinline__ uint32_t gi_block_exscan(uint32_t v, uint32_t *s_wsum
 // with consecutive lanes on consecutive records of a run: the stores coalesce.  ROWS: the
 // caller's per-edge rows (four floats -> four bf16) take the same way into part_rows[pos].
 template <class K, bool ROWS>
-__global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, int chunk, int n_chunks, int pbits,
+__global__ __launch_bounds__(kSplitTpb, GNNTRK_GI_SPLIT_WG * kSplitTpb / 256) void gi_split_kernel(K keys, int64_t E, int chunk, int n_chunks, int pbits,
                                                              uint32_t *__restrict__ tbl,
                                                              const int2 *__restrict__ range,
                                                              uint2 *__restrict__ part, uint2 *__restrict__ part_rows,
@@ -292,8 +412,7 @@ __global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, 
     __shared__ uint32_t s_wsum[kSplitTpb / 64];
     const int tid = threadIdx.x, c = blockIdx.x;
     const int64_t e0 = (int64_t)c * chunk, e1 = e0 + chunk < E ? e0 + chunk : E;
-    int nobad = 0;
-    const int w0 = gi_window_start(keys.key(e0, &nobad));
+    const int w0 = gi_window_start(keys.key(e0, nullptr));
     const int2 r = range[c];
     const int n_r = r.y >= r.x ? r.y - r.x + 1 : 0;         // touched window slots
     const int per = (n_r + kSplitTpb - 1) / kSplitTpb;      // ... per thread in the scans (1 for a collated batch)
@@ -302,53 +421,54 @@ __global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, 
         s_cnt[d] = 0;
     }
     __syncthreads();
-    // the next tile's keys / payloads are loaded while the current tile goes through its LDS phases
-    uint32_t nk[kSplitR], np[kSplitR], nv[kSplitR];
-    uint2 nr[ROWS ? kSplitR : 1];
-    auto prefetch = [&](int64_t t0) {
-#pragma unroll
-        for (int q = 0; q < kSplitR; ++q) {
-            const int64_t e = t0 + (int64_t)q * kSplitTpb + tid;
-            const bool in = e < e1;
-            nk[q] = in ? keys.key(e, &nobad) : 0u;
-            np[q] = in ? keys.payload(e, bad) : 0u;
-            nv[q] = in ? keys.value(e) : 0u;
-            if (ROWS) nr[q] = in ? keys.row(e) : uint2{0u, 0u};
-        }
-    };
-    prefetch(e0);
+    // the next tile's ids are loaded while the current tile goes through its LDS phases; the carried rows of
+    // the current tile are loaded at its start and used in its last phase
+    static_assert(kSplitR == 4, "a lane takes four consecutive edges of a tile");
+    typename K::Raw nraw;
+    keys.load_raw(e0 + 4 * tid, e1, nraw);
     for (int64_t t0 = e0; t0 < e1; t0 += kSplitTile) {
-        uint2 rec[kSplitR], row[ROWS ? kSplitR : 1];
+        uint2 rec[kSplitR];
+        f32x4 rraw[ROWS ? kSplitR : 1];
         uint32_t slot[kSplitR], rk[kSplitR];
+        const int64_t et = t0 + 4 * tid;
+        {
+            uint32_t nk[kSplitR], np[kSplitR], nv[kSplitR];
+            keys.decode(nraw, et, nk, np, nv, bad);
+            keys.load_raw(et + kSplitTile, e1, nraw);
 #pragma unroll
-        for (int q = 0; q < kSplitR; ++q) {
-            const int64_t e = t0 + (int64_t)q * kSplitTpb + tid;
-            slot[q] = 0xffffffffu;
-            if (ROWS) row[q] = nr[q];
-            if (e < e1) {
-                const uint32_t v = nk[q], pl = np[q];
-                const uint32_t b = v >> kSH, low = v & (kBins - 1);
-                const uint32_t d = b - (uint32_t)w0;
-                rec[q] = uint2{nv[q], (low << pbits) | pl};
-                if (d < (uint32_t)kWin) {
-                    slot[q] = d;
-                    rk[q] = atomicAdd(&s_cnt[d], 1u);
-                } else {   // outside the chunk's LDS window: cursor in the table itself, direct stores
-                    const uint32_t pos = atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u);
-                    part[pos] = rec[q];
-                    if (ROWS) part_rows[pos] = row[q];
+            for (int q = 0; q < kSplitR; ++q) {
+                const int64_t e = et + q;
+                slot[q] = 0xffffffffu;
+                if (ROWS) rraw[q] = e < e1 ? keys.row_raw(e) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e < e1) {
+                    const uint32_t v = nk[q], pl = np[q];
+                    const uint32_t b = v >> kSH, low = v & (kBins - 1);
+                    const uint32_t d = b - (uint32_t)w0;
+                    rec[q] = uint2{nv[q], (low << pbits) | pl};
+                    if (d < (uint32_t)kWin) {
+                        slot[q] = d;
+                        rk[q] = atomicAdd(&s_cnt[d], 1u);
+                    } else {   // outside the chunk's LDS window: cursor in the table itself, direct stores
+                        const uint32_t pos = atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u);
+                        part[pos] = rec[q];
+                        if (ROWS) {
+                            const f32x4 rv = rraw[q];
+                            part_rows[pos] = uint2{bf16x2_pack(rv[0], rv[1]), bf16x2_pack(rv[2], rv[3])};
+                        }
+                    }
                 }
             }
         }
-        prefetch(t0 + kSplitTile);
         __syncthreads();
         // tile-local starts: exclusive scan of the counts over the touched range
         const int d0 = r.x + tid * per;
         uint32_t mine = 0;
+#pragma unroll 1
         for (int i = 0; i < per; ++i)
             if (d0 + i <= r.y) mine += s_cnt[d0 + i];
         uint32_t tile_n;
         uint32_t run = gi_block_exscan(mine, s_wsum, &tile_n);
+#pragma unroll 1
         for (int i = 0; i < per; ++i)
             if (d0 + i <= r.y) {
                 const uint32_t cn = s_cnt[d0 + i];
@@ -373,7 +493,10 @@ __global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, 
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < kSplitR; ++q)
-                if (slot[q] != 0xffffffffu) s_stage[sp[q]] = row[q];
+                if (slot[q] != 0xffffffffu) {
+                    const f32x4 rv = rraw[q];
+                    s_stage[sp[q]] = uint2{bf16x2_pack(rv[0], rv[1]), bf16x2_pack(rv[2], rv[3])};
+                }
             __syncthreads();
             for (uint32_t j = tid; j < tile_n; j += kSplitTpb) {
                 const uint32_t d = s_slot[j];
@@ -383,12 +506,14 @@ __global__ __launch_bounds__(kSplitTpb) void gi_split_kernel(K keys, int64_t E, 
         __syncthreads();
         // advance the run cursors by the tile's counts (count = next start - own start; the last
         // touched entry ends at tile_n), then clear the counters for the next tile
+#pragma unroll 1
         for (int i = 0; i < per; ++i)
             if (d0 + i <= r.y) {
                 const int d = d0 + i;
                 s_off[d] += (d == r.y ? tile_n : s_cnt[d + 1]) - s_cnt[d];
             }
         __syncthreads();
+#pragma unroll 1
         for (int i = 0; i < per; ++i)
             if (d0 + i <= r.y) s_cnt[d0 + i] = 0;
         __syncthreads();
@@ -488,13 +613,36 @@ __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *_
                 if (O::kPos) s_pos[sl] = (uint16_t)(tid + q * kSortTpb);
             }
         __syncthreads();
+        // rank every record inside its node's list, then bring the image into the final order in place, so
+        // that the arrays leave with consecutive lanes on consecutive positions (a wave's store touches a few
+        // lines instead of up to 64)
+        uint32_t dst[kSortR];
+        uint16_t ps[O::kPos ? kSortR : 1];
+#pragma unroll
+        for (int q = 0; q < kSortR; ++q) {
+            const uint32_t j = tid + q * kSortTpb;
+            if (j < M) {
+                const uint2 r = s_rec[j];
+                const uint32_t low = r.y >> pbits, st = s_start[low], n = s_hist[low];
+                uint32_t cnt = 0;
+                for (uint32_t t = 0; t < n; ++t) cnt += (s_rec[st + t].x & VM) < (r.x & VM) ? 1u : 0u;
+                rec[q] = r;
+                dst[q] = st + cnt;
+                if (O::kPos) ps[q] = s_pos[j];
+                out.slot(base + j, node0 + low);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kSortR; ++q)
+            if (tid + q * kSortTpb < M) {
+                s_rec[dst[q]] = rec[q];
+                if (O::kPos) s_pos[dst[q]] = ps[q];
+            }
+        __syncthreads();
         for (uint32_t j = tid; j < M; j += kSortTpb) {
             const uint2 r = s_rec[j];
-            const uint32_t low = r.y >> pbits, st = s_start[low], n = s_hist[low];
-            uint32_t cnt = 0;
-            for (uint32_t t = 0; t < n; ++t) cnt += (s_rec[st + t].x & VM) < (r.x & VM) ? 1u : 0u;
-            out.ranked(base + st + cnt, r.x, r.y, base + (O::kPos ? (uint32_t)s_pos[j] : 0u));
-            out.slot(base + j, node0 + low);
+            out.ranked(base + j, r.x, r.y, base + (O::kPos ? (uint32_t)s_pos[j] : 0u));
         }
     } else {
         // a bucket beyond the LDS capacity: groups of consecutive nodes whose lists fit are taken one
@@ -586,7 +734,7 @@ static OwnPlan own_plan(int64_t N, int64_t E, bool rows) {
     int nc = (int)ceil_div(E, 16384);
     if (nc > kMaxChunks) nc = kMaxChunks;
     int64_t chunk = ceil_div(E, nc);
-    chunk = ceil_div(chunk, kSplitTpb) * kSplitTpb;
+    chunk = ceil_div(chunk, 4) * 4;   // (a lane of the count / split kernels takes four consecutive edges)
     p.chunk = (int)chunk;
     p.n_chunks = (int)ceil_div(E, chunk);
     p.T = (int64_t)p.NB * p.n_chunks;
@@ -621,7 +769,7 @@ static int own_sort(const OwnPlan &p, K keys, O out, int pbits, int64_t N, int64
     uint2 *part = reinterpret_cast<uint2 *>(ws + p.off_part);
     int rc = check_hip(hipMemsetAsync(tbl, 0, (size_t)(p.T + 1) * 4, stream), "graph_index_build(memset)");
     if (rc) return rc;
-    hipLaunchKernelGGL((gi_count_kernel<K>), dim3(p.n_chunks), dim3(kSplitTpb), 0, stream, keys, E, p.chunk,
+    hipLaunchKernelGGL((gi_count_kernel<K>), dim3(p.n_chunks), dim3(kCountTpb), 0, stream, keys, E, p.chunk,
                        p.n_chunks, p.NB, tbl, range, bad);
     hipLaunchKernelGGL(gi_scan_sums_kernel, dim3(p.n_tiles), dim3(kScanTpb), 0, stream, tbl, p.T + 1, sums);
     hipLaunchKernelGGL(gi_scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, sums, p.n_tiles);
@@ -774,7 +922,9 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, co
     if (E > 0) {
         const OwnPlan plan = own_plan(N, E, rows != nullptr);
         if (plan.ok && !(flags & 1) && (!plan.dense || (flags & 2))) {
-            const KeysCoo k1{edge_index, edge_index + E, N, label, rows, rows ? cy->rows_stride : 0};
+            const int vec = (((uintptr_t)edge_index | (uintptr_t)(edge_index + E)) & 15) == 0 &&
+                            (!label || ((uintptr_t)label & 3) == 0);
+            const KeysCoo k1{edge_index, edge_index + E, N, label, rows, rows ? cy->rows_stride : 0, vec};
             const uint32_t pmask = (uint32_t)(((uint64_t)1 << plan.bitsN) - 1);
             if (rows) {
                 const OutCsr<true> o1{o->perm, o->tgt, o->src, o->rowptr_t, pmask, label ? cy->label_csr : nullptr,

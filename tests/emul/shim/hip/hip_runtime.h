@@ -95,6 +95,9 @@ struct uint2 {
 struct uint4 {
     unsigned x, y, z, w;
 };
+struct longlong2 {
+    long long x, y;
+};
 inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
 
 // ------------------------------------------------------------- execution model

@@ -559,8 +559,23 @@ struct IoEncoder8 {
     static constexpr BufOpShape store[1] = {};
 };
 
+// Waves per workgroup of the buffer-addressed backward kernels (the hot shapes).  A workgroup is one fragment image
+// + one staging image per wave (9.2 KB with D = 2): four waves (60 KB) give two workgroups = 2 waves per SIMD on
+// a CU; six waves (79 KB) would still be two workgroups = 3 waves per SIMD - but the kernels hold about 250
+// registers (112 + accumulators), and at the 168 of three waves per SIMD they spill 33 (relational) / 83 (head)
+// registers into the tile loop: measured 6.76 against 2.88 ms and 9.88 against 3.67 ms per 64 M rows (round 4,
+// tools/bench_bwd_io.py).  The occupancy of these kernels is set by registers AND LDS; the switch stays for A/B.
+#ifndef GNNTRK_BWD16_BUF_WAVES
+#define GNNTRK_BWD16_BUF_WAVES 4
+#endif
+constexpr int kBwd16BufWaves = GNNTRK_BWD16_BUF_WAVES;
+template <class IO>
+__host__ __device__ constexpr int bwd16_block_waves() {
+    return IO::NL > 0 ? kBwd16BufWaves : kWaves;
+}
+
 template <int KI, int HT, int GT, bool THREE, bool G32, int D_, class IO_ = IoNone>
-__global__ __launch_bounds__(kBlock, HT >= 5 ? 1 : 2) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
+__global__ __launch_bounds__(64 * bwd16_block_waves<IO_>(), HT >= 5 ? 1 : (2 * bwd16_block_waves<IO_>() + 3) / 4) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                                            uint8_t *trash, const BufPlan bp) {
     constexpr int D = D_, OT = 1;
     using IO = IO_;
@@ -812,9 +827,12 @@ inline const char *buf_io_name(const BufPlan &B, int KI, int HT, int GT, bool th
 }
 
 // launches the backward instantiation for (plan, GT, three); G32 = fp32 upstream gradient
+// (grid: workgroups of kWaves waves; grid_buf: of kBwd16BufWaves waves - what the buffer-addressed kernels take;
+// *waves_used: the waves per workgroup of the launch, i.e. grid * waves partial blocks unless reduced in LDS)
 template <bool G32>
-int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, float *part,
-                 uint8_t *trash, hipStream_t stream) {
+int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, int grid_buf, int *waves_used,
+                 float *part, uint8_t *trash, hipStream_t stream) {
+    *waves_used = kWaves;
     const bool three = a->mlp.n_layers == 3;
     bool launched = false;
     BufPlan B;
@@ -867,7 +885,8 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
 #define GNNTRK_BWD16_BUF(HT_, GT_, T_, IO_)                                                           \
     if (!launched && P.HT == HT_ && strcmp(io, #IO_) == 0) {                                          \
         auto kfn = mlp16_bwd_kernel<1, HT_, GT_, T_, G32, 2, IO_>;                                    \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a, part, trash, B);             \
+        hipLaunchKernelGGL(kfn, dim3(grid_buf), dim3(64 * kBwd16BufWaves), 0, stream, *a, part, trash, B); \
+        *waves_used = kBwd16BufWaves;                                                                 \
         launched = true;                                                                              \
     }
         if constexpr (G32) {

@@ -6,7 +6,7 @@
 
 namespace gnntrk {
 
-int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, int grid_buf, int *waves_used, float *part,
+int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, int grid_buf, int *used, float *part,
                      uint8_t *trash, hipStream_t stream);  // mlp_bf16_g32.hip
 
 
@@ -126,20 +126,21 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     // gradient M tiles: 1 or the maximum of the k-step count (keeps the instantiation list short)
     const bool wide_io = a->mlp.out_dim > 16 || P.KI > 2;   // output tiles / wide inputs: every gradient tile
     const int GT = wide_io ? 2 * P.KI : (P.GT == 0 && P.KI == 1) ? 0 : (P.GT <= 1) ? 1 : 2 * P.KI;  // 0: no input gradient wanted
-    int grid = 0, waves = kWaves;
+    int grid = 0, waves = kWaves, used[2] = {0, kWaves};
     if (a->n_rows > 0) {
         // (five / six hidden tiles: one workgroup per CU is resident - its share of the rows is simply larger)
         const int per_cu = (P.HT >= 5 || wide_io || (P.bias_init && P.KI >= 2)) ? 1 : (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu;
         grid = grid16(a->n_rows, per_cu, kWaves);
         // (the buffer-addressed kernels: workgroups of kBwd16BufWaves waves, two resident per CU)
-        const int grid_buf = grid16(a->n_rows, per_cu < kBwd16BlocksPerCu ? per_cu : kBwd16BlocksPerCu, kBwd16BufWaves);
+        const int grid_buf = grid16(a->n_rows, (kBwd16BufWaves == kWaves || per_cu < kBwd16BlocksPerCu) ? per_cu : kBwd16BlocksPerCu, kBwd16BufWaves);
         float *part = reinterpret_cast<float *>(ws);
         uint8_t *trash = reinterpret_cast<uint8_t *>(ws) + bwd16_partial_bytes(&a->mlp);
         rc = (a->epilogue == GNNTRK_EPI_SIGMOID)
-                 ? launch_bwd16_g32(a, P, GT, grid, grid_buf, &waves, part, trash, stream)
-                 : launch_bwd16<false>(a, P, GT, grid, grid_buf, &waves, part, trash, stream);
+                 ? launch_bwd16_g32(a, P, GT, grid, grid_buf, used, part, trash, stream)
+                 : launch_bwd16<false>(a, P, GT, grid, grid_buf, used, part, trash, stream);
         if (rc) return rc;
-        if (waves == kBwd16BufWaves) grid = grid_buf;
+        grid = used[0];
+        waves = used[1];
     }
     if (want_dw) {
         // one partial block per workgroup when the parameters fit the kernel's LDS image

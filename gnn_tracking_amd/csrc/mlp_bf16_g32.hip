@@ -5,9 +5,9 @@
 
 namespace gnntrk {
 
-int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, int grid_buf, int *waves_used,
+int launch_bwd16_g32(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, int grid_buf, int *used,
                      float *part, uint8_t *trash, hipStream_t stream) {
-    return launch_bwd16<true>(a, P, GT, grid, grid_buf, waves_used, part, trash, stream);
+    return launch_bwd16<true>(a, P, GT, grid, grid_buf, used, part, trash, stream);
 }
 
 }  // namespace gnntrk

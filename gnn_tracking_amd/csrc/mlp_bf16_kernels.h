@@ -561,8 +561,8 @@ struct IoEncoder8 {
 
 // Waves per workgroup of the buffer-addressed backward kernels (the hot shapes).  A workgroup is one fragment image
 // + one staging image per wave (9.2 KB with D = 2): four waves (60 KB) give two workgroups = 2 waves per SIMD on
-// a CU; six waves (79 KB) would still be two workgroups = 3 waves per SIMD - but the kernels hold about 250
-// registers (112 + accumulators), and at the 168 of three waves per SIMD they spill 33 (relational) / 83 (head)
+// a CU; six waves (79 KB) would still be two workgroups = 3 waves per SIMD - but the kernels hold 202 - 206
+// registers, and at the 168 of three waves per SIMD they spill 33 (relational) / 83 (head)
 // registers into the tile loop: measured 6.76 against 2.88 ms and 9.88 against 3.67 ms per 64 M rows (round 4,
 // tools/bench_bwd_io.py).  The occupancy of these kernels is set by registers AND LDS; the switch stays for A/B.
 #ifndef GNNTRK_BWD16_BUF_WAVES
@@ -828,11 +828,12 @@ inline const char *buf_io_name(const BufPlan &B, int KI, int HT, int GT, bool th
 
 // launches the backward instantiation for (plan, GT, three); G32 = fp32 upstream gradient
 // (grid: workgroups of kWaves waves; grid_buf: of kBwd16BufWaves waves - what the buffer-addressed kernels take;
-// *waves_used: the waves per workgroup of the launch, i.e. grid * waves partial blocks unless reduced in LDS)
+// *used = {workgroups, waves per workgroup} of the launch: grid * waves partial blocks unless reduced in LDS)
 template <bool G32>
-int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, int grid_buf, int *waves_used,
+int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int grid, int grid_buf, int *used,
                  float *part, uint8_t *trash, hipStream_t stream) {
-    *waves_used = kWaves;
+    used[0] = grid;
+    used[1] = kWaves;
     const bool three = a->mlp.n_layers == 3;
     bool launched = false;
     BufPlan B;
@@ -886,7 +887,8 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     if (!launched && P.HT == HT_ && strcmp(io, #IO_) == 0) {                                          \
         auto kfn = mlp16_bwd_kernel<1, HT_, GT_, T_, G32, 2, IO_>;                                    \
         hipLaunchKernelGGL(kfn, dim3(grid_buf), dim3(64 * kBwd16BufWaves), 0, stream, *a, part, trash, B); \
-        *waves_used = kBwd16BufWaves;                                                                 \
+        used[0] = grid_buf;                                                                           \
+        used[1] = kBwd16BufWaves;                                                                     \
         launched = true;                                                                              \
     }
         if constexpr (G32) {

@@ -80,6 +80,24 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
         if (WIDE && NCH == 2) {
             // two rows per step: both 16-byte loads are in flight before the first is used (the walk
             // is latency bound: ~13 rows per segment over four lanes); same order of the additions
+            // four rows per step first (16 rows of a segment across the four lanes: the mean degree of the
+            // default graphs in one round of loads), then two, then one
+            for (; k + 12 < k1; k += 16) {
+                int64_t r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = pos ? (int64_t)pos[k + 4 * u] : (int64_t)(k + 4 * u);
+                u32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4 *>(rows + r[u] * row_stride);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        s[2 * w + 0] += bf16_lo(v[u][w]);
+                        s[2 * w + 1] += bf16_hi(v[u][w]);
+                    }
+                }
+            }
             for (; k + 4 < k1; k += 8) {
                 const int64_t ra = pos ? (int64_t)pos[k] : (int64_t)k, rb = pos ? (int64_t)pos[k + 4] : (int64_t)(k + 4);
                 const u32x4 va = *reinterpret_cast<const u32x4 *>(rows + ra * row_stride);
@@ -156,15 +174,18 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_pair8_kernel(
         const int32_t k0 = on ? rowptr[n] : 0, k1 = on ? rowptr[n + 1] : 0;
         if (k1 > k0) {
             const int32_t p1 = (k1 - 1) >> 1;
-            for (int32_t p = (k0 >> 1) + j; p <= p1; p += 4) {
-                const int32_t r = 2 * p;
+            auto load_pair = [&](int32_t p) {
                 u32x4 v;
-                if (r + 1 < n_rows) {
+                if (2 * p + 1 < n_rows) {
                     v = *reinterpret_cast<const u32x4 *>(rows + (int64_t)p * 8);
                 } else {  // the odd last row of the whole tensor: nothing may be read behind it
                     const u32x2 h = *reinterpret_cast<const u32x2 *>(rows + (int64_t)p * 8);
                     v[0] = h[0], v[1] = h[1], v[2] = 0u, v[3] = 0u;
                 }
+                return v;
+            };
+            auto add_pair = [&](int32_t p, const u32x4 &v) {
+                const int32_t r = 2 * p;
                 if (r >= k0) {
                     s[0] += bf16_lo(v[0]);
                     s[1] += bf16_hi(v[0]);
@@ -177,7 +198,14 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_pair8_kernel(
                     s[2] += bf16_lo(v[3]);
                     s[3] += bf16_hi(v[3]);
                 }
+            };
+            int32_t p = (k0 >> 1) + j;
+            for (; p + 4 <= p1; p += 8) {   // two pairs per lane in flight (a segment of the default graphs: one round)
+                const u32x4 va = load_pair(p), vb = load_pair(p + 4);
+                add_pair(p, va);
+                add_pair(p + 4, vb);
             }
+            for (; p <= p1; p += 4) add_pair(p, load_pair(p));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -20,6 +20,14 @@ def test_mlp_bf16_backward_emulated():
         P.case_mlp_bf16_backward("cpu")
 
 
+def test_mlp_bf16_backward_many_workgroups_emulated():
+    """Enough rows that every grid cap of the backward launchers is reached on the emulated two-CU device
+    (three light workgroups per CU for the weight-gradient-only shapes, two otherwise): the partial-sum
+    reduction has to read exactly the blocks the launch wrote (the first four default shapes)."""
+    with emulated():
+        P.case_mlp_bf16_backward("cpu", rows=1500, full=False)
+
+
 def test_ec_bf16_emulated():
     with emulated():
         P.case_ec_bf16("cpu")

@@ -789,9 +789,10 @@ def dbscan_short(dev) -> dict:
     return out
 
 
-def gc_resin_short(dev, hits: int = 200_000, edges: int = 3_000_000, steps: int = 10) -> dict:
-    """GraphConstructionResIN at the reference's default hidden_dim = 40 (120 -> 40 -> 40 -> 40 relational model) in
-    bf16 storage: forward + backward on one 200 k-hit / 3 M-edge graph (the output-tile / wide-input kernels)."""
+def gc_resin_short(dev, hits: int = 200_000, edges: int = 3_000_000, steps: int = 10, bf16: bool = True) -> dict:
+    """GraphConstructionResIN at the reference's default hidden_dim = 40 (120 -> 40 -> 40 -> 40 relational model):
+    forward + backward on one 200 k-hit / 3 M-edge graph - in bf16 storage the output-tile / wide-input kernels, in
+    fp32 the wide fused kernels of csrc/mlp_wide.hip."""
     ev = synthetic.make_event(7, hits, edges, dev)
     data = G.Data(x=ev.x, edge_index=ev.edge_index, edge_attr=ev.edge_attr)
     torch.manual_seed(0)
@@ -799,9 +800,10 @@ def gc_resin_short(dev, hits: int = 200_000, edges: int = 3_000_000, steps: int 
 
     def step():
         model.zero_grad()
-        with G.bf16_storage(True):
+        with G.bf16_storage(bf16):
             model(data)["H"].float().square().mean().backward()
 
+    ops._WIDE_WARNED.clear()
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -810,7 +812,8 @@ def gc_resin_short(dev, hits: int = 200_000, edges: int = 3_000_000, steps: int 
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"workload": f"GraphConstructionResIN(hidden_dim=40), {hits} hits, {edges} edges, forward + backward, bf16 storage",
+    return {"workload": f"GraphConstructionResIN(hidden_dim=40), {hits} hits, {edges} edges, forward + backward, "
+                        f"{'bf16 storage' if bf16 else 'fp32'}",
             "steps": steps, "ms_per_step": ms, "value": edges / ms * 1e3, "unit": "edges/s",
             "library_path_taken": sorted(map(str, ops._WIDE_WARNED))}
 
@@ -858,6 +861,7 @@ def extras(args, rank: int, world: int, dev) -> dict:
         ops.clear_graph_index_cache()
         torch.cuda.empty_cache()
         out["gc_resin_default_bf16"] = gc_resin_short(dev)
+        out["gc_resin_default_f32"] = gc_resin_short(dev, bf16=False)
         out["cfg2_hipgraph_bf16"] = hipgraph_cfg2(dev, "bf16", 100)
         out["cfg2_hipgraph_f32"] = hipgraph_cfg2(dev, "f32", 100)
         torch.cuda.empty_cache()

@@ -156,6 +156,85 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
     }
 }
 
+// 16-byte rows in CSR order (the folds of the per-edge gradients of gathered node rows - target side, and
+// source side after the backward kernel's permuted store): the same four-lanes-per-segment sums as above IN THE
+// SAME ORDER (bit-identical), but the rows reach the lanes through a wave-private LDS image that the whole wave
+// fills with coalesced 16-byte loads, four per lane in flight - the walk above waits for one dependent round
+// trip to HBM per 4-16 rows of a segment.  A wave owns 16 consecutive segments at a time and stages their rows
+// in chunks of 256.
+#ifndef GNNTRK_SEGSUM_STREAM
+#define GNNTRK_SEGSUM_STREAM 1
+#endif
+constexpr int kStreamChunk = 256;   // rows per staged chunk (4 KB per wave)
+__global__ __launch_bounds__(kTpb16) void segment_sum_bf16_stream16_kernel(
+    const uint16_t *__restrict__ rows, int dim, const int32_t *__restrict__ rowptr, int64_t n_seg,
+    uint16_t *__restrict__ out, int out_stride) {
+    __shared__ __attribute__((aligned(16))) u32x4 s_buf[kTpb16 / 64][kStreamChunk];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 3, sg = lane >> 2;
+    const int64_t n_groups = (n_seg + 15) >> 4;
+    const u32x4 *r16 = reinterpret_cast<const u32x4 *>(rows);
+    for (int64_t grp = (int64_t)blockIdx.x * (kTpb16 / 64) + wv; grp < n_groups;
+         grp += (int64_t)gridDim.x * (kTpb16 / 64)) {
+        const int64_t n = grp * 16 + sg, n_last = grp * 16 + 16 < n_seg ? grp * 16 + 16 : n_seg;
+        const bool on = n < n_seg;
+        const int32_t k0 = on ? rowptr[n] : 0, k1 = on ? rowptr[n + 1] : 0;
+        const int32_t r0 = rowptr[grp * 16], r1 = rowptr[n_last];   // (wave-uniform)
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        int32_t k = k0 + j;
+        for (int32_t c0 = r0; c0 < r1; c0 += kStreamChunk) {
+            u32x4 v[kStreamChunk / 64];
+#pragma unroll
+            for (int u = 0; u < kStreamChunk / 64; ++u) {
+                const int32_t r = c0 + lane + 64 * u;
+                v[u] = r < r1 ? r16[r] : u32x4{0u, 0u, 0u, 0u};
+            }
+            lds_wave_order();   // (the previous chunk's reads are issued before these writes)
+#pragma unroll
+            for (int u = 0; u < kStreamChunk / 64; ++u) s_buf[wv][lane + 64 * u] = v[u];
+            lds_wave_order();
+            const int32_t lim = k1 < c0 + kStreamChunk ? k1 : c0 + kStreamChunk;
+            for (; k + 4 < lim; k += 8) {
+                const u32x4 va = s_buf[wv][k - c0], vb = s_buf[wv][k + 4 - c0];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s[2 * w + 0] += bf16_lo(va[w]);
+                    s[2 * w + 1] += bf16_hi(va[w]);
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s[2 * w + 0] += bf16_lo(vb[w]);
+                    s[2 * w + 1] += bf16_hi(vb[w]);
+                }
+            }
+            for (; k < lim; k += 4) {
+                const u32x4 va = s_buf[wv][k - c0];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s[2 * w + 0] += bf16_lo(va[w]);
+                    s[2 * w + 1] += bf16_hi(va[w]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s[i] += __shfl_xor(s[i], 1);
+            s[i] += __shfl_xor(s[i], 2);
+        }
+        if (on && j == 0) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int d = dim - 4 * ch;
+                u32x2 o;
+                o[0] = bf16x2_pack(d >= 1 ? s[4 * ch] : 0.f, d >= 2 ? s[4 * ch + 1] : 0.f);
+                o[1] = bf16x2_pack(d >= 3 ? s[4 * ch + 2] : 0.f, d >= 4 ? s[4 * ch + 3] : 0.f);
+                *reinterpret_cast<u32x2 *>(out + n * out_stride + 4 * ch) = o;
+            }
+        }
+    }
+}
+
 // The aggregation of the interaction network (interaction_network.py:36, aggr="add": the edge
 // embeddings e~ [E, 4] summed per target node) - 8-byte rows, contiguous, CSR order.  8-byte
 // loads stream at ~3.2 TB/s on this chip, 16-byte ones at 4+: every lane loads an ALIGNED PAIR
@@ -284,6 +363,12 @@ int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const
         return check_launch("segment_sum_bf16");
     }
     const bool wide = nch % 2 == 0 && row_stride % 8 == 0 && ((uintptr_t)rows & 15) == 0;
+    if (GNNTRK_SEGSUM_STREAM && nch == 2 && wide && row_stride == 8 && !pos && rows) {
+        // contiguous 16-byte rows in CSR order (the gradient folds): rows staged through LDS, same sums
+        hipLaunchKernelGGL(segment_sum_bf16_stream16_kernel, dim3(grid), dim3(kTpb16), 0, stream, rows, dim, rowptr,
+                           n_seg, out, out_stride);
+        return check_launch("segment_sum_bf16");
+    }
 #define GNNTRK_SEGSUM16(N)                                                                              \
     if (nch == N) {                                                                                     \
         if (wide && N % 2 == 0)                                                                         \

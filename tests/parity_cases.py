@@ -1041,7 +1041,8 @@ def case_rows_bf16(device):
     from gnn_tracking_amd import ops_bf16 as B
     g = np.random.default_rng(4)
     for N, E, D in ((1, 0, 4), (7, 20, 5), (300, 4000, 4), (1000, 9000, 9), (50, 333, 4), (5, 1, 3), (9, 2, 2),
-                    (300, 4000, 40), (50, 333, 33)):   # (rows wider than 16 features: 16-column passes)
+                    (300, 4000, 40), (50, 333, 33),   # (rows wider than 16 features: 16-column passes)
+                    (300, 4000, 8), (3, 2000, 7), (17, 5000, 6), (1, 700, 8), (1000, 1500, 5)):   # (16-byte rows: streaming)
         ei = tt(g.integers(0, N, size=(2, E)), device).long()
         gi = ops.graph_index(ei, N, cache=False)
         x32 = tt(g.normal(size=(E, D)).astype(np.float32), device)
@@ -1062,6 +1063,17 @@ def case_rows_bf16(device):
                 node = gi.tgt.cpu().long() if by == "tgt" else gi.src.cpu().long()
                 ref.index_add_(0, node, csr.float().cpu())
             assert_close(out.float(), ref.to(torch.bfloat16).float(), TOL16, f"segment_sum16 {by} N={N} D={D}")
+            if E and B.pad4(D) == 8:
+                # contiguous 16-byte rows take the LDS-staged streaming kernel, rows at a 32-byte stride the
+                # plain four-lane walk: the same sums in the same order, bit for bit
+                padded = torch.zeros(E, 16, dtype=torch.bfloat16, device=csr.device)
+                padded[:, :csr.shape[1]] = csr
+                strided = padded[:, :csr.shape[1]]
+                rowptr, pos = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
+                a = B.segment_sum_raw(csr, rowptr, None, N)
+                b = B.segment_sum_raw(strided, rowptr, None, N)
+                assert strided.stride(0) == 16 and torch.equal(a.view(torch.int16).cpu(), b.view(torch.int16).cpu()), \
+                    f"streaming and walking segment sums differ: {by} N={N} D={D}"
 
 
 def case_segment_sum_f32(device):

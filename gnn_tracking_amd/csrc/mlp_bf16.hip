@@ -132,7 +132,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
         const int per_cu = (P.HT >= 5 || wide_io || (P.bias_init && P.KI >= 2)) ? 1 : (GT == 0 && P.HT <= 3 && !(a->debug_flags & 1024)) ? kBwd16BlocksPerCuLight : kBwd16BlocksPerCu;
         grid = grid16(a->n_rows, per_cu, kWaves);
         // (the buffer-addressed kernels: workgroups of kBwd16BufWaves waves, two resident per CU)
-        const int grid_buf = grid16(a->n_rows, (kBwd16BufWaves == kWaves || per_cu < kBwd16BlocksPerCu) ? per_cu : kBwd16BlocksPerCu, kBwd16BufWaves);
+        const int grid_buf = grid16(a->n_rows, (kBwd16BufD == 1 && per_cu == kBwd16BlocksPerCu) ? 3 : (kBwd16BufWaves == kWaves || per_cu < kBwd16BlocksPerCu) ? per_cu : kBwd16BlocksPerCu, kBwd16BufWaves);
         float *part = reinterpret_cast<float *>(ws);
         uint8_t *trash = reinterpret_cast<uint8_t *>(ws) + bwd16_partial_bytes(&a->mlp);
         rc = (a->epilogue == GNNTRK_EPI_SIGMOID)

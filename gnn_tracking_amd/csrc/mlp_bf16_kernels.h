@@ -569,13 +569,22 @@ struct IoEncoder8 {
 #define GNNTRK_BWD16_BUF_WAVES 4
 #endif
 constexpr int kBwd16BufWaves = GNNTRK_BWD16_BUF_WAVES;
+// Tiles per iteration of the buffer-addressed kernels (2: K = 32 weight-gradient contractions over two 16-row
+// halves; 1: half the per-wave state and staging - 162 registers, 42 KB: three workgroups per CU = 3 waves per
+// SIMD without a spill.  Measured SLOWER, round 4: relational 2.83-2.89 against 2.71 ms, head 3.57 against 3.30 per
+// 64 M rows on one box, alternating - a third wave does not pay for half-used weight-gradient MFMAs and the
+// per-tile overheads no longer shared by two tiles.  A/B switch.)
+#ifndef GNNTRK_BWD16_BUF_D
+#define GNNTRK_BWD16_BUF_D 2
+#endif
+constexpr int kBwd16BufD = GNNTRK_BWD16_BUF_D;
 template <class IO>
 __host__ __device__ constexpr int bwd16_block_waves() {
     return IO::NL > 0 ? kBwd16BufWaves : kWaves;
 }
 
 template <int KI, int HT, int GT, bool THREE, bool G32, int D_, class IO_ = IoNone>
-__global__ __launch_bounds__(64 * bwd16_block_waves<IO_>(), HT >= 5 ? 1 : (2 * bwd16_block_waves<IO_>() + 3) / 4) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
+__global__ __launch_bounds__(64 * bwd16_block_waves<IO_>(), HT >= 5 ? 1 : ((IO_::NL > 0 && D_ == 1) ? 3 : 2) * bwd16_block_waves<IO_>() / 4) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                                            uint8_t *trash, const BufPlan bp) {
     constexpr int D = D_, OT = 1;
     using IO = IO_;
@@ -885,7 +894,7 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
                     B.n_store, B.ones_dword, io[0] ? io : "generic");
 #define GNNTRK_BWD16_BUF(HT_, GT_, T_, IO_)                                                           \
     if (!launched && P.HT == HT_ && strcmp(io, #IO_) == 0) {                                          \
-        auto kfn = mlp16_bwd_kernel<1, HT_, GT_, T_, G32, 2, IO_>;                                    \
+        auto kfn = mlp16_bwd_kernel<1, HT_, GT_, T_, G32, kBwd16BufD, IO_>;                           \
         hipLaunchKernelGGL(kfn, dim3(grid_buf), dim3(64 * kBwd16BufWaves), 0, stream, *a, part, trash, B); \
         used[0] = grid_buf;                                                                           \
         used[1] = kBwd16BufWaves;                                                                     \

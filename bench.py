@@ -850,6 +850,23 @@ def extras(args, rank: int, world: int, dev) -> dict:
         del wl
         ops.clear_graph_index_cache()
         torch.cuda.empty_cache()
+        if getattr(args, "node_ids", "random") != "phi":
+            import copy
+            a_phi = copy.copy(args)
+            a_phi.node_ids = "phi"
+            wl = ECWorkload(a_phi, 0, 1, dev, workload="cfg3", dtype="bf16")
+            dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
+            roof, _ = roofline_of(ks, "bf16")
+            out["cfg3_bf16_phi_ids"] = {
+                "workload": "cfg3 with the hits of every event numbered by phi and edges joining ids at most 64 apart "
+                            "(synthetic.make_event(phi_sorted_ids=True)): the best case for the locality of the node-row "
+                            "gathers and the source-sorted gradient stores; the headline's generator shuffles the ids "
+                            "(worst case); same model, same timed region - NOT the headline",
+                "steps": 5, "warmup": 2, "ms_per_step": dt / 5 * 1e3, "value": wl.edges_per_step_global * 5 / dt,
+                "unit": "edges/s", "final_loss": loss, "roofline": roof}
+            del wl
+            ops.clear_graph_index_cache()
+            torch.cuda.empty_cache()
         wl = ECWorkload(args, 0, 1, dev, workload="cfg3", dtype="bf16", hidden_dim=64)
         dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
         out["cfg3_hidden64_bf16"] = {

@@ -236,16 +236,28 @@ __global__ __launch_bounds__(kCountTpb) void gi_count_kernel(K keys, int64_t E, 
     for (int64_t e = e0 + 4 * tid; e < e1; e += 4 * kCountTpb) {
         uint32_t k4[4];
         keys.keys4(e, e1, k4, bad);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (e + q >= e1) break;
-            const uint32_t b = k4[q] >> kSH;
+        // (consecutive edges of an ordered list share their bucket: one counter update per run of a lane's four)
+        auto bump = [&](uint32_t b, uint32_t by) {
             const uint32_t d = b - (uint32_t)w0;
             if (d < (uint32_t)kWin)
-                atomicAdd(&s_cnt[d], 1u);
+                atomicAdd(&s_cnt[d], by);
             else
-                atomicAdd(&tbl[(size_t)b * n_chunks + c], 1u);
+                atomicAdd(&tbl[(size_t)b * n_chunks + c], by);
+        };
+        uint32_t run_b = k4[0] >> kSH, run_n = 1;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            if (e + q >= e1) break;
+            const uint32_t b = k4[q] >> kSH;
+            if (b == run_b) {
+                run_n += 1;
+            } else {
+                bump(run_b, run_n);
+                run_b = b;
+                run_n = 1;
+            }
         }
+        bump(run_b, run_n);
     }
     __syncthreads();
     int lo = kWin, hi = -1;

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Kernel trace of the headline run with hits numbered by phi (--node-ids phi) -> gpurun_out/<tag>_{kernel_stats,timeline}.md
+TAG=${1:-phi}
+ROOT=$(pwd); OUT=gpurun_out; mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rm -rf /tmp/p_k
+rocprofv3 --kernel-trace -d /tmp/p_k -o k -- python $ROOT/bench.py --no-extra --no-cpu-baseline --steps 4 --warmup 1 --node-ids phi > /dev/null 2>&1
+python $ROOT/tools/rocpd_summary.py /tmp/p_k/k_results.db > $ROOT/$OUT/${TAG}_kernel_stats.md
+(cd $ROOT/tools && python rocpd_timeline.py /tmp/p_k/k_results.db > $ROOT/$OUT/${TAG}_timeline.md)

@@ -874,7 +874,7 @@ def _wide_backward(ctx, gterms, need):
         seg_grads[j] = _segment_sum_raw(row_tmp[j], rowptr, pos, s.shape[0])
     g_res = None
     if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
-        g_res = _axpby_raw(spec.ca, sum_terms(gterms))
+        g_res = _axpby_raw(spec.ca, _sum_terms(gterms))
     outs = [None, *seg_grads]
     if sinks is not None:
         outs += [None] * (2 * nl)
@@ -885,7 +885,7 @@ def _wide_backward(ctx, gterms, need):
     return tuple(outs)
 
 
-def sum_terms(gterms) -> Tensor:
+def _sum_terms(gterms) -> Tensor:
     """The upstream gradient the kernel sums per row, materialised (only the residual epilogue's pass-through
     gradient needs it, and that one has a single un-gathered term)."""
     total = None

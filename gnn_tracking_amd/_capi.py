@@ -120,6 +120,8 @@ _SIGNATURES = {
     "gnntrk_rows_to_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P]),
     "gnntrk_segment_sum_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32,
                                           _P]),
+    "gnntrk_segment_sum_bf16_add": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32, _P,
+                                              C.c_int32, _P]),
     "gnntrk_permute_rows_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32,
                                            C.c_int32, _P]),
     "gnntrk_mlp_forward_bf16": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),

@@ -140,8 +140,14 @@ int gnntrk_rows_to_bf16(const float *in, int32_t dim, int32_t in_stride, const i
 int gnntrk_segment_sum_bf16(const uint16_t *rows, int32_t dim, int32_t row_stride, const int32_t *rowptr,
                             const int32_t *pos, int64_t n_segments, uint16_t *out, int32_t out_stride,
                             void *stream) {
-    return segment_sum_bf16_launch(rows, dim, row_stride, rowptr, pos, n_segments, out, out_stride,
+    return segment_sum_bf16_launch(rows, dim, row_stride, rowptr, pos, n_segments, out, out_stride, nullptr, 0,
                                    (hipStream_t)stream);
+}
+int gnntrk_segment_sum_bf16_add(const uint16_t *rows, int32_t dim, int32_t row_stride, const int32_t *rowptr,
+                                const int32_t *pos, int64_t n_segments, const uint16_t *addend,
+                                int32_t addend_stride, uint16_t *out, int32_t out_stride, void *stream) {
+    return segment_sum_bf16_launch(rows, dim, row_stride, rowptr, pos, n_segments, out, out_stride, addend,
+                                   addend_stride, (hipStream_t)stream);
 }
 int gnntrk_permute_rows_bf16(const uint16_t *in, int32_t dim, int32_t in_stride, const int32_t *idx,
                              int64_t n_rows, uint16_t *out, int32_t out_stride, int32_t scatter, void *stream) {

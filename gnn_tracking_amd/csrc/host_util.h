@@ -102,7 +102,7 @@ int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *
                         uint16_t *out, int out_stride, hipStream_t stream);
 int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const int32_t *rowptr,
                             const int32_t *pos, int64_t n_seg, uint16_t *out, int out_stride,
-                            hipStream_t stream);
+                            const uint16_t *addend, int addend_stride, hipStream_t stream);
 int permute_rows_bf16_launch(const uint16_t *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
                              uint16_t *out, int out_stride, int scatter, hipStream_t stream);
 

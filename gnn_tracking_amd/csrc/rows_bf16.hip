@@ -67,7 +67,8 @@ __global__ __launch_bounds__(kTpb16) void rows4_to_bf16_kernel(const float *__re
 template <int NCH, bool WIDE>  // WIDE: rows are 16-byte aligned -> one 16-byte load per chunk pair
 __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
     const uint16_t *__restrict__ rows, int dim, int row_stride, const int32_t *__restrict__ rowptr,
-    const int32_t *__restrict__ pos, int64_t n_seg, uint16_t *__restrict__ out, int out_stride) {
+    const int32_t *__restrict__ pos, int64_t n_seg, uint16_t *__restrict__ out, int out_stride,
+    const uint16_t *__restrict__ addend, int addend_stride) {
     const int j = threadIdx.x & 3;
     for (int64_t n = ((int64_t)blockIdx.x * kTpb16 + threadIdx.x) >> 2; n < ((n_seg + 63) & ~(int64_t)63);
          n += ((int64_t)gridDim.x * kTpb16) >> 2) {
@@ -147,6 +148,13 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int d = dim - 4 * ch;
+                if (addend) {   // (one more fp32 term before the single rounding)
+                    const u32x2 a = *reinterpret_cast<const u32x2 *>(addend + n * addend_stride + 4 * ch);
+                    s[4 * ch + 0] += bf16_lo(a[0]);
+                    s[4 * ch + 1] += bf16_hi(a[0]);
+                    s[4 * ch + 2] += bf16_lo(a[1]);
+                    s[4 * ch + 3] += bf16_hi(a[1]);
+                }
                 u32x2 o;
                 o[0] = bf16x2_pack(d >= 1 ? s[4 * ch] : 0.f, d >= 2 ? s[4 * ch + 1] : 0.f);
                 o[1] = bf16x2_pack(d >= 3 ? s[4 * ch + 2] : 0.f, d >= 4 ? s[4 * ch + 3] : 0.f);
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
 constexpr int kStreamChunk = 256;   // rows per staged chunk (4 KB per wave)
 __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_stream16_kernel(
     const uint16_t *__restrict__ rows, int dim, const int32_t *__restrict__ rowptr, int64_t n_seg,
-    uint16_t *__restrict__ out, int out_stride) {
+    uint16_t *__restrict__ out, int out_stride, const uint16_t *__restrict__ addend, int addend_stride) {
     __shared__ __attribute__((aligned(16))) u32x4 s_buf[kTpb16 / 64][kStreamChunk];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 3, sg = lane >> 2;
     const int64_t n_groups = (n_seg + 15) >> 4;
@@ -226,6 +234,13 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_stream16_kernel(
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const int d = dim - 4 * ch;
+                if (addend) {
+                    const u32x2 a = *reinterpret_cast<const u32x2 *>(addend + n * addend_stride + 4 * ch);
+                    s[4 * ch + 0] += bf16_lo(a[0]);
+                    s[4 * ch + 1] += bf16_hi(a[0]);
+                    s[4 * ch + 2] += bf16_lo(a[1]);
+                    s[4 * ch + 3] += bf16_hi(a[1]);
+                }
                 u32x2 o;
                 o[0] = bf16x2_pack(d >= 1 ? s[4 * ch] : 0.f, d >= 2 ? s[4 * ch + 1] : 0.f);
                 o[1] = bf16x2_pack(d >= 3 ? s[4 * ch + 2] : 0.f, d >= 4 ? s[4 * ch + 3] : 0.f);
@@ -339,8 +354,9 @@ int rows_to_bf16_launch(const float *in, int dim, int in_stride, const int32_t *
 
 int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const int32_t *rowptr,
                             const int32_t *pos, int64_t n_seg, uint16_t *out, int out_stride,
-                            hipStream_t stream) {
+                            const uint16_t *addend, int addend_stride, hipStream_t stream) {
     if (n_seg == 0) return GNNTRK_OK;
+    if (addend && !rows_ok(addend, dim, addend_stride)) return fail(GNNTRK_EINVAL, "segment_sum_bf16: bad addend rows");
     // rows may be NULL when there are no rows at all (every segment empty)
     if (!rowptr || n_seg < 0 || (rows && !rows_ok(rows, dim, row_stride)) || !rows_ok(out, dim, out_stride))
         return fail(GNNTRK_EINVAL, "segment_sum_bf16: bad argument");
@@ -349,14 +365,15 @@ int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const
         // block of 16 columns - same strides, shifted base pointers (32 bytes: the alignment classes stay)
         for (int c0 = 0; c0 < dim; c0 += 16) {
             const int rc = segment_sum_bf16_launch(rows ? rows + c0 : rows, dim - c0 < 16 ? dim - c0 : 16, row_stride, rowptr,
-                                                   pos, n_seg, out + c0, out_stride, stream);
+                                                   pos, n_seg, out + c0, out_stride, addend ? addend + c0 : addend,
+                                                   addend_stride, stream);
             if (rc) return rc;
         }
         return GNNTRK_OK;
     }
     const int nch = (dim + 3) / 4;
     const int grid = grid_for_threads(n_seg * 4);
-    if (nch == 1 && row_stride == 4 && !pos && rows && ((uintptr_t)rows & 15) == 0) {
+    if (nch == 1 && row_stride == 4 && !pos && rows && !addend && ((uintptr_t)rows & 15) == 0) {
         // contiguous 8-byte rows in CSR order (the message aggregation): aligned 16-byte pair loads
         hipLaunchKernelGGL(segment_sum_bf16_pair8_kernel, dim3(grid), dim3(kTpb16), 0, stream, rows, dim, rowptr,
                            n_seg, out, out_stride);
@@ -366,17 +383,17 @@ int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const
     if (GNNTRK_SEGSUM_STREAM && nch == 2 && wide && row_stride == 8 && !pos && rows) {
         // contiguous 16-byte rows in CSR order (the gradient folds): rows staged through LDS, same sums
         hipLaunchKernelGGL(segment_sum_bf16_stream16_kernel, dim3(grid), dim3(kTpb16), 0, stream, rows, dim, rowptr,
-                           n_seg, out, out_stride);
+                           n_seg, out, out_stride, addend, addend_stride);
         return check_launch("segment_sum_bf16");
     }
 #define GNNTRK_SEGSUM16(N)                                                                              \
     if (nch == N) {                                                                                     \
         if (wide && N % 2 == 0)                                                                         \
             hipLaunchKernelGGL((segment_sum_bf16_kernel<N, (N % 2 == 0)>), dim3(grid), dim3(kTpb16), 0, stream, \
-                               rows, dim, row_stride, rowptr, pos, n_seg, out, out_stride);            \
+                               rows, dim, row_stride, rowptr, pos, n_seg, out, out_stride, addend, addend_stride); \
         else                                                                                            \
             hipLaunchKernelGGL((segment_sum_bf16_kernel<N, false>), dim3(grid), dim3(kTpb16), 0, stream, rows, dim, \
-                               row_stride, rowptr, pos, n_seg, out, out_stride);                       \
+                               row_stride, rowptr, pos, n_seg, out, out_stride, addend, addend_stride); \
     }
     GNNTRK_SEGSUM16(1) GNNTRK_SEGSUM16(2) GNNTRK_SEGSUM16(3) GNNTRK_SEGSUM16(4)
 #undef GNNTRK_SEGSUM16

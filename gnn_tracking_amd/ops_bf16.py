@@ -190,14 +190,24 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
 
 
 # ------------------------------------------------------------------ plain helpers
-def segment_sum_raw(rows: Tensor, rowptr: Tensor, pos: Optional[Tensor], n_seg: int) -> Tensor:
+def segment_sum_raw(rows: Tensor, rowptr: Tensor, pos: Optional[Tensor], n_seg: int,
+                    addend: Optional[Tensor] = None) -> Tensor:
+    """``out[n] = bf16(sum of rows over segment n [+ addend[n]])`` - fp32 accumulation, one rounding."""
     from . import ops
     lib = _capi.load()
     rows = rows16(rows)
     out = empty_rows(n_seg, rows.shape[1], rows.device)
-    _capi.check(lib.gnntrk_segment_sum_bf16(rows.data_ptr(), rows.shape[1], rows.stride(0), ops._p(rowptr),
-                                            ops._p(pos), n_seg, out.data_ptr(), out.stride(0),
-                                            ops._stream(rows)), lib)
+    if addend is None:
+        _capi.check(lib.gnntrk_segment_sum_bf16(rows.data_ptr(), rows.shape[1], rows.stride(0), ops._p(rowptr),
+                                                ops._p(pos), n_seg, out.data_ptr(), out.stride(0),
+                                                ops._stream(rows)), lib)
+        return out
+    addend = rows16(addend)
+    if addend.shape != (n_seg, rows.shape[1]):
+        raise ValueError(f"segment_sum addend must be [{n_seg}, {rows.shape[1]}], got {tuple(addend.shape)}")
+    _capi.check(lib.gnntrk_segment_sum_bf16_add(rows.data_ptr(), rows.shape[1], rows.stride(0), ops._p(rowptr),
+                                                ops._p(pos), n_seg, addend.data_ptr(), addend.stride(0),
+                                                out.data_ptr(), out.stride(0), ops._stream(rows)), lib)
     return out
 
 
@@ -323,6 +333,7 @@ def _backward_common(ctx, gout, need, g_rows):
                                       epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb, gout=gout,
                                       need_seg=need_seg, want_dw=want_dw, mlp=mlp, gidx=gidx, sinks=sinks)
     seg_grads = [None] * ns
+    folded: dict = {}   # (tensor identity) -> index of the segment whose fold holds its gradient so far
     for j, s in enumerate(segs):
         if slices[j] is None:
             continue
@@ -337,7 +348,16 @@ def _backward_common(ctx, gout, need, g_rows):
         else:
             by, gi = spec.reduce[j]
             rowptr = gi.rowptr_t if by == "tgt" else gi.rowptr_s  # (src rows are pre-sorted)
-            seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0])
+            # a tensor gathered twice (the node embedding by target AND by source): the second fold takes the
+            # first as one more fp32 term, and the sum leaves as ONE gradient with one rounding - autograd would
+            # add the two (an N-sized pass, a second rounding, and a re-padding copy of its dense result)
+            first = folded.get((s.data_ptr(), tuple(s.shape), s.stride(0))) if FOLD_ADD else None
+            if first is not None:
+                seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0], addend=seg_grads[first])
+                seg_grads[first] = None
+            else:
+                seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0])
+            folded[(s.data_ptr(), tuple(s.shape), s.stride(0))] = j
     g_res = None
     if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
         g_dense = g_rows if spec.out_idx is None else permute_raw(g_rows, spec.out_idx, False)
@@ -421,6 +441,9 @@ class _Tap(torch.autograd.Function):
         ctx.stash.g = g if ctx.stash.g is None else ctx.stash.g + g
         return None, None
 
+
+#: the folds of a tensor gathered twice leave as one sum (off: autograd adds the two)
+FOLD_ADD = __import__("os").environ.get("GNNTRK_FOLD_ADD", "1") != "0"
 
 #: gradient taps on / off (off: autograd sums the two gradients of a twice-read embedding itself)
 TAP = __import__("os").environ.get("GNNTRK_GRAD_TAP", "1") != "0"

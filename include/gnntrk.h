@@ -283,12 +283,20 @@ int gnntrk_mlp_backward_bf16(const gnntrk_mlp_bwd_args *args, void *workspace,
  *                     edge_attr permuted into CSR order in the same pass.
  *  segment_sum_bf16:  gnntrk_segment_sum over bf16 rows, fp32 accumulation in CSR order, one
  *                     rounding at the end (aggregation and node-gradient folds).
+ *  segment_sum_bf16_add: the same with one more bf16 term per segment, out[n] = bf16(addend[n] + sum):
+ *                     the two folds of a node embedding that an interaction network gathers by
+ *                     target AND by source (interaction_network.py:75-89) leave as one tensor,
+ *                     with one rounding, instead of autograd adding two (addend and out must not overlap).
  *  permute_rows_bf16: gnntrk_permute_rows for padded bf16 rows. */
 int gnntrk_rows_to_bf16(const float *in, int32_t dim, int32_t in_stride, const int32_t *idx,
                         int64_t n_rows, uint16_t *out, int32_t out_stride, void *stream);
 int gnntrk_segment_sum_bf16(const uint16_t *rows, int32_t dim, int32_t row_stride,
                             const int32_t *rowptr, const int32_t *pos, int64_t n_segments,
                             uint16_t *out, int32_t out_stride, void *stream);
+int gnntrk_segment_sum_bf16_add(const uint16_t *rows, int32_t dim, int32_t row_stride,
+                                const int32_t *rowptr, const int32_t *pos, int64_t n_segments,
+                                const uint16_t *addend, int32_t addend_stride, uint16_t *out,
+                                int32_t out_stride, void *stream);
 int gnntrk_permute_rows_bf16(const uint16_t *in, int32_t dim, int32_t in_stride, const int32_t *idx,
                              int64_t n_rows, uint16_t *out, int32_t out_stride, int32_t scatter,
                              void *stream);

@@ -1063,6 +1063,14 @@ def case_rows_bf16(device):
                 node = gi.tgt.cpu().long() if by == "tgt" else gi.src.cpu().long()
                 ref.index_add_(0, node, csr.float().cpu())
             assert_close(out.float(), ref.to(torch.bfloat16).float(), TOL16, f"segment_sum16 {by} N={N} D={D}")
+            if E:
+                # one more term per segment before the single rounding (gnntrk_segment_sum_bf16_add)
+                rowptr_a, pos_a = (gi.rowptr_t, None) if by == "tgt" else (gi.rowptr_s, gi.spos)
+                add32 = tt(g.normal(size=(N, D)).astype(np.float32), device)
+                addend = B.to_rows16(add32)
+                got = B.segment_sum_raw(csr, rowptr_a, pos_a, N, addend=addend)
+                want = (ref.double() + addend.float().cpu().double()).float().to(torch.bfloat16).float()
+                assert_close(got.float(), want, TOL16, f"segment_sum16 + addend {by} N={N} D={D}")
             if E and B.pad4(D) == 8:
                 # contiguous 16-byte rows take the LDS-staged streaming kernel, rows at a 32-byte stride the
                 # plain four-lane walk: the same sums in the same order, bit for bit

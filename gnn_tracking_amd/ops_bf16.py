@@ -271,8 +271,10 @@ class FusedMLP16(torch.autograd.Function):
         if sum(s.shape[1] for s in segs) != mlp.in_dim:
             raise AssertionError(
                 f"Expected feature dimension {mlp.in_dim}, got {sum(s.shape[1] for s in segs)}")
+        ctx.res_key = None
         if spec.epilogue == _capi.EPI_RESIDUAL:
             res = rows16(res)
+            ctx.res_key = (res.data_ptr(), tuple(res.shape), res.stride(0))
         out = mlp_forward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=spec.n_rows,
                               epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb, res=res,
                               out_idx=spec.out_idx, out_rows=spec.out_rows, mlp=mlp)
@@ -361,7 +363,16 @@ def _backward_common(ctx, gout, need, g_rows):
     g_res = None
     if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
         g_dense = g_rows if spec.out_idx is None else permute_raw(g_rows, spec.out_idx, False)
-        g_res = g_dense * spec.ca
+        res_key = getattr(ctx, "res_key", None)
+        same = [j for j, s in enumerate(segs) if FOLD_ADD and res_key is not None and spec.idx[j] is None
+                and seg_grads[j] is not None and (s.data_ptr(), tuple(s.shape), s.stride(0)) == res_key
+                and seg_grads[j].shape == g_dense.shape]
+        if same:
+            # the residue IS an identity segment of this node (resin.py:26: the layer's own input): its
+            # pass-through gradient joins that segment's gradient in one pass instead of a mul and autograd's add
+            seg_grads[same[0]].add_(g_dense, alpha=spec.ca)
+        else:
+            g_res = g_dense * spec.ca
     outs = list(seg_grads)
     if sinks is not None:   # (already added into the parameters' gradient buffers)
         outs += [None] * (2 * nl)

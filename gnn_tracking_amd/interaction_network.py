@@ -75,7 +75,8 @@ class InteractionNetwork(nn.Module, HyperparametersMixin):
         else:
             e_tilde = self.relational_model.fused(rel_segs, n_rows=gi.n_edges)
             aggr = ops.segment_sum(e_tilde, gi, "tgt")
-        segs = [ops.Seg(x, None, relu_in), ops.Seg(aggr)]
+        x_obj, aggr_obj = ops_bf16.node_tap(x, aggr) if x.dtype == torch.bfloat16 else (x, aggr)
+        segs = [ops.Seg(x_obj, None, relu_in), ops.Seg(aggr_obj)]
         if residue is not None:
             ca, cb = float(alpha_residue) ** 0.5, (1.0 - float(alpha_residue)) ** 0.5
             x_out = self.object_model.fused(segs, epilogue=_capi.EPI_RESIDUAL, ca=ca, cb=cb,

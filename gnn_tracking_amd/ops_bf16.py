@@ -303,7 +303,11 @@ class FusedMLP16(torch.autograd.Function):
         return (None, *outs, g_res)
 
 
-def _backward_common(ctx, gout, need, g_rows):
+def _tensor_key(t: Tensor):
+    return (t.data_ptr(), tuple(t.shape), t.stride(0))
+
+
+def _backward_common(ctx, gout, need, g_rows, node_addend=None):
     """Shared by FusedMLP16 and FusedINEdge16: one gnntrk_mlp_backward_bf16 launch for the
     upstream terms ``gout`` + the folds of the gathered input gradients.  ``need`` is laid
     out as [spec, segs..., W..., b..., res].  Returns (grads of segs/W/b, grad of res)."""
@@ -353,13 +357,17 @@ def _backward_common(ctx, gout, need, g_rows):
             # a tensor gathered twice (the node embedding by target AND by source): the second fold takes the
             # first as one more fp32 term, and the sum leaves as ONE gradient with one rounding - autograd would
             # add the two (an N-sized pass, a second rounding, and a re-padding copy of its dense result)
-            first = folded.get((s.data_ptr(), tuple(s.shape), s.stride(0))) if FOLD_ADD else None
+            first = folded.get(_tensor_key(s)) if FOLD_ADD else None
             if first is not None:
                 seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0], addend=seg_grads[first])
                 seg_grads[first] = None
+            elif node_addend is not None and node_addend[0] == _tensor_key(s):
+                # (the object model's gradient of the same embedding, handed over by node_tap)
+                seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0], addend=node_addend[1])
+                node_addend = None
             else:
                 seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0])
-            folded[(s.data_ptr(), tuple(s.shape), s.stride(0))] = j
+            folded[_tensor_key(s)] = j
     g_res = None
     if spec.epilogue == _capi.EPI_RESIDUAL and need[1 + ns + 2 * nl]:
         g_dense = g_rows if spec.out_idx is None else permute_raw(g_rows, spec.out_idx, False)
@@ -373,6 +381,8 @@ def _backward_common(ctx, gout, need, g_rows):
             seg_grads[same[0]].add_(g_dense, alpha=spec.ca)
         else:
             g_res = g_dense * spec.ca
+    if node_addend is not None:
+        raise RuntimeError("a node gradient handed over by node_tap found no fold to join")
     outs = list(seg_grads)
     if sinks is not None:   # (already added into the parameters' gradient buffers)
         outs += [None] * (2 * nl)
@@ -409,6 +419,13 @@ class FusedINEdge16(torch.autograd.Function):
         ctx.save_for_backward(*segs, *weights, *[b for b in biases if b is not None])
         ctx.bias_mask = [b is not None for b in biases]
         _attach_stash(ctx, e_tilde)
+        # the node embedding this layer gathers twice (by target and by source): the object model, which reads
+        # the same embedding next to `aggr`, can hand its gradient to THIS node's backward (node_tap below)
+        ctx.node_stash, ctx.node_key = None, None
+        twice = [j for j in range(ns) if isinstance(spec.reduce[j], tuple) and spec.reduce[j][0] in ("tgt", "src")]
+        if len(twice) == 2 and _tensor_key(segs[twice[0]]) == _tensor_key(segs[twice[1]]):
+            ctx.node_stash, ctx.node_key = _GradStash(), _tensor_key(segs[twice[0]])
+            aggr._gnntrk_node_stash = (ctx.node_stash, ctx.node_key)
         return e_tilde, aggr
 
     @staticmethod
@@ -423,7 +440,9 @@ class FusedINEdge16(torch.autograd.Function):
         if not gout:
             raise RuntimeError("FusedINEdge16.backward without upstream gradients")
         need = ctx.needs_input_grad  # [spec, gi, segs..., W..., b...]
-        outs, _ = _backward_common(ctx, gout, (need[0],) + tuple(need[2:]) + (False,), None)
+        node_g = ctx.node_stash.take() if ctx.node_stash is not None else None
+        outs, _ = _backward_common(ctx, gout, (need[0],) + tuple(need[2:]) + (False,), None,
+                                   node_addend=None if node_g is None else (ctx.node_key, node_g))
         return (None, None, *outs)
 
 
@@ -470,6 +489,39 @@ def grad_tap(t: Tensor) -> Tensor:
     if stash is None or not TAP or not t.requires_grad:
         return t
     return _Tap.apply(t, stash)
+
+
+class _NodeTap(torch.autograd.Function):
+    """Identity on ``(x, aggr)``.  Backward: the gradient of ``x`` goes into the stash, the gradient of ``aggr``
+    passes through - so the producer of ``aggr`` can only run its backward AFTER the stash is filled (a true
+    dependency, not an ordering habit of the engine)."""
+
+    @staticmethod
+    def forward(ctx, x, aggr, stash):
+        ctx.stash = stash
+        return x.view_as(x), aggr.view_as(aggr)
+
+    @staticmethod
+    def backward(ctx, gx, ga):
+        if gx is not None:
+            ctx.stash.g = gx if ctx.stash.g is None else ctx.stash.g + gx
+        return None, ga, None
+
+
+def node_tap(x: Tensor, aggr: Tensor):
+    """``(x, aggr)`` for the object model of an interaction-network layer whose relational model + aggregation
+    node (``FusedINEdge16``, the producer of ``aggr``) gathers the same ``x`` by target and by source: the object
+    model's gradient of ``x`` goes into that node's backward - which can only run once the gradient of ``aggr`` has
+    come through the same tap - and joins its first fold as one more fp32 term, instead of autograd adding two
+    gradients of ``x`` (an N-sized pass plus the re-padding copy of its dense result)."""
+    held = getattr(aggr, "_gnntrk_node_stash", None)
+    if (held is None or not TAP or not FOLD_ADD or not x.requires_grad or not aggr.requires_grad
+            or x.dtype != BF16 or x.dim() != 2):
+        return x, aggr
+    xr = rows16(x)
+    if xr is not x or _tensor_key(xr) != held[1]:
+        return x, aggr
+    return _NodeTap.apply(x, aggr, held[0])
 
 
 def _attach_stash(ctx, out: Tensor) -> None:

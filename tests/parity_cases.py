@@ -1114,6 +1114,81 @@ def case_segment_sum_f32(device):
             assert_close(acc, (base.cpu().double() + ref).float(), TOL_OUT, f"segment_sum accumulate {by} D={D}")
 
 
+def case_node_tap(device):
+    """bf16 storage: the fused gradient plumbing of one interaction-network layer (ops_bf16.node_tap, the folds of
+    a tensor gathered twice, the residual pass-through joining its identity segment) against plain autograd
+    accumulation of the same kernels' gradients (flags off): all gradients within bf16 rounding of each other, for
+    a whole backward, for ``torch.autograd.grad`` w.r.t. the node embedding only, with frozen relational weights,
+    with an input that needs no gradient, and for two backward passes over a retained graph."""
+    from gnn_tracking_amd import ops_bf16 as B
+    from gnn_tracking_amd.interaction_network import InteractionNetwork
+    gen = torch.Generator().manual_seed(31)
+    N, E = 200, 2600
+    net = InteractionNetwork(node_indim=5, edge_indim=4, node_outdim=5, edge_outdim=4).to(device)
+    enc = G.MLP(5, 5, hidden_dim=8, L=2).to(device)   # (kernel outputs are padded rows, as inside a stack)
+    taps = []
+    inner_apply = B._NodeTap.apply
+    ei = torch.randint(0, N, (2, E), generator=gen).to(device)
+    gi = ops.graph_index(ei, N, cache=False)
+    x0 = torch.randn(N, 5, generator=gen)
+    e0 = torch.randn(E, 4, generator=gen)
+    rx, re = torch.randn(N, 5, generator=gen).to(device), torch.randn(E, 4, generator=gen).to(device)
+
+    def run(flags_on, mode):
+        B.TAP = B.FOLD_ADD = flags_on
+        try:
+            net.zero_grad()
+            enc.zero_grad()
+            for p_ in net.parameters():
+                p_.requires_grad_(not (mode == "frozen_rel" and p_ in set(net.relational_model.parameters())))
+            with G.bf16_storage(True):
+                xin = B.to_rows16(x0.to(device)).requires_grad_(mode != "no_x_grad")
+                ein = B.to_rows16(e0.to(device)).requires_grad_(True)
+                with torch.set_grad_enabled(mode != "no_x_grad"):
+                    x1 = enc(xin)
+                xo, eo = net.forward_csr(gi, x1, ein, relu_in=True, residue=x1, alpha_residue=0.5)
+                loss = (xo.float() * rx).sum() + (eo.float() * re).sum()
+                if mode == "grad_x_only":
+                    (gx,) = torch.autograd.grad(loss, [xin])
+                    return {"x": gx.float().clone()}
+                if mode == "twice":
+                    loss.backward(retain_graph=True)
+                    loss.backward()
+                else:
+                    loss.backward()
+            out = {"e": ein.grad.float().clone()}
+            if mode != "no_x_grad":
+                out["x"] = xin.grad.float().clone()
+            for k, v in list(net.named_parameters()) + [("enc." + k_, v_) for k_, v_ in enc.named_parameters()]:
+                if v.grad is not None:
+                    out[k] = v.grad.float().clone()
+            return out
+        finally:
+            B.TAP = B.FOLD_ADD = True
+            for p_ in net.parameters():
+                p_.requires_grad_(True)
+
+    def counting(*a):
+        taps.append(1)
+        return inner_apply(*a)
+
+    for mode in ("all", "grad_x_only", "frozen_rel", "no_x_grad", "twice"):
+        taps.clear()
+        B._NodeTap.apply = counting
+        try:
+            on = run(True, mode)
+        finally:
+            B._NodeTap.apply = inner_apply
+        assert len(taps) == (0 if mode == "no_x_grad" else 1), f"node_tap {mode}: tap taken {len(taps)} times"
+        off = run(False, mode)
+        assert on.keys() == off.keys(), f"node_tap {mode}: different gradients present {on.keys()} vs {off.keys()}"
+        for k in on:
+            scale = max(1.0, float(off[k].abs().max()))
+            err = float((on[k] - off[k]).abs().max())
+            # (both sides round bf16 sums; the fused side rounds once where autograd rounds two or three times)
+            assert err <= 2.0 ** -6 * scale, f"node_tap {mode}: {k} differs by {err:.3e} (scale {scale:.3g})"
+
+
 def case_hipgraph_capture(device):
     """The training step is capturable as a HIP graph (every gnntrk_* call is stream
     ordered, allocation- and sync-free); a replay reproduces the eager gradients bit for bit."""

@@ -20,6 +20,11 @@ def test_mlp_bf16_backward_emulated():
         P.case_mlp_bf16_backward("cpu")
 
 
+def test_node_tap_emulated():
+    with emulated():
+        P.case_node_tap("cpu")
+
+
 def test_mlp_bf16_backward_many_workgroups_emulated():
     """Enough rows that every grid cap of the backward launchers is reached on the emulated two-CU device
     (three light workgroups per CU for the weight-gradient-only shapes, two otherwise): the partial-sum

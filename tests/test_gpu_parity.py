@@ -173,6 +173,10 @@ def test_mlp_wide(dev):
     P.case_mlp_wide(dev)
 
 
+def test_node_tap(dev):
+    P.case_node_tap(dev)
+
+
 def test_segment_sum_f32(dev):
     P.case_segment_sum_f32(dev)
 

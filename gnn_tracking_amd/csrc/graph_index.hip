@@ -38,9 +38,15 @@ namespace gnntrk {
 constexpr int kTpb = 256;
 
 // ------------------------------------------------------------------ own counting sort
-constexpr int kSH = 8;                  // nodes per bucket = 256
+#ifndef GNNTRK_GI_SH
+#define GNNTRK_GI_SH 8
+#endif
+#ifndef GNNTRK_GI_SORT_TPB
+#define GNNTRK_GI_SORT_TPB 512
+#endif
+constexpr int kSH = GNNTRK_GI_SH;       // nodes per bucket = 256
 constexpr int kBins = 1 << kSH;
-constexpr int kSortTpb = 512;
+constexpr int kSortTpb = GNNTRK_GI_SORT_TPB;
 constexpr int kSortR = 10;              // records a thread of the bucket sort holds in registers
 constexpr int kCap = kSortTpb * kSortR; // records of a bucket the bucket sort holds in LDS (5120)
 constexpr int kWin = 4096;              // bucket counters a chunk holds in LDS

@@ -332,7 +332,7 @@ class ECWorkload(Workload):
             cur = self.batches[self.counter % 2]
             nxt = self.batches[(self.counter + 1) % 2]
             self.counter += 1
-            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, self.side)
+            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, self.side, x=nxt.x, batch=getattr(nxt, "batch", None))
             loss = self.module.backward_step(cur)
         else:
             n = len(self.batches)

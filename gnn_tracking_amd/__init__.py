@@ -21,6 +21,7 @@ from .losses_ec import (EdgeWeightBCELoss, EdgeWeightFocalLoss, HaughtyFocalLoss
 from .losses_ml import GraphConstructionHingeEmbeddingLoss
 from .losses_oc import CondensationLossRG, CondensationLossTiger, MultiLossFctReturn
 from .mlp import MLP
+from .locality import node_order
 from .precision import bf16_storage
 from .resin import ResIN
 from .postprocessing import DBSCANFastRescan, dbscan
@@ -34,7 +35,7 @@ __version__ = "0.2.0"
 __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphTCN",
            "EdgeWeightBCELoss", "falsify_low_pt_edges", "MLGraphConstruction",
            "knn_with_max_radius", "get_good_node_mask", "get_good_node_mask_tensors",
-           "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage", "GraphTCN", "ModularGraphTCN",
+           "CondensationLossRG", "CondensationLossTiger", "MultiLossFctReturn", "bf16_storage", "node_order", "GraphTCN", "ModularGraphTCN",
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
            "GraphConstructionFCNN", "HeterogeneousResFCNN", "GraphConstructionHeteroResFCNN",
            "GraphConstructionHeteroEncResFCNN", "GraphConstructionResIN", "PerfectECGraphTCN",

@@ -67,7 +67,8 @@ class GraphIndex(C.Structure):
 
 class GraphIndexCarry(C.Structure):
     _fields_ = [("edge_label", C.c_void_p), ("label_csr", C.c_void_p), ("edge_rows", C.c_void_p),
-                ("rows_csr_bf16", C.c_void_p), ("rows_stride", C.c_int32), ("out_stride", C.c_int32)]
+                ("rows_csr_bf16", C.c_void_p), ("rows_stride", C.c_int32), ("out_stride", C.c_int32),
+                ("node_rank", C.c_void_p)]
 
 
 class OcArgs(C.Structure):
@@ -115,6 +116,8 @@ _SIGNATURES = {
     "gnntrk_graph_index_workspace_bytes_carry": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "gnntrk_graph_index_build_carry": (C.c_int, [_P, C.POINTER(GraphIndex), C.POINTER(GraphIndexCarry), _P, C.c_size_t,
                                                  C.c_int32, _P]),
+    "gnntrk_node_order_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnntrk_node_order": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_bce_csr": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_mlp_forward": (C.c_int, [C.POINTER(MlpFwdArgs), _P]),
     "gnntrk_rows_to_bf16": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P]),
@@ -207,7 +210,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 400   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
+ABI_VERSION = 500   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

@@ -78,22 +78,8 @@ struct KeysCoo {
     const uint8_t *label;
     const float *rows;
     int rows_stride;
-    __device__ __forceinline__ uint32_t key(int64_t e, int *bad) const {
-        int64_t v = tgt[e];
-        if (v < 0 || v >= N) {
-            if (bad) atomicAdd(bad, 1);
-            v = v < 0 ? 0 : N - 1;
-        }
-        return (uint32_t)v;
-    }
-    __device__ __forceinline__ uint32_t payload(int64_t e, int *bad) const {
-        int64_t v = src[e];
-        if (v < 0 || v >= N) {
-            if (bad) atomicAdd(bad, 1);
-            v = v < 0 ? 0 : N - 1;
-        }
-        return (uint32_t)v;
-    }
+    __device__ __forceinline__ uint32_t key(int64_t e, int *bad) const { return checked(tgt[e], bad); }
+    __device__ __forceinline__ uint32_t payload(int64_t e, int *bad) const { return checked(src[e], bad); }
     __device__ __forceinline__ uint32_t value(int64_t e) const {
         return (uint32_t)e | ((label && label[e]) ? 0x80000000u : 0u);
     }
@@ -104,12 +90,16 @@ struct KeysCoo {
     // four consecutive edges e .. e + 3 of one lane (e a multiple of four): with `vec` (16-byte aligned id rows,
     // 4-byte aligned labels) the ids come as 16-byte loads - 8-byte-per-lane streams top out near 3 TB/s here
     int vec;
+    // optional renumbering of the nodes (gnntrk_graph_index_carry.node_rank: old id -> new id, a permutation of
+    // [0, N) that keeps every event's id range): applied where an id is read, so the whole index comes out in
+    // the new numbering.  The table of one event (600 KB at 150 k hits) stays in the XCD's L2.
+    const int32_t *rank;
     __device__ __forceinline__ uint32_t checked(int64_t v, int *bad) const {
         if (v < 0 || v >= N) {
             if (bad) atomicAdd(bad, 1);
             v = v < 0 ? 0 : N - 1;
         }
-        return (uint32_t)v;
+        return rank ? (uint32_t)rank[v] : (uint32_t)v;
     }
     __device__ __forceinline__ void keys4(int64_t e, int64_t e1, uint32_t k[4], int *bad) const {
         if (vec && e + 4 <= e1) {
@@ -803,15 +793,22 @@ static int own_sort(const OwnPlan &p, K keys, O out, int pbits, int64_t N, int64
 }
 
 // -------------------------------------------- library path (shapes outside the own sort)
+// (ids out of range are counted and clamped, as in the own form; `rank`: see KeysCoo)
+__device__ __forceinline__ uint32_t gi_checked(int64_t v, int64_t N, const int32_t *rank, int *bad) {
+    if (v < 0 || v >= N) {
+        atomicAdd(bad, 1);
+        v = v < 0 ? 0 : N - 1;
+    }
+    return rank ? (uint32_t)rank[v] : (uint32_t)v;
+}
 __global__ __launch_bounds__(kTpb) void gi_keys_kernel(const int64_t *__restrict__ ids, int64_t E,
-                                                       int64_t N, uint32_t *__restrict__ keys,
+                                                       int64_t N, const int32_t *__restrict__ rank,
+                                                       uint32_t *__restrict__ keys,
                                                        uint32_t *__restrict__ vals,
                                                        int *__restrict__ bad) {
     for (int64_t e = (int64_t)blockIdx.x * kTpb + threadIdx.x; e < E;
          e += (int64_t)gridDim.x * kTpb) {
-        const int64_t v = ids[e];
-        if (v < 0 || v >= N) atomicAdd(bad, 1);
-        keys[e] = (uint32_t)v;
+        keys[e] = gi_checked(ids[e], N, rank, bad);
         vals[e] = (uint32_t)e;
     }
 }
@@ -819,15 +816,14 @@ __global__ __launch_bounds__(kTpb) void gi_keys_kernel(const int64_t *__restrict
 // src_sorted[k] = src[perm[k]]; also emits the keys/vals of the second (by-source) sort
 __global__ __launch_bounds__(kTpb) void gi_gather_src_kernel(const int64_t *__restrict__ src,
                                                              const uint32_t *__restrict__ perm,
-                                                             int64_t E, int64_t N, int32_t *__restrict__ src_s,
+                                                             int64_t E, int64_t N, const int32_t *__restrict__ rank,
+                                                             int32_t *__restrict__ src_s,
                                                              uint32_t *__restrict__ keys,
                                                              uint32_t *__restrict__ vals,
                                                              int *__restrict__ bad) {
     for (int64_t k = (int64_t)blockIdx.x * kTpb + threadIdx.x; k < E;
          k += (int64_t)gridDim.x * kTpb) {
-        const int64_t v = src[perm[k]];
-        if (v < 0 || v >= N) atomicAdd(bad, 1);
-        const uint32_t s = (uint32_t)v;
+        const uint32_t s = gi_checked(src[perm[k]], N, rank, bad);
         src_s[k] = (int32_t)s;
         keys[k] = s;
         vals[k] = (uint32_t)k;
@@ -880,7 +876,7 @@ __global__ __launch_bounds__(kTpb) void gi_gather_label_kernel(const uint8_t *__
 }
 
 static int library_build(const int64_t *edge_index, const gnntrk_graph_index *o, char *p, int *bad, int64_t N,
-                         int64_t E, hipStream_t stream) {
+                         int64_t E, const int32_t *rank, hipStream_t stream) {
     p += 256;
     const size_t arr = align_up((size_t)(E > 0 ? E : 1) * sizeof(uint32_t), 256);
     uint32_t *keys_a = reinterpret_cast<uint32_t *>(p);
@@ -894,7 +890,7 @@ static int library_build(const int64_t *edge_index, const gnntrk_graph_index *o,
     const int bits = bits_for(N > 1 ? N : 2);
     const int grid = stream_grid(E + 1);
     const int64_t *src = edge_index, *tgt = edge_index + E;
-    hipLaunchKernelGGL(gi_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt, E, N, keys_a, vals_a, bad);
+    hipLaunchKernelGGL(gi_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt, E, N, rank, keys_a, vals_a, bad);
     // the sorted keys ARE the CSR targets: sort straight into the output array
     uint32_t *tgt_sorted = reinterpret_cast<uint32_t *>(o->tgt);
     int rc = sort_pairs_u32(keys_a, tgt_sorted, vals_a, reinterpret_cast<uint32_t *>(o->perm), E, bits, temp,
@@ -902,7 +898,7 @@ static int library_build(const int64_t *edge_index, const gnntrk_graph_index *o,
     if (rc) return rc;
     hipLaunchKernelGGL(gi_rowptr_kernel, dim3(grid), dim3(kTpb), 0, stream, tgt_sorted, E, N, o->rowptr_t);
     hipLaunchKernelGGL(gi_gather_src_kernel, dim3(grid), dim3(kTpb), 0, stream, src,
-                       reinterpret_cast<const uint32_t *>(o->perm), E, N, o->src, keys_a, vals_a, bad);
+                       reinterpret_cast<const uint32_t *>(o->perm), E, N, rank, o->src, keys_a, vals_a, bad);
     rc = sort_pairs_u32(keys_a, keys_b, vals_a, reinterpret_cast<uint32_t *>(o->spos), E, bits, temp, temp_bytes,
                         stream);
     if (rc) return rc;
@@ -923,6 +919,7 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, co
     if (E > 0 && !edge_index) return fail(GNNTRK_EINVAL, "graph_index_build: NULL edge_index");
     const uint8_t *label = cy ? cy->edge_label : nullptr;
     const float *rows = cy ? cy->edge_rows : nullptr;
+    const int32_t *rank = cy ? cy->node_rank : nullptr;
     if (E > 0 && label && !cy->label_csr) return fail(GNNTRK_EINVAL, "graph_index_build: carried label without output");
     if (E > 0 && rows &&
         (!cy->rows_csr_bf16 || cy->rows_stride < 4 || cy->rows_stride % 4 != 0 || ((uintptr_t)rows & 15) != 0 ||
@@ -942,7 +939,7 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, co
         if (plan.ok && !(flags & 1) && (!plan.dense || (flags & 2))) {
             const int vec = (((uintptr_t)edge_index | (uintptr_t)(edge_index + E)) & 15) == 0 &&
                             (!label || ((uintptr_t)label & 3) == 0);
-            const KeysCoo k1{edge_index, edge_index + E, N, label, rows, rows ? cy->rows_stride : 0, vec};
+            const KeysCoo k1{edge_index, edge_index + E, N, label, rows, rows ? cy->rows_stride : 0, vec, rank};
             const uint32_t pmask = (uint32_t)(((uint64_t)1 << plan.bitsN) - 1);
             if (rows) {
                 const OutCsr<true> o1{o->perm, o->tgt, o->src, o->rowptr_t, pmask, label ? cy->label_csr : nullptr,
@@ -959,7 +956,7 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, co
             const OutSrc o2{o->spos, o->spos_inv, o->rowptr_s};
             rc = own_sort<KeysCsr, OutSrc, false>(plan, k2, o2, 0, N, E, p, bad, stream);
         } else {
-            rc = library_build(edge_index, o, p, bad, N, E, stream);
+            rc = library_build(edge_index, o, p, bad, N, E, rank, stream);
             if (rc) return rc;
             if (label)
                 hipLaunchKernelGGL(gi_gather_label_kernel, dim3(stream_grid(E)), dim3(kTpb), 0, stream, label, o->perm, E,
@@ -975,6 +972,55 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, co
         if (rc) return rc;
     }
     return check_launch("graph_index_build");
+}
+
+// ------------------------------------------------------------------ node order (gnntrk_node_order)
+// Per-event renumbering of the nodes by a caller-supplied key (one float per node: the hits' azimuth for
+// tracking graphs, whose edges join hits of neighbouring azimuth): new ids = rank of (event, key, old id).
+// One 64-bit radix sort of N pairs; the graph-index build then reads every node id through `rank`
+// (gnntrk_graph_index_carry.node_rank), so neighbouring nodes of the graph get neighbouring rows - the
+// gathers of x[src] and the source-sorted gradient stores become local.
+__global__ __launch_bounds__(kTpb) void no_keys_kernel(const float *__restrict__ key, int64_t stride,
+                                                       const int64_t *__restrict__ batch, int64_t n,
+                                                       unsigned long long *__restrict__ keys,
+                                                       uint32_t *__restrict__ vals) {
+    for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTpb) {
+        uint32_t u = __float_as_uint(key[i * stride]);
+        u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;   // order-preserving map of the floats (NaNs at the ends)
+        const unsigned long long b = batch ? (unsigned long long)(uint32_t)batch[i] : 0ull;
+        keys[i] = (b << 32) | u;
+        vals[i] = (uint32_t)i;
+    }
+}
+__global__ __launch_bounds__(kTpb) void no_finish_kernel(const uint32_t *__restrict__ sorted, int64_t n,
+                                                         int32_t *__restrict__ perm, int32_t *__restrict__ rank) {
+    for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTpb) {
+        const uint32_t v = sorted[i];
+        perm[i] = (int32_t)v;
+        rank[v] = (int32_t)i;
+    }
+}
+size_t node_order_ws_bytes(int64_t n) {
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    return 2 * align_up(m * 8, 256) + 2 * align_up(m * 4, 256) + align_up(sort_pairs_u64_temp_bytes(n), 256);
+}
+int node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n, int32_t *perm, int32_t *rank,
+               void *ws, size_t ws_bytes, hipStream_t stream) {
+    if (n < 0 || n > 0x7fffffff) return fail(GNNTRK_EUNSUPPORTED, "node_order: sizes must fit int32");
+    if (n == 0) return GNNTRK_OK;
+    if (!key || key_stride < 1 || !perm || !rank) return fail(GNNTRK_EINVAL, "node_order: NULL argument");
+    if (!ws || ws_bytes < node_order_ws_bytes(n)) return fail(GNNTRK_EINVAL, "node_order: workspace too small");
+    char *p = reinterpret_cast<char *>(ws);
+    const size_t k8 = align_up((size_t)n * 8, 256), v4 = align_up((size_t)n * 4, 256);
+    unsigned long long *ka = reinterpret_cast<unsigned long long *>(p), *kb = reinterpret_cast<unsigned long long *>(p + k8);
+    uint32_t *va = reinterpret_cast<uint32_t *>(p + 2 * k8), *vb = reinterpret_cast<uint32_t *>(p + 2 * k8 + v4);
+    void *temp = p + 2 * k8 + 2 * v4;
+    const int grid = stream_grid(n);
+    hipLaunchKernelGGL(no_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, key, key_stride, batch, n, ka, va);
+    const int rc = sort_pairs_u64(ka, kb, va, vb, n, temp, sort_pairs_u64_temp_bytes(n), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(no_finish_kernel, dim3(grid), dim3(kTpb), 0, stream, vb, n, perm, rank);
+    return check_launch("node_order");
 }
 
 }  // namespace gnntrk

@@ -500,6 +500,9 @@ struct BufPlan {
 #ifndef GNNTRK_BWD_REG_FRAGS
 #define GNNTRK_BWD_REG_FRAGS 0   // (1: first- / last-layer weight fragments of the two-tile buffer shapes in registers)
 #endif
+#ifndef GNNTRK_BWD_STATIC_GATE
+#define GNNTRK_BWD_STATIC_GATE 1   // (0: the input ReLU / relu' pattern of the buffer-addressed shapes stays a run-time value - A/B builds)
+#endif
 #ifndef GNNTRK_BWD_STATIC_EPI
 #define GNNTRK_BWD_STATIC_EPI 1   // (0: the epilogue of the buffer-addressed shapes stays a run-time value - A/B builds)
 #endif

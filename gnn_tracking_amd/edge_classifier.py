@@ -19,7 +19,7 @@ import math
 import torch
 from torch import Tensor, nn
 
-from . import _capi, ops, ops_bf16, precision
+from . import _capi, locality, ops, ops_bf16, precision
 from .edge_order import EdgeOrdered
 from .hparams import HyperparametersMixin, assert_feat_dim
 from .mlp import MLP
@@ -86,21 +86,28 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         # gathered through the permutation afterwards: the dataset's 1-byte labels (for this package's
         # losses, which find them on the index) and, in bf16 storage, the four fp32 edge features
         y = getattr(data, "y", None)
+        # node order (locality.py): the index is built in a renumbering that sorts every event's hits by
+        # azimuth, x is gathered through it below and the node embedding handed back in the caller's order
+        col = locality.key_column(x)
+        batch = getattr(data, "batch", None)
         gi = ops.graph_index(edge_index, x.shape[0],
                              carry_label=y if isinstance(y, Tensor) and self.training else None,
-                             carry_rows=edge_attr if bf16 and edge_attr.shape[1] == 4 else None)
+                             carry_rows=edge_attr if bf16 and edge_attr.shape[1] == 4 else None,
+                             order_by=None if col is None else (x, col, batch if isinstance(batch, Tensor) else None))
         E = gi.n_edges
+        nperm = gi.node_perm
 
         if bf16:
             # bf16 storage: the dataset's fp32 features are converted once (edge_attr permuted
             # into CSR order in the same pass); everything downstream is bf16 rows, W is fp32
-            h = self.ec_node_encoder.fused([ops.Seg(ops_bf16.to_rows16(x))], epilogue=_capi.EPI_RELU)
+            h = self.ec_node_encoder.fused([ops.Seg(ops_bf16.to_rows16(x, nperm))], epilogue=_capi.EPI_RELU)
             ea_csr = ops.carried_rows(gi, edge_attr)
             if ea_csr is None:
                 ea_csr = ops_bf16.to_rows16(edge_attr, gi.perm)
             e = self.ec_edge_encoder.fused([ops.Seg(ea_csr)], n_rows=E, epilogue=_capi.EPI_RELU)
         else:
-            h = self.ec_node_encoder.fused([ops.Seg(x)], epilogue=_capi.EPI_RELU)
+            h = self.ec_node_encoder.fused([ops.Seg(x) if nperm is None else ops.Seg(x, nperm, False, "perm")],
+                                           n_rows=x.shape[0], epilogue=_capi.EPI_RELU)
             e = self.ec_edge_encoder.fused([ops.Seg(edge_attr, gi.perm, False, "perm")],
                                            n_rows=E, epilogue=_capi.EPI_RELU)
         h, e, es = self.ec_resin.forward_csr(gi, h, e)
@@ -121,7 +128,7 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         w = self.W.fused(segs, n_rows=E, epilogue=_capi.EPI_SIGMOID, ca=eps, cb=1 - 2 * eps)
         return {
             "W": EdgeOrdered(w.squeeze(), gi),
-            "node_embedding": h,
+            "node_embedding": h if nperm is None else ops.permute_rows(h, gi.node_rank),
             "edge_embedding": EdgeOrdered(e, gi),
         }
 

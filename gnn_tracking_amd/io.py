@@ -168,7 +168,8 @@ class PrefetchLoader:
                             ev.record(side)
                         if self.build_index:
                             from . import ops
-                            ops.prefetch_graph_index(dev_batch.edge_index, dev_batch.num_nodes, side)
+                            ops.prefetch_graph_index(dev_batch.edge_index, dev_batch.num_nodes, side, x=dev_batch.x,
+                                                     batch=getattr(dev_batch, "batch", None))
                         q.put((dev_batch, ev, batch))  # keep the pinned source alive until consumed
                     else:
                         q.put((batch if self.device is None else batch.to(self.device), None, None))

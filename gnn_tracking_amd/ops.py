@@ -173,6 +173,14 @@ class GraphIndex:
     spos: Tensor      # [E] int32: source-sorted order -> CSR position
     spos_inv: Tensor  # [E] int32: CSR position -> position in the source-sorted order
     ready: object = None  # event of a build on a side stream (prefetch_graph_index), joined on first use
+    # node renumbering (graph_index(order_by=...)): tgt / src / rowptr_* are in the NEW numbering
+    node_perm: Optional[Tensor] = None   # [N] int32: new id -> caller's id (gather node inputs through it)
+    node_rank: Optional[Tensor] = None   # [N] int32: caller's id -> new id (gather node results through it)
+    order_sig: object = None
+
+    def node_values(self, t: Tensor) -> Tensor:
+        """Per-node values of the caller (``pt``, ...) in the numbering of ``tgt`` / ``src``."""
+        return t if self.node_perm is None else t.index_select(0, self.node_perm)
 
 
 _GI_CACHE: dict[int, tuple] = {}
@@ -190,9 +198,38 @@ _GI_FLAGS = int(os.environ.get("GNNTRK_GI_FLAGS", "0"))
 CARRY = os.environ.get("GNNTRK_GI_CARRY", "1") != "0"
 
 
+def node_order(x: Tensor, col: int, batch: Optional[Tensor] = None):
+    """``(perm, rank)`` int32 ``[N]``: the nodes of every event (``batch``: int64 ``[N]``, non-decreasing; None =
+    one event) sorted by ``x[:, col]`` (fp32), ties in the old order (gnntrk_node_order)."""
+    _capi.require_device(x)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise TypeError("node_order: x must be fp32 [N, F] with unit column stride")
+    lib = _capi.load()
+    n = int(x.shape[0])
+    key = x[:, col]
+    if batch is not None:
+        if batch.dtype != torch.int64 or batch.numel() != n or batch.device != x.device:
+            raise ValueError("node_order: batch must be int64 [N] on the device of x")
+        batch = batch.contiguous()
+    perm = torch.empty(n, dtype=torch.int32, device=x.device)
+    rank = torch.empty(n, dtype=torch.int32, device=x.device)
+    ws = _ws(lib.gnntrk_node_order_workspace_bytes(n), x)
+    _capi.check(lib.gnntrk_node_order(_p(key), int(x.stride(0)), _p(batch), n, _p(perm), _p(rank), _p(ws), ws.numel(),
+                                      _stream(x)), lib)
+    return perm, rank
+
+
+def _order_sig(order_by):
+    if order_by is None:
+        return None
+    x, col, batch = order_by
+    return (id(x), x._version, int(col), None if batch is None else (id(batch), batch._version))
+
+
 def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
                 validate: Optional[bool] = None, flags: Optional[int] = None,
-                carry_label: Optional[Tensor] = None, carry_rows: Optional[Tensor] = None) -> GraphIndex:
+                carry_label: Optional[Tensor] = None, carry_rows: Optional[Tensor] = None,
+                order_by: Optional[tuple] = None) -> GraphIndex:
     """Build (or fetch) the index of ``edge_index`` ([2,E] int64, unsorted COO).
 
     Cached per tensor OBJECT (weakref + version counter), so the L layers of a
@@ -207,18 +244,24 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     ``edge_attr``): per-edge inputs that ride along into CSR order INSIDE the build
     (``gnntrk_graph_index_carry``) instead of being gathered through ``perm`` afterwards; the
     results are left on the index (``carried_label`` / ``carried_rows`` below return them).
+
+    ``order_by = (x, col, batch)``: build the index in a renumbering of the nodes - every event's nodes sorted
+    by ``x[:, col]`` (``locality.py`` says why) - with ``node_perm`` / ``node_rank`` left on the index.  Only the
+    caller that asked for it sees such an index (the cache keeps the two forms apart).
     """
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
     if edge_index.dtype != torch.int64:
         raise TypeError("edge_index must be int64 (PyG convention)")
     _capi.require_device(edge_index)
-    key = id(edge_index)
+    sig = _order_sig(order_by)
+    key = (id(edge_index), sig is not None)
     if cache:
         hit = _GI_CACHE.get(key)
         if hit is not None:
             ref, ver, nn, gi = hit
-            if ref() is edge_index and ver == edge_index._version and nn == n_nodes:
+            if (ref() is edge_index and ver == edge_index._version and nn == n_nodes and gi.order_sig == sig
+                    and (sig is None or gi._order_ref() is order_by[0])):   # (an id can be reused: same OBJECT)
                 return _join(gi)
     lib = _capi.load()
     ei = edge_index.contiguous()
@@ -229,6 +272,12 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     d = _capi.GraphIndex(n_nodes, E, _p(gi.perm), _p(gi.tgt), _p(gi.src), _p(gi.rowptr_t),
                          _p(gi.rowptr_s), _p(gi.spos), _p(gi.spos_inv))
     cy = _capi.GraphIndexCarry()
+    if order_by is not None:
+        if int(order_by[0].shape[0]) != n_nodes:
+            raise ValueError("graph_index(order_by): x must hold one row per node")
+        gi.node_perm, gi.node_rank = node_order(*order_by)
+        gi.order_sig, gi._order_ref = sig, weakref.ref(order_by[0])
+        cy.node_rank = _p(gi.node_rank)
     lab = rows = None
     if CARRY and carry_label is not None and E > 0 and _carry_label_ok(carry_label, E, dev):
         lab = carry_label.detach().view(torch.uint8).contiguous().view(-1)
@@ -293,7 +342,7 @@ def _cache_put(edge_index: Tensor, n_nodes: int, gi: GraphIndex) -> None:
         _GI_CACHE.pop(k, None)
     while len(_GI_CACHE) >= _GI_CACHE_MAX:
         _GI_CACHE.pop(next(iter(_GI_CACHE)))
-    _GI_CACHE[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, n_nodes, gi)
+    _GI_CACHE[(id(edge_index), gi.order_sig is not None)] = (weakref.ref(edge_index), edge_index._version, n_nodes, gi)
 
 
 def _join(gi: GraphIndex) -> GraphIndex:
@@ -308,13 +357,18 @@ def _join(gi: GraphIndex) -> GraphIndex:
     return gi
 
 
-def prefetch_graph_index(edge_index: Tensor, n_nodes: int, stream) -> GraphIndex:
+def prefetch_graph_index(edge_index: Tensor, n_nodes: int, stream, x: Optional[Tensor] = None,
+                         batch: Optional[Tensor] = None) -> GraphIndex:
     """Build the index of ``edge_index`` on ``stream`` (a side stream: the loader's) while the
     current stream computes, and register it in the cache; ``graph_index()`` for the same
     tensor then joins it instead of building.  The index only depends on the input edge list,
-    so a loader can have it ready one batch ahead (io.PrefetchLoader(build_index=True))."""
+    so a loader can have it ready one batch ahead (io.PrefetchLoader(build_index=True)).  ``x`` / ``batch``:
+    the batch's node features and event ids - with them the index is built in the node order the edge
+    classifier will ask for (locality.py), so that its lookup finds this build."""
+    from . import locality
+    col = None if x is None else locality.key_column(x)
     with torch.cuda.stream(stream):
-        gi = graph_index(edge_index, n_nodes, cache=False)
+        gi = graph_index(edge_index, n_nodes, cache=False, order_by=None if col is None else (x, col, batch))
         gi.ready = torch.cuda.Event()
         gi.ready.record(stream)
     _cache_put(edge_index, n_nodes, gi)
@@ -1273,7 +1327,7 @@ def edge_targets_csr(y: Tensor, gi: GraphIndex, pt: Optional[Tensor] = None, pt_
     ptf = None
     if pt_thld > 0.0:
         assert pt is not None
-        ptf = pt.detach().to(torch.float32).contiguous()
+        ptf = gi.node_values(pt.detach().to(torch.float32)).contiguous()
     out = torch.empty(gi.n_edges, dtype=torch.float32, device=yf.device)
     _capi.check(lib.gnntrk_edge_targets_csr(_p(yf), int(u8), _p(gi.perm), _p(gi.src), _p(ptf), float(pt_thld),
                                             gi.n_edges, _p(out), _stream(yf)), lib)
@@ -1349,6 +1403,7 @@ def bce_loss(w: Tensor, y: Tensor, edge_index: Optional[Tensor] = None,
                 if ptf.device != w_csr.device or ptf.numel() < gi.n_nodes:
                     raise ValueError(f"bce_loss: pt must hold one value per node ({gi.n_nodes}) on {w_csr.device}, "
                                      f"got {ptf.numel()} on {ptf.device}")
+                ptf = gi.node_values(ptf).contiguous()
             return _BCECsr.apply(w_csr, lab, gi.src if pt_thld > 0.0 else None, ptf, float(pt_thld))
         return _BCE.apply(w_csr, edge_targets_csr(y, gi, pt, float(pt_thld)), None, None, 0.0)
     y = y.to(torch.float32)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNNTRK_VERSION 400 /* 0.4.0: + resfcnn_*, hinge_* (metric-learning stage), mlp_*_wide (fp32 in <= 128 / hidden <= 128 / out <= 48); 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
+#define GNNTRK_VERSION 500 /* 0.5.0: + node_order, graph_index_carry.node_rank (node renumbering inside the index build); 0.4.0: + resfcnn_*, hinge_* (metric-learning stage), mlp_*_wide (fp32 in <= 128 / hidden <= 128 / out <= 48); 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
 #define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
 #define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
 #define GNNTRK_MAX_HIDDEN 64
@@ -110,11 +110,29 @@ typedef struct gnntrk_graph_index_carry {
     uint16_t *rows_csr_bf16;   /* [E, out_stride] bf16 out, 8-byte aligned */
     int32_t rows_stride;       /* floats per input row (multiple of 4) */
     int32_t out_stride;        /* bf16 per output row (multiple of 4) */
+    const int32_t *node_rank;  /* [N] or NULL: renumbering old node id -> new node id (a permutation of [0, N),
+                                  gnntrk_node_order.rank) applied to both endpoints of every edge as they are
+                                  read: tgt / src / rowptr_* come out in the NEW numbering, perm / spos still
+                                  refer to the caller's edge order.  The caller gathers its node rows through
+                                  gnntrk_node_order.perm and hands node results back through rank. */
 } gnntrk_graph_index_carry;
 size_t gnntrk_graph_index_workspace_bytes_carry(int64_t n_nodes, int64_t n_edges, int32_t carry_rows);
 int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph_index *out,
                                    const gnntrk_graph_index_carry *carry, void *workspace, size_t workspace_bytes,
                                    int32_t flags, void *stream);
+
+/* Node renumbering for gather locality.  The reference keeps the hits of an event in file order
+ * (graph_construction/graph_builder.py:396-455: node order = order of the hit table; utils/loading.py:17-113
+ * hands the graphs on unchanged), which is unrelated to the geometry; the message passing then gathers
+ * x[edge_index[0]] (models/interaction_network.py:67) from random rows.  gnntrk_node_order sorts the nodes
+ * of every event by a caller-supplied key (one float per node, row stride key_stride floats; for tracking
+ * graphs the azimuth column of data.x - edges join hits of neighbouring azimuth); ties keep the old order:
+ *   perm[new] = old, rank[old] = new, events (batch[i], non-decreasing, or NULL = one event) keep their
+ *   id ranges.  Stable 64-bit radix sort of N pairs; deterministic.
+ * workspace: gnntrk_node_order_workspace_bytes(n_nodes). */
+size_t gnntrk_node_order_workspace_bytes(int64_t n_nodes);
+int gnntrk_node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_nodes, int32_t *perm,
+                      int32_t *rank, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------- fused gather-MLP
  * One kernel family replaces, for every MLP site of the path

@@ -10,6 +10,8 @@ import pathlib
 
 import math
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -112,6 +114,87 @@ def case_graph_index(device, big=False):
         for flags in (0, 1, 2):   # default choice / library sort / own sort forced
             gi = ops.graph_index(ei, N, cache=False, flags=flags)
             _check_graph_index(gi, eic, N, f"{tag} flags={flags}")
+
+
+def case_node_order(device, n_hits=10_000, n_edges=100_000, modes=("f32", "bf16")):
+    """Node renumbering (locality.py, gnntrk_node_order, gnntrk_graph_index_carry.node_rank):
+    (1) the order itself against torch's stable sorts - events keep their id ranges, ties keep the old order;
+    (2) the index built through ``node_rank`` == the index of the relabelled edge list, all three build forms;
+    (3) the edge classifier's training step with the renumbering ON against the CPU oracle in the caller's
+        numbering (W, embeddings, pt-falsified loss, gradients, parameters after Adam: the fp32 bars), and
+        ON against OFF: forward outputs bit for bit (a row's result does not depend on its tile), gradients to
+        summation order."""
+    from gnn_tracking_amd import synthetic
+
+    g = np.random.default_rng(3)
+    sizes = (700, 1, 300, 2049)
+    batch = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)])
+    N = int(batch.numel())
+    x = torch.from_numpy(g.standard_normal((N, 3)).astype(np.float32))
+    x[::7, 1] = 0.25           # ties
+    x[5, 1] = -0.0
+    x[6, 1] = 0.0
+    for b, col in ((batch, 1), (None, 2)):
+        perm, rank = ops.node_order(x.to(device), col, None if b is None else b.to(device))
+        o = torch.argsort(x[:, col], stable=True)
+        if b is not None:
+            o = o[torch.argsort(b[o], stable=True)]
+        assert torch.equal(perm.cpu().long(), o), "node_order: perm is the stable (event, key) sort"
+        inv = torch.empty_like(o)
+        inv[o] = torch.arange(N)
+        assert torch.equal(rank.cpu().long(), inv), "node_order: rank inverts perm"
+    offs, parts = 0, []
+    for n in sizes:
+        parts.append(g.integers(0, n, size=(2, 9 * n + 3)) + offs)
+        offs += n
+    eic = torch.from_numpy(np.concatenate(parts, axis=1)).long()
+    xd, bd, ei = x.to(device), batch.to(device), eic.to(device)
+    for flags in (0, 1, 2):
+        gi = ops.graph_index(ei, N, cache=False, flags=flags, order_by=(xd, 1, bd))
+        _check_graph_index(gi, gi.node_rank.cpu().long()[eic], N, f"node order flags={flags}")
+        assert torch.equal(gi.node_perm.cpu().long()[gi.node_rank.cpu().long()], torch.arange(N))
+
+    ev = synthetic.make_event(1, n_hits, n_edges, "cpu")
+    d = ev.to(device)
+    torch.manual_seed(0)
+    model0 = G.ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=3, hidden_dim=40)
+    params = {k: v.detach().clone() for k, v in model0.state_dict().items()}
+    ref, rloss, rgrads, rafter = O.ec_training_step(ev.x, ev.edge_index, ev.edge_attr, ev.y, params,
+                                                    model_kwargs=dict(L_ec=3), pt=ev.pt, pt_thld=0.9)
+    for mode in modes:
+        runs = {}
+        for order in ("off", 1):
+            model = G.ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=3, hidden_dim=40)
+            model.load_state_dict(params)
+            model = model.to(device)
+            ops.clear_graph_index_cache()
+            with G.node_order(order), (G.bf16_storage() if mode == "bf16" else contextlib.nullcontext()):
+                out = model(d)
+                assert (ops.graph_index(d.edge_index, d.x.shape[0], order_by=(d.x, 1, None)).node_perm is not None) if order == 1 else True
+                loss = G.EdgeWeightBCELoss(pt_thld=0.9)(w=out["W"], y=d.y, pt=d.pt, edge_index=d.edge_index)
+                loss.backward()
+            runs[order] = (torch.as_tensor(out["W"]).detach().float().cpu(), out["node_embedding"].detach().float().cpu(),
+                           torch.as_tensor(out["edge_embedding"]).detach().float().cpu(), loss.detach().cpu(),
+                           {k: v.grad.detach().cpu() for k, v in model.named_parameters()}, model)
+        tag = f"node order {mode}"
+        for i, nm in enumerate(("W", "node_embedding", "edge_embedding")):
+            assert torch.equal(runs["off"][i], runs[1][i]), f"{tag}: {nm} differs between the numberings"
+        if mode == "f32":
+            W, hn, en, loss, grads, model = runs[1]
+            assert_close(W, ref["W"], TOL_OUT, tag + " W")
+            assert_close(hn, ref["node_embedding"], TOL_OUT, tag + " node_embedding")
+            assert_close(en, ref["edge_embedding"], TOL_OUT, tag + " edge_embedding")
+            assert_close(loss, rloss, TOL_OUT, tag + " loss")
+            for k, v in grads.items():
+                assert_close(v, rgrads[k], TOL_GRAD, f"{tag} grad {k}")
+            torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4).step()
+            for k, v in model.state_dict().items():
+                assert_close(v, rafter[k], 1e-6, f"{tag} after Adam {k}")
+        else:
+            assert abs(float(runs["off"][3]) - float(runs[1][3])) <= 1e-6, tag + " loss"
+            for k in runs[1][4]:
+                a, b = runs["off"][4][k], runs[1][4][k]
+                assert (a - b).norm() <= 2e-2 * max(float(a.norm()), 1e-6) + 2e-3 * max(float(torch.cat([v.flatten() for v in runs["off"][4].values()]).norm()), 1e-6), f"{tag} grad {k}"
 
 
 def case_graph_index_carry(device):

@@ -33,7 +33,7 @@ def test_version_and_error_channel(lib_path):
     from gnn_tracking_amd import _capi
 
     lib = _capi.bind(ctypes.CDLL(str(lib_path)))
-    assert lib.gnntrk_version() == 400
+    assert lib.gnntrk_version() == 500
     # argument validation happens on the host, before any launch
     rc = lib.gnntrk_mlp_forward(None, None)
     assert rc == 1 and b"NULL" in lib.gnntrk_last_error()
@@ -47,7 +47,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.MlpFwdArgs) == 448
     assert _capi.MlpFwdArgs.n_rows.offset == 392
     assert ctypes.sizeof(_capi.GraphIndex) == 72
-    assert ctypes.sizeof(_capi.GraphIndexCarry) == 40
+    assert ctypes.sizeof(_capi.GraphIndexCarry) == 48
     assert ctypes.sizeof(_capi.MlpBwdArgs) == 784
     assert ctypes.sizeof(_capi.ResFcnn) == 8 * (5 + 2 * _capi.RESFCNN_MAX_HIDDEN) + 32
     assert ctypes.sizeof(_capi.ResFcnnGrads) == 8 * (5 + 2 * _capi.RESFCNN_MAX_HIDDEN)

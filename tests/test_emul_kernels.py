@@ -17,6 +17,11 @@ def test_graph_index():
         P.case_graph_index("cpu")
 
 
+def test_node_order():
+    with emulated():
+        P.case_node_order("cpu", n_hits=1500, n_edges=15000)
+
+
 def test_graph_index_carry_and_fused_bce():
     with emulated():
         P.case_graph_index_carry("cpu")

@@ -15,12 +15,16 @@ def dev():
     from gnn_tracking_amd import _capi
 
     lib = _capi.load()  # fails loudly if the extension is missing
-    assert lib.gnntrk_version() == 400
+    assert lib.gnntrk_version() == 500
     return "cuda"
 
 
 def test_graph_index(dev):
     P.case_graph_index(dev, big=True)
+
+
+def test_node_order(dev):
+    P.case_node_order(dev)
 
 
 def test_graph_index_carry_and_fused_bce(dev):

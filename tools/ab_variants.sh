@@ -6,6 +6,6 @@ OUT=$1; shift
 for v in "$@"; do
   if [ "$v" = base ]; then unset GNNTRK_LIB; else export GNNTRK_LIB=$(pwd)/tools/_bin/variants/$v/libgnntrk.so; fi
   echo "== $v" >> $OUT
-  python tools/bench_bwd_io.py --only 0 --iters 12 2>&1 | grep -v "^$" >> $OUT
+  python tools/bench_bwd_io.py --only 0 --iters 12 $AB_ARGS 2>&1 | grep -v amdgpu.ids | grep -v "^$" >> $OUT
 done
 cat $OUT

@@ -21,9 +21,12 @@ ap.add_argument("--only", type=int, default=None, help="0: buffer form only, 128
 ap.add_argument("--seq-ids", action="store_true",
                 help="edge k joins nodes (k / 13, k / 13 + 1) and the source order is the CSR order: no random "
                      "gather / scatter - what the kernels cost without the memory system's share")
+ap.add_argument("--node-ids", default="random", choices=("random", "phi"),
+                help="phi: hits numbered by phi (the generator's best case for the gathers / the permuted store)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
-batch = G.collate([synthetic.make_event(100 + i, 150_000, 2_000_000, dev) for i in range(args.events)])
+batch = G.collate([synthetic.make_event(100 + i, 150_000, 2_000_000, dev, phi_sorted_ids=args.node_ids == "phi")
+                   for i in range(args.events)])
 gi = ops.graph_index(batch.edge_index, batch.num_nodes)
 N, E = batch.num_nodes, gi.n_edges
 if args.seq_ids:

@@ -59,6 +59,8 @@ TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r04c_hbm_traffic_
 TRAFFIC_FALLBACK = {"bf16": "r02_hbm_traffic_bf16.json"}
 PIPE_PROFILES = {"cfg5": "r04c_pipe_util_cfg5.json", "dbscan": "r04c_pipe_util_dbscan.json"}
 
+TRAFFIC_NOTES: dict = {}   # kernel -> which committed profile its traffic figure came from, and whether it is stale
+
 EC_MODEL = dict(L_ec=3, hidden_dim=40)
 CFG4_EVENTS, CFG4_SHARDS = 256, 8
 
@@ -188,6 +190,133 @@ def cpu_baseline(event, model, iters: int) -> dict:
             "s_per_iter": dt, "s_all_iters": times, "thread_probe_s": probe}
 
 
+def parity_check(event_cpu, model, dtype: str, dev) -> dict:
+    """The GPU's edge weights and loss on event 0 of the workload (the run's precision, the parameters the run ended
+    with) against the CPU oracle on the same event: fp32 against ``oracle.ec_for_graph_tcn`` (bar 1e-5), bf16 storage
+    against the oracle's restatement of the rounding contract ``ec_for_graph_tcn_bf16`` (bar: one bf16 ulp of W on
+    [0.5, 1) = 2^-8) with the distance to the fp32 oracle next to it.  The checker, not the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu as O
+
+    hp = model.hparams
+    p = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    d = event_cpu.to(dev)
+    was_training = model.training
+    model.eval()
+    with torch.no_grad(), G.bf16_storage(dtype == "bf16"):
+        out = model(d)
+        w = torch.as_tensor(out["W"]).float()
+        loss = float(G.EdgeWeightBCELoss()(w=out["W"], y=d.y.float(), edge_index=d.edge_index, pt=d.pt))
+    model.train(was_training)
+    w = w.cpu()
+    x, ei, ea, y = event_cpu.x, event_cpu.edge_index, event_cpu.edge_attr, event_cpu.y
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref32 = O.ec_for_graph_tcn(x, ei, ea, p, L_ec=hp.L_ec, alpha=hp.alpha)
+        rloss32 = float(O.edge_weight_bce_loss(ref32["W"], y.float()))
+        rec = {"event": f"event 0 of the workload ({x.shape[0]} hits, {ei.shape[1]} edges), parameters after the timed steps",
+               "dtype": dtype, "max_abs_W_vs_fp32_oracle": float((w - ref32["W"]).abs().max()),
+               "loss_gpu": loss, "loss_fp32_oracle": rloss32}
+        if dtype == "bf16":
+            ref16 = O.ec_for_graph_tcn_bf16(x, ei, ea, p, L_ec=hp.L_ec, alpha=hp.alpha)
+            err, bound = float((w - ref16["W"]).abs().max()), 2.0 ** -8
+            rec.update({"oracle": "oracle/ref_cpu.py: ec_for_graph_tcn_bf16 (the kernels' rounding contract restated)",
+                        "max_abs_W": err, "bound": bound,
+                        "loss_abs": abs(loss - float(O.edge_weight_bce_loss(ref16["W"], y.float()))), "loss_bound": 5e-3})
+        else:
+            err, bound = rec["max_abs_W_vs_fp32_oracle"], 1e-5
+            rec.update({"oracle": "oracle/ref_cpu.py: ec_for_graph_tcn (fp32)", "max_abs_W": err, "bound": bound,
+                        "loss_abs": abs(loss - rloss32), "loss_bound": 1e-5})
+    rec["ok"] = bool(rec["max_abs_W"] <= rec["bound"] and rec["loss_abs"] <= rec["loss_bound"])
+    rec["oracle_seconds"] = time.perf_counter() - t0
+    return rec
+
+
+def library_id() -> dict:
+    """What the loaded libgnntrk.so is: sha256 of the file and of the kernel sources it was built from.  Committed
+    profiles carry the source hash they were taken on (tools/make_*_json.py); a block read from a profile of another
+    build says so (``stale``) instead of passing for a measurement of this one."""
+    import hashlib
+    from gnn_tracking_amd import _build
+    h = hashlib.sha256()
+    for f in sorted(list(_build.CSRC.glob("*.hip")) + list(_build.CSRC.glob("*.h")) + list(_build.CSRC.glob("*.inc"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    lib = _build.LIB
+    return {"csrc_sha256": h.hexdigest()[:16],
+            "lib_sha256": hashlib.sha256(lib.read_bytes()).hexdigest()[:16] if lib.exists() else None}
+
+
+def _profile_note(rec_file: dict) -> dict:
+    """``source`` fields of a block taken from a committed profile: which build it describes, and whether that is
+    the build running now."""
+    built = rec_file.get("_csrc_sha256")
+    cur = library_id()["csrc_sha256"]
+    return {"source": "committed_profile", "profile_csrc_sha256": built, "library_csrc_sha256": cur,
+            "stale": built != cur}
+
+
+def access_floor(wl, dev, iters: int = 6) -> dict:
+    """Time of the I/O SKELETON of the dominant kernel (the relational backward with three upstream terms:
+    ``mlp16_bwd_skel_kernel``, debug_flags & 4096 - every load and store of the real kernel, the same descriptors,
+    prefetch distance and occupancy, no arithmetic) on THIS run's batch and node numbering, next to the real kernel
+    launched the same way.  Says how much of the kernel's time its access pattern costs whatever the instruction
+    stream does: the floor an instruction diet cannot go below, and what a better layout has to move."""
+    from gnn_tracking_amd import _capi, locality, ops_bf16 as B
+
+    b = wl.batches[0]
+    col = locality.key_column(b.x)
+    bt = getattr(b, "batch", None)
+    gi = ops.graph_index(b.edge_index, b.num_nodes, order_by=None if col is None else (b.x, col, bt))
+    N, E = b.num_nodes, gi.n_edges
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def rows(n, d):
+        t = B.empty_rows(n, d, dev, zero=True)
+        t.copy_(torch.randn(n, d, device=dev, generator=g))
+        return t
+
+    h, e, ge, gt, ga = rows(N, 5), rows(E, 4), rows(E, 4), rows(E, 4), rows(N, 4)
+    m = G.MLP(14, 4, 40, L=3).to(dev)
+    W = [l.weight.detach().contiguous() for l in m.linears()]
+    bs = [l.bias.detach().contiguous() for l in m.linears()]
+    mlp = ops._fill_mlp(W, bs)
+
+    def launch():
+        return B.mlp_backward_raw([h, h, e], [gi.tgt, gi.src, None], [True, True, True], W, bs, n_rows=E,
+                                  epilogue=_capi.EPI_NONE, ca=0.0, cb=1.0, gout=[(ge, None), (ga, gi.tgt), (gt, None)],
+                                  need_seg=[True, True, True], want_dw=True, mlp=mlp, gidx=[None, gi.spos_inv, None])
+
+    def timed(flags):
+        old, B._DEBUG_FLAGS = B._DEBUG_FLAGS, flags
+        try:
+            ts = []
+            for i in range(iters + 1):
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                out = launch()
+                s1.record()
+                torch.cuda.synchronize()
+                del out
+                if i:
+                    ts.append(s0.elapsed_time(s1))
+            return sorted(ts)[len(ts) // 2]
+        finally:
+            B._DEBUG_FLAGS = old
+
+    real, skel = timed(0), timed(4096)
+    alg = 92.0 * E
+    return {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, false, 2, IoRelational<3> >",
+            "what": "loads + stores of the relational backward (three upstream terms) without its arithmetic, same "
+                    "occupancy and prefetch distance, this run's batch; launched alone (HIP events around launch + "
+                    "partial reduction), median of %d" % iters,
+            "node_order": "renumbered by data.x[:, %d] per event" % col if col is not None else "as given",
+            "skeleton_ms": skel, "kernel_ms_isolated": real, "rows": E,
+            "skeleton_GBps_algorithmic": alg / (skel * 1e-3) / 1e9,
+            "frac": alg / (skel * 1e-3) / 1e9 / (PEAK_HBM_TBPS * 1e3),
+            "share_of_kernel": skel / real}
+
+
 def measured_traffic(kernel: str, rows_per_launch: float, dtype: str):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and
     WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; see the JSON's _about),
@@ -199,8 +328,10 @@ def measured_traffic(kernel: str, rows_per_launch: float, dtype: str):
         if not os.path.exists(path):
             continue
         with open(path) as f:
-            rec = json.load(f)["kernels"].get(kernel)
+            doc = json.load(f)
+        rec = doc["kernels"].get(kernel)
         if rec is not None:
+            TRAFFIC_NOTES[kernel] = dict(_profile_note(doc), profile=name)
             return rec["hbm_bytes_per_launch"] * rows_per_launch / rec["rows_per_launch"]
     return None
 
@@ -214,10 +345,11 @@ def measured_pipe(which: str, kernel_prefix: str):
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        ks = json.load(f)["kernels"]
+        doc = json.load(f)
+    ks = doc["kernels"]
     for name, rec in ks.items():
         if name.startswith(kernel_prefix) and "valu_busy" in rec:
-            return {"source": "committed_profile",   # (NOT measured in this run: a constant read from profiles/)
+            return {**_profile_note(doc),   # (NOT measured in this run: a constant read from profiles/)
                     "profile": PIPE_PROFILES[which],
                     "bound": "valu", "achieved": rec["valu_busy"], "peak": 1.0,
                     "unit": "share of the chip's vector-issue cycles (SQ_INSTS_VALU x 4 / (1024 SIMDs x cycles); "
@@ -682,6 +814,8 @@ def roofline_of(ks: dict, dtype: str):
               "alg_flops_per_launch": d["flops"] / d["launches"],
               "alg_bytes_per_launch": d["bytes"] / d["launches"],
               "traffic": measured_traffic(dom, d["rows"] / d["launches"], dtype)}
+    if common["traffic"] is not None:
+        common["traffic_source"] = TRAFFIC_NOTES.get(dom)
     if dtype == "bf16":
         # bf16 MFMA (2.5 PFLOP/s) leaves the fused kernels HBM / issue bound: the
         # roofline that bounds them is HBM bandwidth
@@ -693,15 +827,17 @@ def roofline_of(ks: dict, dtype: str):
     return roof, kernels
 
 
-def hipgraph_cfg2(dev, dtype: str, steps: int) -> dict:
-    """cfg2 (launch bound: ~100 kernels of a few microseconds) eager and as ONE captured HIP
-    graph: every gnntrk_* entry point is stream ordered, allocation- and sync-free."""
+def hipgraph_cfg2(dev, dtype: str, steps: int, hits: int = 10_000, edges: int = 100_000, seed: int = 1,
+                  label: str = "cfg2") -> dict:
+    """One event per step (the reference's DataLoader default, utils/loading.py:235: batch_size = 1) eager and as ONE
+    captured HIP graph: every gnntrk_* entry point is stream ordered, allocation- and sync-free.  cfg2 (10 k hits:
+    launch bound, ~100 kernels of a few microseconds) and one full-size event of cfg3 (150 k hits, 2 M edges)."""
     torch.manual_seed(0)
     model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_MODEL).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
     mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), bf16=dtype == "bf16", optimizer=lambda p: opt,
                             scheduler=None)
-    batch = G.collate([synthetic.make_event(1, 10_000, 100_000, dev)])
+    batch = G.collate([synthetic.make_event(seed, hits, edges, dev)])
 
     def step():
         ops.clear_graph_index_cache()
@@ -730,9 +866,12 @@ def hipgraph_cfg2(dev, dtype: str, steps: int) -> dict:
     g.replay()
     graph = timed(g.replay, steps)
     E = batch.num_edges
-    return {"workload": "cfg2: 1 event x 10000 hits x 100000 edges, whole step as one hipGraph replay",
+    return {"workload": f"{label}: 1 event x {hits} hits x {edges} edges per step (graph index + forward + BCE + backward "
+                        "+ Adam), eager and the whole step as one hipGraph replay",
             "dtype": dtype, "steps": steps, "eager_ms_per_step": eager, "ms_per_step": graph,
-            "value": E / graph * 1e3, "unit": "edges/s", "roofline": "n/a (cache resident, launch bound)"}
+            "value": E / graph * 1e3, "eager_value": E / eager * 1e3, "unit": "edges/s",
+            "roofline": "n/a (cache resident, launch bound)" if edges <= 200_000 else
+                        "see the headline's roofline block (same kernels, 1/32 of the rows per launch)"}
 
 
 def cfg4_short(args, rank: int, world: int, dev) -> dict:
@@ -867,6 +1006,20 @@ def extras(args, rank: int, world: int, dev) -> dict:
             del wl
             ops.clear_graph_index_cache()
             torch.cuda.empty_cache()
+        from gnn_tracking_amd import locality
+        if locality.mode() != "off":
+            with G.node_order("off"):
+                wl = ECWorkload(args, 0, 1, dev, workload="cfg3", dtype="bf16")
+                dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
+            roof, _ = roofline_of(ks, "bf16")
+            out["cfg3_bf16_node_order_off"] = {
+                "workload": "cfg3 exactly as the headline but with the node renumbering switched off (GNNTRK_NODE_ORDER=off: "
+                            "the graph index and every gather in the generator's shuffled numbering, as in rounds 1-4)",
+                "steps": 5, "warmup": 2, "ms_per_step": dt / 5 * 1e3, "value": wl.edges_per_step_global * 5 / dt,
+                "unit": "edges/s", "final_loss": loss, "roofline": roof}
+            del wl
+            ops.clear_graph_index_cache()
+            torch.cuda.empty_cache()
         wl = ECWorkload(args, 0, 1, dev, workload="cfg3", dtype="bf16", hidden_dim=64)
         dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
         out["cfg3_hidden64_bf16"] = {
@@ -881,6 +1034,9 @@ def extras(args, rank: int, world: int, dev) -> dict:
         out["gc_resin_default_f32"] = gc_resin_short(dev, bf16=False)
         out["cfg2_hipgraph_bf16"] = hipgraph_cfg2(dev, "bf16", 100)
         out["cfg2_hipgraph_f32"] = hipgraph_cfg2(dev, "f32", 100)
+        # the reference's default operating point: ONE full-size event per step (utils/loading.py:235)
+        out["one_event_150k_2M_bf16"] = hipgraph_cfg2(dev, "bf16", 50, 150_000, 2_000_000, 100, "one event of cfg3")
+        out["one_event_150k_2M_f32"] = hipgraph_cfg2(dev, "f32", 30, 150_000, 2_000_000, 100, "one event of cfg3")
         torch.cuda.empty_cache()
         out["cfg5_oc_step_f32"] = cfg5_short(args, dev)
         out["cfg5_oc_step_bf16"] = cfg5_short(args, dev, "bf16")
@@ -936,6 +1092,15 @@ def main(argv=None):
     roof_fn = getattr(wl, "roofline", None)
     cpu_fn = getattr(wl, "cpu_baseline", None)
     stages = wl.stages() if hasattr(wl, "stages") else None
+    floor = None
+    if (rank == 0 and world == 1 and not args.stub and isinstance(wl, ECWorkload) and args.workload == "cfg3"
+            and args.dtype == "bf16" and not args.no_extra):
+        try:
+            floor = access_floor(wl, dev)
+        except Exception as e:   # (the headline survives a failing side measurement)
+            floor = {"error": f"{type(e).__name__}: {e}"}
+        ops.clear_graph_index_cache()
+        torch.cuda.empty_cache()
     extra = None
     if want_extra:
         del wl
@@ -946,12 +1111,18 @@ def main(argv=None):
             roof, kernels = roof_fn(ks)
         else:
             roof, kernels = roofline_of(ks, args.dtype)
-        cpu = None
+        if roof is not None and floor is not None:
+            roof["access_floor"] = floor
+        cpu = parity = None
         if world == 1 and not args.no_cpu_baseline and not args.stub:
             if cpu_fn is not None:
                 cpu = cpu_fn(args.cpu_iters)
             elif model_for_cpu[0] is not None:
                 cpu = cpu_baseline(model_for_cpu[0], model_for_cpu[1], args.cpu_iters)
+                try:
+                    parity = parity_check(model_for_cpu[0], model_for_cpu[1], wdtype, dev)
+                except Exception as e:
+                    parity = {"ok": False, "error": f"{type(e).__name__}: {e}"}
         total = edges_per_step * args.steps
         line = {
             "metric": "edges_per_sec_fwd_bwd" if not args.stub else "stub_not_a_measurement",
@@ -989,6 +1160,8 @@ def main(argv=None):
             "roofline": roof,
             "kernels": kernels,
             "cpu_baseline": cpu,
+            "parity_check": parity,
+            "library": library_id() if not args.stub else None,
         }
         if stages is not None:
             line["stages"] = stages

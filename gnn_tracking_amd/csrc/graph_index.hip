@@ -161,6 +161,126 @@ struct KeysCoo {
         return *reinterpret_cast<const f32x4 *>(rows + e * rows_stride);
     }
 };
+// first sort over a RENUMBERED edge list (gnntrk_graph_index_carry.node_rank): gi_remap_kernel has written both
+// endpoint rows as validated int32 new ids (one streaming pass with every lane's eight table lookups in flight:
+// inside the count / split kernels, whose occupancy is one workgroup per CU, the same lookups cost 1.7 ms per
+// 64 M edges, here about a third of that); the count and split then read 4 + 8 bytes per edge instead of 8 + 16
+struct KeysCoo32 {
+    const int32_t *src, *tgt;
+    const uint8_t *label;
+    const float *rows;
+    int rows_stride;
+    int vec;   // 4-byte aligned labels
+    __device__ __forceinline__ uint32_t key(int64_t e, int *) const { return (uint32_t)tgt[e]; }
+    __device__ __forceinline__ uint32_t payload(int64_t e, int *) const { return (uint32_t)src[e]; }
+    __device__ __forceinline__ uint32_t value(int64_t e) const {
+        return (uint32_t)e | ((label && label[e]) ? 0x80000000u : 0u);
+    }
+    __device__ __forceinline__ uint2 row(int64_t e) const {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(rows + e * rows_stride);
+        return uint2{bf16x2_pack(v[0], v[1]), bf16x2_pack(v[2], v[3])};
+    }
+    __device__ __forceinline__ void keys4(int64_t e, int64_t e1, uint32_t k[4], int *) const {
+        if (e + 4 <= e1) {   // (own 16-byte aligned arrays; e is a multiple of four)
+            const int4 a = *reinterpret_cast<const int4 *>(tgt + e);
+            k[0] = (uint32_t)a.x;
+            k[1] = (uint32_t)a.y;
+            k[2] = (uint32_t)a.z;
+            k[3] = (uint32_t)a.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) k[q] = e + q < e1 ? (uint32_t)tgt[e + q] : 0u;
+        }
+    }
+    struct Raw {
+        int4 t, s;
+        uint32_t l4;
+    };
+    __device__ __forceinline__ void load_raw(int64_t e, int64_t e1, Raw &r) const {
+        if (e + 4 <= e1) {
+            r.t = *reinterpret_cast<const int4 *>(tgt + e);
+            r.s = *reinterpret_cast<const int4 *>(src + e);
+            if (!label) {
+                r.l4 = 0u;
+            } else if (vec) {
+                r.l4 = *reinterpret_cast<const uint32_t *>(label + e);
+            } else {
+                r.l4 = (label[e] ? 1u : 0u) | (label[e + 1] ? 0x100u : 0u) | (label[e + 2] ? 0x10000u : 0u) |
+                       (label[e + 3] ? 0x1000000u : 0u);
+            }
+        } else {
+            int t[4], u[4];
+            r.l4 = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = e + q < e1;
+                t[q] = in ? tgt[e + q] : 0;
+                u[q] = in ? src[e + q] : 0;
+                if (in && label && label[e + q]) r.l4 |= 1u << (8 * q);
+            }
+            r.t = int4{t[0], t[1], t[2], t[3]};
+            r.s = int4{u[0], u[1], u[2], u[3]};
+        }
+    }
+    __device__ __forceinline__ void decode(const Raw &r, int64_t e, uint32_t k[4], uint32_t p[4], uint32_t v[4],
+                                           int *) const {
+        k[0] = (uint32_t)r.t.x;
+        k[1] = (uint32_t)r.t.y;
+        k[2] = (uint32_t)r.t.z;
+        k[3] = (uint32_t)r.t.w;
+        p[0] = (uint32_t)r.s.x;
+        p[1] = (uint32_t)r.s.y;
+        p[2] = (uint32_t)r.s.z;
+        p[3] = (uint32_t)r.s.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (uint32_t)(e + q) | (((r.l4 >> (8 * q)) & 0xffu) ? 0x80000000u : 0u);
+    }
+    __device__ __forceinline__ f32x4 row_raw(int64_t e) const {
+        return *reinterpret_cast<const f32x4 *>(rows + e * rows_stride);
+    }
+};
+// both endpoint rows of the COO list through the renumbering: ids checked (counted, clamped), translated, written
+// as int32.  A lane takes four consecutive edges: 16-byte id loads, eight lookups in flight, 16-byte stores.
+__global__ __launch_bounds__(kTpb) void gi_remap_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ tgt,
+                                                        int64_t E, int64_t N, const int32_t *__restrict__ rank, int vec,
+                                                        int32_t *__restrict__ src32, int32_t *__restrict__ tgt32,
+                                                        int *__restrict__ bad) {
+    auto chk = [&](long long v) -> long long {
+        if (v < 0 || v >= N) {
+            atomicAdd(bad, 1);
+            v = v < 0 ? 0 : N - 1;
+        }
+        return v;
+    };
+    const int64_t n4 = (E + 3) / 4;
+    for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kTpb) {
+        const int64_t e = 4 * i;
+        if (vec && e + 4 <= E) {
+            const longlong2 ta = *reinterpret_cast<const longlong2 *>(tgt + e);
+            const longlong2 tb = *reinterpret_cast<const longlong2 *>(tgt + e + 2);
+            const longlong2 sa = *reinterpret_cast<const longlong2 *>(src + e);
+            const longlong2 sb = *reinterpret_cast<const longlong2 *>(src + e + 2);
+            const long long it[4] = {chk(ta.x), chk(ta.y), chk(tb.x), chk(tb.y)};
+            const long long is[4] = {chk(sa.x), chk(sa.y), chk(sb.x), chk(sb.y)};
+            int4 ot, os;
+            ot.x = rank[it[0]];
+            ot.y = rank[it[1]];
+            ot.z = rank[it[2]];
+            ot.w = rank[it[3]];
+            os.x = rank[is[0]];
+            os.y = rank[is[1]];
+            os.z = rank[is[2]];
+            os.w = rank[is[3]];
+            *reinterpret_cast<int4 *>(tgt32 + e) = ot;
+            *reinterpret_cast<int4 *>(src32 + e) = os;
+        } else {
+            for (int q = 0; q < 4 && e + q < E; ++q) {
+                tgt32[e + q] = rank[chk(tgt[e + q])];
+                src32[e + q] = rank[chk(src[e + q])];
+            }
+        }
+    }
+}
 // second sort: key = source of the CSR-ordered list (already validated), value = CSR position
 struct KeysCsr {
     const int32_t *src;
@@ -861,10 +981,13 @@ static size_t library_ws_bytes(int64_t E) {
     return 256 /* flags */ + 3 * arr + align_up(sort_pairs_temp_bytes(E), 256);
 }
 
-size_t graph_index_ws_bytes(int64_t N, int64_t E, int carry_rows) {
+// (carry: bit 0 = carried rows, bit 1 = node_rank given: room for the renumbered int32 edge list behind the plan)
+static size_t remap_arr_bytes(int64_t E) { return align_up((size_t)(E > 0 ? E : 1) * sizeof(int32_t), 256); }
+size_t graph_index_ws_bytes(int64_t N, int64_t E, int carry) {
     const size_t lib = library_ws_bytes(E);
-    const OwnPlan p = own_plan(N, E, carry_rows != 0);
-    return p.ok && p.bytes > lib ? p.bytes : lib;
+    const OwnPlan p = own_plan(N, E, (carry & 1) != 0);
+    const size_t own = p.ok ? align_up(p.bytes, 256) + ((carry & 2) ? 2 * remap_arr_bytes(E) : 0) : 0;
+    return own > lib ? own : lib;
 }
 
 // the carried per-edge inputs behind the library form: plain gathers through perm
@@ -927,7 +1050,7 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, co
         return fail(GNNTRK_EINVAL,
                     "graph_index_build: carried rows must be 16-byte aligned fp32 [E, 4] with a row stride that is a "
                     "multiple of 4 floats; the bf16 output 8-byte aligned with a stride that is a multiple of 4");
-    if (!ws || ws_bytes < graph_index_ws_bytes(N, E, rows != nullptr))
+    if (!ws || ws_bytes < graph_index_ws_bytes(N, E, (rows ? 1 : 0) | (rank ? 2 : 0)))
         return fail(GNNTRK_EINVAL, "graph_index_build: workspace too small");
 
     char *p = reinterpret_cast<char *>(ws);
@@ -939,16 +1062,26 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, co
         if (plan.ok && !(flags & 1) && (!plan.dense || (flags & 2))) {
             const int vec = (((uintptr_t)edge_index | (uintptr_t)(edge_index + E)) & 15) == 0 &&
                             (!label || ((uintptr_t)label & 3) == 0);
-            const KeysCoo k1{edge_index, edge_index + E, N, label, rows, rows ? cy->rows_stride : 0, vec, rank};
+            const KeysCoo k1{edge_index, edge_index + E, N, label, rows, rows ? cy->rows_stride : 0, vec, nullptr};
             const uint32_t pmask = (uint32_t)(((uint64_t)1 << plan.bitsN) - 1);
-            if (rows) {
-                const OutCsr<true> o1{o->perm, o->tgt, o->src, o->rowptr_t, pmask, label ? cy->label_csr : nullptr,
-                                      reinterpret_cast<const uint2 *>(p + plan.off_rows), cy->rows_csr_bf16,
-                                      cy->out_stride};
-                rc = own_sort<KeysCoo, OutCsr<true>, true>(plan, k1, o1, plan.bitsN, N, E, p, bad, stream);
+            const OutCsr<true> o1r{o->perm, o->tgt, o->src, o->rowptr_t, pmask, label ? cy->label_csr : nullptr,
+                                   reinterpret_cast<const uint2 *>(p + plan.off_rows), rows ? cy->rows_csr_bf16 : nullptr,
+                                   rows ? cy->out_stride : 0};
+            const OutCsr<false> o1{o->perm, o->tgt, o->src, o->rowptr_t, pmask, label ? cy->label_csr : nullptr,
+                                   nullptr, nullptr, 0};
+            if (rank) {   // renumbered: one pass writes the translated int32 list, the sort reads that
+                int32_t *src32 = reinterpret_cast<int32_t *>(p + align_up(plan.bytes, 256));
+                int32_t *tgt32 = reinterpret_cast<int32_t *>(p + align_up(plan.bytes, 256) + remap_arr_bytes(E));
+                const int vec_ids = (((uintptr_t)edge_index | (uintptr_t)(edge_index + E)) & 15) == 0;
+                hipLaunchKernelGGL(gi_remap_kernel, dim3(stream_grid((E + 3) / 4)), dim3(kTpb), 0, stream, edge_index,
+                                   edge_index + E, E, N, rank, vec_ids, src32, tgt32, bad);
+                const KeysCoo32 k32{src32, tgt32, label, rows, rows ? cy->rows_stride : 0,
+                                    (!label || ((uintptr_t)label & 3) == 0) ? 1 : 0};
+                rc = rows ? own_sort<KeysCoo32, OutCsr<true>, true>(plan, k32, o1r, plan.bitsN, N, E, p, bad, stream)
+                          : own_sort<KeysCoo32, OutCsr<false>, false>(plan, k32, o1, plan.bitsN, N, E, p, bad, stream);
+            } else if (rows) {
+                rc = own_sort<KeysCoo, OutCsr<true>, true>(plan, k1, o1r, plan.bitsN, N, E, p, bad, stream);
             } else {
-                const OutCsr<false> o1{o->perm, o->tgt, o->src, o->rowptr_t, pmask, label ? cy->label_csr : nullptr,
-                                       nullptr, nullptr, 0};
                 rc = own_sort<KeysCoo, OutCsr<false>, false>(plan, k1, o1, plan.bitsN, N, E, p, bad, stream);
             }
             if (rc) return rc;

@@ -589,7 +589,20 @@ __host__ __device__ constexpr int bwd16_block_waves() {
 template <int KI, int HT, int GT, bool THREE, bool G32, int D_, class IO_ = IoNone>
 __global__ __launch_bounds__(64 * bwd16_block_waves<IO_>(), HT >= 5 ? 1 : ((IO_::NL > 0 && D_ == 1) ? 3 : 2) * bwd16_block_waves<IO_>() / 4) void mlp16_bwd_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                                            uint8_t *trash, const BufPlan bp) {
-    constexpr int D = D_, OT = 1;
+    constexpr int D = D_, OT = 1, kSkel = 0;
+    using IO = IO_;
+    constexpr bool BI = false;
+#include "mlp_bf16_bwd_body.inc"
+}
+// The I/O SKELETON of a buffer-addressed launch (debug_flags & 4096; results are NOT gradients): every load and
+// every store of the kernel above with the same descriptors, offsets, prefetch distance, workgroup shape and
+// launch bounds, and no arithmetic between them.  Its time is the floor this ACCESS PATTERN sets for the real
+// kernel at its occupancy, whatever the instruction stream does (bench.py: roofline.access_floor; round 5
+// measured 2.52 of 2.75 ms for the relational shape on shuffled node ids, 1.35 ms on sequential ones).
+template <int KI, int HT, int GT, bool THREE, bool G32, int D_, class IO_>
+__global__ __launch_bounds__(64 * bwd16_block_waves<IO_>(), 2 * bwd16_block_waves<IO_>() / 4) void mlp16_bwd_skel_kernel(
+    const gnntrk_mlp_bwd_args a, float *part, uint8_t *trash, const BufPlan bp) {
+    constexpr int D = D_, OT = 1, kSkel = 128;
     using IO = IO_;
     constexpr bool BI = false;
 #include "mlp_bf16_bwd_body.inc"
@@ -599,7 +612,7 @@ __global__ __launch_bounds__(64 * bwd16_block_waves<IO_>(), HT >= 5 ? 1 : ((IO_:
 template <int KI, int HT, int OT_, bool THREE>
 __global__ __launch_bounds__(kBlock, 1) void mlp16_bwd_ot_kernel(const gnntrk_mlp_bwd_args a, float *part, uint8_t *trash,
                                                                 const BufPlan bp) {
-    constexpr int D = 1, OT = OT_, GT = 2 * KI;
+    constexpr int D = 1, OT = OT_, GT = 2 * KI, kSkel = 0;
     using IO = IoNone;
     constexpr bool BI = false, G32 = false;
 #include "mlp_bf16_bwd_body.inc"
@@ -608,7 +621,7 @@ __global__ __launch_bounds__(kBlock, 1) void mlp16_bwd_ot_kernel(const gnntrk_ml
 template <int KI, int HT, int GT, bool THREE, bool G32>
 __global__ __launch_bounds__(kBlock, (HT >= 5 || KI >= 2) ? 1 : 2) void mlp16_bwd_bi_kernel(const gnntrk_mlp_bwd_args a, float *part,
                                                                                           uint8_t *trash, const BufPlan bp) {
-    constexpr int D = 1, OT = 1;
+    constexpr int D = 1, OT = 1, kSkel = 0;
     using IO = IoNone;
     constexpr bool BI = true;
 #include "mlp_bf16_bwd_body.inc"
@@ -895,6 +908,21 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
             fprintf(stderr, "mlp_backward_bf16: KI %d HT %d GT %d three %d rows %lld plan ok %d (loads %d ids %d+%d gout %d stores %d ones %d) -> %s\n",
                     P.KI, P.HT, GT, (int)three, (long long)a->n_rows, B.ok, B.n_load, B.n_ids, B.n_sids, B.n_gout,
                     B.n_store, B.ones_dword, io[0] ? io : "generic");
+#define GNNTRK_BWD16_SKEL(IO_)                                                                        \
+    if (!launched && (a->debug_flags & 4096) && P.HT == 3 && kBwd16BufD == 2 && strcmp(io, #IO_) == 0) { \
+        auto kfn = mlp16_bwd_skel_kernel<1, 3, 2, true, G32, 2, IO_>;                                 \
+        hipLaunchKernelGGL(kfn, dim3(grid_buf), dim3(64 * kBwd16BufWaves), 0, stream, *a, part, trash, B); \
+        used[0] = grid_buf;                                                                           \
+        used[1] = kBwd16BufWaves;                                                                     \
+        launched = true;                                                                              \
+    }
+        if constexpr (G32) {
+            GNNTRK_BWD16_SKEL(IoHead)
+        } else {
+            GNNTRK_BWD16_SKEL(IoRelational<2>)
+            GNNTRK_BWD16_SKEL(IoRelational<3>)
+        }
+#undef GNNTRK_BWD16_SKEL
 #define GNNTRK_BWD16_BUF(HT_, GT_, T_, IO_)                                                           \
     if (!launched && P.HT == HT_ && strcmp(io, #IO_) == 0) {                                          \
         auto kfn = mlp16_bwd_kernel<1, HT_, GT_, T_, G32, kBwd16BufD, IO_>;                           \

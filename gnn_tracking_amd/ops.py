@@ -289,7 +289,7 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
         rows_csr = ops_bf16.empty_rows(E, 4, dev)
         cy.edge_rows, cy.rows_csr_bf16 = _p(rows), _p(rows_csr)
         cy.rows_stride, cy.out_stride = int(rows.stride(0)), int(rows_csr.stride(0))
-    ws = _ws(lib.gnntrk_graph_index_workspace_bytes_carry(n_nodes, E, int(rows is not None)), ei)
+    ws = _ws(lib.gnntrk_graph_index_workspace_bytes_carry(n_nodes, E, int(rows is not None) | (2 if gi.node_rank is not None else 0)), ei)
     _capi.check(lib.gnntrk_graph_index_build_carry(_p(ei), C.byref(d), C.byref(cy), _p(ws), ws.numel(),
                                                    _GI_FLAGS if flags is None else int(flags), _stream(ei)), lib)
     if lab is not None:

@@ -116,6 +116,7 @@ typedef struct gnntrk_graph_index_carry {
                                   refer to the caller's edge order.  The caller gathers its node rows through
                                   gnntrk_node_order.perm and hands node results back through rank. */
 } gnntrk_graph_index_carry;
+/* carry_rows: bit 0 = edge_rows are carried, bit 1 = node_rank is given (room for the translated int32 edge list) */
 size_t gnntrk_graph_index_workspace_bytes_carry(int64_t n_nodes, int64_t n_edges, int32_t carry_rows);
 int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph_index *out,
                                    const gnntrk_graph_index_carry *carry, void *workspace, size_t workspace_bytes,

@@ -60,6 +60,11 @@ def main():
             rec["wait_share"] = round(m.get("SQ_WAIT_ANY", 0.0) / wave, 4)
             rec["stall_share"] = round(m.get("SQ_WAIT_INST_ANY", 0.0) / wave, 4)
         out["kernels"][k] = rec
+    # which build the counters describe: bench.py marks a block read from a profile of another build as stale
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["_csrc_sha256"] = bench.library_id()["csrc_sha256"]
     json.dump(out, sys.stdout, indent=1)
 
 

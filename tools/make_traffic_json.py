@@ -48,6 +48,11 @@ def main():
         out["kernels"][k] = {"rows_per_launch": rows, "FETCH_SIZE_KiB": f[k], "WRITE_SIZE_KiB": w[k],
                              "hbm_bytes_per_launch": b, "hbm_bytes_per_row": round(b / rows, 2),
                              "avg_us_under_pmc": round(fdur[k], 1), "launches_profiled": fn[k]}
+    # which build the counters describe: bench.py marks a block read from a profile of another build as stale
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["_csrc_sha256"] = bench.library_id()["csrc_sha256"]
     json.dump(out, sys.stdout, indent=1)
 
 

@@ -71,7 +71,7 @@ int focal_backward_launch(const float *, const float *, const int64_t *, const f
 // graph_index.hip
 size_t graph_index_ws_bytes(int64_t, int64_t, int);
 size_t node_order_ws_bytes(int64_t);
-int node_order(const float *, int64_t, const int64_t *, int64_t, int32_t *, int32_t *, void *, size_t, hipStream_t);
+int node_order(const float *, int64_t, const int64_t *, int64_t, int64_t, int32_t *, int32_t *, void *, size_t, hipStream_t);
 int graph_index_build(const int64_t *, const gnntrk_graph_index *, const gnntrk_graph_index_carry *, void *, size_t, int,
                       hipStream_t);
 
@@ -132,9 +132,10 @@ int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph
     return graph_index_build(edge_index, out, carry, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
 size_t gnntrk_node_order_workspace_bytes(int64_t n_nodes) { return node_order_ws_bytes(n_nodes); }
-int gnntrk_node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_nodes, int32_t *perm,
-                      int32_t *rank, void *workspace, size_t workspace_bytes, void *stream) {
-    return node_order(key, key_stride, batch, n_nodes, perm, rank, workspace, workspace_bytes, (hipStream_t)stream);
+int gnntrk_node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_events, int64_t n_nodes,
+                      int32_t *perm, int32_t *rank, void *workspace, size_t workspace_bytes, void *stream) {
+    return node_order(key, key_stride, batch, n_events, n_nodes, perm, rank, workspace, workspace_bytes,
+                      (hipStream_t)stream);
 }
 
 int gnntrk_mlp_forward(const gnntrk_mlp_fwd_args *args, void *stream) {

@@ -256,23 +256,27 @@ __global__ __launch_bounds__(kTpb) void gi_remap_kernel(const int64_t *__restric
     for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kTpb) {
         const int64_t e = 4 * i;
         if (vec && e + 4 <= E) {
-            const longlong2 ta = *reinterpret_cast<const longlong2 *>(tgt + e);
-            const longlong2 tb = *reinterpret_cast<const longlong2 *>(tgt + e + 2);
-            const longlong2 sa = *reinterpret_cast<const longlong2 *>(src + e);
-            const longlong2 sb = *reinterpret_cast<const longlong2 *>(src + e + 2);
-            const long long it[4] = {chk(ta.x), chk(ta.y), chk(tb.x), chk(tb.y)};
-            const long long is[4] = {chk(sa.x), chk(sa.y), chk(sb.x), chk(sb.y)};
-            int4 ot, os;
-            ot.x = rank[it[0]];
-            ot.y = rank[it[1]];
-            ot.z = rank[it[2]];
-            ot.w = rank[it[3]];
-            os.x = rank[is[0]];
-            os.y = rank[is[1]];
-            os.z = rank[is[2]];
-            os.w = rank[is[3]];
-            *reinterpret_cast<int4 *>(tgt32 + e) = ot;
-            *reinterpret_cast<int4 *>(src32 + e) = os;
+            // (the id streams and the outputs pass through once: non-temporal, the lookup table keeps the L2)
+            typedef int i4_hw __attribute__((ext_vector_type(4)));
+            auto ld2 = [](const int64_t *p, long long &a, long long &b) {   // two ids as one 16-byte non-temporal load
+                const i4_hw v = __builtin_nontemporal_load(reinterpret_cast<const i4_hw *>(p));
+                a = (long long)(((unsigned long long)(uint32_t)v[1] << 32) | (uint32_t)v[0]);
+                b = (long long)(((unsigned long long)(uint32_t)v[3] << 32) | (uint32_t)v[2]);
+            };
+            long long it[4], is[4];
+            ld2(tgt + e, it[0], it[1]);
+            ld2(tgt + e + 2, it[2], it[3]);
+            ld2(src + e, is[0], is[1]);
+            ld2(src + e + 2, is[2], is[3]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                it[q] = chk(it[q]);
+                is[q] = chk(is[q]);
+            }
+            const i4_hw ot = {rank[it[0]], rank[it[1]], rank[it[2]], rank[it[3]]};
+            const i4_hw os = {rank[is[0]], rank[is[1]], rank[is[2]], rank[is[3]]};
+            __builtin_nontemporal_store(ot, reinterpret_cast<i4_hw *>(tgt32 + e));
+            __builtin_nontemporal_store(os, reinterpret_cast<i4_hw *>(src32 + e));
         } else {
             for (int q = 0; q < 4 && e + q < E; ++q) {
                 tgt32[e + q] = rank[chk(tgt[e + q])];
@@ -1137,8 +1141,8 @@ size_t node_order_ws_bytes(int64_t n) {
     const size_t m = (size_t)(n > 0 ? n : 1);
     return 2 * align_up(m * 8, 256) + 2 * align_up(m * 4, 256) + align_up(sort_pairs_u64_temp_bytes(n), 256);
 }
-int node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n, int32_t *perm, int32_t *rank,
-               void *ws, size_t ws_bytes, hipStream_t stream) {
+int node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_events, int64_t n, int32_t *perm,
+               int32_t *rank, void *ws, size_t ws_bytes, hipStream_t stream) {
     if (n < 0 || n > 0x7fffffff) return fail(GNNTRK_EUNSUPPORTED, "node_order: sizes must fit int32");
     if (n == 0) return GNNTRK_OK;
     if (!key || key_stride < 1 || !perm || !rank) return fail(GNNTRK_EINVAL, "node_order: NULL argument");
@@ -1150,7 +1154,13 @@ int node_order(const float *key, int64_t key_stride, const int64_t *batch, int64
     void *temp = p + 2 * k8 + 2 * v4;
     const int grid = stream_grid(n);
     hipLaunchKernelGGL(no_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, key, key_stride, batch, n, ka, va);
-    const int rc = sort_pairs_u64(ka, kb, va, vb, n, temp, sort_pairs_u64_temp_bytes(n), stream);
+    // sorted bits: the 32 of the key + what the event ids need (n_events <= 0: not stated - all 32)
+    int ebits = batch ? 32 : 0;
+    if (batch && n_events > 0) {
+        ebits = 0;
+        while (ebits < 32 && ((int64_t)1 << ebits) < n_events) ++ebits;
+    }
+    const int rc = sort_pairs_u64_bits(ka, kb, va, vb, n, 32 + ebits, temp, sort_pairs_u64_temp_bytes(n), stream);
     if (rc) return rc;
     hipLaunchKernelGGL(no_finish_kernel, dim3(grid), dim3(kTpb), 0, stream, vb, n, perm, rank);
     return check_launch("node_order");

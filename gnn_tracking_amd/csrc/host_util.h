@@ -28,6 +28,9 @@ int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *
 size_t sort_pairs_u64_temp_bytes(int64_t n);
 int sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
                    uint32_t *vals_out, int64_t n, void *temp, size_t temp_bytes, hipStream_t stream);
+// (keys whose bits from `end_bit` up are all zero: the passes over them are skipped)
+int sort_pairs_u64_bits(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
+                        uint32_t *vals_out, int64_t n, int end_bit, void *temp, size_t temp_bytes, hipStream_t stream);
 
 // knn.hip: points sorted by (event, Morton code) in chunks of 64 with bounding boxes
 void scan_counts_launch(const int32_t *cnt, int k_take, int64_t n, int64_t *off, hipStream_t stream);

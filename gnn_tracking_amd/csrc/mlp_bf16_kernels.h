@@ -500,6 +500,18 @@ struct BufPlan {
 #ifndef GNNTRK_BWD_REG_FRAGS
 #define GNNTRK_BWD_REG_FRAGS 0   // (1: first- / last-layer weight fragments of the two-tile buffer shapes in registers)
 #endif
+#ifndef GNNTRK_BWD_HOT
+#define GNNTRK_BWD_HOT 1      // (0: the relational shape takes the generic tile body too - A/B builds)
+#endif
+#ifndef GNNTRK_BWD_SGB
+#define GNNTRK_BWD_SGB 0      // (1: sched_group_barrier pipeline over the tile body of the hot buffer-addressed shapes - A/B builds)
+#endif
+#ifndef GNNTRK_BWD_SGB_N
+#define GNNTRK_BWD_SGB_N 62   // MFMAs of the tile body
+#define GNNTRK_BWD_SGB_V 4    // VALU instructions per MFMA
+#define GNNTRK_BWD_SGB_R 1    // DS reads per MFMA
+#define GNNTRK_BWD_SGB_WP 4   // one DS write every so many MFMAs
+#endif
 #ifndef GNNTRK_BWD_STATIC_GATE
 #define GNNTRK_BWD_STATIC_GATE 1   // (0: the input ReLU / relu' pattern of the buffer-addressed shapes stays a run-time value - A/B builds)
 #endif

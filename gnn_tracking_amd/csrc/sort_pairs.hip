@@ -41,14 +41,19 @@ size_t sort_pairs_u64_temp_bytes(int64_t n) {
     return bytes;
 }
 
-int sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out,
-                   const uint32_t *vals_in, uint32_t *vals_out, int64_t n, void *temp,
-                   size_t temp_bytes, hipStream_t stream) {
+int sort_pairs_u64_bits(const unsigned long long *keys_in, unsigned long long *keys_out,
+                        const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit, void *temp,
+                        size_t temp_bytes, hipStream_t stream) {
     if (n <= 0) return GNNTRK_OK;
     size_t need = temp_bytes;
     hipError_t e = rocprim::radix_sort_pairs(temp, need, keys_in, keys_out, vals_in, vals_out,
-                                             (size_t)n, 0u, 64u, stream, false);
+                                             (size_t)n, 0u, (unsigned)end_bit, stream, false);
     return check_hip(e, "radix_sort_pairs(u64)");
+}
+int sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out,
+                   const uint32_t *vals_in, uint32_t *vals_out, int64_t n, void *temp,
+                   size_t temp_bytes, hipStream_t stream) {
+    return sort_pairs_u64_bits(keys_in, keys_out, vals_in, vals_out, n, 64, temp, temp_bytes, stream);
 }
 
 }  // namespace gnntrk

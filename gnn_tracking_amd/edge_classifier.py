@@ -26,6 +26,13 @@ from .mlp import MLP
 from .resin import ResIN
 
 
+def _n_events(data) -> int:
+    """Events of a collated batch where the container says so without a device read (``ptr`` of ``collate`` /
+    PyG's ``Batch``: one more entry than events); 0 = not stated."""
+    ptr = getattr(data, "ptr", None)
+    return int(ptr.numel()) - 1 if isinstance(ptr, Tensor) and ptr.numel() > 1 else 0
+
+
 class ECForGraphTCN(nn.Module, HyperparametersMixin):
     def __init__(self, *, node_indim: int, edge_indim: int, interaction_node_dim: int = 5,
                  interaction_edge_dim: int = 4, hidden_dim: int | float | None = None,
@@ -93,7 +100,8 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         gi = ops.graph_index(edge_index, x.shape[0],
                              carry_label=y if isinstance(y, Tensor) and self.training else None,
                              carry_rows=edge_attr if bf16 and edge_attr.shape[1] == 4 else None,
-                             order_by=None if col is None else (x, col, batch if isinstance(batch, Tensor) else None))
+                             order_by=None if col is None else (x, col, batch if isinstance(batch, Tensor) else None,
+                                                                _n_events(data)))
         E = gi.n_edges
         nperm = gi.node_perm
 

@@ -198,9 +198,10 @@ _GI_FLAGS = int(os.environ.get("GNNTRK_GI_FLAGS", "0"))
 CARRY = os.environ.get("GNNTRK_GI_CARRY", "1") != "0"
 
 
-def node_order(x: Tensor, col: int, batch: Optional[Tensor] = None):
+def node_order(x: Tensor, col: int, batch: Optional[Tensor] = None, n_events: int = 0):
     """``(perm, rank)`` int32 ``[N]``: the nodes of every event (``batch``: int64 ``[N]``, non-decreasing; None =
-    one event) sorted by ``x[:, col]`` (fp32), ties in the old order (gnntrk_node_order)."""
+    one event; ``n_events``: number of events if known - fewer radix passes) sorted by ``x[:, col]`` (fp32), ties
+    in the old order (gnntrk_node_order)."""
     _capi.require_device(x)
     if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise TypeError("node_order: x must be fp32 [N, F] with unit column stride")
@@ -214,7 +215,7 @@ def node_order(x: Tensor, col: int, batch: Optional[Tensor] = None):
     perm = torch.empty(n, dtype=torch.int32, device=x.device)
     rank = torch.empty(n, dtype=torch.int32, device=x.device)
     ws = _ws(lib.gnntrk_node_order_workspace_bytes(n), x)
-    _capi.check(lib.gnntrk_node_order(_p(key), int(x.stride(0)), _p(batch), n, _p(perm), _p(rank), _p(ws), ws.numel(),
+    _capi.check(lib.gnntrk_node_order(_p(key), int(x.stride(0)), _p(batch), int(n_events), n, _p(perm), _p(rank), _p(ws), ws.numel(),
                                       _stream(x)), lib)
     return perm, rank
 
@@ -222,7 +223,7 @@ def node_order(x: Tensor, col: int, batch: Optional[Tensor] = None):
 def _order_sig(order_by):
     if order_by is None:
         return None
-    x, col, batch = order_by
+    x, col, batch = order_by[:3]
     return (id(x), x._version, int(col), None if batch is None else (id(batch), batch._version))
 
 
@@ -753,6 +754,9 @@ def fused_mlp(segs: Sequence[Seg], weights: Sequence[Tensor],
             spec = _MlpSpec(len(segs), len(weights), any(b is not None for b in biases),
                             [s.idx for s in segs], [s.relu for s in segs], [s.reduce for s in segs],
                             epilogue, float(ca), float(cb), None, int(n_rows), int(n_rows))
+            # (inside forward() grad mode is off and needs_input_grad is True for trainable parameters even under
+            #  no_grad(): the caller's grad mode travels on the spec - inference does not store the activations)
+            spec.grad_on = torch.is_grad_enabled()
             return _FusedMLPWide.apply(spec, *[s.t for s in segs], *weights, *biases, res)
         return _wide_mlp(segs, weights, biases, n_rows=int(n_rows), epilogue=epilogue, ca=float(ca), cb=float(cb),
                          res=res, out_idx=out_idx, out_rows=int(out_rows if out_rows is not None else n_rows))
@@ -955,7 +959,7 @@ class _FusedMLPWide(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec: _MlpSpec, *tensors):
-        return _wide_forward(ctx, spec, tensors, any(ctx.needs_input_grad))
+        return _wide_forward(ctx, spec, tensors, getattr(spec, "grad_on", True) and any(ctx.needs_input_grad))
 
     @staticmethod
     def backward(ctx, g_out):
@@ -970,7 +974,7 @@ class _FusedINEdgeWide(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec: _MlpSpec, gi: GraphIndex, *tensors):
-        e_tilde = _wide_forward(ctx, spec, tensors, any(ctx.needs_input_grad))
+        e_tilde = _wide_forward(ctx, spec, tensors, getattr(spec, "grad_on", True) and any(ctx.needs_input_grad))
         ctx.gi = gi
         ctx.set_materialize_grads(False)
         return e_tilde, _segment_sum_raw(e_tilde, gi.rowptr_t, None, gi.n_nodes)
@@ -994,6 +998,7 @@ def in_edge_wide(segs, weights, biases, gi: GraphIndex, n_rows: int):
     spec = _MlpSpec(len(segs), len(weights), any(b is not None for b in biases),
                     [s.idx for s in segs], [s.relu for s in segs], [s.reduce for s in segs],
                     _capi.EPI_NONE, 0.0, 1.0, None, int(n_rows), int(n_rows))
+    spec.grad_on = torch.is_grad_enabled()
     return _FusedINEdgeWide.apply(spec, gi, *[s.t for s in segs], *weights, *biases)
 
 

@@ -43,7 +43,7 @@ def _model(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Optional[Tenso
 
 class _ResFCNN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, scale, alpha: float, normalize: bool, out_relu: bool, n_layers: int, *params):
+    def forward(ctx, x, scale, alpha: float, normalize: bool, out_relu: bool, n_layers: int, grad_on: bool, *params):
         weights = [w.contiguous() for w in params[:n_layers]]
         biases = [None if b is None else b.contiguous() for b in params[n_layers:]]
         _capi.require_device(x, *weights)
@@ -57,7 +57,10 @@ class _ResFCNN(torch.autograd.Function):
         sc = None if scale is None else scale.detach().to(torch.float32).contiguous()
         m = _model(x, weights, biases, alpha, normalize, out_relu, sc)
         out = torch.empty(n, m.out_dim, dtype=torch.float32, device=x.device)
-        need = any(ctx.needs_input_grad)
+        # (needs_input_grad is True under no_grad() too while the parameters are trainable, and inside forward()
+        #  grad mode is always off: the caller's grad mode comes in as an argument - inference must not pay for
+        #  the saved activations)
+        need = grad_on and any(ctx.needs_input_grad)
         acts = None
         if need and n > 0:
             hp = int(lib.gnntrk_resfcnn_hidden_pad(m.hidden))
@@ -94,14 +97,15 @@ class _ResFCNN(torch.autograd.Function):
         _capi.check(lib.gnntrk_resfcnn_backward(C.byref(m), _p(x), int(x.stride(0)) if n > 1 else int(x.shape[1]), n,
                                                 _p(acts), _p(out), m.out_dim, _p(g), int(g.stride(0)) if n > 1 else m.out_dim,
                                                 _p(gx), int(x.shape[1]), C.byref(gr), 0, _p(ws), ws.numel(), _stream(x)), lib)
-        return (gx, gs, None, None, None, None, *gW, *gb)
+        return (gx, gs, None, None, None, None, None, *gW, *gb)
 
 
 def res_fcnn(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]], *, alpha: float,
              normalize: bool = True, out_relu: bool = False, scale: Optional[Tensor] = None) -> Tensor:
     """``weights = [W_enc, W_hidden_1 .., W_dec]`` (``nn.Linear`` storage), ``biases`` likewise (entries may be
     None).  ``scale``: one-element parameter multiplied onto the output (``_latent_normalization``)."""
-    return _ResFCNN.apply(x, scale, float(alpha), bool(normalize), bool(out_relu), len(weights), *weights, *biases)
+    return _ResFCNN.apply(x, scale, float(alpha), bool(normalize), bool(out_relu), len(weights), torch.is_grad_enabled(),
+                          *weights, *biases)
 
 
 # ----------------------------------------------------------------------------------- hinge loss
@@ -127,8 +131,20 @@ class _HingeTerm(torch.autograd.Function):
             raise ValueError("hinge loss: edges must be int64 [2, E]")
         e = edges if edges.stride(1) == 1 or edges.shape[1] <= 1 else edges.contiguous()
         n_e = int(e.shape[1])
-        m8 = None if mask is None else mask.view(torch.uint8).contiguous()
-        pid = None if pid is None else pid.contiguous()
+        # the kernel reads one byte per node of the mask and one int64 per node of the particle ids: any other
+        # dtype is converted here (the reference's boolean / integer indexing takes them all), sizes are checked
+        n_nodes = int(x.shape[0])
+        m8 = None
+        if mask is not None:
+            m8 = (mask.view(torch.uint8) if mask.dtype in (torch.bool, torch.uint8) else (mask != 0).view(torch.uint8)).contiguous()
+            if m8.numel() != n_nodes or m8.device != x.device:
+                raise ValueError(f"hinge loss: node_mask must hold one value per node ({n_nodes}) on {x.device}")
+        if pid is not None:
+            if pid.is_floating_point() or pid.dtype == torch.bool:
+                raise TypeError("hinge loss: particle_id must be an integer tensor")
+            pid = pid.to(torch.int64).contiguous()
+            if pid.numel() != n_nodes or pid.device != x.device:
+                raise ValueError(f"hinge loss: particle_id must hold one value per node ({n_nodes}) on {x.device}")
         nrm = None if norm is None else norm.detach().to(torch.float32).reshape(1).contiguous()
         out = torch.empty(3, dtype=torch.float32, device=x.device)
         a = _hinge_args(x, m8, pid, r_emb, p, repulsive)

@@ -128,12 +128,13 @@ int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph
  * x[edge_index[0]] (models/interaction_network.py:67) from random rows.  gnntrk_node_order sorts the nodes
  * of every event by a caller-supplied key (one float per node, row stride key_stride floats; for tracking
  * graphs the azimuth column of data.x - edges join hits of neighbouring azimuth); ties keep the old order:
- *   perm[new] = old, rank[old] = new, events (batch[i], non-decreasing, or NULL = one event) keep their
- *   id ranges.  Stable 64-bit radix sort of N pairs; deterministic.
+ *   perm[new] = old, rank[old] = new, events (batch[i] in [0, n_events), non-decreasing, or NULL = one event) keep
+ *   their id ranges; n_events <= 0: not stated (all 32 bits of batch[i] are sorted).  Stable radix sort of N
+ *   pairs over 32 + log2(n_events) key bits; deterministic.
  * workspace: gnntrk_node_order_workspace_bytes(n_nodes). */
 size_t gnntrk_node_order_workspace_bytes(int64_t n_nodes);
-int gnntrk_node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_nodes, int32_t *perm,
-                      int32_t *rank, void *workspace, size_t workspace_bytes, void *stream);
+int gnntrk_node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_events, int64_t n_nodes,
+                      int32_t *perm, int32_t *rank, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------- fused gather-MLP
  * One kernel family replaces, for every MLP site of the path

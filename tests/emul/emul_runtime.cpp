@@ -204,4 +204,21 @@ int sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_o
     std::copy(v.begin(), v.end(), vals_out);
     return 0;
 }
+// (only the bits below end_bit order the keys, as in the device library's radix passes)
+int sort_pairs_u64_bits(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
+                        uint32_t *vals_out, int64_t n, int end_bit, void *, size_t, hipStream_t) {
+    const unsigned long long m = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1);
+    std::vector<int64_t> o(n);
+    std::iota(o.begin(), o.end(), 0);
+    std::stable_sort(o.begin(), o.end(), [&](int64_t a, int64_t b) { return (keys_in[a] & m) < (keys_in[b] & m); });
+    std::vector<unsigned long long> k(n);
+    std::vector<uint32_t> v(n);
+    for (int64_t i = 0; i < n; ++i) {
+        k[i] = keys_in[o[i]];
+        v[i] = vals_in[o[i]];
+    }
+    std::copy(k.begin(), k.end(), keys_out);
+    std::copy(v.begin(), v.end(), vals_out);
+    return 0;
+}
 }  // namespace gnntrk

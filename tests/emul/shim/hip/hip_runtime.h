@@ -211,6 +211,10 @@ inline void __syncthreads() { hipemul::cur_block->bar.wait("__syncthreads"); }
 inline void __builtin_amdgcn_wave_barrier() { hipemul::wave().bar.wait("wave_barrier"); }
 inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}   // (a scheduling fence for the device compiler: nothing to model)
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
+// cache-policy hints of the device compiler: plain accesses here
+template <class T> inline T __builtin_nontemporal_load(const T *p) { return *p; }
+template <class T> inline void __builtin_nontemporal_store(T v, T *p) { *p = v; }
 #define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
 
 // v_mfma_f32_16x16x4_f32: D = A(16x4) * B(4x16) + C, exact f32 fmaf chain in k order

@@ -177,3 +177,13 @@ def test_tc_training_step_event_scale_emulated():
     """golden G14b (1500 hits, 21 617 built edges), the Tiger / orphan-masking variant"""
     with emulated():
         P.case_tc_step_event("cpu", names=("tiger_orphans_h24",))
+
+
+def test_reference_configs_from_class_path():
+    with emulated():
+        P.case_class_path_configs("cpu")
+
+
+def test_cfg3_event_case_small():
+    with emulated():
+        P.case_cfg3_event("cpu", n_hits=1500, n_edges=15000)

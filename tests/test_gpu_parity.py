@@ -341,3 +341,12 @@ def test_pruned_paths_random_stress(dev):
     r = subprocess.run([sys.executable, str(root / "tools" / "gpu_stress_pruned.py"), "5", "10"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "pruned stress ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_cfg3_full_size_event_against_oracle(dev):
+    rep = P.case_cfg3_event(dev)
+    print("cfg3 event:", rep)
+
+
+def test_reference_configs_from_class_path(dev):
+    P.case_class_path_configs(dev)

@@ -2313,8 +2313,11 @@ def case_cfg3_event(device, n_hits=150_000, n_edges=2_000_000, modes=("f32", "bf
             for k, v in model.named_parameters():
                 assert_close(v.grad, rgrads[k], TOL_GRAD, f"{tag} grad {k}")
             torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4).step()
-            for k, v in model.state_dict().items():
-                assert_close(v, rafter[k], 1e-6, f"{tag} after Adam {k}")
+            # (Adam normalises g + weight_decay * p: where that sum is below 1e-6 - the mean over 2 M edges leaves
+            #  gradient elements of that size, and on this event one of them cancels its decay term to 4e-9 - rounding
+            #  noise becomes a step of up to lr in either direction: _check_after_adam on the EFFECTIVE gradient)
+            geff = {k: rgrads[k] + 1e-4 * params[k] for k in rgrads}
+            _check_after_adam(model, geff, rafter, tag, lr_step=1e-4)
             report[mode] = {"W": (W - ref["W"]).abs().max().item()}
         else:
             with torch.no_grad():

@@ -1129,6 +1129,20 @@ __global__ __launch_bounds__(kTpb) void no_keys_kernel(const float *__restrict__
         vals[i] = (uint32_t)i;
     }
 }
+// the same as ONE 32-bit key where the event ids need at most eight bits: event in the top `ebits` bits, below it
+// the top 32 - ebits bits of the key's order-preserving image (>= 24: sign, exponent and 15 mantissa bits - keys
+// that agree that far keep their old order) - four radix passes over 4-byte keys instead of five over 8-byte ones
+__global__ __launch_bounds__(kTpb) void no_keys32_kernel(const float *__restrict__ key, int64_t stride,
+                                                         const int64_t *__restrict__ batch, int64_t n, int ebits,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTpb) {
+        uint32_t u = __float_as_uint(key[i * stride]);
+        u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+        const uint32_t b = (batch && ebits > 0) ? (uint32_t)batch[i] << (32 - ebits) : 0u;
+        keys[i] = b | (ebits > 0 ? u >> ebits : u);
+        vals[i] = (uint32_t)i;
+    }
+}
 __global__ __launch_bounds__(kTpb) void no_finish_kernel(const uint32_t *__restrict__ sorted, int64_t n,
                                                          int32_t *__restrict__ perm, int32_t *__restrict__ rank) {
     for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTpb) {
@@ -1139,7 +1153,8 @@ __global__ __launch_bounds__(kTpb) void no_finish_kernel(const uint32_t *__restr
 }
 size_t node_order_ws_bytes(int64_t n) {
     const size_t m = (size_t)(n > 0 ? n : 1);
-    return 2 * align_up(m * 8, 256) + 2 * align_up(m * 4, 256) + align_up(sort_pairs_u64_temp_bytes(n), 256);
+    const size_t t64 = sort_pairs_u64_temp_bytes(n), t32 = sort_pairs_temp_bytes(n);
+    return 2 * align_up(m * 8, 256) + 2 * align_up(m * 4, 256) + align_up(t64 > t32 ? t64 : t32, 256);
 }
 int node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_events, int64_t n, int32_t *perm,
                int32_t *rank, void *ws, size_t ws_bytes, hipStream_t stream) {
@@ -1153,14 +1168,21 @@ int node_order(const float *key, int64_t key_stride, const int64_t *batch, int64
     uint32_t *va = reinterpret_cast<uint32_t *>(p + 2 * k8), *vb = reinterpret_cast<uint32_t *>(p + 2 * k8 + v4);
     void *temp = p + 2 * k8 + 2 * v4;
     const int grid = stream_grid(n);
-    hipLaunchKernelGGL(no_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, key, key_stride, batch, n, ka, va);
     // sorted bits: the 32 of the key + what the event ids need (n_events <= 0: not stated - all 32)
     int ebits = batch ? 32 : 0;
     if (batch && n_events > 0) {
         ebits = 0;
         while (ebits < 32 && ((int64_t)1 << ebits) < n_events) ++ebits;
     }
-    const int rc = sort_pairs_u64_bits(ka, kb, va, vb, n, 32 + ebits, temp, sort_pairs_u64_temp_bytes(n), stream);
+    int rc;
+    if (ebits <= 8) {   // one 32-bit key (see no_keys32_kernel)
+        uint32_t *k32a = reinterpret_cast<uint32_t *>(ka), *k32b = reinterpret_cast<uint32_t *>(kb);
+        hipLaunchKernelGGL(no_keys32_kernel, dim3(grid), dim3(kTpb), 0, stream, key, key_stride, batch, n, ebits, k32a, va);
+        rc = sort_pairs_u32(k32a, k32b, va, vb, n, 32, temp, sort_pairs_temp_bytes(n), stream);
+    } else {
+        hipLaunchKernelGGL(no_keys_kernel, dim3(grid), dim3(kTpb), 0, stream, key, key_stride, batch, n, ka, va);
+        rc = sort_pairs_u64_bits(ka, kb, va, vb, n, 32 + ebits, temp, sort_pairs_u64_temp_bytes(n), stream);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(no_finish_kernel, dim3(grid), dim3(kTpb), 0, stream, vb, n, perm, rank);
     return check_launch("node_order");

@@ -144,7 +144,7 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
     }
     if (want_dw) {
         // one partial block per workgroup when the parameters fit the kernel's LDS image
-        const bool via_lds = part_total(a->mlp) <= bwd16_img_dwords(P.KI, P.HT, GT, three) && (P.HT <= 4 || GNNTRK_WIDE_LDS_REDUCE) && !(a->debug_flags & 2048);
+        const bool via_lds = part_total(a->mlp) <= bwd16_img_dwords(P.KI, P.HT, GT, three) && P.HT <= 4 && !(a->debug_flags & 2048);
         rc = reduce_partials_launch(reinterpret_cast<const float *>(ws), via_lds ? grid : grid * waves, &a->mlp,
                                     a->gW, a->gb, a->accumulate_params, stream);
     }

@@ -27,10 +27,6 @@
 namespace gnntrk {
 namespace {
 
-#ifndef GNNTRK_WIDE_LDS_REDUCE
-#define GNNTRK_WIDE_LDS_REDUCE 0   // (1: diagnostics build - the in-LDS partial reduction also for five and more hidden tiles)
-#endif
-
 constexpr uint32_t kBf16One = 0x3f80u;
 constexpr int kFwdDepth = 4;  // tiles per wave and pipeline stage (forward)
 

@@ -130,7 +130,9 @@ int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph
  * graphs the azimuth column of data.x - edges join hits of neighbouring azimuth); ties keep the old order:
  *   perm[new] = old, rank[old] = new, events (batch[i] in [0, n_events), non-decreasing, or NULL = one event) keep
  *   their id ranges; n_events <= 0: not stated (all 32 bits of batch[i] are sorted).  Stable radix sort of N
- *   pairs over 32 + log2(n_events) key bits; deterministic.
+ *   pairs, deterministic: with b = ceil(log2(n_events)) <= 8 one 32-bit key {event : b bits, top 32 - b bits of
+ *   the key's order-preserving integer image} - keys that agree in those bits keep their old order -, otherwise
+ *   32 + b bits of a 64-bit key (the full key).
  * workspace: gnntrk_node_order_workspace_bytes(n_nodes). */
 size_t gnntrk_node_order_workspace_bytes(int64_t n_nodes);
 int gnntrk_node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_events, int64_t n_nodes,

@@ -134,12 +134,18 @@ def case_node_order(device, n_hits=10_000, n_edges=100_000, modes=("f32", "bf16"
     x[::7, 1] = 0.25           # ties
     x[5, 1] = -0.0
     x[6, 1] = 0.0
-    for b, col in ((batch, 1), (None, 2)):
-        perm, rank = ops.node_order(x.to(device), col, None if b is None else b.to(device))
-        o = torch.argsort(x[:, col], stable=True)
+    def image(v):   # the order-preserving integer image of a float (gnntrk_node_order)
+        u = v.contiguous().view(torch.int32).long() & 0xffffffff
+        return torch.where(u >> 31 == 1, u ^ 0xffffffff, u ^ 0x80000000)
+
+    for b, col, n_ev in ((batch, 1, 0), (None, 2, 0), (batch, 1, len(sizes)), (batch, 2, 200), (batch, 1, 1000)):
+        perm, rank = ops.node_order(x.to(device), col, None if b is None else b.to(device), n_ev)
+        ebits = 0 if b is None else (32 if n_ev <= 0 else max(0, (n_ev - 1).bit_length()))
+        q = image(x[:, col]) >> (ebits if ebits <= 8 else 0)   # (up to eight event bits: the key keeps its top 32 - b bits)
+        o = torch.argsort(q, stable=True)
         if b is not None:
             o = o[torch.argsort(b[o], stable=True)]
-        assert torch.equal(perm.cpu().long(), o), "node_order: perm is the stable (event, key) sort"
+        assert torch.equal(perm.cpu().long(), o), f"node_order: perm is the stable (event, key) sort (n_events {n_ev})"
         inv = torch.empty_like(o)
         inv[o] = torch.arange(N)
         assert torch.equal(rank.cpu().long(), inv), "node_order: rank inverts perm"

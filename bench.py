@@ -55,9 +55,9 @@ from gnn_tracking_amd.precision import bf16_storage  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
 PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
-TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r04c_hbm_traffic_bf16.json"}
-TRAFFIC_FALLBACK = {"bf16": "r02_hbm_traffic_bf16.json"}
-PIPE_PROFILES = {"cfg5": "r04c_pipe_util_cfg5.json", "dbscan": "r04c_pipe_util_dbscan.json"}
+TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r05_hbm_traffic_bf16.json"}
+TRAFFIC_FALLBACK = {"bf16": "r04c_hbm_traffic_bf16.json"}
+PIPE_PROFILES = {"cfg5": "r05_pipe_util_cfg5.json", "dbscan": "r05_pipe_util_dbscan.json"}
 
 TRAFFIC_NOTES: dict = {}   # kernel -> which committed profile its traffic figure came from, and whether it is stale
 

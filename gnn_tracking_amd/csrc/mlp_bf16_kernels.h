@@ -496,6 +496,9 @@ struct BufPlan {
 #ifndef GNNTRK_BWD_REG_FRAGS
 #define GNNTRK_BWD_REG_FRAGS 0   // (1: first- / last-layer weight fragments of the two-tile buffer shapes in registers)
 #endif
+#ifndef GNNTRK_PROBE_SKIP_PACK
+#define GNNTRK_PROBE_SKIP_PACK 0   // (1: timing probe of the kernels' prologue - no fragment packing, results are garbage)
+#endif
 #ifndef GNNTRK_BWD_HOT
 #define GNNTRK_BWD_HOT 1      // (0: the relational shape takes the generic tile body too - A/B builds)
 #endif

@@ -388,7 +388,7 @@ class ECWorkload(Workload):
     """cfg2 / cfg3 / cfg4: ECForGraphTCN training step(s) on collated events."""
 
     def __init__(self, args, rank: int, world: int, dev, *, workload: str, dtype: str, index: str = "inline",
-                 hidden_dim: int | None = None):
+                 hidden_dim: int | None = None, loader_renumbered: bool = False):
         self.name, self.dtype = workload, dtype
         torch.manual_seed(0)  # identical initial weights on every rank
         model_kw = dict(EC_MODEL, **({"hidden_dim": hidden_dim} if hidden_dim else {}))
@@ -427,6 +427,9 @@ class ECWorkload(Workload):
                       for i in range(n_ev)]
             if rank == 0 and world == 1:
                 self.first_event_cpu = events[0].cpu()
+            if loader_renumbered:   # (what io.GraphDataset(renumber=True) does per graph, once)
+                from gnn_tracking_amd import io as gio
+                events = [gio.renumber_nodes(e) for e in events]
             self.batches = [G.collate(events)]
             del events
             b = self.batches[0]
@@ -464,7 +467,8 @@ class ECWorkload(Workload):
             cur = self.batches[self.counter % 2]
             nxt = self.batches[(self.counter + 1) % 2]
             self.counter += 1
-            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, self.side, x=nxt.x, batch=getattr(nxt, "batch", None))
+            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, self.side, x=None if "node_order_key" in nxt else nxt.x,
+                                     batch=getattr(nxt, "batch", None))
             loss = self.module.backward_step(cur)
         else:
             n = len(self.batches)
@@ -1020,6 +1024,19 @@ def extras(args, rank: int, world: int, dev) -> dict:
             del wl
             ops.clear_graph_index_cache()
             torch.cuda.empty_cache()
+        wl = ECWorkload(args, 0, 1, dev, workload="cfg3", dtype="bf16", loader_renumbered=True)
+        dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
+        roof, _ = roofline_of(ks, "bf16")
+        out["cfg3_bf16_loader_renumbered"] = {
+            "workload": "cfg3 with every event renumbered ONCE by the loader-side transform (io.renumber_nodes, what "
+                        "GraphDataset(renumber=True) does when a graph is read) OUTSIDE the timed steps - the cost a static "
+                        "dataset pays once per event, AMORTISED here, not the headline (whose batches arrive in the "
+                        "generator's shuffled order and are renumbered inside every step); same generator, model and timed region",
+            "steps": 5, "warmup": 2, "ms_per_step": dt / 5 * 1e3, "value": wl.edges_per_step_global * 5 / dt,
+            "unit": "edges/s", "final_loss": loss, "roofline": roof}
+        del wl
+        ops.clear_graph_index_cache()
+        torch.cuda.empty_cache()
         wl = ECWorkload(args, 0, 1, dev, workload="cfg3", dtype="bf16", hidden_dim=64)
         dt, loss, ks = timed_steps(wl, 1, dev, 5, 2, kernel_timer=True)
         out["cfg3_hidden64_bf16"] = {

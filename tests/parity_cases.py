@@ -185,6 +185,24 @@ def case_node_order(device, n_hits=10_000, n_edges=100_000, modes=("f32", "bf16"
         tag = f"node order {mode}"
         for i, nm in enumerate(("W", "node_embedding", "edge_embedding")):
             assert torch.equal(runs["off"][i], runs[1][i]), f"{tag}: {nm} differs between the numberings"
+        # the loader-side form (io.renumber_nodes: the event renumbered ONCE, on the host, when it is read): the step
+        # then does not renumber again, per-edge outputs are the original event's bit for bit, per-node outputs are
+        # its rows in the new order
+        from gnn_tracking_amd import io as gio
+        ev2 = gio.renumber_nodes(ev)
+        assert torch.equal(ev2.x[:, 1], ev.x[:, 1][ev2.node_perm]) and bool((ev2.x[1:, 1] >= ev2.x[:-1, 1]).all())
+        assert torch.equal(ev2.node_perm[ev2.edge_index], ev.edge_index)
+        d2 = G.collate([ev2]).to(device)
+        model = G.ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=3, hidden_dim=40)
+        model.load_state_dict(params)
+        model = model.to(device)
+        ops.clear_graph_index_cache()
+        with G.node_order(1), (G.bf16_storage() if mode == "bf16" else contextlib.nullcontext()):
+            out2 = model(d2)
+            gi2 = ops.graph_index(d2.edge_index, d2.x.shape[0])
+        assert gi2.node_perm is None, tag + ": an event ordered by the loader was renumbered again"
+        assert torch.equal(torch.as_tensor(out2["W"]).detach().float().cpu(), runs["off"][0]), tag + " loader-ordered W"
+        assert torch.equal(out2["node_embedding"].detach().float().cpu(), runs["off"][1][ev2.node_perm]), tag + " loader-ordered nodes"
         if mode == "f32":
             W, hn, en, loss, grads, model = runs[1]
             assert_close(W, ref["W"], TOL_OUT, tag + " W")

@@ -20,7 +20,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _capi, locality, ops, ops_bf16, precision
-from .edge_order import EdgeOrdered
+from .edge_order import EdgeOrdered, NodeOrdered
 from .hparams import HyperparametersMixin, assert_feat_dim
 from .mlp import MLP
 from .resin import ResIN
@@ -147,7 +147,7 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         w = self.W.fused(segs, n_rows=E, epilogue=_capi.EPI_SIGMOID, ca=eps, cb=1 - 2 * eps)
         return {
             "W": EdgeOrdered(w.squeeze(), gi),
-            "node_embedding": h if nperm is None else ops.permute_rows(h, gi.node_rank),
+            "node_embedding": h if nperm is None else NodeOrdered(h, gi),
             "edge_embedding": EdgeOrdered(e, gi),
         }
 

@@ -101,6 +101,25 @@ class EdgeOrdered(Tensor):
         return self.in_edge_index_order().__reduce_ex__(proto)
 
 
+class NodeOrdered(EdgeOrdered):
+    """The per-node twin (round 5): a node tensor held in the RENUMBERED node order of a graph index built with
+    ``order_by`` (locality.py) that presents itself in the caller's node order - ``node_embedding`` of the edge
+    classifier, which nothing reads in edge-classifier training; any use gathers it through ``node_rank`` once."""
+
+    def in_edge_index_order(self) -> Tensor:   # (here: the caller's NODE order)
+        if self._coo is None:
+            from . import ops
+
+            with torch._C.DisableTorchFunctionSubclass():
+                self._coo = ops.permute_rows(self._csr, self._gi.node_rank)
+        return self._coo
+
+    def __repr__(self):
+        return f"NodeOrdered({self.in_edge_index_order()!r})"
+
+    __str__ = __repr__
+
+
 def as_tensor(t):
     """``t`` itself, or the ``edge_index``-ordered tensor behind an ``EdgeOrdered``."""
     return t.in_edge_index_order() if isinstance(t, EdgeOrdered) else t

@@ -65,7 +65,7 @@ def test_prefetch_loader_to_device(tmp_path):
     # the loader can also build the graph index of a staged batch on its side stream
     from gnn_tracking_amd import ops
     for b in gio.PrefetchLoader(ds, batch_size=2, device="cuda:0", depth=2, build_index=True):
-        hit = ops._GI_CACHE.get(id(b.edge_index))
+        hit = ops._GI_CACHE.get((id(b.edge_index), False))   # (key: the tensor, renumbered build or not)
         assert hit is not None and hit[3].ready is not None, "index was not prefetched"
         gi = ops.graph_index(b.edge_index, b.num_nodes)
         assert gi is hit[3] and gi.ready is None

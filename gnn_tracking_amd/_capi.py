@@ -116,6 +116,8 @@ _SIGNATURES = {
     "gnntrk_graph_index_workspace_bytes_carry": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "gnntrk_graph_index_build_carry": (C.c_int, [_P, C.POINTER(GraphIndex), C.POINTER(GraphIndexCarry), _P, C.c_size_t,
                                                  C.c_int32, _P]),
+    "gnntrk_graph_index_place": (C.c_int, [C.POINTER(GraphIndex), C.c_int64, C.c_int64, C.POINTER(GraphIndex), _P, _P, _P, _P,
+                                           _P, _P, _P, _P, _P]),
     "gnntrk_node_order_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnntrk_node_order": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "gnntrk_bce_csr": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P, _P, _P, C.c_size_t, _P]),

@@ -70,6 +70,8 @@ int focal_backward_launch(const float *, const float *, const int64_t *, const f
                           int, int64_t, const float *, float *, hipStream_t);
 // graph_index.hip
 size_t graph_index_ws_bytes(int64_t, int64_t, int);
+int graph_index_place(const gnntrk_graph_index *, int64_t, int64_t, const gnntrk_graph_index *, const uint8_t *, uint8_t *,
+                      const uint16_t *, uint16_t *, const int32_t *, int32_t *, const int32_t *, int32_t *, hipStream_t);
 size_t node_order_ws_bytes(int64_t);
 int node_order(const float *, int64_t, const int64_t *, int64_t, int64_t, int32_t *, int32_t *, void *, size_t, hipStream_t);
 int graph_index_build(const int64_t *, const gnntrk_graph_index *, const gnntrk_graph_index_carry *, void *, size_t, int,
@@ -130,6 +132,13 @@ int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph
                                    const gnntrk_graph_index_carry *carry, void *workspace, size_t workspace_bytes,
                                    int32_t flags, void *stream) {
     return graph_index_build(edge_index, out, carry, workspace, workspace_bytes, flags, (hipStream_t)stream);
+}
+int gnntrk_graph_index_place(const gnntrk_graph_index *part, int64_t node_offset, int64_t edge_offset,
+                             const gnntrk_graph_index *batch, const uint8_t *label_part, uint8_t *label_batch,
+                             const uint16_t *rows_part, uint16_t *rows_batch, const int32_t *node_perm_part,
+                             int32_t *node_perm_batch, const int32_t *node_rank_part, int32_t *node_rank_batch, void *stream) {
+    return graph_index_place(part, node_offset, edge_offset, batch, label_part, label_batch, rows_part, rows_batch,
+                             node_perm_part, node_perm_batch, node_rank_part, node_rank_batch, (hipStream_t)stream);
 }
 size_t gnntrk_node_order_workspace_bytes(int64_t n_nodes) { return node_order_ws_bytes(n_nodes); }
 int gnntrk_node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_events, int64_t n_nodes,

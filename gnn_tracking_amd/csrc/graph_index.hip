@@ -1111,6 +1111,86 @@ int graph_index_build(const int64_t *edge_index, const gnntrk_graph_index *o, co
     return check_launch("graph_index_build");
 }
 
+// ------------------------------------------------------------------ collation of per-event indices
+// A collated batch is a list of disjoint graphs with contiguous id / edge ranges, so its stable target sort, its
+// source sort and their inverse are the events' own, shifted: one streaming pass per event places a cached
+// per-event index into the batch arrays (20 B/edge + 8 B/node read and written, + the carried label / row bytes)
+// instead of sorting the batch again (gnntrk_graph_index_place).
+__global__ __launch_bounds__(kTpb) void gi_place_kernel(gnntrk_graph_index part, gnntrk_graph_index batch, int32_t noff,
+                                                        int32_t eoff, const uint8_t *__restrict__ lab_in,
+                                                        uint8_t *__restrict__ lab_out, const uint2 *__restrict__ rows_in,
+                                                        uint2 *__restrict__ rows_out, const int32_t *__restrict__ nperm_in,
+                                                        int32_t *__restrict__ nperm_out, const int32_t *__restrict__ nrank_in,
+                                                        int32_t *__restrict__ nrank_out) {
+    const int64_t E = part.n_edges, N = part.n_nodes;
+    const int64_t n4 = (E + 3) / 4;
+    const bool vec = ((eoff & 3) == 0);   // (16-byte aligned destinations)
+    for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kTpb) {
+        const int64_t k = 4 * i;
+        if (vec && k + 4 <= E) {
+            auto mv = [&](const int32_t *src, int32_t *dst, int32_t add) {
+                int4 v = *reinterpret_cast<const int4 *>(src + k);
+                v.x += add;
+                v.y += add;
+                v.z += add;
+                v.w += add;
+                *reinterpret_cast<int4 *>(dst + eoff + k) = v;
+            };
+            mv(part.perm, batch.perm, eoff);
+            mv(part.tgt, batch.tgt, noff);
+            mv(part.src, batch.src, noff);
+            mv(part.spos, batch.spos, eoff);
+            if (part.spos_inv && batch.spos_inv) mv(part.spos_inv, batch.spos_inv, eoff);
+            if (lab_in) *reinterpret_cast<uint32_t *>(lab_out + eoff + k) = *reinterpret_cast<const uint32_t *>(lab_in + k);
+            if (rows_in) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rows_out[eoff + k + q] = rows_in[k + q];
+            }
+        } else {
+            for (int q = 0; q < 4 && k + q < E; ++q) {
+                const int64_t j = k + q;
+                batch.perm[eoff + j] = part.perm[j] + eoff;
+                batch.tgt[eoff + j] = part.tgt[j] + noff;
+                batch.src[eoff + j] = part.src[j] + noff;
+                batch.spos[eoff + j] = part.spos[j] + eoff;
+                if (part.spos_inv && batch.spos_inv) batch.spos_inv[eoff + j] = part.spos_inv[j] + eoff;
+                if (lab_in) lab_out[eoff + j] = lab_in[j];
+                if (rows_in) rows_out[eoff + j] = rows_in[j];
+            }
+        }
+    }
+    for (int64_t n = (int64_t)blockIdx.x * kTpb + threadIdx.x; n <= N; n += (int64_t)gridDim.x * kTpb) {
+        batch.rowptr_t[noff + n] = part.rowptr_t[n] + eoff;   // (entry N of an event = entry 0 of the next: same value)
+        batch.rowptr_s[noff + n] = part.rowptr_s[n] + eoff;
+        if (n < N && nperm_in) {
+            nperm_out[noff + n] = nperm_in[n] + noff;
+            nrank_out[noff + n] = nrank_in[n] + noff;
+        }
+    }
+}
+int graph_index_place(const gnntrk_graph_index *part, int64_t node_offset, int64_t edge_offset,
+                      const gnntrk_graph_index *batch, const uint8_t *label_part, uint8_t *label_batch,
+                      const uint16_t *rows_part, uint16_t *rows_batch, const int32_t *node_perm_part,
+                      int32_t *node_perm_batch, const int32_t *node_rank_part, int32_t *node_rank_batch,
+                      hipStream_t stream) {
+    if (!part || !batch) return fail(GNNTRK_EINVAL, "graph_index_place: NULL descriptor");
+    if (node_offset < 0 || edge_offset < 0 || node_offset + part->n_nodes > batch->n_nodes ||
+        edge_offset + part->n_edges > batch->n_edges || batch->n_edges > 0x7fffffff || batch->n_nodes > 0x7fffffff)
+        return fail(GNNTRK_EINVAL, "graph_index_place: the event does not fit the batch at these offsets");
+    if ((label_part != nullptr) != (label_batch != nullptr) || (rows_part != nullptr) != (rows_batch != nullptr) ||
+        (node_perm_part != nullptr) != (node_perm_batch != nullptr) || (node_perm_part != nullptr) != (node_rank_part != nullptr) ||
+        (node_rank_part != nullptr) != (node_rank_batch != nullptr))
+        return fail(GNNTRK_EINVAL, "graph_index_place: carried / node-order arrays must come in pairs");
+    if (rows_part && ((((uintptr_t)rows_part | (uintptr_t)rows_batch) & 7) != 0))
+        return fail(GNNTRK_EINVAL, "graph_index_place: carried rows are 8-byte rows");
+    const int64_t work = part->n_edges / 4 > part->n_nodes ? part->n_edges / 4 : part->n_nodes;
+    hipLaunchKernelGGL(gi_place_kernel, dim3(stream_grid(work + 1)), dim3(kTpb), 0, stream, *part, *batch,
+                       (int32_t)node_offset, (int32_t)edge_offset, label_part, label_batch,
+                       reinterpret_cast<const uint2 *>(rows_part), reinterpret_cast<uint2 *>(rows_batch), node_perm_part,
+                       node_perm_batch, node_rank_part, node_rank_batch);
+    return check_launch("graph_index_place");
+}
+
 // ------------------------------------------------------------------ node order (gnntrk_node_order)
 // Per-event renumbering of the nodes by a caller-supplied key (one float per node: the hits' azimuth for
 // tracking graphs, whose edges join hits of neighbouring azimuth): new ids = rank of (event, key, old id).

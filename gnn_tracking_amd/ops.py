@@ -307,6 +307,69 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     return gi
 
 
+def place_graph_indices(parts: Sequence[GraphIndex], batch) -> GraphIndex:
+    """The graph index of a collated ``batch`` (``data.collate`` of the events the ``parts`` were built from, in that
+    order) from CACHED per-event indices: every part is copied into the batch arrays at its node / edge offset
+    (gnntrk_graph_index_place) - identical to building the index of ``batch.edge_index``, carried labels / edge
+    features and node order included, for one streaming pass instead of two sorts.  For datasets that stay on the
+    device across epochs (the reference's are static: utils/loading.py:97-100): build ``graph_index(ev.edge_index,
+    ev.num_nodes, cache=False, carry_label=ev.y, carry_rows=ev.edge_attr, order_by=...)`` once per event, collate
+    as usual, call this per batch.  The result is registered in the cache under ``batch.edge_index`` (and the
+    batch's ``y`` / ``edge_attr`` / ``x``), so ``ECForGraphTCN`` and the losses find it."""
+    parts = list(parts)
+    if not parts:
+        raise ValueError("place_graph_indices: no parts")
+    ei = batch.edge_index
+    _capi.require_device(ei)
+    lib = _capi.load()
+    dev = ei.device
+    N, E = sum(p.n_nodes for p in parts), sum(p.n_edges for p in parts)
+    if int(batch.x.shape[0]) != N or int(ei.shape[1]) != E:
+        raise ValueError(f"place_graph_indices: the parts hold {N} nodes / {E} edges, the batch {batch.x.shape[0]} / {ei.shape[1]}")
+    mk = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
+    gi = GraphIndex(N, E, mk(E), mk(E), mk(E), mk(N + 1), mk(N + 1), mk(E), mk(E))
+    ordered = [p.node_perm is not None for p in parts]
+    lab = [getattr(p, "_label_csr", None) for p in parts]
+    rows = [getattr(p, "_rows_csr", None) for p in parts]
+    full = [i for i, p in enumerate(parts) if p.n_edges > 0]   # (an event without edges carries nothing)
+    has_lab = bool(full) and lab[full[0]] is not None
+    has_rows = bool(full) and rows[full[0]] is not None
+    if any(ordered) != all(ordered) or any((lab[i] is not None) != has_lab or (rows[i] is not None) != has_rows for i in full):
+        raise ValueError("place_graph_indices: the parts must agree in node order and carried inputs")
+    if ordered[0]:
+        gi.node_perm, gi.node_rank = mk(N), mk(N)
+    lab_b = torch.empty(E, dtype=torch.uint8, device=dev) if has_lab else None
+    rows_b = None
+    if has_rows:
+        from . import ops_bf16
+        rows_b = ops_bf16.empty_rows(E, 4, dev)
+    d = _capi.GraphIndex(N, E, _p(gi.perm), _p(gi.tgt), _p(gi.src), _p(gi.rowptr_t), _p(gi.rowptr_s), _p(gi.spos),
+                         _p(gi.spos_inv))
+    no = eo = 0
+    st = _stream(ei)
+    for p, l, r in zip(parts, lab, rows):
+        dp = _capi.GraphIndex(p.n_nodes, p.n_edges, _p(p.perm), _p(p.tgt), _p(p.src), _p(p.rowptr_t), _p(p.rowptr_s),
+                              _p(p.spos), _p(p.spos_inv))
+        _capi.check(lib.gnntrk_graph_index_place(
+            C.byref(dp), no, eo, C.byref(d), _p(None if l is None else l[3]), _p(None if l is None else lab_b),
+            _p(None if r is None else r[3]), _p(None if r is None else rows_b), _p(p.node_perm), _p(gi.node_perm), _p(p.node_rank),
+            _p(gi.node_rank), st), lib)
+        no += p.n_nodes
+        eo += p.n_edges
+    y, ea = getattr(batch, "y", None), getattr(batch, "edge_attr", None)
+    if lab_b is not None and isinstance(y, Tensor):
+        gi._label_csr = (id(y), y._version, weakref.ref(y), lab_b)
+    if rows_b is not None and isinstance(ea, Tensor):
+        gi._rows_csr = (id(ea), ea._version, weakref.ref(ea), rows_b)
+    if ordered[0]:
+        col = parts[0].order_sig[2]
+        bt = getattr(batch, "batch", None)
+        gi.order_sig, gi._order_ref = _order_sig((batch.x, col, bt if isinstance(bt, Tensor) else None)), weakref.ref(batch.x)
+    gi._built_from = (weakref.ref(ei), ei._version)
+    _cache_put(ei, N, gi)
+    return gi
+
+
 def _carry_label_ok(y: Tensor, E: int, dev) -> bool:
     return y.dtype in (torch.bool, torch.uint8) and y.numel() == E and y.device == dev
 

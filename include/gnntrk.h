@@ -122,6 +122,20 @@ int gnntrk_graph_index_build_carry(const int64_t *edge_index, const gnntrk_graph
                                    const gnntrk_graph_index_carry *carry, void *workspace, size_t workspace_bytes,
                                    int32_t flags, void *stream);
 
+/* A cached per-event index placed into the arrays of a collated batch.  The reference's datasets are static across
+ * epochs (utils/loading.py:97-100) and its DataLoader collates disjoint graphs with shifted ids (utils/loading.py:
+ * 233-239, PyG Batch): the batch's stable target sort, source sort and inverses are the events' own, shifted by the
+ * event's node / edge offset - so an index built ONCE per event is copied, not sorted again:
+ *   batch.perm[eo + k] = part.perm[k] + eo, .tgt / .src + no, .spos / .spos_inv + eo, .rowptr_*[no + n] = part + eo
+ *   (n = 0 .. part.n_nodes), carried label_csr / 8-byte rows_csr rows copied (pairs of NULL: not carried),
+ *   node_perm / node_rank + no (gnntrk_node_order of the event; NULL: not renumbered).
+ * One call per event; the calls of a batch write disjoint ranges (entry n_nodes of an event's row pointers equals
+ * entry 0 of the next event's).  Identical to gnntrk_graph_index_build_carry on the collated edge list. */
+int gnntrk_graph_index_place(const gnntrk_graph_index *part, int64_t node_offset, int64_t edge_offset,
+                             const gnntrk_graph_index *batch, const uint8_t *label_part, uint8_t *label_batch,
+                             const uint16_t *rows_part, uint16_t *rows_batch, const int32_t *node_perm_part,
+                             int32_t *node_perm_batch, const int32_t *node_rank_part, int32_t *node_rank_batch, void *stream);
+
 /* Node renumbering for gather locality.  The reference keeps the hits of an event in file order
  * (graph_construction/graph_builder.py:396-455: node order = order of the hit table; utils/loading.py:17-113
  * hands the graphs on unchanged), which is unrelated to the geometry; the message passing then gathers

@@ -221,6 +221,46 @@ def case_node_order(device, n_hits=10_000, n_edges=100_000, modes=("f32", "bf16"
                 assert (a - b).norm() <= 2e-2 * max(float(a.norm()), 1e-6) + 2e-3 * max(float(torch.cat([v.flatten() for v in runs["off"][4].values()]).norm()), 1e-6), f"{tag} grad {k}"
 
 
+def case_graph_index_place(device, sizes=((700, 6301), (1, 3), (300, 2500), (2049, 18002), (64, 0)), order=True):
+    """Cached per-event indices placed into a collated batch (gnntrk_graph_index_place, ops.place_graph_indices)
+    against the index BUILT from the collated edge list: every array bit for bit - permutations, row pointers, the
+    carried labels / edge features, the node order -, with edge offsets off the 16-byte grid, an event without edges
+    and a one-node event; and the edge classifier finds the placed index (no second build) and returns the same W."""
+    from gnn_tracking_amd import synthetic
+
+    g = np.random.default_rng(5)
+    events = []
+    for i, (n, e) in enumerate(sizes):
+        ev = G.Data(x=torch.from_numpy(g.standard_normal((n, 14)).astype(np.float32)),
+                    edge_index=torch.from_numpy(g.integers(0, n, size=(2, e))).long(),
+                    edge_attr=torch.from_numpy(g.standard_normal((e, 4)).astype(np.float32)),
+                    y=torch.from_numpy(g.integers(0, 2, size=e).astype(bool)),
+                    pt=torch.from_numpy(g.random(n).astype(np.float32)))
+        events.append(ev.to(device))
+    col = 1 if order else None
+    parts = [ops.graph_index(ev.edge_index, ev.num_nodes, cache=False, carry_label=ev.y, carry_rows=ev.edge_attr,
+                             order_by=None if col is None else (ev.x, col, None)) for ev in events]
+    b = G.collate(events)
+    ops.clear_graph_index_cache()
+    gi = ops.place_graph_indices(parts, b)
+    ref = ops.graph_index(b.edge_index, b.num_nodes, cache=False, carry_label=b.y, carry_rows=b.edge_attr,
+                          order_by=None if col is None else (b.x, col, b.batch))
+    for k in ("perm", "tgt", "src", "rowptr_t", "rowptr_s", "spos", "spos_inv") + (("node_perm", "node_rank") if order else ()):
+        assert torch.equal(getattr(gi, k), getattr(ref, k)), f"placed index: {k} differs from the built one"
+    assert torch.equal(ops.carried_label(gi, b.y), ops.carried_label(ref, b.y)), "placed index: carried labels"
+    assert torch.equal(ops.carried_rows(gi, b.edge_attr).view(torch.int16), ops.carried_rows(ref, b.edge_attr).view(torch.int16))
+    # the model takes the placed index from the cache (same object) and computes the same weights as on a built one
+    torch.manual_seed(0)
+    model = G.ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=2, hidden_dim=40).to(device)
+    with G.node_order(col if order else "off", min_nodes=0), G.bf16_storage():
+        w1 = torch.as_tensor(model(b)["W"]).detach().float().cpu()
+        hit = ops.graph_index(b.edge_index, b.num_nodes, order_by=None if col is None else (b.x, col, b.batch))
+        assert hit is gi, "the edge classifier did not take the placed index"
+        ops.clear_graph_index_cache()
+        w2 = torch.as_tensor(model(b)["W"]).detach().float().cpu()
+    assert torch.equal(w1, w2), "W on the placed index differs from W on the built index"
+
+
 def case_graph_index_carry(device):
     """Per-edge inputs carried into CSR order inside the build (gnntrk_graph_index_carry): identical to
     the gathers through perm, in both forms of the build, incl. buckets beyond the LDS capacity; and

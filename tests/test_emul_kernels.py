@@ -22,6 +22,12 @@ def test_node_order():
         P.case_node_order("cpu", n_hits=1500, n_edges=15000)
 
 
+def test_graph_index_placed_from_cached_events():
+    with emulated():
+        P.case_graph_index_place("cpu")
+        P.case_graph_index_place("cpu", order=False)
+
+
 def test_graph_index_carry_and_fused_bce():
     with emulated():
         P.case_graph_index_carry("cpu")

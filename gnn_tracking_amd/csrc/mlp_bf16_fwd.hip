@@ -5,13 +5,30 @@
 
 namespace gnntrk {
 
+// The persistent grid of an instantiation = the workgroups of it that are RESIDENT at once (asked of the runtime once
+// per instantiation: registers and LDS decide), not a fixed five per CU: a larger grid runs in rounds whose last one
+// leaves CUs idle (round 5: the hot instantiations hold 164-230 registers = two, not five, workgroups per CU).
+#define GNNTRK_FWD16_GRID(kfn_)                                                         \
+    {                                                                                   \
+        static int occ_ = 0;                                                            \
+        if (occ_ <= 0) {                                                                \
+            int o_ = 0;                                                                 \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, kfn_, kBlock, 0) != hipSuccess || o_ < 1) \
+                o_ = kFwd16BlocksPerCu;                                                 \
+            occ_ = o_ > 8 ? 8 : o_;                                                     \
+        }                                                                               \
+        grid = grid16(a->n_rows, occ_, kWaves);                                         \
+        if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;             \
+    }
 #define GNNTRK_FWD16_LAUNCH(KI_, HT_, T_, S_, R_)                                       \
     {                                                                                   \
         if (wide) {                                                                     \
             auto kfn = mlp16_fwd_kernel<KI_, HT_, T_, S_, R_, true>;                    \
+            GNNTRK_FWD16_GRID(kfn)                                                      \
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);           \
         } else {                                                                        \
             auto kfn = mlp16_fwd_kernel<KI_, HT_, T_, S_, R_, false>;                   \
+            GNNTRK_FWD16_GRID(kfn)                                                      \
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);           \
         }                                                                               \
     }

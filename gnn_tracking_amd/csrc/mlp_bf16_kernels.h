@@ -344,8 +344,30 @@ __device__ uint8_t g_fwd_trash[(size_t)kFwdMaxBlocks * kBlock * 16];
 // rows rotated by 4v, so tile v lands in lane group v, the four last-layer MFMA chains
 // accumulate into ONE tile (the other row blocks of each fragment are zero: exact), and a
 // single full-wave store writes 4 x 16 rows.  R = 1 is the plain layout (wider outputs).
+// Waves per SIMD the forward kernels of up to four hidden tiles are compiled for, and workgroups per CU their
+// persistent grid is sized for (the two have to agree: a grid larger than what is resident runs in rounds, the last
+// one part empty).  Round 5 found the hot instantiations at 216 registers = TWO waves per SIMD under a grid of five
+// workgroups per CU (the max-ilp scheduling strategy of mlp_bf16_fwd.hip had doubled the 108 of round 1).
+#ifndef GNNTRK_FWD16_WAVES_PER_SIMD
+#define GNNTRK_FWD16_WAVES_PER_SIMD 0   // (0: no bound stated)
+#endif
+#ifndef GNNTRK_FWD16_BLOCKS_PER_CU
+#define GNNTRK_FWD16_BLOCKS_PER_CU 5
+#endif
+// (measured per instantiation, same box, alternating - tools/ab_step.sh: the two-layer encoders are fastest at four
+//  waves per SIMD (126 registers, no spill: edge encoder 0.58 -> 0.48 ms per 64 M rows), the three-layer bf16-output
+//  shapes at three (154-165 registers: relational 0.77 -> 0.76, object 0.131 -> 0.118), the edge-weight head without a
+//  bound (230 registers, two waves: 1.16 against 1.25 at three); at four the three-layer shapes spill 17-42 registers
+//  and run at half speed)
+template <int KI, int HT, bool THREE, bool SIG, int R, bool WIDE>
+__host__ __device__ constexpr int fwd16_waves_per_simd() {
+    if (GNNTRK_FWD16_WAVES_PER_SIMD > 0) return HT <= 4 ? GNNTRK_FWD16_WAVES_PER_SIMD : 1;
+    if (KI != 1 || HT > 3) return 1;
+    if (!THREE) return (R == 4 && WIDE && !SIG) ? 4 : 3;   // (the other two-layer forms spill 4-12 registers at four)
+    return SIG ? 1 : 3;
+}
 template <int KI, int HT, bool THREE, bool SIG, int R_, bool WIDE_>
-__global__ __launch_bounds__(kBlock) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
+__global__ __launch_bounds__(kBlock, (fwd16_waves_per_simd<KI, HT, THREE, SIG, R_, WIDE_>())) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
     constexpr int R = R_, OT = 1;
     constexpr bool WIDE = WIDE_, BI = false;
 #include "mlp_bf16_fwd_body.inc"
@@ -840,7 +862,7 @@ inline bool buf_plan_is(const BufPlan &B) {
     return true;
 }
 
-constexpr int kFwd16BlocksPerCu = 5;
+constexpr int kFwd16BlocksPerCu = GNNTRK_FWD16_BLOCKS_PER_CU;
 constexpr int kBwd16BlocksPerCu = 2;
 // weight-gradient-only launches (GT = 0: the encoders of raw dataset features) need 50 KB of LDS and
 // under 100 registers: three workgroups per CU are resident, and the latency-bound tile loop takes them

@@ -56,6 +56,8 @@ enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+// (the emulated device: two workgroups of any kernel resident per CU)
+template <class F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, F, int, size_t) { *n = 2; return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
     memset(p, v, n);

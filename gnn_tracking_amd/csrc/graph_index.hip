@@ -871,7 +871,11 @@ static OwnPlan own_plan(int64_t N, int64_t E, bool rows) {
     p.n_chunks = (int)ceil_div(E, chunk);
     p.T = (int64_t)p.NB * p.n_chunks;
     if (p.T > kMaxTable) return p;
-    p.dense = E / p.NB > kCap * 3 / 4;   // very dense (multi)graphs
+    // very dense (multi)graphs: most buckets would overflow the LDS capacity of the bucket sort and take its tiled
+    // path.  (The bar was 3/4 of the capacity until round 5: a kNN graph with k = 16 - 200 k hits, 3.07 M edges, at
+    // most 4 096 records per bucket of 256 nodes - sat at 0.77 and took the library form: two radix sorts for a
+    // graph whose every bucket fits.)
+    p.dense = E / p.NB > kCap * 9 / 10;
     p.n_tiles = (int)ceil_div(p.T + 1, kScanTile);
     size_t o = 256;
     p.off_range = o;

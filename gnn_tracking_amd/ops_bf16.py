@@ -272,6 +272,7 @@ class FusedMLP16(torch.autograd.Function):
             raise AssertionError(
                 f"Expected feature dimension {mlp.in_dim}, got {sum(s.shape[1] for s in segs)}")
         ctx.res_key = None
+        ctx.dup_of, ctx.res_same = _alias_tables(tensors[:ns], res if spec.epilogue == _capi.EPI_RESIDUAL else None)
         if spec.epilogue == _capi.EPI_RESIDUAL:
             res = rows16(res)
             ctx.res_key = (res.data_ptr(), tuple(res.shape), res.stride(0))
@@ -305,6 +306,24 @@ class FusedMLP16(torch.autograd.Function):
 
 def _tensor_key(t: Tensor):
     return (t.data_ptr(), tuple(t.shape), t.stride(0))
+
+
+def _same_autograd(a, b) -> bool:
+    """The two inputs are ONE tensor for autograd's purposes: the same object, or one is the identity view this
+    module itself made of the other (``node_tap`` / ``grad_tap`` mark their outputs).  Two unrelated autograd tensors
+    that merely alias memory (``x`` and ``x.detach().requires_grad_()``) are not: their gradients stay apart."""
+    if a is None or b is None:
+        return False
+    return a is b or getattr(a, "_gnntrk_tap_of", None) is b or getattr(b, "_gnntrk_tap_of", None) is a
+
+
+def _alias_tables(seg_tensors, res=None):
+    """(dup_of, res_same): for every segment the first earlier segment that is the same autograd tensor (-1: none),
+    and the segments that are the same autograd tensor as the residue - recorded at forward time, where the
+    tensors' identity is still known (the saved tensors of the backward are unpacked copies)."""
+    ts = list(seg_tensors)
+    dup_of = [next((k for k in range(j) if _same_autograd(ts[j], ts[k])), -1) for j in range(len(ts))]
+    return dup_of, [j for j in range(len(ts)) if _same_autograd(res, ts[j])]
 
 
 def _backward_common(ctx, gout, need, g_rows, node_addend=None):
@@ -357,7 +376,10 @@ def _backward_common(ctx, gout, need, g_rows, node_addend=None):
             # a tensor gathered twice (the node embedding by target AND by source): the second fold takes the
             # first as one more fp32 term, and the sum leaves as ONE gradient with one rounding - autograd would
             # add the two (an N-sized pass, a second rounding, and a re-padding copy of its dense result)
+            # (same memory AND the same autograd tensor: two unrelated tensors that alias keep separate gradients)
             first = folded.get(_tensor_key(s)) if FOLD_ADD else None
+            if first is not None and getattr(ctx, "dup_of", None) is not None and ctx.dup_of[j] != first:
+                first = None
             if first is not None:
                 seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0], addend=seg_grads[first])
                 seg_grads[first] = None
@@ -374,7 +396,7 @@ def _backward_common(ctx, gout, need, g_rows, node_addend=None):
         res_key = getattr(ctx, "res_key", None)
         same = [j for j, s in enumerate(segs) if FOLD_ADD and res_key is not None and spec.idx[j] is None
                 and seg_grads[j] is not None and (s.data_ptr(), tuple(s.shape), s.stride(0)) == res_key
-                and seg_grads[j].shape == g_dense.shape]
+                and seg_grads[j].shape == g_dense.shape and j in getattr(ctx, "res_same", (j,))]
         if same:
             # the residue IS an identity segment of this node (resin.py:26: the layer's own input): its
             # pass-through gradient joins that segment's gradient in one pass instead of a mul and autograd's add
@@ -416,6 +438,7 @@ class FusedINEdge16(torch.autograd.Function):
                                   out_idx=None, out_rows=spec.out_rows, mlp=mlp)
         aggr = segment_sum_raw(e_tilde, gi.rowptr_t, None, gi.n_nodes)
         ctx.spec, ctx.gi = spec, gi
+        ctx.dup_of, ctx.res_same = _alias_tables(tensors[:ns])
         ctx.save_for_backward(*segs, *weights, *[b for b in biases if b is not None])
         ctx.bias_mask = [b is not None for b in biases]
         _attach_stash(ctx, e_tilde)
@@ -521,7 +544,9 @@ def node_tap(x: Tensor, aggr: Tensor):
     xr = rows16(x)
     if xr is not x or _tensor_key(xr) != held[1]:
         return x, aggr
-    return _NodeTap.apply(x, aggr, held[0])
+    xt, at = _NodeTap.apply(x, aggr, held[0])
+    xt._gnntrk_tap_of = x   # (an identity view of x made here: the same tensor as far as gradient folds go)
+    return xt, at
 
 
 def _attach_stash(ctx, out: Tensor) -> None:

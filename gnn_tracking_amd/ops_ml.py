@@ -131,6 +131,12 @@ class _HingeTerm(torch.autograd.Function):
             raise ValueError("hinge loss: edges must be int64 [2, E]")
         e = edges if edges.stride(1) == 1 or edges.shape[1] <= 1 else edges.contiguous()
         n_e = int(e.shape[1])
+        if ops._VALIDATE and n_e > 0:
+            # (GNNTRK_VALIDATE, as for ops.graph_index: ids outside [0, N) raise as torch's indexing would - a host
+            #  synchronisation, so off by default; unchecked ids out of range read out of bounds)
+            lo, hi = int(e.min()), int(e.max())
+            if lo < 0 or hi >= int(x.shape[0]):
+                raise IndexError(f"hinge loss: node ids in [{lo}, {hi}] outside [0, {int(x.shape[0])})")
         # the kernel reads one byte per node of the mask and one int64 per node of the particle ids: any other
         # dtype is converted here (the reference's boolean / integer indexing takes them all), sizes are checked
         n_nodes = int(x.shape[0])

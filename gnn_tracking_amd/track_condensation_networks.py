@@ -85,8 +85,12 @@ class ResFCNN(nn.Module):
                 and ops_ml.res_fcnn_supported(in_dim, hidden, out_dim, len(lin) - 1):
             # ONE launch for the whole network, any depth (gnntrk_resfcnn_forward: L2 normalisation, encoder,
             # residual layers, decoder, output scale / ReLU; fp32, activations in registers)
-            return ops_ml.res_fcnn(x.float(), ws, bs, alpha=self._alpha, normalize=True,
-                                   out_relu=epilogue == _capi.EPI_RELU, scale=scale)
+            relu = epilogue == _capi.EPI_RELU
+            if relu and scale is not None:
+                # (the kernel applies the scale BEFORE its ReLU, the paths below - and the reference's callers - after:
+                #  the two differ for a negative scale; no model of the reference combines them - scale outside)
+                return ops_ml.res_fcnn(x.float(), ws, bs, alpha=self._alpha, normalize=True, out_relu=True) * scale
+            return ops_ml.res_fcnn(x.float(), ws, bs, alpha=self._alpha, normalize=True, out_relu=relu, scale=scale)
         x = nn.functional.normalize(x.float(), p=2.0, dim=1, eps=1e-12)
         if self._fusable_depth:
             # bf16 storage: one fused MLP launch where the instantiations hold the widths, the same operator as

@@ -1336,6 +1336,34 @@ def case_node_tap(device):
             assert err <= 2.0 ** -6 * scale, f"node_tap {mode}: {k} differs by {err:.3e} (scale {scale:.3g})"
 
 
+def case_fold_alias(device):
+    """Gradient folds only merge gradients of ONE autograd tensor: two distinct autograd tensors that alias the same
+    memory (``x`` and ``x.detach().requires_grad_()``) gathered by target and by source keep separate gradients, equal
+    to the run in which the second one is a copy."""
+    from gnn_tracking_amd import ops_bf16 as B
+    gen = torch.Generator().manual_seed(7)
+    N, E = 120, 900
+    ei = torch.randint(0, N, (2, E), generator=gen).to(device)
+    gi = ops.graph_index(ei, N, cache=False)
+    mlp = G.MLP(14, 4, hidden_dim=40, L=3).to(device)
+    lin = mlp.linears()
+    x0 = torch.randn(N, 5, generator=gen).to(device)
+    e0 = torch.randn(E, 4, generator=gen).to(device)
+    grads = {}
+    for alias in (True, False):
+        with G.bf16_storage(True):
+            xa = B.to_rows16(x0).requires_grad_(True)
+            xb = (xa.detach() if alias else xa.detach().clone()).requires_grad_(True)
+            ee = B.to_rows16(e0).requires_grad_(True)
+            segs = [ops.Seg(xa, gi.tgt, False, ("tgt", gi)), ops.Seg(xb, gi.src, False, ("src", gi)), ops.Seg(ee)]
+            out = ops.fused_mlp(segs, [m.weight for m in lin], [m.bias for m in lin], n_rows=E)
+            out.float().square().sum().backward()
+        assert xa.grad is not None and xb.grad is not None, "an aliased input lost its gradient"
+        grads[alias] = (xa.grad.float().cpu(), xb.grad.float().cpu())
+    assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1]), \
+        "gradients of two aliasing autograd tensors were merged"
+
+
 def case_hipgraph_capture(device):
     """The training step is capturable as a HIP graph (every gnntrk_* call is stream
     ordered, allocation- and sync-free); a replay reproduces the eager gradients bit for bit."""

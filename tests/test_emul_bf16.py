@@ -23,6 +23,7 @@ def test_mlp_bf16_backward_emulated():
 def test_node_tap_emulated():
     with emulated():
         P.case_node_tap("cpu")
+        P.case_fold_alias("cpu")
 
 
 def test_mlp_bf16_backward_many_workgroups_emulated():

@@ -38,6 +38,10 @@ def test_graph_index_carry_and_fused_bce(dev):
     P.case_ec_carry_equals_gather(dev)
 
 
+def test_gradient_folds_need_one_autograd_tensor(dev):
+    P.case_fold_alias(dev)
+
+
 def test_parameter_gradients_added_in_place_equal_autograd_accumulation(dev):
     P.case_grad_sink(dev)
 

@@ -848,7 +848,20 @@ int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     int kt = (a->mlp.in_dim + 15) / 16;
     const int ht = (a->mlp.hidden + 15) / 16;
     while (4 * kt + 4 < n_items) ++kt;  // the load list of an instantiation holds 4*KT+4 items
-    const int grid = grid_for(a->n_rows, kFwdBlocksPerCu);
+    int grid = grid_for(a->n_rows, kFwdBlocksPerCu);
+    // (the persistent grid of an instantiation = its resident workgroups, asked of the runtime once per instantiation:
+    //  the static shapes hold 124-156 registers = three, not four, workgroups per CU - see mlp_bf16_fwd.hip)
+#define GNNTRK_FWD32_GRID(kfn_)                                                                 \
+    {                                                                                           \
+        static int occ_ = 0;                                                                    \
+        if (occ_ <= 0) {                                                                        \
+            int o_ = 0;                                                                         \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, kfn_, kBlock, 0) != hipSuccess || o_ < 1) \
+                o_ = kFwdBlocksPerCu;                                                           \
+            occ_ = o_ > 8 ? 8 : o_;                                                             \
+        }                                                                                       \
+        grid = grid_for(a->n_rows, occ_);                                                       \
+    }
     const int ksh = make_dimmap(a->mlp.hidden).ks, kso = make_dimmap(a->mlp.out_dim).ks;
     const bool three = a->mlp.n_layers == 3;
     // static instantiations need their own load-list capacity
@@ -856,17 +869,20 @@ int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
 #define CALL_FWD_S(KSI, KSH, KSO, THREE, NIT)                                                  \
     if (!done_ && ksi == KSI && ksh == KSH && kso == KSO && three == THREE && n_items <= NIT) { \
         auto kfn = mlp_fwd_kernel<(KSI + 3) / 4, (KSH + 3) / 4, StaticDims<KSI, KSH, KSO, THREE, NIT>>; \
+        GNNTRK_FWD32_GRID(kfn)                                                                  \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);                       \
         done_ = true;                                                                           \
     }
 #define CALL_FWD_D(K, H)                                                                \
     {                                                                                   \
         auto kfn = mlp_fwd_kernel<K, H, DynDims>;                                       \
+        GNNTRK_FWD32_GRID(kfn)                                                          \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);               \
     }
     GNNTRK_DISPATCH(CALL_FWD_S, CALL_FWD_D)
 #undef CALL_FWD_S
 #undef CALL_FWD_D
+#undef GNNTRK_FWD32_GRID
     return check_launch("mlp_forward");
 }
 

@@ -464,8 +464,8 @@ struct RawGout {
 // ---- buffer-addressed I/O of the backward tile loop ----------------------------------------
 // The generic I/O above gives every lane its own pointers (lanes of one load read different
 // tensors): per tile and half about 45 VALU instructions of 64-bit address arithmetic, "no index"
-// selects, pad masks and store redirections next to about 95 of arithmetic - in a kernel whose
-// issue port is full.  For the shapes of the default models the same accesses are made through
+// selects, pad masks and store redirections next to about 95 of arithmetic (round 3 read the kernel as
+// issue bound; round 5 measured its access floor and the issue costs - DESIGN.md 4.3 - and it is neither).  For the shapes of the default models the same accesses are made through
 // WAVE-UNIFORM buffer descriptors (tile_bf16.h): one access per TENSOR, executed by all lanes; a
 // lane that takes no part carries the offset 2^31 and falls out in the hardware range check, as do
 // rows past the end; rows of the tile itself go through the scalar offset, gathered rows through

@@ -686,7 +686,7 @@ struct OutSrc {   // second sort
 template <class O>
 __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *__restrict__ part,
                                                                   const uint32_t *__restrict__ base_arr, int NB,
-                                                                  int64_t N, int64_t E, int pbits, O out) {
+                                                                  int64_t N, int64_t E, int pbits, int chunk, O out) {
     constexpr uint32_t VM = O::kValMask;
     __shared__ uint32_t s_hist[kBins], s_start[kBins], s_wsum[kBins / 64];
     __shared__ uint2 s_rec[kCap];
@@ -790,27 +790,50 @@ __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *_
             const uint32_t st0 = s_start[g0];
             int g1 = g0;
             while (g1 < kBins && (g1 + 1 < kBins ? s_start[g1 + 1] : M) - st0 <= kCapG) ++g1;
-            if (g1 == g0) {   // hub node g0
+            if (g1 == g0) {   // hub node g0: its list alone exceeds the LDS capacity
+                // The bucket's region is a sequence of runs, one per CHUNK of the edge list, in chunk order (step 2's
+                // scan lays (bucket, chunk) out chunk after chunk), and a record's value - an edge id / a CSR position -
+                // says which chunk it came from: value / chunk.  So a hub record's rank is the number of hub records
+                // in earlier runs (a histogram over the chunks) + the number of hub records of its OWN run with a
+                // smaller value (a walk over that run only).  Until round 5 every hub record was compared with every
+                // record of the bucket: O(M^2 / 512) per workgroup - seconds for a million-edge hub.
                 const uint32_t n = s_hist[g0];
-                for (uint32_t i0 = 0; i0 < M; i0 += kSortTpb) {
-                    const uint32_t i = i0 + tid;
-                    const uint2 r = i < M ? part[base + i] : uint2{0u, 0u};
-                    const bool have = i < M && (int)(r.y >> pbits) == g0;
-                    uint32_t cnt = 0;
-                    for (uint32_t t0 = 0; t0 < M; t0 += kCap) {
-                        const uint32_t tn = M - t0 < (uint32_t)kCap ? M - t0 : (uint32_t)kCap;
-                        __syncthreads();
-                        for (uint32_t t = tid; t < tn; t += kSortTpb) s_rec[t] = part[base + t0 + t];
-                        __syncthreads();
-                        if (have)
-                            for (uint32_t t = 0; t < tn; ++t) {
-                                const uint2 q = s_rec[t];
-                                cnt += ((int)(q.y >> pbits) == g0 && (q.x & VM) < (r.x & VM)) ? 1u : 0u;
-                            }
+                uint32_t *h_all = reinterpret_cast<uint32_t *>(s_rec), *h_hub = h_all + kMaxChunks;   // (s_rec is free here)
+                __syncthreads();
+                for (int t = tid; t < 2 * kMaxChunks; t += kSortTpb) h_all[t] = 0u;
+                __syncthreads();
+                for (uint32_t i = tid; i < M; i += kSortTpb) {
+                    const uint2 r = part[base + i];
+                    const uint32_t ck = (r.x & VM) / (uint32_t)chunk;
+                    atomicAdd(&h_all[ck], 1u);
+                    if ((int)(r.y >> pbits) == g0) atomicAdd(&h_hub[ck], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {   // exclusive scans over at most 512 chunks
+                    uint32_t a_ = 0, h_ = 0;
+                    for (int ck = 0; ck < kMaxChunks; ++ck) {
+                        const uint32_t va = h_all[ck], vh = h_hub[ck];
+                        h_all[ck] = a_;
+                        h_hub[ck] = h_;
+                        a_ += va;
+                        h_ += vh;
                     }
-                    if (have) out.ranked(base + st0 + cnt, r.x, r.y, base + i);
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < M; i += kSortTpb) {
+                    const uint2 r = part[base + i];
+                    if ((int)(r.y >> pbits) != g0) continue;
+                    const uint32_t ck = (r.x & VM) / (uint32_t)chunk;
+                    const uint32_t r0 = h_all[ck], r1 = ck + 1 < (uint32_t)kMaxChunks ? h_all[ck + 1] : M;
+                    uint32_t cnt = h_hub[ck];
+                    for (uint32_t t = r0; t < r1; ++t) {
+                        const uint2 q = part[base + t];
+                        cnt += ((int)(q.y >> pbits) == g0 && (q.x & VM) < (r.x & VM)) ? 1u : 0u;
+                    }
+                    out.ranked(base + st0 + cnt, r.x, r.y, base + i);
                 }
                 for (uint32_t j = tid; j < n; j += kSortTpb) out.slot(base + st0 + j, node0 + (uint32_t)g0);
+                __syncthreads();   // (the histograms lived in s_rec: the next group refills it)
                 g0 += 1;
                 continue;
             }
@@ -916,7 +939,7 @@ static int own_sort(const OwnPlan &p, K keys, O out, int pbits, int64_t N, int64
     hipLaunchKernelGGL((gi_split_kernel<K, ROWS>), dim3(p.n_chunks), dim3(kSplitTpb), 0, stream, keys, E, p.chunk,
                        p.n_chunks, pbits, tbl, range, part, part_rows, bad);
     hipLaunchKernelGGL((gi_bucket_sort_kernel<O>), dim3(p.NB), dim3(kSortTpb), 0, stream, part, base, p.NB, N, E,
-                       pbits, out);
+                       pbits, p.chunk, out);
     return GNNTRK_OK;
 }
 

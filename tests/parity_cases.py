@@ -108,6 +108,12 @@ def case_graph_index(device, big=False):
     cases.append(("spread", g.integers(0, 300_000, size=(2, 20000)), 300_000))
     if big:   # more buckets than a chunk's LDS window (8192 x 256 nodes), ids unsorted
         cases.append(("wide", g.integers(0, 3_000_000, size=(2, 400_000)), 3_000_000))
+        # a 300 000-edge hub (as target and, for a third of the edges, as source) spread over 37 chunks of the edge
+        # list: the hub ranking through the chunk runs of the bucket's region
+        hb = g.integers(0, 5000, size=(2, 600_000))
+        hb[1, ::2] = 1234
+        hb[0, 1::3] = 77
+        cases.append(("hub_big", hb, 5000))
     for tag, arr, N in cases:
         ei = tt(arr, device).long()
         eic = ei.cpu()

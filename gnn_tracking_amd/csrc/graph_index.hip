@@ -65,6 +65,9 @@ constexpr int kCountTpb = 1024;
 constexpr int kSplitR = 4;              // edges per thread and tile of the split
 constexpr int kSplitTile = kSplitTpb * kSplitR;
 constexpr int kMaxChunks = 512;
+#ifndef GNNTRK_GI_HUB_BITMAP_MIN
+#define GNNTRK_GI_HUB_BITMAP_MIN 65536   // hub nodes above this degree are ranked through per-run bitmaps (the emulator build: 8192)
+#endif
 constexpr int64_t kMaxTable = (int64_t)96 << 20;   // table entries (4 B each)
 constexpr int kScanTpb = 256, kScanItems = 16, kScanTile = kScanTpb * kScanItems;
 
@@ -820,17 +823,77 @@ __global__ __launch_bounds__(kSortTpb) void gi_bucket_sort_kernel(const uint2 *_
                     }
                 }
                 __syncthreads();
-                for (uint32_t i = tid; i < M; i += kSortTpb) {
-                    const uint2 r = part[base + i];
-                    if ((int)(r.y >> pbits) != g0) continue;
-                    const uint32_t ck = (r.x & VM) / (uint32_t)chunk;
-                    const uint32_t r0 = h_all[ck], r1 = ck + 1 < (uint32_t)kMaxChunks ? h_all[ck + 1] : M;
-                    uint32_t cnt = h_hub[ck];
-                    for (uint32_t t = r0; t < r1; ++t) {
-                        const uint2 q = part[base + t];
-                        cnt += ((int)(q.y >> pbits) == g0 && (q.x & VM) < (r.x & VM)) ? 1u : 0u;
+                if (n <= (uint32_t)GNNTRK_GI_HUB_BITMAP_MIN) {   // a walk over the record's own run
+                    for (uint32_t i = tid; i < M; i += kSortTpb) {
+                        const uint2 r = part[base + i];
+                        if ((int)(r.y >> pbits) != g0) continue;
+                        const uint32_t ck = (r.x & VM) / (uint32_t)chunk;
+                        const uint32_t r0 = h_all[ck], r1 = ck + 1 < (uint32_t)kMaxChunks ? h_all[ck + 1] : M;
+                        uint32_t cnt = h_hub[ck];
+                        for (uint32_t t = r0; t < r1; ++t) {
+                            const uint2 q = part[base + t];
+                            cnt += ((int)(q.y >> pbits) == g0 && (q.x & VM) < (r.x & VM)) ? 1u : 0u;
+                        }
+                        out.ranked(base + st0 + cnt, r.x, r.y, base + i);
                     }
-                    out.ranked(base + st0 + cnt, r.x, r.y, base + i);
+                } else {
+                    // a large hub: the values of a run are distinct ids of ONE chunk, so the hub records of a run
+                    // are the set bits of a bitmap over the chunk's id range (spans of 128 K ids: 16 KB of LDS) and
+                    // a record's rank inside its run is the number of set bits below its own - linear in the
+                    // bucket's size (a 2 M-edge hub: 5 s with the walk above, milliseconds this way)
+                    constexpr uint32_t kSpanW = 4096, kSpan = kSpanW * 32;
+                    uint32_t *bm = h_all + 2 * kMaxChunks, *pw = bm + kSpanW;
+                    static_assert((2 * kMaxChunks + 2 * 4096) * sizeof(uint32_t) <= sizeof(s_rec), "hub scratch exceeds s_rec");
+                    for (int ck = 0; ck < kMaxChunks; ++ck) {
+                        const uint32_t r0 = h_all[ck], r1 = ck + 1 < kMaxChunks ? h_all[ck + 1] : M;
+                        const uint32_t hub_here = (ck + 1 < kMaxChunks ? h_hub[ck + 1] : n) - h_hub[ck];
+                        if (hub_here == 0u) continue;   // (uniform)
+                        uint32_t before = h_hub[ck];
+                        for (uint32_t lo = (uint32_t)ck * (uint32_t)chunk, sub = 0; sub < (uint32_t)chunk; sub += kSpan, lo += kSpan) {
+                            __syncthreads();
+                            for (uint32_t w = tid; w < kSpanW; w += kSortTpb) bm[w] = 0u;
+                            __syncthreads();
+                            for (uint32_t t = r0 + tid; t < r1; t += kSortTpb) {
+                                const uint2 q = part[base + t];
+                                const uint32_t d = (q.x & VM) - lo;
+                                if ((int)(q.y >> pbits) == g0 && d < kSpan) atomicOr(&bm[d >> 5], 1u << (d & 31u));
+                            }
+                            __syncthreads();
+                            // exclusive prefix of the words' bit counts: eight words per thread + a scan of the
+                            // 512 thread sums through pw's upper half
+                            uint32_t mine = 0;
+                            constexpr uint32_t kPer = kSpanW / kSortTpb;
+                            for (uint32_t j = 0; j < kPer; ++j) mine += (uint32_t)__popc(bm[tid * kPer + j]);
+                            uint32_t *ts = pw;   // thread sums, scanned in place
+                            ts[tid] = mine;
+                            __syncthreads();
+                            for (uint32_t off = 1; off < (uint32_t)kSortTpb; off <<= 1) {
+                                const uint32_t v = tid >= (int)off ? ts[tid - off] : 0u;
+                                __syncthreads();
+                                ts[tid] += v;
+                                __syncthreads();
+                            }
+                            const uint32_t excl = ts[tid] - mine, span_total = ts[kSortTpb - 1];
+                            __syncthreads();
+                            uint32_t run_ = excl;
+                            for (uint32_t j = 0; j < kPer; ++j) {
+                                const uint32_t w = tid * kPer + j, c_ = (uint32_t)__popc(bm[w]);
+                                pw[w] = run_;
+                                run_ += c_;
+                            }
+                            __syncthreads();
+                            for (uint32_t t = r0 + tid; t < r1; t += kSortTpb) {
+                                const uint2 q = part[base + t];
+                                const uint32_t d = (q.x & VM) - lo;
+                                if ((int)(q.y >> pbits) == g0 && d < kSpan) {
+                                    const uint32_t w = d >> 5;
+                                    const uint32_t below = (uint32_t)__popc(bm[w] & ((1u << (d & 31u)) - 1u));
+                                    out.ranked(base + st0 + before + pw[w] + below, q.x, q.y, base + t);
+                                }
+                            }
+                            before += span_total;
+                        }
+                    }
                 }
                 for (uint32_t j = tid; j < n; j += kSortTpb) out.slot(base + st0 + j, node0 + (uint32_t)g0);
                 __syncthreads();   // (the histograms lived in s_rec: the next group refills it)

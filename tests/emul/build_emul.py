@@ -34,6 +34,7 @@ def build(asan: bool = False, verbose: bool = False) -> pathlib.Path:
         return lib
     flags = ["-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
              "-Wno-attributes", "-Wno-unknown-pragmas", "-Wno-ignored-attributes",
+             "-DGNNTRK_GI_HUB_BITMAP_MIN=8192",   # (the graph index's large-hub path from 8 192 edges on: reachable at emulator sizes)
              f"-I{HERE / 'shim'}", f"-I{REPO / 'include'}", f"-I{CSRC}"]
     if asan:
         flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]

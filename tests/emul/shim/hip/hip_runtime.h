@@ -417,6 +417,7 @@ inline unsigned atomicAdd(unsigned *p, unsigned v) {
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
     return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
+inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 inline int atomicMin(int *p, int v) {
     int old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED,
@@ -445,6 +446,7 @@ inline float __fadd_rn(float a, float b) { return a + b; }
 inline float __fsub_rn(float a, float b) { return a - b; }
 inline float __fsqrt_rn(float a) { return sqrtf(a); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned int v) { return __builtin_popcount(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 inline unsigned __float_as_uint(float f) {
     unsigned u;

@@ -103,6 +103,9 @@ def case_graph_index(device, big=False):
     hub[1, ::2] = 17           # half of the edges end in one node (15 000 > the LDS capacity)
     hub[0, 1::3] = 300
     cases.append(("hub", hub, 600))
+    hub2 = g.integers(0, 600, size=(2, 14000))
+    hub2[1, ::2] = 333          # a 7 000-edge hub: just over the LDS capacity (the run walk; "hub" above takes the
+    cases.append(("hub_small", hub2, 600))   # per-run bitmaps in the emulator build, the walk on the GPU)
     cases.append(("dense", g.integers(0, 7, size=(2, 12000)), 7))
     # more than 1024 touched buckets per chunk: several window slots per thread in the split's scans
     cases.append(("spread", g.integers(0, 300_000, size=(2, 20000)), 300_000))

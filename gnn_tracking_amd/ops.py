@@ -203,8 +203,10 @@ def node_order(x: Tensor, col: int, batch: Optional[Tensor] = None, n_events: in
     one event; ``n_events``: number of events if known - fewer radix passes) sorted by ``x[:, col]`` (fp32), ties
     in the old order (gnntrk_node_order)."""
     _capi.require_device(x)
-    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
-        raise TypeError("node_order: x must be fp32 [N, F] with unit column stride")
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise TypeError("node_order: x must be fp32 [N, F]")
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        x = x.contiguous()   # (a transposed / expanded view: the key column is read through the row stride)
     lib = _capi.load()
     n = int(x.shape[0])
     key = x[:, col]

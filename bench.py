@@ -849,9 +849,12 @@ def hipgraph_cfg2(dev, dtype: str, steps: int, hits: int = 10_000, edges: int = 
     launch bound, ~100 kernels of a few microseconds) and one full-size event of cfg3 (150 k hits, 2 M edges)."""
     torch.manual_seed(0)
     model = G.ECForGraphTCN(node_indim=14, edge_indim=4, **EC_MODEL).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
-    mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), bf16=dtype == "bf16", optimizer=lambda p: opt,
-                            scheduler=None)
+    # (parameters and gradients in one bucket, as in the headline: one Adam over the bucket and the weight gradients
+    #  added by the backward launches themselves - with 45 separate tensors the captured step carried 137 more
+    #  launches of a few microseconds each, profiles/r05_one_event_timeline.md)
+    flat = gdist.FlatParameters(model)
+    mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), bf16=dtype == "bf16", flat=flat, scheduler=None,
+                            optimizer=lambda p: torch.optim.Adam(p, lr=1e-4, weight_decay=1e-4, capturable=True))
     batch = G.collate([synthetic.make_event(seed, hits, edges, dev)])
 
     def step():

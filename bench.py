@@ -590,7 +590,7 @@ class TCWorkload(Workload):
                 out = m(data, _preprocessed=True)
             with st("oc_loss_forward"):
                 loss, _ = m.get_losses(out, data, metrics=False)
-            with st("backward"):
+            with st("backward"), ops.grad_sinks_armed():
                 loss.backward()
         with st("allreduce_adam"):
             self.flat.all_reduce_grads()

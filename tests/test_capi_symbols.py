@@ -39,6 +39,28 @@ def test_version_and_error_channel(lib_path):
     assert rc == 1 and b"NULL" in lib.gnntrk_last_error()
 
 
+def test_round5_entry_points_validate_on_the_host(lib_path):
+    """gnntrk_node_order / gnntrk_graph_index_place refuse bad arguments before any launch (include/gnntrk.h)."""
+    from gnn_tracking_amd import _capi
+
+    lib = _capi.bind(ctypes.CDLL(str(lib_path)))
+    assert lib.gnntrk_node_order_workspace_bytes(1000) >= 1000 * 24
+    assert lib.gnntrk_node_order(None, 1, None, 0, 0, None, None, None, 0, None) == 0      # nothing to order
+    assert lib.gnntrk_node_order(None, 1, None, 0, 10, None, None, None, 0, None) == 1 and b"NULL" in lib.gnntrk_last_error()
+    buf = (ctypes.c_float * 16)()
+    out = (ctypes.c_int32 * 16)()
+    rc = lib.gnntrk_node_order(buf, 1, None, 0, 16, out, out, buf, 8, None)
+    assert rc == 1 and b"workspace" in lib.gnntrk_last_error()
+    assert lib.gnntrk_node_order(buf, 1, None, 0, 1 << 32, out, out, buf, 8, None) == 4   # GNNTRK_EUNSUPPORTED: sizes must fit int32
+    assert lib.gnntrk_graph_index_place(None, 0, 0, None, *([None] * 8), None) == 1
+    part, batch = _capi.GraphIndex(), _capi.GraphIndex()
+    part.n_nodes, part.n_edges, batch.n_nodes, batch.n_edges = 10, 20, 15, 30
+    rc = lib.gnntrk_graph_index_place(ctypes.byref(part), 6, 0, ctypes.byref(batch), *([None] * 8), None)
+    assert rc == 1 and b"does not fit" in lib.gnntrk_last_error()
+    rc = lib.gnntrk_graph_index_place(ctypes.byref(part), 0, 0, ctypes.byref(batch), out, None, *([None] * 6), None)
+    assert rc == 1 and b"pairs" in lib.gnntrk_last_error()
+
+
 def test_struct_layout_matches_header():
     from gnn_tracking_amd import _capi
 

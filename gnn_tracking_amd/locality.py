@@ -29,7 +29,7 @@ AUTO_COLUMN = 1   # phi of the reference's node features (graph_builder.py: r, p
 
 def _parse(mode) -> str:
     m = str(mode).lower()
-    if m in ("off", "none", "0n", "false"):
+    if m in ("off", "none", "no", "false"):
         return "off"
     if m == "auto":
         return "auto"

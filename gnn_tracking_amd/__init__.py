@@ -11,7 +11,7 @@ no CPU fallback.
 """
 
 from .data import Data, collate
-from .io import GraphDataset, PrefetchLoader, load_graph, renumber_nodes
+from .io import GraphDataset, PrefetchLoader, ResidentDataset, load_graph, renumber_nodes
 from .edge_classifier import ECForGraphTCN, PerfectEdgeClassification
 from .interaction_network import InteractionNetwork
 from .graph_construction import MLGraphConstruction, MLPCTransformer, knn_scan, knn_with_max_radius
@@ -39,4 +39,4 @@ __all__ = ["Data", "collate", "MLP", "InteractionNetwork", "ResIN", "ECForGraphT
            "PreTrainedECGraphTCN", "ResFCNN", "GraphConstructionHingeEmbeddingLoss",
            "GraphConstructionFCNN", "HeterogeneousResFCNN", "GraphConstructionHeteroResFCNN",
            "GraphConstructionHeteroEncResFCNN", "GraphConstructionResIN", "PerfectECGraphTCN",
-           "GraphTCNForMLGCPipeline", "PerfectEdgeClassification", "MLPCTransformer", "knn_scan", "EdgeWeightFocalLoss", "HaughtyFocalLoss", "binary_focal_loss", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader", "renumber_nodes"]
+           "GraphTCNForMLGCPipeline", "PerfectEdgeClassification", "MLPCTransformer", "knn_scan", "EdgeWeightFocalLoss", "HaughtyFocalLoss", "binary_focal_loss", "DBSCANFastRescan", "dbscan", "load_graph", "GraphDataset", "PrefetchLoader", "ResidentDataset", "renumber_nodes"]

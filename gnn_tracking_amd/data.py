@@ -145,7 +145,14 @@ def collate(graphs: Iterable[Data]) -> Data:
         if not torch.is_tensor(vals[0]):
             setattr(out, k, vals)
         elif "index" in k:
-            setattr(out, k, torch.cat([v + o for v, o in zip(vals, offs)], dim=-1))
+            # (offset while copying: one read and one write of every id instead of a shifted temporary and its copy)
+            cat = torch.empty(*vals[0].shape[:-1], sum(int(v.shape[-1]) for v in vals), dtype=vals[0].dtype,
+                              device=vals[0].device)
+            a = 0
+            for v, o in zip(vals, offs):
+                torch.add(v, o, out=cat[..., a:a + v.shape[-1]])
+                a += int(v.shape[-1])
+            setattr(out, k, cat)
         elif vals[0].dim() == 0:
             setattr(out, k, torch.stack(vals))
         else:

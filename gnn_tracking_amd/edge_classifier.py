@@ -108,11 +108,14 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         if col is not None and _ordered_by(data) == col:
             col = None   # (io.renumber_nodes / GraphDataset(renumber=True) ordered these events when they were read)
         batch = getattr(data, "batch", None)
-        gi = ops.graph_index(edge_index, x.shape[0],
-                             carry_label=y if isinstance(y, Tensor) and self.training else None,
-                             carry_rows=edge_attr if bf16 and edge_attr.shape[1] == 4 else None,
-                             order_by=None if col is None else (x, col, batch if isinstance(batch, Tensor) else None,
-                                                                _n_events(data)))
+        # (a batch collated by io.ResidentDataset comes with its index placed from the per-event ones)
+        gi = ops.placed_graph_index(edge_index, x.shape[0])
+        if gi is None:
+            gi = ops.graph_index(edge_index, x.shape[0],
+                                 carry_label=y if isinstance(y, Tensor) and self.training else None,
+                                 carry_rows=edge_attr if bf16 and edge_attr.shape[1] == 4 else None,
+                                 order_by=None if col is None else (x, col, batch if isinstance(batch, Tensor) else None,
+                                                                    _n_events(data)))
         E = gi.n_edges
         nperm = gi.node_perm
 

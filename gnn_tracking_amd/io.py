@@ -169,6 +169,75 @@ class GraphDataset:
         return g
 
 
+class ResidentDataset:
+    """A static dataset kept ON THE DEVICE, with the graph index of every event built ONCE.
+
+    The reference's datasets do not change between epochs (utils/loading.py:97-100: the same files every epoch,
+    shuffled), and 288 GB of HBM hold thousands of 2 M-edge events (about 150 MB each with the index).  Every
+    event is read, copied and indexed on first use - node order (``locality.py``), 1-byte labels and, for bf16
+    storage, the edge features carried into CSR order; ``batches`` collates events as the reference's DataLoader
+    does and PLACES their indices into the batch's arrays (``ops.place_graph_indices``: one streaming pass per
+    event, the arrays identical to building the index of the collated list) instead of sorting 64 M edges in every
+    step.  ``ECForGraphTCN`` finds the placed index through ``ops.placed_graph_index``.
+
+        ds = ResidentDataset(GraphDataset(dirs), "cuda:0")
+        for epoch in range(n):
+            for batch in ds.batches(32, shuffle=True, seed=epoch):
+                module.optimisation_step(batch)
+    """
+
+    def __init__(self, events, device, *, bf16: bool = True, order: bool | int = True):
+        """``events``: a sequence of ``Data`` (``GraphDataset``, a list); ``bf16``: carry the four fp32 edge features
+        as bf16 rows (what ``bf16_storage`` reads; fp32 runs gather ``edge_attr`` through the permutation);
+        ``order``: True = follow the node-order policy of ``locality.py`` (column ``AUTO_COLUMN`` unless the policy is
+        off - whatever the size: the sort is paid once), a column number, or False."""
+        self.source, self.device = events, torch.device(device)
+        self.bf16, self.order = bool(bf16), order
+        self._events: list = [None] * len(events)
+        self._parts: list = [None] * len(events)
+
+    def __len__(self) -> int:
+        return len(self._events)
+
+    def _key_column(self, e: Data):
+        from . import locality
+
+        if self.order is False or "node_order_key" in e or (self.order is True and locality.mode() == "off"):
+            return None
+        col = int(self.order) if self.order is not True else (
+            locality.AUTO_COLUMN if locality.mode() == "auto" else int(locality.mode()))
+        x = e.x
+        return col if x.dim() == 2 and x.dtype == torch.float32 and 0 <= col < x.shape[1] and x.shape[0] >= 2 else None
+
+    def event(self, i: int):
+        """``(data, index)`` of event ``i`` on the device (read and indexed on first use)."""
+        if self._events[i] is None:
+            from . import ops
+
+            e = self.source[i].to(self.device)
+            col = self._key_column(e)
+            y, ea = getattr(e, "y", None), getattr(e, "edge_attr", None)
+            part = ops.graph_index(e.edge_index, e.num_nodes, cache=False,
+                                   carry_label=y if torch.is_tensor(y) else None,
+                                   carry_rows=ea if self.bf16 and torch.is_tensor(ea) and ea.dim() == 2 and ea.shape[1] == 4 else None,
+                                   order_by=None if col is None else (e.x, col, None))
+            self._events[i], self._parts[i] = e, part
+        return self._events[i], self._parts[i]
+
+    def batches(self, batch_size: int = 1, *, shuffle: bool = False, seed: int = 0) -> Iterator[Data]:
+        """Collated batches of ``batch_size`` events with their graph index placed (see the class)."""
+        from . import ops
+
+        idx = list(range(len(self)))
+        if shuffle:
+            idx = torch.randperm(len(idx), generator=torch.Generator().manual_seed(seed)).tolist()
+        for s in range(0, len(idx), int(batch_size)):
+            evs = [self.event(i) for i in idx[s:s + int(batch_size)]]
+            batch = collate([e for e, _ in evs])
+            ops.place_graph_indices([p for _, p in evs], batch)
+            yield batch
+
+
 class PrefetchLoader:
     """Iterate over batches of ``batch_size`` collated graphs on ``device``.  A background
     thread reads and collates the next ``depth`` batches into pinned memory; the

@@ -177,6 +177,7 @@ class GraphIndex:
     node_perm: Optional[Tensor] = None   # [N] int32: new id -> caller's id (gather node inputs through it)
     node_rank: Optional[Tensor] = None   # [N] int32: caller's id -> new id (gather node results through it)
     order_sig: object = None
+    placed: bool = False   # collated from cached per-event indices (place_graph_indices): the loader chose the node order
 
     def node_values(self, t: Tensor) -> Tensor:
         """Per-node values of the caller (``pt``, ...) in the numbering of ``tgt`` / ``src``."""
@@ -368,8 +369,20 @@ def place_graph_indices(parts: Sequence[GraphIndex], batch) -> GraphIndex:
         bt = getattr(batch, "batch", None)
         gi.order_sig, gi._order_ref = _order_sig((batch.x, col, bt if isinstance(bt, Tensor) else None)), weakref.ref(batch.x)
     gi._built_from = (weakref.ref(ei), ei._version)
+    gi.placed = True
     _cache_put(ei, N, gi)
     return gi
+
+
+def placed_graph_index(edge_index: Tensor, n_nodes: int) -> Optional[GraphIndex]:
+    """The index ``place_graph_indices`` left for exactly this ``edge_index`` (same object, unmodified), in whichever
+    node order the loader indexed the events in, or None.  ``ECForGraphTCN`` asks here first: a loader that keeps
+    per-event indices (``io.ResidentDataset``) has already decided the node order of the batch."""
+    for renumbered in (True, False):
+        hit = _GI_CACHE.get((id(edge_index), renumbered))
+        if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == n_nodes and hit[3].placed:
+            return _join(hit[3])
+    return None
 
 
 def _carry_label_ok(y: Tensor, E: int, dev) -> bool:

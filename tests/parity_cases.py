@@ -270,6 +270,60 @@ def case_graph_index_place(device, sizes=((700, 6301), (1, 3), (300, 2500), (204
     assert torch.equal(w1, w2), "W on the placed index differs from W on the built index"
 
 
+def case_resident_dataset(device, sizes=((700, 6301), (300, 2500), (2049, 18002), (1000, 9000), (50, 333))):
+    """io.ResidentDataset: a static dataset on the device with one index per event; ``batches`` collates and PLACES.
+    Against the same events collated and indexed inline: (1) every index array of every batch bit for bit,
+    (2) one optimisation step per batch (bf16 storage and fp32): loss, W and the flat gradient bucket identical -
+    the node-order policy says "off" for batches this small, the loader orders anyway (paid once) and the model takes
+    the loader's index; (3) a second epoch reuses the per-event indices (no new build) in a new shuffle."""
+    from gnn_tracking_amd import dist as gdist, io as gio, training
+
+    g = np.random.default_rng(11)
+    events = []
+    for n, e in sizes:
+        events.append(G.Data(x=torch.from_numpy(g.standard_normal((n, 14)).astype(np.float32)),
+                             edge_index=torch.from_numpy(g.integers(0, n, size=(2, e))).long(),
+                             edge_attr=torch.from_numpy(g.standard_normal((e, 4)).astype(np.float32)),
+                             y=torch.from_numpy(g.integers(0, 2, size=e).astype(bool)),
+                             pt=torch.from_numpy(g.random(n).astype(np.float32))))
+    for bf16 in (True, False):
+        ds = gio.ResidentDataset(events, device, bf16=bf16)
+        assert len(ds) == len(events)
+        seen = []
+        for epoch in range(2):
+            for b in ds.batches(2, shuffle=True, seed=epoch):
+                gi = ops.placed_graph_index(b.edge_index, b.num_nodes)
+                assert gi is not None and gi.node_perm is not None, "ResidentDataset: no placed, ordered index"
+                ref = ops.graph_index(b.edge_index, b.num_nodes, cache=False, carry_label=b.y,
+                                      carry_rows=b.edge_attr if bf16 else None, order_by=(b.x, 1, b.batch))
+                for k in ("perm", "tgt", "src", "rowptr_t", "rowptr_s", "spos", "spos_inv", "node_perm", "node_rank"):
+                    assert torch.equal(getattr(gi, k), getattr(ref, k)), f"resident batch: {k} differs from the inline build"
+                assert torch.equal(ops.carried_label(gi, b.y), ops.carried_label(ref, b.y))
+                seen.append(int(b.num_edges))
+        assert sum(seen) == 2 * sum(e for _, e in sizes), "every event once per epoch"
+        parts = [ds.event(i)[1] for i in range(len(ds))]
+        assert all(p is ds.event(i)[1] for i, p in enumerate(parts)), "per-event indices are kept"
+
+        def run(resident: bool):
+            torch.manual_seed(0)
+            model = G.ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=2, hidden_dim=40).to(device)
+            flat = gdist.FlatParameters(model)
+            mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), flat=flat, bf16=bf16, scheduler=None,
+                                    optimizer=lambda p: torch.optim.SGD(p, lr=0.0))
+            out = []
+            for b in ds.batches(3, shuffle=True, seed=7):
+                if not resident:   # the same events collated and indexed inside the step, renumbered there
+                    ops.clear_graph_index_cache()
+                with G.node_order("auto" if resident else 1, min_nodes=None if resident else 0):
+                    loss = mod.optimisation_step(b)
+                out.append((float(loss), flat.grad.detach().clone().cpu()))
+            return out
+
+        a, c = run(True), run(False)
+        for (la, ga), (lc, gc) in zip(a, c):
+            assert la == lc and torch.equal(ga, gc), "ResidentDataset step differs from the inline step"
+
+
 def case_graph_index_carry(device):
     """Per-edge inputs carried into CSR order inside the build (gnntrk_graph_index_carry): identical to
     the gathers through perm, in both forms of the build, incl. buckets beyond the LDS capacity; and

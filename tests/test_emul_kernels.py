@@ -28,6 +28,11 @@ def test_graph_index_placed_from_cached_events():
         P.case_graph_index_place("cpu", order=False)
 
 
+def test_resident_dataset():
+    with emulated():
+        P.case_resident_dataset("cpu", sizes=((300, 2500), (97, 800), (513, 4000), (50, 333)))
+
+
 def test_graph_index_carry_and_fused_bce():
     with emulated():
         P.case_graph_index_carry("cpu")

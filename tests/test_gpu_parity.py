@@ -33,6 +33,10 @@ def test_graph_index_placed_from_cached_events(dev):
     P.case_graph_index_place(dev, sizes=((150_000, 2_000_000), (70_001, 1_000_002), (150_000, 2_000_000)))
 
 
+def test_resident_dataset(dev):
+    P.case_resident_dataset(dev)
+
+
 def test_graph_index_carry_and_fused_bce(dev):
     P.case_graph_index_carry(dev)
     P.case_ec_carry_equals_gather(dev)

@@ -868,7 +868,8 @@ def hipgraph_cfg2(dev, dtype: str, steps: int, hits: int = 10_000, edges: int = 
     #  launches of a few microseconds each, profiles/r05_one_event_timeline.md)
     flat = gdist.FlatParameters(model)
     mod = training.ECModule(model, loss_fct=G.EdgeWeightBCELoss(), bf16=dtype == "bf16", flat=flat, scheduler=None,
-                            optimizer=lambda p: torch.optim.Adam(p, lr=1e-4, weight_decay=1e-4, capturable=True))
+                            optimizer=lambda p: torch.optim.Adam(p, lr=1e-4, weight_decay=1e-4, capturable=True,
+                                                                 fused=os.environ.get("GNNTRK_BENCH_FUSED_ADAM", "1") != "0"))
     batch = G.collate([synthetic.make_event(seed, hits, edges, dev)])
 
     def step():
@@ -899,7 +900,7 @@ def hipgraph_cfg2(dev, dtype: str, steps: int, hits: int = 10_000, edges: int = 
     graph = timed(g.replay, steps)
     E = batch.num_edges
     return {"workload": f"{label}: 1 event x {hits} hits x {edges} edges per step (graph index + forward + BCE + backward "
-                        "+ Adam), eager and the whole step as one hipGraph replay",
+                        "+ Adam: one fused kernel over the parameter bucket), eager and the whole step as one hipGraph replay",
             "dtype": dtype, "steps": steps, "eager_ms_per_step": eager, "ms_per_step": graph,
             "value": E / graph * 1e3, "eager_value": E / eager * 1e3, "unit": "edges/s",
             "roofline": "n/a (cache resident, launch bound)" if edges <= 200_000 else

@@ -26,11 +26,12 @@ A step does everything a training step does, including rebuilding the graph inde
 raw COO edge_index (the cache is cleared every step: a new batch would arrive every step).
 The only collective is one RCCL all-reduce of the flat gradient buffer per step.
 
-Prints ONE JSON line (rank 0).  ``roofline`` describes the dominant fused gather-MLP kernel
-from HIP-event timings taken inside the timed region; ``cpu_baseline`` is the CPU oracle
-(oracle/ref_cpu.py, a restatement of the reference pinned against it) timed on this box's
-host cores on one event of the same workload; ``extra`` (N = 1 default run) holds short
-driver-timed runs of the other configurations.
+Prints ONE JSON line of at most 6 KB on stdout (rank 0).  ``roofline`` describes the dominant fused
+gather-MLP kernel from HIP-event timings taken inside the timed region; ``cpu_baseline`` is the CPU
+oracle (oracle/ref_cpu.py, a restatement of the reference pinned against it) timed on this box's
+host cores on one event of the same workload; ``kernels`` / ``extra`` are digests (a few numbers per
+kernel / per short run of the other configurations at N = 1): the full records go to
+``bench_extra.json`` next to this file (and under ``gpurun_out/``) and to stderr (``emit``).
 """
 
 from __future__ import annotations
@@ -193,8 +194,8 @@ def cpu_baseline(event, model, iters: int) -> dict:
 def parity_check(event_cpu, model, dtype: str, dev) -> dict:
     """The GPU's edge weights and loss on event 0 of the workload (the run's precision, the parameters the run ended
     with) against the CPU oracle on the same event: fp32 against ``oracle.ec_for_graph_tcn`` (bar 1e-5), bf16 storage
-    against the oracle's restatement of the rounding contract ``ec_for_graph_tcn_bf16`` (bar: one bf16 ulp of W on
-    [0.5, 1) = 2^-8) with the distance to the fp32 oracle next to it.  The checker, not the thing measured."""
+    against the oracle's restatement of the rounding contract ``ec_for_graph_tcn_bf16`` (bar 5e-4: rare one-ulp flips of
+    a hidden activation, 1.1e-4 measured) with the distance to the fp32 oracle next to it.  The checker, not the thing measured."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_cpu as O
 
@@ -219,10 +220,10 @@ def parity_check(event_cpu, model, dtype: str, dev) -> dict:
                "loss_gpu": loss, "loss_fp32_oracle": rloss32}
         if dtype == "bf16":
             ref16 = O.ec_for_graph_tcn_bf16(x, ei, ea, p, L_ec=hp.L_ec, alpha=hp.alpha)
-            err, bound = float((w - ref16["W"]).abs().max()), 2.0 ** -8
+            err, bound = float((w - ref16["W"]).abs().max()), 5e-4   # (1.1e-4 measured; tests/parity_cases.py: BF16_ORACLE_W)
             rec.update({"oracle": "oracle/ref_cpu.py: ec_for_graph_tcn_bf16 (the kernels' rounding contract restated)",
                         "max_abs_W": err, "bound": bound,
-                        "loss_abs": abs(loss - float(O.edge_weight_bce_loss(ref16["W"], y.float()))), "loss_bound": 5e-3})
+                        "loss_abs": abs(loss - float(O.edge_weight_bce_loss(ref16["W"], y.float()))), "loss_bound": 1e-4})
         else:
             err, bound = rec["max_abs_W_vs_fp32_oracle"], 1e-5
             rec.update({"oracle": "oracle/ref_cpu.py: ec_for_graph_tcn (fp32)", "max_abs_W": err, "bound": bound,
@@ -483,8 +484,9 @@ class ECWorkload(Workload):
             cur = self.batches[self.counter % 2]
             nxt = self.batches[(self.counter + 1) % 2]
             self.counter += 1
-            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, self.side, x=None if "node_order_key" in nxt else nxt.x,
-                                     batch=getattr(nxt, "batch", None))
+            from gnn_tracking_amd import locality
+            ops.prefetch_graph_index(nxt.edge_index, nxt.num_nodes, self.side,
+                                     x=None if locality.order_column(nxt) is None else nxt.x, batch=getattr(nxt, "batch", None))
             loss = self.module.backward_step(cur)
         elif getattr(self, "dataset", None) is not None:
             # one epoch of one batch: the events in a new order, collated on the device, their indices placed
@@ -1119,6 +1121,84 @@ def extras(args, rank: int, world: int, dev) -> dict:
     return out
 
 
+
+# ------------------------------------------------------------------------------- the line
+LINE_LIMIT = 6000          # bytes of the final stdout line (the driver parses that line; round 5's 22 KB line was lost)
+EXTRA_FILE = "bench_extra.json"
+_SIDE_KEYS = ("s_all_iters", "thread_probe_s", "oracle_seconds", "alg_flops_per_launch", "what", "oracle", "event")
+
+
+def _short(v, n: int = 6):
+    """Floats to n significant digits, recursively (a line of 17-digit floats is a third longer for nothing)."""
+    if isinstance(v, float):
+        return float(f"{v:.{n}g}")
+    if isinstance(v, dict):
+        return {k: _short(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_short(x, n) for x in v]
+    return v
+
+
+def _drop(d, keys):
+    if isinstance(d, dict):
+        return {k: _drop(v, keys) for k, v in d.items() if k not in keys}
+    return d
+
+
+def extra_digest(extra: dict | None) -> dict | None:
+    """name -> the few numbers of a side run that belong next to the headline (everything else: EXTRA_FILE)."""
+    if not extra:
+        return None
+    out = {}
+    for k, v in extra.items():
+        if not isinstance(v, dict):
+            out[k] = v if not isinstance(v, str) else v[:200]
+            continue
+        d = {f: v[f] for f in ("ms_per_step", "eager_ms_per_step", "dtype", "n_gpus", "radius_graph_ms", "rescan_ms_per_trial",
+                               "launches_per_step") if f in v}
+        if isinstance(v.get("roofline"), dict) and "frac" in v["roofline"]:
+            d["roofline_frac"] = v["roofline"]["frac"]
+        if isinstance(v.get("stages"), dict):
+            d["stage_ms"] = {s: t.get("avg_ms") for s, t in v["stages"].items() if isinstance(t, dict)}
+        out[k] = d
+    return out
+
+
+def kernel_digest(kernels: dict | None) -> dict | None:
+    """kernel -> [avg ms per launch, algorithmic GB/s, HBM fraction from the committed traffic pass or null]."""
+    if not kernels:
+        return None
+    return {k: [d["avg_ms"], d["alg_GBps"], d.get("hbm_frac")] for k, d in kernels.items()}
+
+
+def emit(line: dict, kernels: dict | None, extra: dict | None) -> None:
+    """Everything measured goes to EXTRA_FILE (next to bench.py and, where the directory exists, under gpurun_out/)
+    and to stderr as one line; stdout gets exactly ONE line of at most LINE_LIMIT bytes: the contract's keys,
+    ``roofline`` (with the access floors), ``cpu_baseline``, ``parity_check``, ``library``, ``stages`` and a digest
+    of the per-kernel table and of the side runs."""
+    full = dict(line, kernels=kernels, extra=extra)
+    blob = json.dumps(full)
+    for path in (os.path.join(ROOT, EXTRA_FILE), os.path.join(ROOT, "gpurun_out", EXTRA_FILE)):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(blob + "\n")
+        except OSError:
+            pass
+    print("bench_extra " + blob, file=sys.stderr, flush=True)
+    out = _short(_drop(line, _SIDE_KEYS))
+    out["extra_file"] = EXTRA_FILE
+    out["kernels"] = _short(kernel_digest(kernels), 4)
+    out["extra"] = _short(extra_digest(extra), 5)
+    for victim in ("kernels", "extra", "stages", "parity_check"):   # (never needed so far; the line must stay parseable)
+        if len(json.dumps(out)) <= LINE_LIMIT:
+            break
+        out[victim] = f"see {EXTRA_FILE}"
+    text = json.dumps(out)
+    assert len(text) <= LINE_LIMIT or line.get("data") == "stub", f"bench line is {len(text)} bytes"
+    print(text, flush=True)
+
+
 # ----------------------------------------------------------------------------------- main
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -1197,9 +1277,6 @@ def main(argv=None):
         total = edges_per_step * args.steps
         line = {
             "metric": "edges_per_sec_fwd_bwd" if not args.stub else "stub_not_a_measurement",
-            "timed_region": ("graph index build + forward + loss + backward + gradient all-reduce + optimizer step "
-                             "(everything a training step does; SURVEY 8d counts the optimizer separately: "
-                             "stages.allreduce_adam carries its share)"),
             "value": total / dt,
             "unit": "edges/s",
             "n_gpus": world,
@@ -1225,20 +1302,18 @@ def main(argv=None):
                                 + ")" if world > 1 else "dp1 (single process, no collective)"),
                 **info,
             },
+            "timed_region": "graph index + forward + loss + backward + grad all-reduce + optimizer step",
             "edge_layers_per_sec": total * EC_MODEL["L_ec"] / dt,
             "final_loss": final_loss,
             "param_checksum": param_checksum,
             "roofline": roof,
-            "kernels": kernels,
             "cpu_baseline": cpu,
             "parity_check": parity,
             "library": library_id() if not args.stub else None,
         }
         if stages is not None:
             line["stages"] = stages
-        if extra is not None:
-            line["extra"] = extra
-        print(json.dumps(line), flush=True)
+        emit(line, kernels, extra)
     barrier(world)
     if world > 1:
         torch.distributed.destroy_process_group()

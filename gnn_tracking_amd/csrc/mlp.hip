@@ -15,6 +15,7 @@
 //
 // Weights are packed once per workgroup into LDS as ready-to-use A fragments.
 // Bound: fp32 matrix pipe (157 TF) for hidden width 40; see DESIGN.md.
+#include <atomic>
 #include "tile_mlp.h"
 
 #include "host_util.h"
@@ -851,15 +852,20 @@ int mlp_forward_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
     int grid = grid_for(a->n_rows, kFwdBlocksPerCu);
     // (the persistent grid of an instantiation = its resident workgroups, asked of the runtime once per instantiation:
     //  the static shapes hold 124-156 registers = three, not four, workgroups per CU - see mlp_bf16_fwd.hip)
-#define GNNTRK_FWD32_GRID(kfn_)                                                                 \
-    {                                                                                           \
-        static int occ_ = 0;                                                                    \
-        if (occ_ <= 0) {                                                                        \
-            int o_ = 0;                                                                         \
+#define GNNTRK_FWD32_GRID(kfn_)  /* (occupancy cached per DEVICE ordinal, atomically: launch threads race, devices differ) */ \
+    {                                                                                   \
+        static std::atomic<int> occ_dev_[16];                                           \
+        int dev_ = 0;                                                                   \
+        (void)hipGetDevice(&dev_);                                                      \
+        std::atomic<int>& slot_ = occ_dev_[dev_ & 15];                                  \
+        int occ_ = slot_.load(std::memory_order_relaxed);                               \
+        if (occ_ <= 0) {                                                                \
+            int o_ = 0;                                                                 \
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, kfn_, kBlock, 0) != hipSuccess || o_ < 1) \
-                o_ = kFwdBlocksPerCu;                                                           \
-            occ_ = o_ > 8 ? 8 : o_;                                                             \
-        }                                                                                       \
+                o_ = kFwdBlocksPerCu;                                                 \
+            occ_ = o_ > 8 ? 8 : o_;                                                     \
+            slot_.store(occ_, std::memory_order_relaxed);                               \
+        }                                                                               \
         grid = grid_for(a->n_rows, occ_);                                                       \
     }
     const int ksh = make_dimmap(a->mlp.hidden).ks, kso = make_dimmap(a->mlp.out_dim).ks;

@@ -1,6 +1,7 @@
 // Forward launchers of the bf16-storage fused MLP kernels (mlp_bf16_kernels.h).  Own translation
 // unit: the forward kernels are compiled with -amdgpu-sched-strategy=max-ilp (_build.py), which
 // suits their load-heavy tile loop (edge-weight head 1.58 -> 1.39 ms) but not the backward.
+#include <atomic>
 #include "mlp_bf16_kernels.h"
 
 namespace gnntrk {
@@ -8,14 +9,19 @@ namespace gnntrk {
 // The persistent grid of an instantiation = the workgroups of it that are RESIDENT at once (asked of the runtime once
 // per instantiation: registers and LDS decide), not a fixed five per CU: a larger grid runs in rounds whose last one
 // leaves CUs idle (round 5: the hot instantiations hold 164-230 registers = two, not five, workgroups per CU).
-#define GNNTRK_FWD16_GRID(kfn_)                                                         \
+#define GNNTRK_FWD16_GRID(kfn_)  /* (occupancy cached per DEVICE ordinal, atomically: launch threads race, devices differ) */ \
     {                                                                                   \
-        static int occ_ = 0;                                                            \
+        static std::atomic<int> occ_dev_[16];                                           \
+        int dev_ = 0;                                                                   \
+        (void)hipGetDevice(&dev_);                                                      \
+        std::atomic<int>& slot_ = occ_dev_[dev_ & 15];                                  \
+        int occ_ = slot_.load(std::memory_order_relaxed);                               \
         if (occ_ <= 0) {                                                                \
             int o_ = 0;                                                                 \
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, kfn_, kBlock, 0) != hipSuccess || o_ < 1) \
                 o_ = kFwd16BlocksPerCu;                                                 \
             occ_ = o_ > 8 ? 8 : o_;                                                     \
+            slot_.store(occ_, std::memory_order_relaxed);                               \
         }                                                                               \
         grid = grid16(a->n_rows, occ_, kWaves);                                         \
         if (grid > kFwdMaxBlocks) grid = kFwdMaxBlocks - kFwdMaxBlocks % 8;             \

@@ -150,6 +150,9 @@ def collate(graphs: Iterable[Data]) -> Data:
                               device=vals[0].device)
             a = 0
             for v, o in zip(vals, offs):
+                if v.shape[:-1] != vals[0].shape[:-1] or v.dtype != vals[0].dtype:   # (what torch.cat would refuse)
+                    raise RuntimeError(f"collate: '{k}' of the events disagrees in shape / dtype: {tuple(vals[0].shape)} "
+                                       f"{vals[0].dtype} against {tuple(v.shape)} {v.dtype}")
                 torch.add(v, o, out=cat[..., a:a + v.shape[-1]])
                 a += int(v.shape[-1])
             setattr(out, k, cat)

@@ -33,15 +33,6 @@ def _n_events(data) -> int:
     return int(ptr.numel()) - 1 if isinstance(ptr, Tensor) and ptr.numel() > 1 else 0
 
 
-def _ordered_by(data):
-    """Key column the events of ``data`` were renumbered by when they were loaded (``io.renumber_nodes``: one value
-    per event after ``collate``), or None."""
-    k = getattr(data, "node_order_key", None)
-    if isinstance(k, (list, tuple)):
-        return k[0] if k and all(v == k[0] for v in k) else None
-    return k
-
-
 class ECForGraphTCN(nn.Module, HyperparametersMixin):
     def __init__(self, *, node_indim: int, edge_indim: int, interaction_node_dim: int = 5,
                  interaction_edge_dim: int = 4, hidden_dim: int | float | None = None,
@@ -104,9 +95,8 @@ class ECForGraphTCN(nn.Module, HyperparametersMixin):
         y = getattr(data, "y", None)
         # node order (locality.py): the index is built in a renumbering that sorts every event's hits by
         # azimuth, x is gathered through it below and the node embedding handed back in the caller's order
-        col = locality.key_column(x)
-        if col is not None and _ordered_by(data) == col:
-            col = None   # (io.renumber_nodes / GraphDataset(renumber=True) ordered these events when they were read)
+        # (None as well when io.renumber_nodes / GraphDataset(renumber=True) ordered these events when they were read)
+        col = locality.order_column(data)
         batch = getattr(data, "batch", None)
         # (a batch collated by io.ResidentDataset comes with its index placed from the per-event ones)
         gi = ops.placed_graph_index(edge_index, x.shape[0])

@@ -111,8 +111,10 @@ def renumber_nodes(data: Data, col: int | None = None) -> Data:
     read back unchanged by utils/loading.py:17-113); its datasets are static, so a loader can pay for the geometric
     order ONCE per event (``GraphDataset(renumber=True)``) instead of the 1.4 ms per 64 M-edge step that
     ``ECForGraphTCN`` spends when a batch arrives in file order.  An event that carries
-    ``node_order_key`` is not renumbered again in the step.  Same order as the in-step renumbering: stable sort of the
-    key's order-preserving integer image."""
+    ``node_order_key`` is not renumbered again in the step (``locality.order_column``).  The order is the stable sort
+    of the key's order-preserving integer image; the in-step renumbering of a batch sorts by a QUANTISED image of the
+    same key (ties stable), so the two numberings agree in locality, not id for id - results are equal up to
+    summation order either way."""
     import copy
 
     from . import locality
@@ -282,9 +284,11 @@ class PrefetchLoader:
                             ev.record(side)
                         if self.build_index:
                             from . import ops
-                            # (events renumbered when they were read keep their order: no x, no renumbering in the build)
+                            from . import locality
+                            # (the same predicate as the step's: events renumbered by the policy's column when they
+                            #  were read keep their order - no x, no renumbering in the build)
                             ops.prefetch_graph_index(dev_batch.edge_index, dev_batch.num_nodes, side,
-                                                     x=None if "node_order_key" in dev_batch else dev_batch.x,
+                                                     x=None if locality.order_column(dev_batch) is None else dev_batch.x,
                                                      batch=getattr(dev_batch, "batch", None))
                         q.put((dev_batch, ev, batch))  # keep the pinned source alive until consumed
                     else:

@@ -70,3 +70,21 @@ def key_column(x) -> int | None:
         return None
     col = AUTO_COLUMN if _MODE == "auto" else int(_MODE)
     return col if 0 <= col < x.shape[1] else None
+
+
+def loaded_order(data):
+    """Key column the events of ``data`` were renumbered by when they were loaded (``io.renumber_nodes``: one value
+    per event after ``collate``), or None (not renumbered, or the events disagree)."""
+    k = getattr(data, "node_order_key", None)
+    if isinstance(k, (list, tuple)):
+        return k[0] if k and all(v == k[0] for v in k) else None
+    return k
+
+
+def order_column(data) -> int | None:
+    """THE predicate for "this batch is renumbered inside the step": the policy's column for ``data.x``, unless every
+    event of the batch was already renumbered by that very column when it was read.  ``ECForGraphTCN`` and whoever
+    builds the index ahead of it (``io.PrefetchLoader``, ``bench.py``) ask this one function, so a prefetched index
+    is always the one the step looks up."""
+    col = key_column(data.x)
+    return None if col is None or loaded_order(data) == col else col

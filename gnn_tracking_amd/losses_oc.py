@@ -208,42 +208,65 @@ class CondensationLossRG(_CondensationLoss):
             q_min: minimal charge (object condensation paper)
             pt_thld: pt threshold of the particles of interest
             max_eta: eta threshold of the particles of interest
-            max_num_neighbors: neighbour cap of the reference's radius graph.  Kept for
-                interface parity; the fused kernel sums over ALL hits within the unit radius
-                (the reference's result whenever the cap is not reached - with the cap reached
-                torch_cluster keeps an implementation-defined subset)
+            max_num_neighbors: neighbour cap of the reference's radius graph (oc.py:115-117).  Applied when
+                it can bind (``neighbor_cap``, below): the fused kernel sums over ALL hits within the unit
+                radius, which is the reference's result whenever no hit has more neighbours than the cap
             sample_pids: fraction of the hits of interest that take part (random, per call)
         """
         super().__init__()
         self.save_hyperparameters()
 
     _cap_notice_given = False
-    #: "off" (default): ``max_num_neighbors`` is not applied - every hit inside the unit radius of a
-    #: condensation point contributes (the reference's result whenever no hit has more neighbours than
-    #: the cap).  "nearest": the cap is applied nearest first - a condensation point only repels a hit
-    #: if it is among that hit's ``max_num_neighbors`` nearest hits (one extra kNN search per call;
-    #: what the CPU oracle's radius graph does; torch_cluster itself keeps an implementation-defined
-    #: subset).  Class attribute so that YAML configurations stay those of the reference.
-    neighbor_cap = "off"
+    #: "auto" (default): a count pass over the hits (``ops.max_radius_count``) decides - if no hit has more than
+    #: ``max_num_neighbors`` other hits inside the unit radius the cap cannot bind and every hit inside the radius of
+    #: a condensation point contributes (= the reference); if one has, the cap is applied nearest first (and a notice
+    #: is logged once).  The count is a hits x hits pass (4.6 ms at 200 k hits - the fused loss itself only ever looks
+    #: at (hit, condensation point) pairs, 0.6 ms), so it runs on the first call and then on every
+    #: ``cap_check_every``-th one; calls in between reuse the last decision (an embedding space drifts over many
+    #: steps; ``cap_check_every = 1`` decides on every call).  "nearest": always applied nearest first - a
+    #: condensation point only repels a hit if it is among that hit's ``max_num_neighbors`` nearest hits (one extra
+    #: kNN search per call; what the CPU oracle's radius graph does; torch_cluster itself keeps an
+    #: implementation-defined subset: the first ones found, differently on CPU and GPU).  "off": never applied.
+    #: Class attributes so that YAML configurations stay those of the reference.
+    neighbor_cap = "auto"
+    cap_check_every = 64
 
     def _neighbor_cap(self, x):
-        if self.neighbor_cap == "off":
+        mode = self.neighbor_cap
+        if mode == "off":
             return None
-        if self.neighbor_cap != "nearest":
-            raise ValueError(f"CondensationLossRG.neighbor_cap must be 'off' or 'nearest', got {self.neighbor_cap!r}")
-        return ops.knn_kth_neighbor(x, int(self.hparams.max_num_neighbors), 1.0)
+        if mode not in ("auto", "nearest"):
+            raise ValueError(f"CondensationLossRG.neighbor_cap must be 'auto', 'nearest' or 'off', got {mode!r}")
+        k = int(self.hparams.max_num_neighbors)
+        if mode == "auto":
+            if x.shape[0] - 1 <= k:
+                return None
+            calls = self._cap_calls = getattr(self, "_cap_calls", -1) + 1
+            known = getattr(self, "_cap_binds", None)
+            if x.is_cuda and torch.cuda.is_current_stream_capturing():
+                # the decision needs a device read: a captured step replays the one its eager warm-up made
+                if known is None:
+                    raise RuntimeError("CondensationLossRG(neighbor_cap='auto') inside a stream capture needs one eager "
+                                       "call first (or neighbor_cap = 'off' / 'nearest')")
+                binds = known
+            elif known is None or calls % max(int(self.cap_check_every), 1) == 0:
+                # (radius widened by 1e-6: the count's fp64 `d2 <= r^2` then covers the fp32 `dist < 1` of the graph)
+                binds = self._cap_binds = bool(int(ops.max_radius_count(x, 1.0 + 1e-6)) > k)
+            else:
+                binds = known
+            if not binds:
+                return None
+            if not CondensationLossRG._cap_notice_given:
+                CondensationLossRG._cap_notice_given = True
+                import logging
+                logging.getLogger("gnn_tracking_amd").warning(
+                    "CondensationLossRG: a hit has more than max_num_neighbors=%s hits inside the unit radius - the cap "
+                    "is applied nearest first (torch_cluster.radius_graph keeps an implementation-defined subset there, "
+                    "differently on CPU and GPU).", k)
+        return ops.knn_kth_neighbor(x, k, 1.0)
 
     def forward(self, *, beta: T, x: T, particle_id: T, reconstructable: T, pt: T,
                 ec_hit_mask: T | None = None, eta: T, **kwargs) -> MultiLossFctReturn:
-        if self.neighbor_cap == "off" and not CondensationLossRG._cap_notice_given:
-            CondensationLossRG._cap_notice_given = True
-            import logging
-            logging.getLogger("gnn_tracking_amd").warning(
-                "CondensationLossRG: max_num_neighbors=%s is not applied - every hit inside the unit radius of a "
-                "condensation point contributes.  This equals the reference whenever no hit has more than that many "
-                "neighbours inside the radius; beyond that torch_cluster.radius_graph keeps an implementation-defined "
-                "subset (the first ones found, differently on CPU and GPU).  CondensationLossRG.neighbor_cap = "
-                "'nearest' applies it nearest first.", self.hparams.max_num_neighbors)
         # NB: like the reference (oc.py:207-213) eta is NOT sliced by ec_hit_mask here
         return self._forward(beta=beta, x=x, particle_id=particle_id,
                              reconstructable=reconstructable, pt=pt, ec_hit_mask=ec_hit_mask,

@@ -337,9 +337,20 @@ def place_graph_indices(parts: Sequence[GraphIndex], batch) -> GraphIndex:
     full = [i for i, p in enumerate(parts) if p.n_edges > 0]   # (an event without edges carries nothing)
     has_lab = bool(full) and lab[full[0]] is not None
     has_rows = bool(full) and rows[full[0]] is not None
-    if any(ordered) != all(ordered) or any((lab[i] is not None) != has_lab or (rows[i] is not None) != has_rows for i in full):
-        raise ValueError("place_graph_indices: the parts must agree in node order and carried inputs")
-    if ordered[0]:
+    if any((lab[i] is not None) != has_lab or (rows[i] is not None) != has_rows for i in full):
+        raise ValueError("place_graph_indices: the parts must agree in their carried inputs")
+    ptr = getattr(batch, "ptr", None)
+    if isinstance(ptr, Tensor) and ptr.numel() == len(parts) + 1 and not ptr.is_cuda:
+        sizes = (ptr[1:] - ptr[:-1]).tolist()
+        if sizes != [p.n_nodes for p in parts]:
+            raise ValueError(f"place_graph_indices: the events of the batch hold {sizes} nodes, the parts {[p.n_nodes for p in parts]}")
+    # an event the loader left unordered (fewer than two hits, no key column) among ordered ones is its own order
+    ident = {}
+    if any(ordered) and not all(ordered):
+        for i, p in enumerate(parts):
+            if not ordered[i]:
+                ident[i] = torch.arange(p.n_nodes, dtype=torch.int32, device=dev)
+    if any(ordered):
         gi.node_perm, gi.node_rank = mk(N), mk(N)
     lab_b = torch.empty(E, dtype=torch.uint8, device=dev) if has_lab else None
     rows_b = None
@@ -350,12 +361,13 @@ def place_graph_indices(parts: Sequence[GraphIndex], batch) -> GraphIndex:
                          _p(gi.spos_inv))
     no = eo = 0
     st = _stream(ei)
-    for p, l, r in zip(parts, lab, rows):
+    for i, (p, l, r) in enumerate(zip(parts, lab, rows)):
         dp = _capi.GraphIndex(p.n_nodes, p.n_edges, _p(p.perm), _p(p.tgt), _p(p.src), _p(p.rowptr_t), _p(p.rowptr_s),
                               _p(p.spos), _p(p.spos_inv))
+        pperm, prank = (ident[i], ident[i]) if i in ident else (p.node_perm, p.node_rank)
         _capi.check(lib.gnntrk_graph_index_place(
             C.byref(dp), no, eo, C.byref(d), _p(None if l is None else l[3]), _p(None if l is None else lab_b),
-            _p(None if r is None else r[3]), _p(None if r is None else rows_b), _p(p.node_perm), _p(gi.node_perm), _p(p.node_rank),
+            _p(None if r is None else r[3]), _p(None if r is None else rows_b), _p(pperm), _p(gi.node_perm), _p(prank),
             _p(gi.node_rank), st), lib)
         no += p.n_nodes
         eo += p.n_edges
@@ -364,8 +376,8 @@ def place_graph_indices(parts: Sequence[GraphIndex], batch) -> GraphIndex:
         gi._label_csr = (id(y), y._version, weakref.ref(y), lab_b)
     if rows_b is not None and isinstance(ea, Tensor):
         gi._rows_csr = (id(ea), ea._version, weakref.ref(ea), rows_b)
-    if ordered[0]:
-        col = parts[0].order_sig[2]
+    if any(ordered):
+        col = parts[ordered.index(True)].order_sig[2]
         bt = getattr(batch, "batch", None)
         gi.order_sig, gi._order_ref = _order_sig((batch.x, col, bt if isinstance(bt, Tensor) else None)), weakref.ref(batch.x)
     gi._built_from = (weakref.ref(ei), ei._version)
@@ -430,8 +442,14 @@ def _join(gi: GraphIndex) -> GraphIndex:
     if gi.ready is not None:
         cur = torch.cuda.current_stream(gi.perm.device)
         cur.wait_event(gi.ready)
-        for t in (gi.perm, gi.tgt, gi.src, gi.rowptr_t, gi.rowptr_s, gi.spos, gi.spos_inv):
-            t.record_stream(cur)
+        # every array the build allocated in the side stream's pool, the node order and the carried
+        # label / edge-feature buffers included: without the hand-over the allocator may give their
+        # blocks to the loader's next copy while queued consumer kernels still read them
+        carried = [getattr(gi, slot)[3] for slot in ("_label_csr", "_rows_csr") if getattr(gi, slot, None) is not None]
+        for t in (gi.perm, gi.tgt, gi.src, gi.rowptr_t, gi.rowptr_s, gi.spos, gi.spos_inv,
+                  getattr(gi, "node_perm", None), getattr(gi, "node_rank", None), *carried):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
         gi.ready = None
     return gi
 
@@ -1222,6 +1240,25 @@ def knn_kth_neighbor(x: Tensor, k: int, max_radius: Optional[float] = None) -> T
     _knn_search(lib, x, int(k), r, None, nbr, cnt, _stream(x))
     last = nbr.view(n, k)[:, k - 1]
     return torch.where(cnt >= k, last, torch.full_like(last, -1)).contiguous()
+
+
+def max_radius_count(x: Tensor, radius: float) -> Tensor:
+    """int32 scalar tensor (on the device): the largest number of OTHER rows of ``x`` within ``radius`` of a row - one
+    count pass of the pruned radius graph (``gnntrk_radius_count_ws``: fp64 distances, ``d2 <= r^2``).  What decides
+    whether the neighbour cap of ``CondensationLossRG``'s radius graph can bind at all."""
+    _capi.require_device(x)
+    lib = _capi.load()
+    x = _as_rows(x.detach().to(torch.float32))
+    n, dim = int(x.shape[0]), int(x.shape[1])
+    if n < 2:
+        return torch.zeros((), dtype=torch.int32, device=x.device)
+    cnt = torch.empty(n, dtype=torch.int32, device=x.device)
+    off = torch.empty(n + 1, dtype=torch.int64, device=x.device)
+    nb = int(lib.gnntrk_radius_points_workspace_bytes(n, dim))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+    _capi.check(lib.gnntrk_radius_count_ws(_p(x), n, dim, _row_stride(x), float(radius), _p(cnt), _p(off),
+                                           _p(ws) if ws is not None else None, nb, 0, _stream(x)), lib)
+    return cnt.max() - 1   # (every row is its own neighbour in that graph)
 
 
 def knn_scan(x: Tensor, ks: Sequence[int], max_radius: Optional[float] = None) -> dict:

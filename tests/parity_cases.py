@@ -1087,9 +1087,11 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0", "h64", "h128")):
             ref = O.ec_for_graph_tcn_bf16(x.cpu(), ei.cpu(), ea.cpu(), p, L_ec=kw["L_ec"],
                                           alpha=kw.get("alpha", 0.5))
             # same rounding points: differences come from rare 1-ulp flips propagating
-            assert_close(out["W"], ref["W"], 4 * TOL16, name + " W vs bf16 oracle")
-            assert_close(out["node_embedding"].float(), ref["node_embedding"], 4 * TOL16, name + " node")
-            assert_close(out["edge_embedding"].float(), ref["edge_embedding"], 4 * TOL16, name + " edge")
+            # (measured: W 6e-8 .. 7e-7 on the fused kernels, 1.3e-4 on wide_h128's library GEMMs; embeddings equal)
+            errW = (out["W"].detach().cpu() - ref["W"]).abs().max().item()
+            assert errW <= BF16_ORACLE_W, f"{name}: |W - W_oracle16| {errW:.2e}"
+            assert_close(out["node_embedding"].float(), ref["node_embedding"], TOL16, name + " node")
+            assert_close(out["edge_embedding"].float(), ref["edge_embedding"], TOL16, name + " edge")
         # distance to the reference-pinned fp32 results
         assert_close(out["W"], z[f"{name}/W"], 0.03, name + " W vs fp32 golden")
         assert_close(loss, z[f"{name}/loss"], 0.01, name + " loss vs fp32 golden")
@@ -1100,11 +1102,14 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0", "h64", "h128")):
                 continue
             assert v.grad.dtype == torch.float32
             err = (v.grad.detach().cpu().double() - gref).norm() / max(gref.norm().item(), 1e-6)
-            assert err < 0.1, f"{name} grad {k}: relative L2 error {err:.3f} vs fp32 golden"
+            # (253 edges: a handful of bf16 roundings decide a gradient - measured 1.9 % on the headline shape,
+            #  up to 6.0 % on the skip2 / skip-top / 128-wide variants of this graph; the full-size event: 1.2 %)
+            bar = BF16_GRAD_REL_L2 if name in ("skip1_L3_h40", "skip1_L2_h2", "alpha0") else 0.07
+            assert err < bar, f"{name} grad {k}: relative L2 error {err:.3f} vs fp32 golden (bar {bar})"
         # THE PIN AGAINST THE REFERENCE IN ITS OWN MIXED PRECISION (golden G2b): W within one
         # bf16 ulp of the reference's bf16-rounded W (2^-8 on [0.5, 1)), embeddings within
         # BF16_PIN_EMB of the largest reference entry, loss 5e-3 (the reference rounds W itself to bf16), parameter gradients 6 %
-        # relative L2 (measured: W <= 2.9e-3, embeddings <= 3.1e-3, gradients <= 2.9 %; the reference's own scatter-add accumulates in bf16; ours in fp32).
+        # relative L2 bar 4 % (measured: W <= 2.9e-3, embeddings <= 3.1e-3, gradients <= 2.9 %; the reference's own scatter-add accumulates in bf16; ours in fp32).
         rep = report.setdefault(name, {})
         rep["W"] = (out["W"].detach().cpu() - tt(za[f"{name}/W"])).abs().max().item()
         for k in ("node_embedding", "edge_embedding"):
@@ -1120,7 +1125,7 @@ def case_ec_bf16(device, names=("skip1_L3_h40", "alpha0", "h64", "h128")):
         rep["grad_rel_l2"] = worst
         assert rep["W"] <= BF16_PIN_W, f"{name}: |W - W_autocast| {rep['W']:.2e}"
         assert rep["node_embedding"] <= BF16_PIN_EMB and rep["edge_embedding"] <= BF16_PIN_EMB, (name, rep)
-        assert rep["loss"] <= 5e-3 and rep["grad_rel_l2"] <= 0.06, (name, rep)
+        assert rep["loss"] <= 5e-3 and rep["grad_rel_l2"] <= 0.04, (name, rep)
     return report
 
 
@@ -1223,6 +1228,13 @@ def case_grad_sink(device, name="skip1_L3_h40"):
 
 
 BF16_PIN_W = 2.0 ** -8       # one ulp of the reference's bf16 W on [0.5, 1)
+#: against OUR restatement of the rounding contract (oracle.ec_for_graph_tcn_bf16: same rounding points, so only rare
+#: one-ulp flips of a hidden activation propagate): measured 6e-8 on the golden graph, 6.4e-6 at 20 k edges, 1.1e-4
+#: at 2 M edges - the bar is 5e-4, not the bf16 ulp of W (3.9e-3) that rounds 2-5 accepted
+BF16_ORACLE_W = 5e-4
+#: parameter gradients of a bf16-storage run against the fp32 oracle, relative L2 of the worst parameter: 1.2 % measured
+#: on the headline shape from 20 k edges on (the bf16 rounding of activations and activation gradients; fp32 accumulation)
+BF16_GRAD_REL_L2 = 0.03
 BF16_PIN_EMB = 2.0 ** -6     # four bf16 ulps relative to the largest entry
 
 
@@ -2430,23 +2442,24 @@ def case_cfg12_event(device):
             assert_close(v, rafter[k], 1e-6, f"{tag} after Adam {k}")
 
 
-def case_cfg3_event(device, n_hits=150_000, n_edges=2_000_000, modes=("f32", "bf16")):
+def case_cfg3_event(device, n_hits=150_000, n_edges=2_000_000, modes=("f32", "bf16"), seed=100, pt_thld=0.0):
     """ONE event of BASELINE.json configs[2] at its full size (seed 100: event 0 of the bench's batch; 150 000 hits,
     2 000 000 edges) against the CPU oracle - the size the headline number is measured at, compared value for
     value, not through properties: fp32 against ``oracle.ec_training_step`` (W / embeddings / loss 1e-5, every
     parameter gradient 1e-4, parameters after Adam(lr=1e-4, weight_decay=1e-4) 1e-6); bf16 storage against the
-    oracle's restatement of the rounding contract ``ec_for_graph_tcn_bf16`` (W within one bf16 ulp on [0.5, 1) =
-    2^-8, loss 5e-3) and its gradients against the fp32 oracle's (relative L2 6 %: the bound of ``case_ec_bf16``).
-    Runs with the package's default node order (renumbered from 65 536 hits on)."""
+    oracle's restatement of the rounding contract ``ec_for_graph_tcn_bf16`` (``BF16_ORACLE_W`` = 5e-4: 1.1e-4
+    measured; loss 1e-4) and its gradients against the fp32 oracle's (relative L2 3 %: 1.2 % measured).
+    Runs with the package's default node order (renumbered from 65 536 hits on).  ``seed`` / ``pt_thld``: another
+    event of the batch, and the loss with ``falsify_low_pt_edges`` on (losses/ec.py:71-92)."""
     from gnn_tracking_amd import synthetic
 
-    ev = synthetic.make_event(100, n_hits, n_edges, "cpu")
+    ev = synthetic.make_event(seed, n_hits, n_edges, "cpu")
     d = ev.to(device)
     torch.manual_seed(0)
     model0 = G.ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=3, hidden_dim=40)
     params = {k: v.detach().clone() for k, v in model0.state_dict().items()}
     ref, rloss, rgrads, rafter = O.ec_training_step(ev.x, ev.edge_index, ev.edge_attr, ev.y, params,
-                                                    model_kwargs=dict(L_ec=3))
+                                                    model_kwargs=dict(L_ec=3), pt=ev.pt, pt_thld=pt_thld)
     report = {}
     for mode in modes:
         model = G.ECForGraphTCN(node_indim=14, edge_indim=4, L_ec=3, hidden_dim=40)
@@ -2455,7 +2468,7 @@ def case_cfg3_event(device, n_hits=150_000, n_edges=2_000_000, modes=("f32", "bf
         ops.clear_graph_index_cache()
         with (G.bf16_storage() if mode == "bf16" else contextlib.nullcontext()):
             out = model(d)
-            loss = G.EdgeWeightBCELoss()(w=out["W"], y=d.y, pt=d.pt, edge_index=d.edge_index)
+            loss = G.EdgeWeightBCELoss(pt_thld=pt_thld)(w=out["W"], y=d.y, pt=d.pt, edge_index=d.edge_index)
             loss.backward()
         W = torch.as_tensor(out["W"]).detach().float().cpu()
         tag = f"cfg3 event {mode}"
@@ -2478,16 +2491,17 @@ def case_cfg3_event(device, n_hits=150_000, n_edges=2_000_000, modes=("f32", "bf
             with torch.no_grad():
                 ref16 = O.ec_for_graph_tcn_bf16(ev.x, ev.edge_index, ev.edge_attr, params, L_ec=3)
             errW = (W - ref16["W"]).abs().max().item()
-            assert errW <= BF16_PIN_W, f"{tag}: |W - W_oracle16| {errW:.2e}"
-            assert abs(float(loss) - float(O.edge_weight_bce_loss(ref16["W"], ev.y.float()))) <= 5e-3, tag + " loss"
-            assert_close(W, ref["W"], 0.03, tag + " W vs fp32 oracle")
+            assert errW <= BF16_ORACLE_W, f"{tag}: |W - W_oracle16| {errW:.2e}"
+            loss16 = O.edge_weight_bce_loss(ref16["W"], ev.y.float(), ev.edge_index, ev.pt, pt_thld)
+            assert abs(float(loss) - float(loss16)) <= 1e-4, tag + " loss"
+            assert_close(W, ref["W"], 2e-3, tag + " W vs fp32 oracle")   # (3.9e-4 measured)
             worst = 0.0
             for k, v in model.named_parameters():
                 g = rgrads[k].double()
                 if g.norm().item() < 1e-6:
                     continue
                 worst = max(worst, ((v.grad.detach().cpu().double() - g).norm() / g.norm()).item())
-            assert worst <= 0.06, f"{tag}: parameter gradients {worst:.3f} relative L2 from the fp32 oracle"
+            assert worst <= BF16_GRAD_REL_L2, f"{tag}: parameter gradients {worst:.3f} relative L2 from the fp32 oracle"
             report[mode] = {"W": errW, "grad_rel_l2": worst}
     return report
 
@@ -3157,5 +3171,25 @@ def case_rg_neighbor_cap(device, caps=(4, 16, 256), n_hits=None):
         off = CondensationLossRG(lw_repulsive=2.0, max_num_neighbors=4)(beta=beta32.clone().to(device),
                                                                         x=x32.clone().to(device), **kw)
         assert small < 0.9 * float(off.loss_dct["repulsive"]), "the cap should have removed repulsive pairs in this case"
+        # "auto" (the default): one count pass decides - nearest first where a hit has more neighbours than the cap,
+        # the plain sum (= the reference) where none has
+        CondensationLossRG.neighbor_cap = "auto"
+        for cap, want in ((caps[0], small if len(caps) > 1 and caps[0] != 256 else None), (100000, float(off.loss_dct["repulsive"]))):
+            m = CondensationLossRG(lw_repulsive=2.0, max_num_neighbors=cap)
+            ret = m(beta=beta32.clone().to(device), x=x32.clone().to(device), **kw)
+            if cap == 100000:
+                assert m._cap_binds is False if x32.shape[0] - 1 > cap else getattr(m, "_cap_binds", None) is None
+                assert_close(ret.loss_dct["repulsive"], want, 1e-6, "auto == off where the cap cannot bind")
+            else:
+                assert m._cap_binds is True, "auto must notice that the cap binds"
+                CondensationLossRG.neighbor_cap = "nearest"
+                ref = CondensationLossRG(lw_repulsive=2.0, max_num_neighbors=cap)(
+                    beta=beta32.clone().to(device), x=x32.clone().to(device), **kw)
+                CondensationLossRG.neighbor_cap = "auto"
+                assert float(ret.loss_dct["repulsive"]) == float(ref.loss_dct["repulsive"]), "auto == nearest where it binds"
+        m = CondensationLossRG(lw_repulsive=2.0, max_num_neighbors=min(256, x32.shape[0] - 2))
+        ret = m(beta=beta32.clone().to(device), x=x32.clone().to(device), **kw)
+        assert m._cap_binds is False
+        assert_close(ret.loss_dct["repulsive"], float(off.loss_dct["repulsive"]), 1e-6, "auto == off at the default cap on this cloud")
     finally:
         CondensationLossRG.neighbor_cap = old

@@ -362,5 +362,38 @@ def test_cfg3_full_size_event_against_oracle(dev):
     print("cfg3 event:", rep)
 
 
+def test_cfg3_full_size_event_second_seed_low_pt_falsified(dev):
+    """Another event of the bench's batch (seed 117) with ``EdgeWeightBCELoss(pt_thld=0.9)`` - the labels of edges
+    whose source hit is below the pt threshold falsified inside the loss kernel (losses/ec.py:71-92) - in the
+    headline's precision, value for value against the oracle."""
+    rep = P.case_cfg3_event(dev, modes=("bf16",), seed=117, pt_thld=0.9)
+    print("cfg3 event, seed 117, pt_thld 0.9:", rep)
+
+
+def test_bench_default_line_is_one_small_json_line(dev):
+    """``python bench.py`` (here: two events, no side runs) prints exactly ONE stdout line, well below the size the
+    driver's parser lost in round 5, carrying ``roofline`` (with the live access floors), ``cpu_baseline`` and
+    ``parity_check``; the full record goes to ``bench_extra.json`` and stderr."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--events", "2", "--steps", "3", "--warmup", "2",
+                        "--cpu-iters", "1", "--no-extra"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1 and len(out[0].encode()) < 8192, (len(out), [len(o) for o in out])
+    d = json.loads(out[0])
+    assert d["metric"] == "edges_per_sec_fwd_bwd" and d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "bf16"
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1 and roof["peak"] == 8000.0 and "IoRelational" in roof["kernel"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["parity_check"]["ok"] is True and d["parity_check"]["max_abs_W"] <= d["parity_check"]["bound"] <= 5e-4
+    full = json.loads((root / "bench_extra.json").read_text())
+    assert full["ms_per_step"] == __import__("pytest").approx(d["ms_per_step"], rel=1e-4) and len(full["kernels"]) >= 8
+
+
 def test_reference_configs_from_class_path(dev):
     P.case_class_path_configs(dev)

@@ -56,9 +56,10 @@ from gnn_tracking_amd.precision import bf16_storage  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = fp32 vector peak
 PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
-TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r05_hbm_traffic_bf16.json"}
-TRAFFIC_FALLBACK = {"bf16": "r04c_hbm_traffic_bf16.json"}
-PIPE_PROFILES = {"cfg5": "r05_pipe_util_cfg5.json", "dbscan": "r05_pipe_util_dbscan.json"}
+TRAFFIC_PROFILES = {"f32": "r01_hbm_traffic_v5.json", "bf16": "r06_hbm_traffic_bf16.json"}
+TRAFFIC_FALLBACK = {"bf16": "r05_hbm_traffic_bf16.json"}
+PIPE_PROFILES = {"cfg5": "r06_pipe_util_cfg5.json", "dbscan": "r06_pipe_util_dbscan.json"}
+PIPE_FALLBACK = {"cfg5": "r05_pipe_util_cfg5.json", "dbscan": "r05_pipe_util_dbscan.json"}
 
 TRAFFIC_NOTES: dict = {}   # kernel -> which committed profile its traffic figure came from, and whether it is stale
 
@@ -295,7 +296,7 @@ def access_floor(wl, dev, iters: int = 6) -> dict:
             for i in range(iters + 1):
                 s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s0.record()
-                out = launch()
+                out = launch()   # (the name is rebound for the head's launch below)
                 s1.record()
                 torch.cuda.synchronize()
                 del out
@@ -307,7 +308,32 @@ def access_floor(wl, dev, iters: int = 6) -> dict:
 
     real, skel = timed(0), timed(4096)
     alg = 92.0 * E
-    return {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, false, 2, IoRelational<3> >",
+    # the edge-weight head's backward the same way (h[src] | h[tgt] | four edge embeddings, fp32 upstream gradient)
+    head = None
+    try:
+        es = [rows(E, 4) for _ in range(4)]
+        mh = G.MLP(26, 1, 40, L=3).to(dev)
+        Wh = [l.weight.detach().contiguous() for l in mh.linears()]
+        bh = [l.bias.detach().contiguous() for l in mh.linears()]
+        mlph = ops._fill_mlp(Wh, bh)
+        gw = torch.randn(E, 1, device=dev, generator=g)
+
+        def launch_head():
+            return B.mlp_backward_raw([h, h, *es], [gi.src, gi.tgt, None, None, None, None], [False] * 6, Wh, bh, n_rows=E,
+                                      epilogue=_capi.EPI_SIGMOID, ca=0.001, cb=0.998, gout=[(gw, None)],
+                                      need_seg=[True] * 6, want_dw=True, mlp=mlph,
+                                      gidx=[gi.spos_inv, None, None, None, None, None])
+
+        launch_rel, launch = launch, launch_head
+        hreal, hskel = timed(0), timed(4096)
+        launch = launch_rel
+        halg = (2 * 16 + 4 * 8 + 4 + 8 + 2 * 16 + 4 * 8 + 4) * E   # rows read + ids + upstream + gradient rows + permutation ids
+        head = {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, true, 2, IoHead>", "skeleton_ms": hskel,
+                "kernel_ms_isolated": hreal, "frac": halg / (hskel * 1e-3) / 1e9 / (PEAK_HBM_TBPS * 1e3),
+                "share_of_kernel": hskel / hreal}
+    except Exception as e:   # (the relational floor survives a failing head launch)
+        head = {"error": f"{type(e).__name__}: {e}"}
+    return {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, false, 2, IoRelational<3> >", "head": head,
             "what": "loads + stores of the relational backward (three upstream terms) without its arithmetic, same "
                     "occupancy and prefetch distance, this run's batch; launched alone (HIP events around launch + "
                     "partial reduction), median of %d" % iters,
@@ -342,7 +368,11 @@ def measured_pipe(which: str, kernel_prefix: str):
     committed SQ-counter pass (tools/make_pipe_json.py): what the pruned searches / spatial loss
     passes are priced with - they visit a data-dependent few per cent of the pairs, so a flop count
     divided by their time is not a roofline."""
-    path = os.path.join(ROOT, "profiles", PIPE_PROFILES[which])
+    name = PIPE_PROFILES[which]
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        name = PIPE_FALLBACK[which]
+        path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -351,10 +381,10 @@ def measured_pipe(which: str, kernel_prefix: str):
     for name, rec in ks.items():
         if name.startswith(kernel_prefix) and "valu_busy" in rec:
             return {**_profile_note(doc),   # (NOT measured in this run: a constant read from profiles/)
-                    "profile": PIPE_PROFILES[which],
+                    "profile": name,
                     "bound": "valu", "achieved": rec["valu_busy"], "peak": 1.0,
                     "unit": "share of the chip's vector-issue cycles (SQ_INSTS_VALU x 4 / (1024 SIMDs x cycles); "
-                            f"rocprofv3 --pmc, profiles/{PIPE_PROFILES[which]})",
+                            f"rocprofv3 --pmc, profiles/{name})",
                     "frac": rec["valu_busy"], "kernel": name, "kernel_us_under_pmc": rec["avg_us_under_pmc"],
                     "issue_share_of_wave_cycles": rec.get("issue_share"), "wait_share": rec.get("wait_share"),
                     "stall_share": rec.get("stall_share")}

@@ -51,12 +51,16 @@ class GSeg(C.Structure):
                 ("accumulate", C.c_int32)]
 
 
+class GFold(C.Structure):
+    _fields_ = [("ids", C.c_void_p), ("n_nodes", C.c_int64), ("seg", C.c_int32), ("_pad", C.c_int32)]
+
+
 class MlpBwdArgs(C.Structure):
     _fields_ = [("mlp", Mlp), ("n_seg", C.c_int32), ("epilogue", C.c_int32),
                 ("seg", Seg * MAX_SEGS), ("n_rows", C.c_int64), ("ca", C.c_float),
                 ("cb", C.c_float), ("n_gout", C.c_int32), ("accumulate_params", C.c_int32),
                 ("gout", GTerm * 3), ("gseg", GSeg * MAX_SEGS), ("gW", C.c_void_p * 3),
-                ("gb", C.c_void_p * 3), ("debug_flags", C.c_int32), ("_pad", C.c_int32)]
+                ("gb", C.c_void_p * 3), ("debug_flags", C.c_int32), ("_pad", C.c_int32), ("fold", GFold)]
 
 
 class GraphIndex(C.Structure):
@@ -133,6 +137,8 @@ _SIGNATURES = {
     "gnntrk_mlp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
     "gnntrk_mlp_backward_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp)]),
     "gnntrk_mlp_backward_bf16_max_terms": (C.c_int, [C.POINTER(MlpBwdArgs)]),
+    "gnntrk_mlp_backward_bf16_can_fold": (C.c_int, [C.POINTER(MlpBwdArgs)]),
+    "gnntrk_fold_finish_bf16": (C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int64, _P, C.c_int32, _P]),
     "gnntrk_mlp_backward_bf16": (C.c_int, [C.POINTER(MlpBwdArgs), _P, C.c_size_t, _P]),
     "gnntrk_mlp_forward_bf16_kernel_name": (C.c_int, [C.POINTER(MlpFwdArgs), C.c_char_p, C.c_size_t]),
     "gnntrk_mlp_backward_bf16_kernel_name": (C.c_int, [C.POINTER(MlpBwdArgs), C.c_char_p, C.c_size_t]),
@@ -212,7 +218,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 500   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
+ABI_VERSION = 600   # include/gnntrk.h: GNNTRK_VERSION the ctypes table below was written for
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

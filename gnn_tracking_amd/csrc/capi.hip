@@ -9,7 +9,7 @@
 static_assert(sizeof(gnntrk_seg) == 32, "gnntrk_seg layout");
 static_assert(sizeof(gnntrk_mlp) == 64, "gnntrk_mlp layout");
 static_assert(sizeof(gnntrk_mlp_fwd_args) == 448, "gnntrk_mlp_fwd_args layout");
-static_assert(sizeof(gnntrk_mlp_bwd_args) == 784, "gnntrk_mlp_bwd_args layout");
+static_assert(sizeof(gnntrk_mlp_bwd_args) == 808, "gnntrk_mlp_bwd_args layout");
 static_assert(sizeof(gnntrk_graph_index) == 72, "gnntrk_graph_index layout");
 static_assert(sizeof(gnntrk_graph_index_carry) == 48, "gnntrk_graph_index_carry layout");
 static_assert(sizeof(gnntrk_resfcnn) == 8 * (5 + 2 * GNNTRK_RESFCNN_MAX_HIDDEN) + 32, "gnntrk_resfcnn layout");
@@ -178,6 +178,12 @@ size_t gnntrk_mlp_backward_bf16_workspace_bytes(const gnntrk_mlp *mlp) {
     return mlp_backward_bf16_ws_bytes(mlp);
 }
 int gnntrk_mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *args) { return mlp_backward_bf16_max_terms(args); }
+int gnntrk_mlp_backward_bf16_can_fold(const gnntrk_mlp_bwd_args *args) { return mlp_backward_bf16_can_fold(args); }
+int gnntrk_fold_finish_bf16(uint16_t *out, int32_t out_stride, int64_t n_nodes, const int32_t *rowptr,
+                            int64_t n_units, const uint16_t *x, int32_t x_stride, void *stream) {
+    return fold_finish_bf16_launch(out, out_stride, n_nodes, rowptr, out + n_nodes * out_stride, n_units, x, x_stride,
+                                   (hipStream_t)stream);
+}
 int gnntrk_mlp_backward_bf16(const gnntrk_mlp_bwd_args *args, void *workspace, size_t workspace_bytes,
                              void *stream) {
     return mlp_backward_bf16_launch(args, workspace, workspace_bytes, (hipStream_t)stream);

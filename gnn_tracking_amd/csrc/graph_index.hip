@@ -37,6 +37,9 @@ namespace gnntrk {
 
 constexpr int kTpb = 256;
 
+#ifndef GNNTRK_NO_LIBRARY_SORT_OFF
+#define GNNTRK_NO_LIBRARY_SORT_OFF 0   // (1: gnntrk_node_order always takes the exact radix form - A/B builds)
+#endif
 // ------------------------------------------------------------------ own counting sort
 #ifndef GNNTRK_GI_SH
 #define GNNTRK_GI_SH 8
@@ -1321,10 +1324,114 @@ __global__ __launch_bounds__(kTpb) void no_finish_kernel(const uint32_t *__restr
         rank[v] = (int32_t)i;
     }
 }
+// ---- own form (round 6): a counting sort on a QUANTISED key - locality is all the key has to buy (locality.py), so
+// the per-event order need not resolve more than the 65 536 levels of
+//     q = trunc((key - lo) * (65535 / (hi - lo))),   lo / hi = min / max of the key over the nodes of the call (fp32),
+// and the pair (event, q) is one small integer: the two-level counting sort of the edge lists above takes it as a
+// "node id" (records = nodes, value = old id, stable: nodes that share a level keep their old order).  One min / max
+// pass, one key pass and the sort's own passes over N records instead of four radix passes of the library.
+constexpr int kNoLevels = 1 << 16;
+constexpr int kNoMaxEvents = 64;
+// per EVENT: mm[2 b] = max of the INVERTED order-preserving image of the key (= the minimum), mm[2 b + 1] = max of the
+// image; both start from a zero fill.  (Per event, not per call: an event then gets the same levels - hence the same
+// order - whether it is ordered alone or inside a collated batch, which is what lets cached per-event indices be
+// placed into a batch, gnntrk_graph_index_place.)
+__global__ __launch_bounds__(kTpb) void no_minmax_kernel(const float *__restrict__ key, int64_t stride,
+                                                         const int64_t *__restrict__ batch, int64_t n, int64_t n_events,
+                                                         uint32_t *__restrict__ mm) {
+    __shared__ uint32_t s_mm[2 * kNoMaxEvents];
+    for (int t = threadIdx.x; t < 2 * kNoMaxEvents; t += kTpb) s_mm[t] = 0u;
+    __syncthreads();
+    for (int64_t i0 = (int64_t)blockIdx.x * kTpb; i0 < n; i0 += (int64_t)gridDim.x * kTpb) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool in = i < n;
+        const float v = in ? key[i * stride] : 0.f;
+        long long b = (in && batch) ? batch[i] : 0;
+        b = b < 0 ? 0 : b >= n_events ? n_events - 1 : b;   // (counted as bad in the key pass)
+        uint32_t u = __float_as_uint(v);
+        u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+        const bool on = in && v == v;   // (NaN keys take the last level, they do not set the range)
+        uint32_t nlo = on ? ~u : 0u, hi = on ? u : 0u;
+        const int b0 = __shfl((int)b, 0);
+        if (__ballot(in && (int)b != b0) == 0ull) {   // one event per wave (the rule): one LDS atomic pair per wave
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t l2 = (uint32_t)__shfl_xor((int)nlo, o), h2 = (uint32_t)__shfl_xor((int)hi, o);
+                nlo = l2 > nlo ? l2 : nlo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicMax(&s_mm[2 * b0], nlo);
+                atomicMax(&s_mm[2 * b0 + 1], hi);
+            }
+        } else if (on) {
+            atomicMax(&s_mm[2 * (int)b], nlo);
+            atomicMax(&s_mm[2 * (int)b + 1], hi);
+        }
+    }
+    __syncthreads();
+    // (maxima: the result does not depend on the order of the atomics)
+    for (int t = threadIdx.x; t < 2 * kNoMaxEvents; t += kTpb)
+        if (s_mm[t]) atomicMax(&mm[t], s_mm[t]);
+}
+__device__ __forceinline__ float no_unimage(uint32_t u) {
+    return __uint_as_float((u >> 31) ? (u ^ 0x80000000u) : ~u);
+}
+__global__ __launch_bounds__(kTpb) void no_qkeys_kernel(const float *__restrict__ key, int64_t stride,
+                                                        const int64_t *__restrict__ batch, int64_t n, int64_t n_events,
+                                                        const uint32_t *__restrict__ mm, int32_t *__restrict__ q,
+                                                        int *__restrict__ bad) {
+    __shared__ float s_lo[kNoMaxEvents], s_scale[kNoMaxEvents];
+    for (int t = threadIdx.x; t < kNoMaxEvents; t += kTpb) {
+        const uint32_t ulo = ~mm[2 * t], uhi = mm[2 * t + 1];
+        const bool any = t < n_events && ulo <= uhi;   // (no finite key in the event: one level)
+        const float lo = any ? no_unimage(ulo) : 0.f, hi = any ? no_unimage(uhi) : 0.f;
+        s_lo[t] = lo;
+        s_scale[t] = hi > lo ? (float)(kNoLevels - 1) / (hi - lo) : 0.f;
+    }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kTpb + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTpb) {
+        const float v = key[i * stride];
+        long long b = batch ? batch[i] : 0;
+        if (b < 0 || b >= n_events) {   // (an event id outside the stated count: counted, clamped - the caller checks)
+            atomicAdd(bad, 1);
+            b = b < 0 ? 0 : n_events - 1;
+        }
+        float t = (v - s_lo[b]) * s_scale[b];
+        t = t < 0.f ? 0.f : t;
+        const uint32_t lvl = (v != v || t >= (float)(kNoLevels - 1)) ? (uint32_t)(kNoLevels - 1) : (uint32_t)t;
+        q[i] = (int32_t)((uint32_t)b * (uint32_t)kNoLevels + lvl);
+    }
+}
+struct OutNode {   // the sort's outputs for the node order: perm[new] = old, rank[old] = new
+    static constexpr uint32_t kValMask = 0xffffffffu;
+    static constexpr bool kPos = false;
+    int32_t *perm, *rank, *rowptr;
+    __device__ __forceinline__ void ranked(uint32_t k, uint32_t val, uint32_t, uint32_t) const {
+        perm[k] = (int32_t)val;
+        rank[val] = (int32_t)k;
+    }
+    __device__ __forceinline__ void slot(uint32_t, uint32_t) const {}
+};
+// (event, level) pairs the own form takes: the table of the counting sort is bounded by it
+constexpr int64_t kNoMaxKeys = (int64_t)kNoMaxEvents * kNoLevels;
+static bool node_order_own(int64_t n, int64_t n_events, const int64_t *batch, OwnPlan &plan, int64_t &keys) {
+    if (GNNTRK_NO_LIBRARY_SORT_OFF) return false;
+    const int64_t ev = batch ? n_events : 1;
+    if (ev < 1) return false;   // (event count not stated: the exact radix form)
+    if (ev > kNoMaxEvents) return false;
+    keys = ev * kNoLevels;
+    if (keys > kNoMaxKeys) return false;
+    plan = own_plan(keys, n, false);
+    return plan.ok && !plan.dense;
+}
 size_t node_order_ws_bytes(int64_t n) {
     const size_t m = (size_t)(n > 0 ? n : 1);
     const size_t t64 = sort_pairs_u64_temp_bytes(n), t32 = sort_pairs_temp_bytes(n);
-    return 2 * align_up(m * 8, 256) + 2 * align_up(m * 4, 256) + align_up(t64 > t32 ? t64 : t32, 256);
+    const size_t lib = 2 * align_up(m * 8, 256) + 2 * align_up(m * 4, 256) + align_up(t64 > t32 ? t64 : t32, 256);
+    // own form: min / max + flag words | quantised keys | row pointers of the (event, level) pairs | the sort's plan
+    const OwnPlan p = own_plan(kNoMaxKeys, n > 0 ? n : 1, false);
+    const size_t own = 1024 + align_up(m * 4, 256) + align_up((size_t)(kNoMaxKeys + 1) * 4, 256) + (p.ok ? p.bytes : 0);
+    return lib > own ? lib : own;
 }
 int node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_events, int64_t n, int32_t *perm,
                int32_t *rank, void *ws, size_t ws_bytes, hipStream_t stream) {
@@ -1333,11 +1440,30 @@ int node_order(const float *key, int64_t key_stride, const int64_t *batch, int64
     if (!key || key_stride < 1 || !perm || !rank) return fail(GNNTRK_EINVAL, "node_order: NULL argument");
     if (!ws || ws_bytes < node_order_ws_bytes(n)) return fail(GNNTRK_EINVAL, "node_order: workspace too small");
     char *p = reinterpret_cast<char *>(ws);
+    const int grid = stream_grid(n);
+    OwnPlan plan;
+    int64_t n_keys = 0;
+    if (node_order_own(n, n_events, batch, plan, n_keys)) {
+        uint32_t *mm = reinterpret_cast<uint32_t *>(p);          // per event {~min image, max image}; [128]: bad event ids
+        int32_t *q = reinterpret_cast<int32_t *>(p + 1024);
+        int32_t *rowptr = reinterpret_cast<int32_t *>(p + 1024 + align_up((size_t)n * 4, 256));
+        char *sort_ws = reinterpret_cast<char *>(rowptr) + align_up((size_t)(kNoMaxKeys + 1) * 4, 256);
+        int rc = check_hip(hipMemsetAsync(mm, 0, 1024, stream), "node_order(memset)");
+        if (rc) return rc;
+        const int64_t ev = batch ? n_events : 1;
+        hipLaunchKernelGGL(no_minmax_kernel, dim3(grid), dim3(kTpb), 0, stream, key, key_stride, batch, n, ev, mm);
+        hipLaunchKernelGGL(no_qkeys_kernel, dim3(grid), dim3(kTpb), 0, stream, key, key_stride, batch, n, ev, mm, q,
+                           reinterpret_cast<int *>(mm + 2 * kNoMaxEvents));
+        KeysCsr keys{q};
+        OutNode out{perm, rank, rowptr};
+        rc = own_sort<KeysCsr, OutNode, false>(plan, keys, out, 0, n_keys, n, sort_ws, reinterpret_cast<int *>(mm + 2 * kNoMaxEvents), stream);
+        if (rc) return rc;
+        return check_launch("node_order");
+    }
     const size_t k8 = align_up((size_t)n * 8, 256), v4 = align_up((size_t)n * 4, 256);
     unsigned long long *ka = reinterpret_cast<unsigned long long *>(p), *kb = reinterpret_cast<unsigned long long *>(p + k8);
     uint32_t *va = reinterpret_cast<uint32_t *>(p + 2 * k8), *vb = reinterpret_cast<uint32_t *>(p + 2 * k8 + v4);
     void *temp = p + 2 * k8 + 2 * v4;
-    const int grid = stream_grid(n);
     // sorted bits: the 32 of the key + what the event ids need (n_events <= 0: not stated - all 32)
     int ebits = batch ? 32 : 0;
     if (batch && n_events > 0) {

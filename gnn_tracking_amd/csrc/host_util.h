@@ -66,6 +66,7 @@ int launch_bwd16_bi8(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, in
 size_t mlp_backward_bf16_ws_bytes(const gnntrk_mlp *m);
 int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_bytes, hipStream_t stream);
 int mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *a);
+int mlp_backward_bf16_can_fold(const gnntrk_mlp_bwd_args *a);
 
 
 // compact.hip
@@ -108,5 +109,7 @@ int segment_sum_bf16_launch(const uint16_t *rows, int dim, int row_stride, const
                             const uint16_t *addend, int addend_stride, hipStream_t stream);
 int permute_rows_bf16_launch(const uint16_t *in, int dim, int in_stride, const int32_t *idx, int64_t n_rows,
                              uint16_t *out, int out_stride, int scatter, hipStream_t stream);
+int fold_finish_bf16_launch(uint16_t *out, int out_stride, int64_t n_nodes, const int32_t *rowptr, const uint16_t *carry,
+                            int64_t n_units, const uint16_t *x, int x_stride, hipStream_t stream);
 
 }  // namespace gnntrk

@@ -72,6 +72,22 @@ int mlp_backward_bf16_max_terms(const gnntrk_mlp_bwd_args *a) {
     return (io[0] && B.n_gout == 3) ? 3 : 2;
 }
 
+// 1 if the launch described by `a` (fold block filled in) runs on an instantiation that folds inside the kernel
+int mlp_backward_bf16_can_fold(const gnntrk_mlp_bwd_args *a) {
+    if (!a || !a->fold.ids || a->fold.seg < 0 || a->fold.seg >= a->n_seg || a->n_rows <= 0 || a->n_rows > 0x7fffffff ||
+        a->n_gout < 1 || a->n_gout > 3 || (a->debug_flags & (64 | 128)))
+        return 0;
+    SlotPlan P;
+    make_slot_plan(P, a->mlp, a->n_seg, a->seg, a->gseg);
+    if (!P.ok || P.KI != 1 || P.bias_init || a->mlp.out_dim > 16) return 0;
+    const int GT = (P.GT == 0) ? 0 : (P.GT <= 1) ? 1 : 2;
+    BufPlan B;
+    make_buf_plan(B, P, a, GT);
+    const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, a->epilogue == GNNTRK_EPI_SIGMOID, a->debug_flags,
+                                 a->epilogue);
+    return (io[0] && B.fold_on) ? 1 : 0;
+}
+
 // workspace = one partial block per wave | one 8-byte trash slot per lane
 constexpr int kBwd16MaxWaves = kBwd16BufWaves > kWaves ? kBwd16BufWaves : kWaves;
 static size_t bwd16_partial_bytes(const gnntrk_mlp *m) {
@@ -109,6 +125,15 @@ int mlp_backward_bf16_launch(const gnntrk_mlp_bwd_args *a, void *ws, size_t ws_b
             return fail(GNNTRK_EINVAL, "mlp_backward_bf16: gradient slices must be padded bf16 rows");
     }
     if (a->n_rows < 0 || a->n_rows > 0x7fffffff) return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad n_rows");
+    if (a->fold.ids && !empty) {
+        const gnntrk_gfold &f = a->fold;
+        if (f.seg < 0 || f.seg >= a->n_seg || !a->gseg[f.seg].ptr || a->gseg[f.seg].idx || a->seg[f.seg].idx != f.ids ||
+            f.n_nodes <= 0 || a->gseg[f.seg].stride != 8 || ((uintptr_t)a->gseg[f.seg].ptr & 15) != 0 ||
+            false)
+            return fail(GNNTRK_EINVAL, "mlp_backward_bf16: bad fold block (include/gnntrk.h: gnntrk_gfold)");
+        if (!mlp_backward_bf16_can_fold(a))
+            return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: this launch does not take a fold (gnntrk_mlp_backward_bf16_can_fold)");
+    }
     if (a->n_gout == 3 && a->n_rows > 0 && mlp_backward_bf16_max_terms(a) < 3)
         return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: three upstream terms only on the buffer-addressed shapes "
                                          "(gnntrk_mlp_backward_bf16_max_terms)");

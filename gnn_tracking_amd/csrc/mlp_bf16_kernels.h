@@ -510,6 +510,13 @@ struct BufPlan {
     BufOpShape load_s[kBufLoads], gout_s[kBufGouts], store_s[kBufStores];
     BufOpArgs load[kBufLoads], gout[kBufGouts], store[kBufStores];
     BufOpArgs ids[kBufIds], sids[kBufIds];   // int32 id streams of the loads (one unit ahead) / of the stores
+    // target-side fold of one gathered segment's gradient inside the kernel (gnntrk_gfold; IO::kFold): the lane
+    // groups of gradient tile 0 that hold the folded slice take no per-row store - one row per NODE leaves the kernel
+    int32_t fold_on;
+    uint32_t fold_part;     // bit g: lane group g holds a chunk of the folded slice
+    BufOpArgs fold_out;     // folded rows [n_nodes] (off8[g]: byte offset of group g's chunk inside a row)
+    int32_t fold_stream;    // which id stream of the loads (ids[]) the folded segment is gathered through
+    uint32_t fold_nodes;    // node rows in fold_out; the units' carry rows follow them in the same allocation
 };
 
 #ifndef GNNTRK_ABLATE
@@ -542,6 +549,9 @@ struct BufPlan {
 constexpr int kEpiOf(int e) { return GNNTRK_BWD_STATIC_EPI ? e : -1; }
 
 struct IoNone {   // the generic per-lane I/O
+    static constexpr bool kFold = false;
+    static constexpr uint32_t kFoldPart = 0;
+    static constexpr int kFoldStream = 0;
     static constexpr int kEpi = -1;
     static constexpr int NL = 0, NI = 0, NSI = 0, NS = 0, NG = 0, kOnesDword = -1;
     static constexpr BufOpShape load[1] = {}, gout[1] = {}, store[1] = {};
@@ -550,19 +560,29 @@ struct IoNone {   // the generic per-lane I/O
 // node rows, one descriptor, two id streams), e (8-byte rows of the tile); upstream gradient
 // g_e~ + g_aggr[tgt]; gradient slices g_x_i (tile rows), g_x_j (rows through the source-sort
 // permutation), g_e
-template <int NG_>   // NG_ = 3: a third upstream term on the tile's rows (the edge-weight head's share, see ops_bf16.grad_tap)
+// FOLD_ (round 6, gnntrk_gfold): g_x_i leaves the kernel summed per target node - its per-row store is gone
+template <int NG_, bool FOLD_ = false>   // NG_ = 3: a third upstream term on the tile's rows (the edge-weight head's share, see ops_bf16.grad_tap)
 struct IoRelational {
     static constexpr int kEpi = kEpiOf(GNNTRK_EPI_NONE);
-    static constexpr int NL = 2, NI = 2, NSI = 1, NS = 3, NG = NG_, kOnesDword = 2;
+    static constexpr bool kFold = FOLD_;
+    static constexpr uint32_t kFoldPart = 0b0011;
+    static constexpr int kFoldStream = 0;   // x_i is gathered through the first id stream (the CSR targets)
+    static constexpr int NL = 2, NI = 2, NSI = 1, NS = FOLD_ ? 2 : 3, NG = NG_, kOnesDword = 2;
     static constexpr BufOpShape load[2] = {{1, 1, 0, 1, 0b0011, 0b0010, 0, 0}, {0, 0, -1, -1, 0b0100, 0, 0, 0}};
     static constexpr BufOpShape gout[3] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 1, 0, -1, 0b0001, 0, 0, 0},
                                            {0, 0, -1, -1, 0b0001, 0, 0, 0}};
-    static constexpr BufOpShape store[3] = {{0, 0, -1, -1, 0b0011, 0, 0, 0}, {0, 1, 0, -1, 0b1100, 0, 0, 0},
-                                            {0, 0, -1, -1, 0b0001, 0, 1, 0}};
+    static constexpr BufOpShape kXi = {0, 0, -1, -1, 0b0011, 0, 0, 0}, kXj = {0, 1, 0, -1, 0b1100, 0, 0, 0},
+                                kE = {0, 0, -1, -1, 0b0001, 0, 1, 0};
+    static constexpr BufOpShape store[3] = {FOLD_ ? kXj : kXi, FOLD_ ? kE : kXj, FOLD_ ? BufOpShape{} : kE};
 };
+using IoRelationalF2 = IoRelational<2, true>;   // (names without a comma: the launch macros take them as one argument)
+using IoRelationalF3 = IoRelational<3, true>;
 // object model (interaction_network.py:92-103): x (16-byte rows) | aggr (8-byte rows), all rows of
 // the tile; one upstream term; gradient slices g_x, g_aggr
 struct IoObject {
+    static constexpr bool kFold = false;
+    static constexpr uint32_t kFoldPart = 0;
+    static constexpr int kFoldStream = 0;
     static constexpr int kEpi = kEpiOf(GNNTRK_EPI_RESIDUAL);
     static constexpr int NL = 2, NI = 0, NSI = 0, NS = 2, NG = 1, kOnesDword = 2;
     static constexpr BufOpShape load[2] = {{1, 0, -1, -1, 0b0001, 0, 0, 0}, {0, 0, -1, -1, 0b0010, 0, 0, 0}};
@@ -573,21 +593,32 @@ struct IoObject {
 // two id streams), four 8-byte edge tensors of the tile's rows; fp32 upstream gradient of the one
 // weight per edge; gradient slices g_h[src] (rows through the source-sort permutation), g_h[tgt],
 // g_e0 .. g_e3
-struct IoHead {
+template <bool FOLD_ = false>   // FOLD_: g_h[tgt] leaves the kernel summed per target node (gnntrk_gfold)
+struct IoHeadT {
     static constexpr int kEpi = kEpiOf(GNNTRK_EPI_SIGMOID);
-    static constexpr int NL = 5, NI = 2, NSI = 1, NS = 6, NG = 1, kOnesDword = 2;
+    static constexpr bool kFold = FOLD_;
+    static constexpr uint32_t kFoldPart = 0b1100;
+    static constexpr int kFoldStream = 1;   // h[src] | h[tgt]: the targets are the second id stream
+    static constexpr int NL = 5, NI = 2, NSI = 1, NS = FOLD_ ? 5 : 6, NG = 1, kOnesDword = 2;
     static constexpr BufOpShape load[5] = {{1, 1, 0, 1, 0b0011, 0b0010, 0, 0}, {0, 0, -1, -1, 0b0100, 0, 0, 0},
                                            {0, 0, -1, -1, 0b0100, 0, 2, 0}, {0, 0, -1, -1, 0b1000, 0, 0, 0},
                                            {0, 0, -1, -1, 0b1000, 0, 2, 0}};
     static constexpr BufOpShape gout[1] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}};
-    static constexpr BufOpShape store[6] = {{0, 1, 0, -1, 0b0011, 0, 0, 0}, {0, 0, -1, -1, 0b1100, 0, 0, 0},
-                                            {0, 0, -1, -1, 0b0001, 0, 1, 0}, {0, 0, -1, -1, 0b0010, 0, 1, 0},
-                                            {0, 0, -1, -1, 0b0100, 0, 1, 0}, {0, 0, -1, -1, 0b1000, 0, 1, 0}};
+    static constexpr BufOpShape kHs = {0, 1, 0, -1, 0b0011, 0, 0, 0}, kHt = {0, 0, -1, -1, 0b1100, 0, 0, 0},
+                                kE0 = {0, 0, -1, -1, 0b0001, 0, 1, 0}, kE1 = {0, 0, -1, -1, 0b0010, 0, 1, 0},
+                                kE2 = {0, 0, -1, -1, 0b0100, 0, 1, 0}, kE3 = {0, 0, -1, -1, 0b1000, 0, 1, 0};
+    static constexpr BufOpShape store[6] = {kHs, FOLD_ ? kE0 : kHt, FOLD_ ? kE1 : kE0, FOLD_ ? kE2 : kE1,
+                                            FOLD_ ? kE3 : kE2, FOLD_ ? BufOpShape{} : kE3};
 };
+using IoHead = IoHeadT<false>;
+using IoHeadF = IoHeadT<true>;
 // bias-free encoder of 8-byte rows (edge_classifier.py:66-69 on the four edge features): one tensor,
 // rows of the tile, weight gradients only
 template <int NG_>
 struct IoEncoder8 {
+    static constexpr bool kFold = false;
+    static constexpr uint32_t kFoldPart = 0;
+    static constexpr int kFoldStream = 0;
     static constexpr int kEpi = kEpiOf(GNNTRK_EPI_RELU);
     static constexpr int NL = 1, NI = 0, NSI = 0, NS = 0, NG = NG_, kOnesDword = -1;
     static constexpr BufOpShape load[1] = {{0, 0, -1, -1, 0b0001, 0, 0, 0}};
@@ -838,6 +869,26 @@ inline void make_buf_plan(BufPlan &B, const SlotPlan &P, const gnntrk_mlp_bwd_ar
             const gnntrk_gseg &gs = a->gseg[j];
             uint8_t shift;
             if (!buf_pow2((int64_t)gs.stride * 2, shift)) return;
+            if (a->fold.ids && j == a->fold.seg) {
+                // folded inside the kernel: no per-row store; one row per node (+ a carry row per unit) instead
+                const gnntrk_seg &sg = a->seg[j];
+                const int64_t units = (M + 31) / 32;
+                if (T != 0 || gs.idx || !sg.idx || sg.idx != a->fold.ids || sg.rows <= 0 || shift != 4 ||
+                    a->fold.n_nodes <= 0 || (a->fold.n_nodes + units) * 16 >= (int64_t)kBufOut)
+                    return;
+                if (!B.fold_on) {
+                    B.fold_on = 1;
+                    B.fold_out = BufOpArgs{gs.ptr, (uint32_t)((a->fold.n_nodes + units) * 16), 4, {0, 0, 0, 0}, {0, 0, 0}};
+                    B.fold_nodes = (uint32_t)a->fold.n_nodes;
+                    B.fold_stream = -1;
+                    for (int i = 0; i < B.n_ids; ++i)
+                        if (B.ids[i].ptr == (const void *)a->fold.ids) B.fold_stream = i;
+                    if (B.fold_stream < 0) return;
+                }
+                B.fold_part |= 1u << g;
+                B.fold_out.off8[g] = (uint8_t)(8 * P.first[p]);
+                continue;
+            }
             const bool gathered = gs.idx != nullptr;
             const int stream = gathered ? buf_stream(B.sids, B.n_sids, gs.idx, M) : -1;
             if (gathered && stream < 0) return;
@@ -845,11 +896,14 @@ inline void make_buf_plan(BufPlan &B, const SlotPlan &P, const gnntrk_mlp_bwd_ar
                          T, g, 8 * P.first[p]))
                 return;
         }
+    if (a->fold.ids && !B.fold_on) return;   // (a fold that found no gradient chunk of its segment)
+    if (B.fold_on && B.gate_mode == 2) return;   // (the folded gate is the uniform one)
     B.ok = 1;
 }
 
 template <class IO>
 inline bool buf_plan_is(const BufPlan &B) {
+    if ((B.fold_on != 0) != IO::kFold || (IO::kFold && (B.fold_part != IO::kFoldPart || B.fold_stream != IO::kFoldStream))) return false;
     if (!B.ok || B.n_load != IO::NL || B.n_ids != IO::NI || B.n_sids != IO::NSI || B.n_store != IO::NS ||
         B.n_gout != IO::NG || B.ones_dword != IO::kOnesDword)
         return false;
@@ -875,9 +929,13 @@ inline const char *buf_io_name(const BufPlan &B, int KI, int HT, int GT, bool th
                                int epilogue) {
     if (!B.ok || (debug_flags & (64 | 128)) || KI != 1 || (HT != 1 && HT != 3)) return "";
     auto epi_ok = [&](int k) { return k < 0 || k == epilogue; };   // (a class with a static epilogue only takes that one)
-    if (g32) return (GT == 2 && three && epi_ok(IoHead::kEpi) && buf_plan_is<IoHead>(B)) ? "IoHead" : "";
+    if (g32)
+        return (GT == 2 && three && epi_ok(IoHead::kEpi) && buf_plan_is<IoHead>(B)) ? "IoHead"
+               : (GT == 2 && three && HT == 3 && kBwd16BufD == 2 && epi_ok(IoHeadF::kEpi) && buf_plan_is<IoHeadF>(B)) ? "IoHeadF" : "";
     if (GT == 2 && three && epi_ok(IoRelational<2>::kEpi) && buf_plan_is<IoRelational<2>>(B)) return "IoRelational<2>";
     if (GT == 2 && three && epi_ok(IoRelational<3>::kEpi) && buf_plan_is<IoRelational<3>>(B)) return "IoRelational<3>";
+    if (GT == 2 && three && HT == 3 && kBwd16BufD == 2 && epi_ok(IoRelationalF2::kEpi) && buf_plan_is<IoRelationalF2>(B)) return "IoRelationalF2";
+    if (GT == 2 && three && HT == 3 && kBwd16BufD == 2 && epi_ok(IoRelationalF3::kEpi) && buf_plan_is<IoRelationalF3>(B)) return "IoRelationalF3";
     if (GT == 1 && three && epi_ok(IoObject::kEpi) && buf_plan_is<IoObject>(B)) return "IoObject";
     if (GT == 0 && !three && epi_ok(IoEncoder8<1>::kEpi) && buf_plan_is<IoEncoder8<1>>(B)) return "IoEncoder8<1>";
     if (GT == 0 && !three && epi_ok(IoEncoder8<2>::kEpi) && buf_plan_is<IoEncoder8<2>>(B)) return "IoEncoder8<2>";
@@ -951,9 +1009,12 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
     }
         if constexpr (G32) {
             GNNTRK_BWD16_SKEL(IoHead)
+            GNNTRK_BWD16_SKEL(IoHeadF)
         } else {
             GNNTRK_BWD16_SKEL(IoRelational<2>)
             GNNTRK_BWD16_SKEL(IoRelational<3>)
+            GNNTRK_BWD16_SKEL(IoRelationalF2)
+            GNNTRK_BWD16_SKEL(IoRelationalF3)
         }
 #undef GNNTRK_BWD16_SKEL
 #define GNNTRK_BWD16_BUF(HT_, GT_, T_, IO_)                                                           \
@@ -967,9 +1028,12 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
         if constexpr (G32) {
             GNNTRK_BWD16_BUF(3, 2, true, IoHead)
             GNNTRK_BWD16_BUF(1, 2, true, IoHead)
+            GNNTRK_BWD16_BUF(3, 2, true, IoHeadF)
         } else {
             GNNTRK_BWD16_BUF(3, 2, true, IoRelational<2>)
             GNNTRK_BWD16_BUF(3, 2, true, IoRelational<3>)
+            GNNTRK_BWD16_BUF(3, 2, true, IoRelationalF2)
+            GNNTRK_BWD16_BUF(3, 2, true, IoRelationalF3)
             GNNTRK_BWD16_BUF(1, 2, true, IoRelational<2>)
             GNNTRK_BWD16_BUF(1, 2, true, IoRelational<3>)
             GNNTRK_BWD16_BUF(3, 1, true, IoObject)
@@ -982,6 +1046,7 @@ int launch_bwd16(const gnntrk_mlp_bwd_args *a, const SlotPlan &P, int GT, int gr
 #undef GNNTRK_BWD16_BUF
         if (launched) return check_launch("mlp_backward_bf16");
     }
+    if (a->fold.ids) return fail(GNNTRK_EUNSUPPORTED, "mlp_backward_bf16: this launch does not take a fold (gnntrk_mlp_backward_bf16_can_fold)");
 // D = 2 (two 16-row halves per iteration, K = 32 weight-gradient contractions) wherever the
 // doubled staging images fit the workgroup's LDS budget: one k-step, up to three hidden tiles -
 // every shape of the reference's default models.  debug_flags & 64 forces D = 1 (A/B timing).

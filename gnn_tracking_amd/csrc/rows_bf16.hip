@@ -411,4 +411,66 @@ int permute_rows_bf16_launch(const uint16_t *in, int dim, int in_stride, const i
     return check_launch("permute_rows_bf16");
 }
 
+// ------------------------------------------------------------------ carries + gate of the in-kernel target fold
+// gnntrk_gfold (include/gnntrk.h): a unit of the backward kernel (32 consecutive rows) writes the part of a run of
+// equal target ids that began in an EARLIER unit to carry[unit] (8 bf16).  A node's rows are [rowptr[n], rowptr[n + 1]),
+// so the units it reaches after its first are known from the row pointers: one thread per node adds their carry rows
+// in unit order onto the node's row (fixed order, one rounding) and applies the relu' gate of the folded segment
+// (x: the segment's own input rows) - once per node instead of once per edge.
+__global__ __launch_bounds__(kTpb16) void fold_finish_bf16_kernel(uint16_t *__restrict__ out, int out_stride, int64_t n_nodes,
+                                                                  const int32_t *__restrict__ rowptr,
+                                                                  const uint16_t *__restrict__ carry, int64_t n_units,
+                                                                  const uint16_t *__restrict__ x, int x_stride) {
+    for (int64_t n = (int64_t)blockIdx.x * kTpb16 + threadIdx.x; n < n_nodes; n += (int64_t)gridDim.x * kTpb16) {
+        const int32_t r0 = rowptr[n], r1 = rowptr[n + 1];
+        if (r1 <= r0) continue;   // (no row: the caller's zero stays)
+        const int64_t u0 = r0 >> 5, u1 = (int64_t)(r1 - 1) >> 5;
+        if (u1 == u0 && !x) continue;
+        uint16_t *row = out + n * out_stride;
+        const uint4 rv = *reinterpret_cast<const uint4 *>(row);
+        uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+        if (u1 > u0) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * i] = bf16_lo(rw[i]);
+                acc[2 * i + 1] = bf16_hi(rw[i]);
+            }
+            for (int64_t u = u0 + 1; u <= u1 && u < n_units; ++u) {
+                const uint4 cv = *reinterpret_cast<const uint4 *>(carry + 8 * u);
+                const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[2 * i] += bf16_lo(cw[i]);
+                    acc[2 * i + 1] += bf16_hi(cw[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rw[i] = bf16x2_pack(acc[2 * i], acc[2 * i + 1]);
+        }
+        if (x) {
+            const uint4 xv = *reinterpret_cast<const uint4 *>(x + n * x_stride);
+            const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // keep a half where the input's half is a positive bf16
+                const uint32_t lo = ((int16_t)(xw[i] & 0xffffu) > 0) ? 0x0000ffffu : 0u;
+                const uint32_t hi = ((int16_t)(xw[i] >> 16) > 0) ? 0xffff0000u : 0u;
+                rw[i] &= lo | hi;
+            }
+        }
+        *reinterpret_cast<uint4 *>(row) = uint4{rw[0], rw[1], rw[2], rw[3]};
+    }
+}
+
+int fold_finish_bf16_launch(uint16_t *out, int out_stride, int64_t n_nodes, const int32_t *rowptr, const uint16_t *carry,
+                            int64_t n_units, const uint16_t *x, int x_stride, hipStream_t stream) {
+    if (n_units == 0 || n_nodes == 0) return GNNTRK_OK;
+    if (!out || !carry || !rowptr || n_units < 0 || n_nodes < 0 || out_stride != 8 || ((uintptr_t)out & 15) != 0 ||
+        ((uintptr_t)carry & 15) != 0 || (x && (x_stride != 8 || ((uintptr_t)x & 15) != 0)))
+        return fail(GNNTRK_EINVAL, "fold_finish_bf16: bad argument (rows of 8 bf16, 16-byte aligned)");
+    hipLaunchKernelGGL(fold_finish_bf16_kernel, dim3(grid_for_threads(n_nodes)), dim3(kTpb16), 0, stream, out, out_stride,
+                       n_nodes, rowptr, carry, n_units, x, x_stride);
+    return check_launch("fold_finish_bf16");
+}
+
 }  // namespace gnntrk

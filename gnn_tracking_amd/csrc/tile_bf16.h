@@ -119,6 +119,9 @@ __device__ __forceinline__ u32x2 buf_load_u32x2(buf_rsrc_t r, uint32_t voff, uin
 __device__ __forceinline__ u32x4 buf_load_u32x4(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+__device__ __forceinline__ void buf_store_u32(uint32_t v, buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ void buf_store_u32x2(u32x2 v, buf_rsrc_t r, uint32_t voff, uint32_t soff) {
     typedef unsigned int v2u_hw __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_hw, v), r, (int)voff, (int)soff, 0);

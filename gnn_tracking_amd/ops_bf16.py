@@ -109,13 +109,26 @@ def mlp_forward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], rel
     return out
 
 
+#: on: the gradient of a target-gathered segment leaves the backward kernel summed per node (include/gnntrk.h:
+#: gnntrk_gfold) where the launch takes it.  OFF by default: built in round 6, parity green (case_mlp_bf16_fold),
+#: and measured slower - the segment matrix, five more MFMAs and their packs cost the relational backward
+#: +0.35 ms per 64 M rows (2.34 -> 2.68-2.76) and the head +0.24 ms (3.02 -> 3.26), more than the 0.23 ms streaming
+#: fold + the 16 B/row store they replace: cfg3 step 24.1 against 23.4 ms
+FOLD_IN_KERNEL = __import__("os").environ.get("GNNTRK_FOLD_IN_KERNEL", "0") != "0"
+
+
 def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], relu: Sequence[bool],
                      weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]], *, n_rows: int,
                      epilogue: int, ca: float, cb: float, gout: Sequence[tuple], need_seg: Sequence[bool],
-                     want_dw: bool, mlp, gidx: Optional[Sequence[Optional[Tensor]]] = None, sinks=None):
+                     want_dw: bool, mlp, gidx: Optional[Sequence[Optional[Tensor]]] = None, sinks=None,
+                     fold: Optional[tuple] = None):
     """One launch of gnntrk_mlp_backward_bf16.  ``gout``: 1-2 tuples (rows, idx) - padded
     bf16 rows, or one fp32 ``[*, out]`` tensor for EPI_SIGMOID.  Returns (row-aligned
-    per-segment gradient slices ``[n_rows, dim]`` bf16 or None, gW list, gb list)."""
+    per-segment gradient slices ``[n_rows, dim]`` bf16 or None, gW list, gb list).
+    ``fold = (j, n_nodes, rowptr)``: segment ``j`` is gathered through sorted ids (the CSR targets; ``rowptr``: their
+    int32 row pointers ``[n_nodes + 1]``) - where the launch takes it (``gnntrk_mlp_backward_bf16_can_fold``) its
+    gradient comes back ALREADY SUMMED per node as ``[n_nodes, dim]`` rows in ``slices[j]`` and ``j`` is listed in
+    the returned ``slices.folded`` set."""
     from . import ops
     lib = _capi.load()
     a = _capi.MlpBwdArgs()
@@ -125,12 +138,39 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
     for j, s in enumerate(segs):
         a.seg[j] = _seg16(s, idx[j], relu[j])
     dev = segs[0].device
-    slices = [None] * len(segs)
+    slices = _Slices([None] * len(segs))
     for j, s in enumerate(segs):
         if need_seg[j]:
             slices[j] = empty_rows(n_rows, s.shape[1], dev)
             gi_j = None if gidx is None else gidx[j]
             a.gseg[j] = _capi.GSeg(slices[j].data_ptr(), ops._p(gi_j), slices[j].stride(0), 0)
+    fold_bufs = None
+
+    def try_fold():
+        """Arm the in-kernel fold of segment ``fold[0]`` if this launch takes it (asked once the terms are set)."""
+        nonlocal fold_bufs
+        if fold is None or not FOLD_IN_KERNEL or _DEBUG_FLAGS:
+            return
+        j, n_nodes, rowptr = fold
+        if not need_seg[j] or idx[j] is None or segs[j].shape[1] > 8 or n_rows < 1 or n_nodes < 1:
+            return
+        if segs[j].stride(0) != 8 or segs[j].data_ptr() % 16 or any(bool(r) != bool(relu[j]) for k, r in enumerate(relu) if need_seg[k]):
+            return   # (the finishing pass gates with 16-byte rows of the segment itself; one ReLU flag for all slices)
+        if gidx is not None and gidx[j] is not None:
+            return
+        units = (n_rows + 31) // 32
+        # (node rows, zero-filled, and the units' carry rows behind them: one allocation, one descriptor in the kernel)
+        out = empty_rows(n_nodes + units, segs[j].shape[1], dev, zero=True)
+        if out.stride(0) != 8:
+            return
+        old = (a.gseg[j].ptr, a.gseg[j].idx, a.gseg[j].stride, a.gseg[j].accumulate)
+        a.gseg[j] = _capi.GSeg(out.data_ptr(), None, 8, 0)
+        a.fold = _capi.GFold(idx[j].data_ptr(), n_nodes, j, 0)
+        if int(lib.gnntrk_mlp_backward_bf16_can_fold(C.byref(a))) != 1:
+            a.gseg[j] = _capi.GSeg(*old)
+            a.fold = _capi.GFold(None, 0, -1, 0)
+            return
+        fold_bufs = (j, out, rowptr, units, n_nodes)
 
     def set_terms(terms):
         a.n_gout = len(terms)
@@ -157,6 +197,7 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
             del gout[-1]
         gout[j] = (rows16(r1 + r2), None)
     set_terms(gout)
+    try_fold()
     gW = [None] * len(weights)
     gb = [None] * len(weights)
     if want_dw:
@@ -173,6 +214,8 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
     a.accumulate_params = 1 if (want_dw and sinks is not None) else 0
     # (debug_flags: 64 one 16-row tile per iteration instead of two, 128 generic per-lane I/O - A/B timing)
     M = n_rows
+    # (algorithmic bytes as SURVEY 8d counts them: a gathered row and its gradient per edge, whether or not the
+    #  gradient leaves this kernel already folded)
     nbytes = M * (sum(2 * s.shape[1] + (4 if idx[j] is not None else 0)
                       + (2 * s.shape[1] if need_seg[j] else 0) for j, s in enumerate(segs))
                   + sum((4 if epilogue == _capi.EPI_SIGMOID else 2) * mlp.out_dim
@@ -186,7 +229,23 @@ def mlp_backward_raw(segs: Sequence[Tensor], idx: Sequence[Optional[Tensor]], re
     with ops._timed(ref, key, 3 * ops._mlp_flops_per_row(mlp) * M, nbytes, M):
         _capi.check(lib.gnntrk_mlp_backward_bf16(C.byref(a), ops._p(ws), 0 if ws is None else ws.numel(),
                                                  ops._stream(ref)), lib)
+    if fold_bufs is not None:
+        j, out, rowptr, units, n_nodes = fold_bufs
+        gate = segs[j] if relu[j] else None   # (relu' of the segment: once per node, by its own input row)
+        _capi.check(lib.gnntrk_fold_finish_bf16(out.data_ptr(), 8, n_nodes, ops._p(rowptr), units,
+                                                None if gate is None else gate.data_ptr(), 8, ops._stream(ref)), lib)
+        slices[j] = out[:n_nodes]
+        slices.folded.add(j)
     return slices, gW, gb
+
+
+class _Slices(list):
+    """The per-segment gradient slices of one backward launch; ``folded``: segments whose entry is already the
+    per-node sum (in-kernel fold) instead of one row per edge."""
+
+    def __init__(self, it):
+        super().__init__(it)
+        self.folded = set()
 
 
 # ------------------------------------------------------------------ plain helpers
@@ -354,12 +413,20 @@ def _backward_common(ctx, gout, need, g_rows, node_addend=None):
     if want_dw:
         sinks = ops._param_grad_sinks(weights, biases, need[1 + ns:1 + ns + nl],
                                       [need[1 + ns + nl + i] or biases[i] is None for i in range(nl)])
+    # the target-gathered segment (CSR order = sorted by target): folded inside the kernel where the launch takes it
+    fold = next(((j, int(segs[j].shape[0]), spec.reduce[j][1].rowptr_t) for j in range(ns)
+                 if need_seg[j] and isinstance(spec.reduce[j], tuple) and spec.reduce[j][0] == "tgt"
+                 and spec.idx[j] is spec.reduce[j][1].tgt), None)
     slices, gW, gb = mlp_backward_raw(segs, spec.idx, spec.relu, weights, biases, n_rows=M,
                                       epilogue=spec.epilogue, ca=spec.ca, cb=spec.cb, gout=gout,
-                                      need_seg=need_seg, want_dw=want_dw, mlp=mlp, gidx=gidx, sinks=sinks)
+                                      need_seg=need_seg, want_dw=want_dw, mlp=mlp, gidx=gidx, sinks=sinks, fold=fold)
     seg_grads = [None] * ns
     folded: dict = {}   # (tensor identity) -> index of the segment whose fold holds its gradient so far
-    for j, s in enumerate(segs):
+    # (segments the kernel folded itself come first: a later fold of the same tensor then takes the result as its
+    #  fp32 addend - one pass, one rounding - instead of a torch add of two N-sized tensors)
+    order = sorted(range(ns), key=lambda j: (j not in slices.folded, j))
+    for j in order:
+        s = segs[j]
         if slices[j] is None:
             continue
         if spec.idx[j] is None:
@@ -378,9 +445,19 @@ def _backward_common(ctx, gout, need, g_rows, node_addend=None):
             # add the two (an N-sized pass, a second rounding, and a re-padding copy of its dense result)
             # (same memory AND the same autograd tensor: two unrelated tensors that alias keep separate gradients)
             first = folded.get(_tensor_key(s)) if FOLD_ADD else None
-            if first is not None and getattr(ctx, "dup_of", None) is not None and ctx.dup_of[j] != first:
+            if (first is not None and getattr(ctx, "dup_of", None) is not None and ctx.dup_of[j] != first
+                    and ctx.dup_of[first] != j):   # (either order: the kernel-folded segment goes first)
                 first = None
-            if first is not None:
+            if j in slices.folded:
+                # summed per node by the backward kernel itself (gnntrk_gfold): nothing to read back per edge
+                seg_grads[j] = slices[j]
+                if first is not None:
+                    seg_grads[j] = rows16(seg_grads[j] + seg_grads[first])
+                    seg_grads[first] = None
+                elif node_addend is not None and node_addend[0] == _tensor_key(s):
+                    seg_grads[j] = rows16(seg_grads[j] + rows16(node_addend[1]))
+                    node_addend = None
+            elif first is not None:
                 seg_grads[j] = segment_sum_raw(slices[j], rowptr, None, s.shape[0], addend=seg_grads[first])
                 seg_grads[first] = None
             elif node_addend is not None and node_addend[0] == _tensor_key(s):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNNTRK_VERSION 500 /* 0.5.0: + node_order, graph_index_carry.node_rank (node renumbering inside the index build); 0.4.0: + resfcnn_*, hinge_* (metric-learning stage), mlp_*_wide (fp32 in <= 128 / hidden <= 128 / out <= 48); 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
+#define GNNTRK_VERSION 600 /* 0.6.0: + the gfold block of the bf16 backward arguments: target-side gradient fold inside the kernel, mlp_backward_bf16_can_fold, fold_finish_bf16; 0.5.0: + node_order, graph_index_carry.node_rank (node renumbering inside the index build); 0.4.0: + resfcnn_*, hinge_* (metric-learning stage), mlp_*_wide (fp32 in <= 128 / hidden <= 128 / out <= 48); 0.3.0: + graph_index_build_ex / _carry (own counting sort), bce_csr; 0.2.3: + radius_*_ws; 0.2.2: oc_*_spatial; 0.2.1: knn_search_ws / knn_workspace_bytes (0.2.0: edge_targets_csr, knn_search_batched, oc_backward workspace, oc_args.rep_keep_prob/rep_seed) */
 #define GNNTRK_MAX_SEGS 10 /* concat segments of one fused MLP input           */
 #define GNNTRK_MAX_IN 48   /* max concatenated input width of a fused MLP      */
 #define GNNTRK_MAX_HIDDEN 64
@@ -143,10 +143,15 @@ int gnntrk_graph_index_place(const gnntrk_graph_index *part, int64_t node_offset
  * of every event by a caller-supplied key (one float per node, row stride key_stride floats; for tracking
  * graphs the azimuth column of data.x - edges join hits of neighbouring azimuth); ties keep the old order:
  *   perm[new] = old, rank[old] = new, events (batch[i] in [0, n_events), non-decreasing, or NULL = one event) keep
- *   their id ranges; n_events <= 0: not stated (all 32 bits of batch[i] are sorted).  Stable radix sort of N
- *   pairs, deterministic: with b = ceil(log2(n_events)) <= 8 one 32-bit key {event : b bits, top 32 - b bits of
- *   the key's order-preserving integer image} - keys that agree in those bits keep their old order -, otherwise
- *   32 + b bits of a 64-bit key (the full key).
+ *   their id ranges.  Locality is all the key has to buy (any order gives the same results up to summation order), so
+ *   with the event count stated (1 <= n_events <= 64; batch == NULL counts as one event) the key is
+ *   QUANTISED to 65 536 levels, q = trunc((key - lo) * (65535 / (hi - lo))) in fp32 with lo / hi the smallest / largest
+ *   key of the node's own EVENT (so an event is ordered the same alone and inside a batch; NaN keys: the last level), and the nodes are put in (event, q) order by this library's own
+ *   counting sort (the two-level sort of the graph index, records = nodes): nodes of one event that share a level
+ *   keep their old order - deterministic, no library sort.  Otherwise (n_events <= 0: not stated - all 32 bits of
+ *   batch[i] are sorted; more events; events beyond a million nodes) a stable radix sort of N pairs: with b = ceil(log2(n_events)) <= 8
+ *   one 32-bit key {event : b bits, top 32 - b bits of the key's order-preserving integer image} - keys that agree in
+ *   those bits keep their old order -, otherwise 32 + b bits of a 64-bit key (the full key).
  * workspace: gnntrk_node_order_workspace_bytes(n_nodes). */
 size_t gnntrk_node_order_workspace_bytes(int64_t n_nodes);
 int gnntrk_node_order(const float *key, int64_t key_stride, const int64_t *batch, int64_t n_events, int64_t n_nodes,
@@ -272,6 +277,34 @@ typedef struct gnntrk_gseg {
     int32_t accumulate;
 } gnntrk_gseg;
 
+/* Target-side fold of ONE gathered segment's gradient inside gnntrk_mlp_backward_bf16 (round 6).
+ *
+ * The rows of an interaction network's relational model / of the edge-weight head are in CSR order, i.e. sorted by
+ * target node (models/interaction_network.py:67,75-89; models/edge_classifier.py:108-116), so the gradient of the
+ * target-gathered node rows can leave the kernel already summed per node instead of as one row per edge that a
+ * segment sum re-reads (16 B written + 16 B read per edge).  With `seg >= 0`:
+ *   - gseg[seg].ptr addresses the FOLDED gradient: [n_nodes] padded bf16 rows of gseg[seg].stride elements,
+ *     ZERO-FILLED by the caller (nodes without an edge are not written); gseg[seg].idx must be NULL;
+ *   - ids = the sorted id stream the segment is gathered through (== seg[seg].idx: int32[n_rows], non-decreasing);
+ *   - a unit of the kernel is 32 consecutive rows: every run of equal ids that STARTS in a unit is written to its
+ *     node's row (its part inside the unit, NOT yet gated by the segment's ReLU); the part of a run that began in
+ *     an earlier unit goes to the unit's carry row (8 bf16 = 16 bytes per unit: row n_nodes + unit of the same
+ *     allocation - gseg[seg].ptr addresses n_nodes + (n_rows + 31) / 32 rows).  gnntrk_fold_finish_bf16 then
+ *     adds, per node, the carries of the units its run continues into (unit order: deterministic, one thread per
+ *     node) and applies the relu' gate of the segment - call it on the same stream after the backward;
+ *   - arithmetic: the hidden-layer gradient (bf16, as the per-row form uses it) is summed per node in fp32 by an
+ *     MFMA against a 0/1 segment matrix, rounded to bf16 once, and goes through W1^T like a row's: one rounding
+ *     per node and unit instead of one per edge.
+ * Only the launches gnntrk_mlp_backward_bf16_can_fold says 1 for (the buffer-addressed relational / head shapes
+ * with two 16-row halves per unit, every gradient segment under the same ReLU flag); everything else rejects a
+ * fold with GNNTRK_EUNSUPPORTED. */
+typedef struct gnntrk_gfold {
+    const int32_t *ids; /* int32[n_rows], non-decreasing; NULL: no fold */
+    int64_t n_nodes;    /* node rows behind gseg[seg].ptr; (n_rows + 31) / 32 carry rows follow them */
+    int32_t seg;        /* folded segment */
+    int32_t _pad;
+} gnntrk_gfold;
+
 typedef struct gnntrk_mlp_bwd_args {
     gnntrk_mlp mlp;
     int32_t n_seg;
@@ -289,7 +322,18 @@ typedef struct gnntrk_mlp_bwd_args {
                             1 skip input-gradient stores, 2 skip input loads (zeros),
                             8 skip the LDS transposes (weight grads become garbage)      */
     int32_t _pad;
+    gnntrk_gfold fold;   /* ids == NULL: off (a zero-filled block is a valid "no fold") */
 } gnntrk_mlp_bwd_args;
+
+/* 1 if the launch described by `args` (filled as for the launch, fold included) takes the in-kernel fold. */
+int gnntrk_mlp_backward_bf16_can_fold(const gnntrk_mlp_bwd_args *args);
+/* Completes a fold: for every node n with rows [rowptr[n], rowptr[n + 1]) (the CSR row pointers of the sorted ids)
+ * out[n] = gate(bf16(out[n] + sum of the carry rows out[n_nodes + u] of the units u after the first one its rows reach)), fp32 adds in
+ * unit order, one rounding; gate: x != NULL (the folded segment's own input rows, read through a ReLU by the
+ * launch) zeroes the features whose input is not positive - the relu' of the segment, applied once per node.
+ * out: the folded rows of the launch (gseg[fold.seg].ptr; stride in elements, 8). */
+int gnntrk_fold_finish_bf16(uint16_t *out, int32_t out_stride, int64_t n_nodes, const int32_t *rowptr,
+                            int64_t n_units, const uint16_t *x, int32_t x_stride, void *stream);
 
 /* How many upstream-gradient terms gnntrk_mlp_backward_bf16 takes for this launch (args filled as for
  * the launch, n_gout ignored): 3 for the shapes that run on buffer descriptors (an edge embedding read by

@@ -360,6 +360,10 @@ inline u32x4_emul buf_load_u32x4(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
     for (int i = 0; i < 4; ++i) v[i] = hipemul_buf_dword(r, (uint64_t)voff + soff + 4 * i);
     return v;
 }
+inline void buf_store_u32(uint32_t v, buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const uint64_t off = (uint64_t)voff + soff;
+    if (off + 4 <= r.n) memcpy(r.base + off, &v, 4);
+}
 inline void buf_store_u32x2(u32x2_emul v, buf_rsrc_t r, uint32_t voff, uint32_t soff) {
     const uint64_t off = (uint64_t)voff + soff;
     for (int i = 0; i < 2; ++i)
@@ -432,6 +436,12 @@ inline int atomicMax(int *p, int v) {
     }
     return old;
 }
+inline unsigned atomicMax(unsigned *p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return old;
+}
 inline float atomicAdd(float *p, float v) {
     float old = *p, nw;
     do {
@@ -459,3 +469,4 @@ inline float __uint_as_float(unsigned u) {
     return f;
 }
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }  // callers pass uniform values
+inline unsigned __builtin_amdgcn_readlane(unsigned v, int srclane) { return hipemul_shfl(v, srclane); }   // (all lanes call it)

@@ -147,10 +147,26 @@ def case_node_order(device, n_hits=10_000, n_edges=100_000, modes=("f32", "bf16"
         u = v.contiguous().view(torch.int32).long() & 0xffffffff
         return torch.where(u >> 31 == 1, u ^ 0xffffffff, u ^ 0x80000000)
 
+    def levels(v, ev):   # the quantised key of the counting-sort form (include/gnntrk.h: gnntrk_node_order), fp32 step by step
+        out = torch.zeros(v.numel(), dtype=torch.int64)
+        for e in ev.unique().tolist():   # (lo / hi per event)
+            m = ev == e
+            w = v[m]
+            fin = w[~torch.isnan(w)]
+            lo, hi = (fin.min(), fin.max()) if fin.numel() else (torch.tensor(0.0), torch.tensor(0.0))
+            scale = torch.tensor(65535.0) / (hi - lo) if hi > lo else torch.tensor(0.0)
+            t = ((w - lo) * scale).clamp_min(0.0)
+            out[m] = torch.where(torch.isnan(w) | (t >= 65535.0), torch.tensor(65535), t.to(torch.int64))
+        return out
+
+    # (the own counting-sort form with 1 .. 64 stated events - no batch = one event -, the radix forms otherwise)
     for b, col, n_ev in ((batch, 1, 0), (None, 2, 0), (batch, 1, len(sizes)), (batch, 2, 200), (batch, 1, 1000)):
         perm, rank = ops.node_order(x.to(device), col, None if b is None else b.to(device), n_ev)
-        ebits = 0 if b is None else (32 if n_ev <= 0 else max(0, (n_ev - 1).bit_length()))
-        q = image(x[:, col]) >> (ebits if ebits <= 8 else 0)   # (up to eight event bits: the key keeps its top 32 - b bits)
+        if b is None or 1 <= n_ev <= 64:
+            q = levels(x[:, col], torch.zeros_like(batch) if b is None else b)
+        else:
+            ebits = 32 if n_ev <= 0 else max(0, (n_ev - 1).bit_length())
+            q = image(x[:, col]) >> (ebits if ebits <= 8 else 0)   # (up to eight event bits: the key keeps its top 32 - b bits)
         o = torch.argsort(q, stable=True)
         if b is not None:
             o = o[torch.argsort(b[o], stable=True)]
@@ -158,6 +174,21 @@ def case_node_order(device, n_hits=10_000, n_edges=100_000, modes=("f32", "bf16"
         inv = torch.empty_like(o)
         inv[o] = torch.arange(N)
         assert torch.equal(rank.cpu().long(), inv), "node_order: rank inverts perm"
+    # the counting-sort form: 5 events of 900 .. 3000 nodes (two empty ones in between), ties, a NaN, infinities apart
+    sizes2 = (900, 0, 3000, 1, 1200, 0)
+    batch2 = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes2)])
+    x2 = torch.from_numpy(g.uniform(-1, 1, (int(batch2.numel()), 3)).astype(np.float32))
+    x2[::11, 1] = 0.125
+    x2[17, 1] = float("nan")
+    for b, col, n_ev in ((batch2, 1, len(sizes2)), (None, 2, 0), (batch2, 2, 64)):
+        perm, rank = ops.node_order(x2.to(device), col, None if b is None else b.to(device), n_ev)
+        o = torch.argsort(levels(x2[:, col], torch.zeros_like(batch2) if b is None else b), stable=True)
+        if b is not None:
+            o = o[torch.argsort(b[o], stable=True)]
+        assert torch.equal(perm.cpu().long(), o), f"node_order (counting sort): perm is the stable (event, level) sort (n_events {n_ev})"
+        inv = torch.empty_like(o)
+        inv[o] = torch.arange(o.numel())
+        assert torch.equal(rank.cpu().long(), inv), "node_order (counting sort): rank inverts perm"
     offs, parts = 0, []
     for n in sizes:
         parts.append(g.integers(0, n, size=(2, 9 * n + 3)) + offs)
@@ -253,7 +284,7 @@ def case_graph_index_place(device, sizes=((700, 6301), (1, 3), (300, 2500), (204
     ops.clear_graph_index_cache()
     gi = ops.place_graph_indices(parts, b)
     ref = ops.graph_index(b.edge_index, b.num_nodes, cache=False, carry_label=b.y, carry_rows=b.edge_attr,
-                          order_by=None if col is None else (b.x, col, b.batch))
+                          order_by=None if col is None else (b.x, col, b.batch, len(sizes)))   # (event count stated, as the model does)
     for k in ("perm", "tgt", "src", "rowptr_t", "rowptr_s", "spos", "spos_inv") + (("node_perm", "node_rank") if order else ()):
         assert torch.equal(getattr(gi, k), getattr(ref, k)), f"placed index: {k} differs from the built one"
     assert torch.equal(ops.carried_label(gi, b.y), ops.carried_label(ref, b.y)), "placed index: carried labels"
@@ -295,7 +326,8 @@ def case_resident_dataset(device, sizes=((700, 6301), (300, 2500), (2049, 18002)
                 gi = ops.placed_graph_index(b.edge_index, b.num_nodes)
                 assert gi is not None and gi.node_perm is not None, "ResidentDataset: no placed, ordered index"
                 ref = ops.graph_index(b.edge_index, b.num_nodes, cache=False, carry_label=b.y,
-                                      carry_rows=b.edge_attr if bf16 else None, order_by=(b.x, 1, b.batch))
+                                      carry_rows=b.edge_attr if bf16 else None,
+                                      order_by=(b.x, 1, b.batch, int(b.ptr.numel()) - 1))   # (event count stated, as the model does)
                 for k in ("perm", "tgt", "src", "rowptr_t", "rowptr_s", "spos", "spos_inv", "node_perm", "node_rank"):
                     assert torch.equal(getattr(gi, k), getattr(ref, k)), f"resident batch: {k} differs from the inline build"
                 assert torch.equal(ops.carried_label(gi, b.y), ops.carried_label(ref, b.y))
@@ -769,13 +801,14 @@ TOL16 = 2.0 ** -7
 TOL16_SIG = 1e-4
 
 
-def _rand_rows16(rows, dim, device, gen):
+def _rand_rows16(rows, dim, device, gen, poison=True):
     from gnn_tracking_amd import ops_bf16 as B
     t = B.empty_rows(rows, dim, "cpu", zero=True)
     t.copy_(torch.randn(rows, dim, generator=gen))
-    # poison the padding: the kernels must ignore it
+    # poison the padding: the kernels must ignore it (poison=False: the buffer-addressed shapes read pads as stored -
+    # every producer of padded rows in the library writes zeros, include/gnntrk.h)
     buf = t.as_strided((rows, B.pad4(dim)), (B.pad4(dim), 1))
-    if B.pad4(dim) > dim:
+    if B.pad4(dim) > dim and poison:
         buf[:, dim:] = float("nan")
     return t.to(device) if device != "cpu" else t
 
@@ -976,6 +1009,124 @@ def case_mlp_bf16_backward(device, rows=75, full=True, cases=None, seed=1):
             assert_close(gW[i], dW[i], TOL16, f"{tag} gW{i}")
             if bias:
                 assert_close(gb[i], db[i], TOL16, f"{tag} gb{i}")
+
+
+def case_mlp_bf16_fold(device, seed=5, sizes=(1, 31, 32, 33, 75, 640, 2050)):
+    """The in-kernel target fold of the bf16 backward (include/gnntrk.h: gnntrk_gfold): the gradient of the segment
+    gathered through SORTED ids leaves the kernel summed per node.  Relational shape (x_i | x_j | e, with and without
+    the ReLU on load, two and three upstream terms) and the edge-weight head's shape (h[src] | h[tgt] | four edge
+    tensors, fp32 upstream gradient), id patterns that exercise every arm of the unit logic: runs that cross units
+    (carry rows), a hub node spanning several units (a carry chain), ids more than 16 apart inside a unit (the
+    window loop), isolated nodes (rows the kernel never writes), row counts around the 32-row unit.  Against the
+    oracle's per-row gradients summed per node, against the per-row form + segment sum of the same launch, and the
+    parameter gradients of the two forms bit for bit."""
+    from gnn_tracking_amd import _capi, ops_bf16 as B
+
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    lib = _capi.load()
+    shapes = [
+        # (dims, gathered, relu, hidden, out, epilogue, n_gout, folded segment)
+        ((5, 5, 4), (True, True, False), (True, True, True), 40, 4, "none", 2, 0),
+        ((5, 5, 4), (True, True, False), (False, False, False), 40, 4, "none", 3, 0),
+        ((5, 5, 4, 4, 4, 4), (True, True, False, False, False, False), (False,) * 6, 40, 1, "sigmoid", 1, 1),
+    ]
+    epi_code = {"none": _capi.EPI_NONE, "sigmoid": _capi.EPI_SIGMOID}
+
+    def sorted_ids(rows, n_nodes, kind):
+        if kind == "random":       # degrees ~ 6: most runs cross a 16-row half, many a 32-row unit
+            ids = torch.sort(torch.randint(0, n_nodes, (rows,), generator=gen)).values
+        elif kind == "hub":        # one node owns 100 consecutive rows (a chain of carries), the rest random
+            ids = torch.sort(torch.cat([torch.randint(0, n_nodes, (max(rows - 100, 0),), generator=gen),
+                                        torch.full((min(rows, 100),), n_nodes // 2)])).values
+        elif kind == "sparse":     # ids 40 apart on average: windows beyond the first, isolated nodes everywhere
+            ids = torch.sort(torch.randint(0, n_nodes, (rows,), generator=gen) // 40 * 40).values
+        else:                      # "one": every row the same node
+            ids = torch.full((rows,), n_nodes - 1)
+        return ids.int()
+
+    checked = 0
+    for dims, gath, relu, hid, out, epi, n_gout, jf in shapes:
+        for rows in sizes:
+            for kind in ("random", "hub", "sparse", "one"):
+                n_nodes = 977 if kind == "sparse" else max(rows // 6, 3)
+                n_src = n_nodes
+                segs, idxs = [], []
+                for j, (d, gflag) in enumerate(zip(dims, gath)):
+                    # (the two gathered segments read ONE node tensor - by target and by source - as in the models:
+                    #  one descriptor with two id streams is what the buffer-addressed shapes are)
+                    segs.append(segs[0] if gflag and j > 0 else B.rows16(_rand_rows16(n_src if gflag else rows, d, device, gen, poison=False)))
+                    if not gflag:
+                        idxs.append(None)
+                    elif j == jf:
+                        idxs.append(sorted_ids(rows, n_nodes, kind).to(device))
+                    else:
+                        idxs.append(torch.randint(0, n_src, (rows,), generator=gen).int().to(device))
+                m = G.MLP(sum(dims), out, hid, L=3, bias=True)
+                weights = [l.weight.detach() for l in m.linears()]
+                biases = [l.bias.detach() for l in m.linears()]
+                ca, cb = (0.001, 0.998) if epi == "sigmoid" else (0.0, 1.0)
+                gout, g_sum = [], torch.zeros(rows, out)
+                if epi == "sigmoid":
+                    gfull = torch.randn(rows, out, generator=gen)
+                    gout.append((gfull.to(device), None))
+                    g_sum = gfull
+                else:
+                    for t in range(n_gout):
+                        if t == 1:   # the aggregation's share, gathered through the sorted ids
+                            gt = B.rows16(_rand_rows16(n_src, out, device, gen, poison=False))
+                            gout.append((gt, idxs[jf]))
+                            g_sum = g_sum + gt.float().cpu()[idxs[jf].cpu().long()]
+                        else:
+                            gt = B.rows16(_rand_rows16(rows, out, device, gen, poison=False))
+                            gout.append((gt, None))
+                            g_sum = g_sum + gt.float().cpu()
+                xin, raw = [], []
+                for t, idx, r in zip(segs, idxs, relu):
+                    v = t.float().cpu()
+                    if idx is not None:
+                        v = v[idx.cpu().long()]
+                    raw.append(v)
+                    xin.append(torch.relu(v) if r else v)
+                gin, dW, db = O.mlp_bf16_backward(torch.cat(xin, 1), weights, biases, g_sum, epi, ca, cb)
+                wd = [w.to(device).contiguous() for w in weights]
+                bd = [b.to(device).contiguous() for b in biases]
+                need = [True] * len(dims)
+                other = 1 - jf   # the source-gathered twin: its rows leave through a permutation, as in the step
+                gperm = torch.randperm(rows, generator=gen)
+                gidx = [gperm.int().to(device) if j == other else None for j in range(len(dims))]
+                kw = dict(n_rows=rows, epilogue=epi_code[epi], ca=ca, cb=cb, gout=gout, need_seg=need, want_dw=True,
+                          gidx=gidx)
+                res = {}
+                for mode in (True, False):
+                    old, B.FOLD_IN_KERNEL = B.FOLD_IN_KERNEL, mode
+                    try:
+                        rowptr = torch.searchsorted(idxs[jf].cpu().long(), torch.arange(n_nodes + 1)).int().to(device)
+                        slices, gW, gb = B.mlp_backward_raw(segs, idxs, relu, wd, bd, mlp=ops._fill_mlp(wd, bd),
+                                                            fold=(jf, n_nodes, rowptr), **kw)
+                    finally:
+                        B.FOLD_IN_KERNEL = old
+                    res[mode] = (slices, [g.clone() for g in gW], [g.clone() for g in gb])
+                tag = f"bf16 fold {dims}->{hid}->{out} {epi} gout={n_gout} rows={rows} ids={kind}"
+                sl_f, gW_f, gb_f = res[True]
+                sl_p, gW_p, gb_p = res[False]
+                assert jf in sl_f.folded, f"{tag}: the launch did not take the fold"
+                assert not sl_p.folded and tuple(sl_p[jf].shape) == (rows, dims[jf])
+                assert tuple(sl_f[jf].shape) == (n_nodes, dims[jf])
+                col = sum(dims[:jf])
+                want_rows = gin[:, col:col + dims[jf]] * ((raw[jf] > 0) if relu[jf] else 1.0)
+                want = torch.zeros(n_nodes, dims[jf]).index_add_(0, idxs[jf].cpu().long(), want_rows.float())
+                assert_rows_close(sl_f[jf].float(), want, 2 * TOL16, f"{tag} folded vs oracle")
+                per_row = torch.zeros(n_nodes, dims[jf]).index_add_(0, idxs[jf].cpu().long(), sl_p[jf].float().cpu())
+                assert_rows_close(sl_f[jf].float(), per_row, 2 * TOL16, f"{tag} folded vs per-row form")
+                # everything else of the launch is the same arithmetic: identical bits
+                for j in range(len(dims)):
+                    if j != jf:
+                        assert torch.equal(sl_f[j], sl_p[j]), f"{tag}: slice {j} differs between the two forms"
+                for i in range(3):
+                    assert torch.equal(gW_f[i], gW_p[i]) and torch.equal(gb_f[i], gb_p[i]), f"{tag}: parameter gradients differ"
+                checked += 1
+    return checked
 
 
 def case_bf16_shape_rules_agree(device, hiddens=(1, 16, 31, 32, 33, 40, 47, 48, 63, 64, 65, 95, 96, 97, 112, 127, 128, 129),

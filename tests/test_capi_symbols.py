@@ -33,7 +33,7 @@ def test_version_and_error_channel(lib_path):
     from gnn_tracking_amd import _capi
 
     lib = _capi.bind(ctypes.CDLL(str(lib_path)))
-    assert lib.gnntrk_version() == 500
+    assert lib.gnntrk_version() == 600
     # argument validation happens on the host, before any launch
     rc = lib.gnntrk_mlp_forward(None, None)
     assert rc == 1 and b"NULL" in lib.gnntrk_last_error()
@@ -70,7 +70,7 @@ def test_struct_layout_matches_header():
     assert _capi.MlpFwdArgs.n_rows.offset == 392
     assert ctypes.sizeof(_capi.GraphIndex) == 72
     assert ctypes.sizeof(_capi.GraphIndexCarry) == 48
-    assert ctypes.sizeof(_capi.MlpBwdArgs) == 784
+    assert ctypes.sizeof(_capi.MlpBwdArgs) == 808 and ctypes.sizeof(_capi.GFold) == 24
     assert ctypes.sizeof(_capi.ResFcnn) == 8 * (5 + 2 * _capi.RESFCNN_MAX_HIDDEN) + 32
     assert ctypes.sizeof(_capi.ResFcnnGrads) == 8 * (5 + 2 * _capi.RESFCNN_MAX_HIDDEN)
     assert ctypes.sizeof(_capi.HingeArgs) == 56 and _capi.HingeArgs.r_emb.offset == 40

@@ -78,3 +78,10 @@ def test_batch_gradient_is_sum_of_event_gradients_emulated():
     hits x 2 400 edges, fp32 and bf16 storage."""
     with emulated():
         print(P.case_full_size_backward("cpu", n_events=4, n_nodes=300, n_edges=2400))
+
+
+def test_mlp_bf16_in_kernel_fold_emulated():
+    """gnntrk_gfold on the wave64 emulator (the same kernel sources): carries, carry chains, windows, isolated
+    nodes, the tail unit - relational and head shapes."""
+    with emulated():
+        assert P.case_mlp_bf16_fold("cpu", sizes=(1, 31, 33, 75, 640)) == 3 * 5 * 4

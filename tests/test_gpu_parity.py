@@ -15,7 +15,7 @@ def dev():
     from gnn_tracking_amd import _capi
 
     lib = _capi.load()  # fails loudly if the extension is missing
-    assert lib.gnntrk_version() == 500
+    assert lib.gnntrk_version() == 600
     return "cuda"
 
 
@@ -355,6 +355,12 @@ def test_pruned_paths_random_stress(dev):
     r = subprocess.run([sys.executable, str(root / "tools" / "gpu_stress_pruned.py"), "5", "10"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "pruned stress ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_mlp_bf16_in_kernel_fold(dev):
+    """gnntrk_gfold: the target-gathered segment's gradient summed per node inside the backward kernel - relational
+    and head shapes, carries / carry chains / id windows / isolated nodes / the tail unit (60 + 24 configurations)."""
+    assert P.case_mlp_bf16_fold(dev) == 3 * 7 * 4
 
 
 def test_cfg3_full_size_event_against_oracle(dev):

@@ -14,7 +14,7 @@ SQ="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAI
 cd /tmp
 rocprofv3 --kernel-trace -d /tmp/p_k -o k -- $B > /dev/null 2>&1
 python $ROOT/tools/rocpd_summary.py /tmp/p_k/k_results.db > $ROOT/$OUT/${TAG}_bench_cfg3_bf16_kernel_stats.md
-(cd $ROOT/tools && python rocpd_timeline.py /tmp/p_k/k_results.db --mark no_keys > $ROOT/$OUT/${TAG}_step_timeline.md)
+(cd $ROOT/tools && python rocpd_timeline.py /tmp/p_k/k_results.db --mark no_minmax > $ROOT/$OUT/${TAG}_step_timeline.md)
 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -o f -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -o w -- $B > /dev/null 2>&1
 python $ROOT/tools/make_traffic_json.py /tmp/p_f/f_results.db /tmp/p_w/w_results.db 64000000 \

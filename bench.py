@@ -328,12 +328,12 @@ def access_floor(wl, dev, iters: int = 6) -> dict:
         hreal, hskel = timed(0), timed(4096)
         launch = launch_rel
         halg = (2 * 16 + 4 * 8 + 4 + 8 + 2 * 16 + 4 * 8 + 4) * E   # rows read + ids + upstream + gradient rows + permutation ids
-        head = {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, true, 2, IoHead>", "skeleton_ms": hskel,
+        head = {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, true, 2, IoHeadT<false> >", "skeleton_ms": hskel,
                 "kernel_ms_isolated": hreal, "frac": halg / (hskel * 1e-3) / 1e9 / (PEAK_HBM_TBPS * 1e3),
                 "share_of_kernel": hskel / hreal}
     except Exception as e:   # (the relational floor survives a failing head launch)
         head = {"error": f"{type(e).__name__}: {e}"}
-    return {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, false, 2, IoRelational<3> >", "head": head,
+    return {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, false, 2, IoRelational<3, false> >", "head": head,
             "what": "loads + stores of the relational backward (three upstream terms) without its arithmetic, same "
                     "occupancy and prefetch distance, this run's batch; launched alone (HIP events around launch + "
                     "partial reduction), median of %d" % iters,

@@ -44,7 +44,15 @@ int mlp16_bwd_kernel_name(const gnntrk_mlp_bwd_args *a, char *buf, size_t len) {
     make_buf_plan(B, P, a, GT);
     const char *io = buf_io_name(B, P.KI, P.HT, GT, a->mlp.n_layers == 3, g32, a->debug_flags, a->epilogue);
     // (as rocprofv3 prints the instantiation: a template argument that itself ends in '>' is followed by a space)
-    const char *ion = io[0] ? io : "IoNone";
+    // (as rocprofv3 prints the class: the fold flag is a template argument, the launch tables use comma-free aliases)
+    const char *ion = !io[0] ? "IoNone"
+                      : !strcmp(io, "IoRelational<2>") ? "IoRelational<2, false>"
+                      : !strcmp(io, "IoRelational<3>") ? "IoRelational<3, false>"
+                      : !strcmp(io, "IoRelationalF2") ? "IoRelational<2, true>"
+                      : !strcmp(io, "IoRelationalF3") ? "IoRelational<3, true>"
+                      : !strcmp(io, "IoHead") ? "IoHeadT<false>"
+                      : !strcmp(io, "IoHeadF") ? "IoHeadT<true>"
+                      : io;
     snprintf(buf, len, "mlp16_bwd_kernel<%d, %d, %d, %s, %s, %d, %s%s>", P.KI, P.HT, GT,
              a->mlp.n_layers == 3 ? "true" : "false", g32 ? "true" : "false", D, ion,
              ion[strlen(ion) - 1] == '>' ? " " : "");

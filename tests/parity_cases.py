@@ -189,6 +189,15 @@ def case_node_order(device, n_hits=10_000, n_edges=100_000, modes=("f32", "bf16"
         inv = torch.empty_like(o)
         inv[o] = torch.arange(o.numel())
         assert torch.equal(rank.cpu().long(), inv), "node_order (counting sort): rank inverts perm"
+    if device != "cpu":   # the headline's size: 32 events x 150 000 hits, azimuth-like keys (fp32 uniform: many shared levels)
+        nb, ne = 150_000, 32
+        xb = torch.from_numpy(g.uniform(-1, 1, (nb * ne, 2)).astype(np.float32))
+        bb = torch.arange(ne).repeat_interleave(nb)
+        perm, rank = ops.node_order(xb.to(device), 1, bb.to(device), ne)
+        o = torch.argsort(levels(xb[:, 1], bb), stable=True)
+        o = o[torch.argsort(bb[o], stable=True)]
+        assert torch.equal(perm.cpu().long(), o), "node_order (counting sort, 4.8 M nodes): perm is the stable (event, level) sort"
+        assert torch.equal(rank.cpu().long()[o], torch.arange(nb * ne)), "node_order (4.8 M nodes): rank inverts perm"
     offs, parts = 0, []
     for n in sizes:
         parts.append(g.integers(0, n, size=(2, 9 * n + 3)) + offs)

@@ -310,6 +310,7 @@ def access_floor(wl, dev, iters: int = 6) -> dict:
     alg = 92.0 * E
     # the edge-weight head's backward the same way (h[src] | h[tgt] | four edge embeddings, fp32 upstream gradient)
     head = None
+    launch_rel = launch
     try:
         es = [rows(E, 4) for _ in range(4)]
         mh = G.MLP(26, 1, 40, L=3).to(dev)
@@ -324,7 +325,7 @@ def access_floor(wl, dev, iters: int = 6) -> dict:
                                       need_seg=[True] * 6, want_dw=True, mlp=mlph,
                                       gidx=[gi.spos_inv, None, None, None, None, None])
 
-        launch_rel, launch = launch, launch_head
+        launch = launch_head
         hreal, hskel = timed(0), timed(4096)
         launch = launch_rel
         halg = (2 * 16 + 4 * 8 + 4 + 8 + 2 * 16 + 4 * 8 + 4) * E   # rows read + ids + upstream + gradient rows + permutation ids
@@ -333,7 +334,22 @@ def access_floor(wl, dev, iters: int = 6) -> dict:
                 "share_of_kernel": hskel / hreal}
     except Exception as e:   # (the relational floor survives a failing head launch)
         head = {"error": f"{type(e).__name__}: {e}"}
-    return {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, false, 2, IoRelational<3, false> >", "head": head,
+    # ... and the relational FORWARD (x[tgt] | x[src] | e -> e~): mlp16_fwd_skel_kernel
+    fwd = None
+    try:
+        def launch_fwd():
+            return B.mlp_forward_raw([h, h, e], [gi.tgt, gi.src, None], [True, True, True], W, bs, n_rows=E,
+                                     epilogue=_capi.EPI_NONE, ca=0.0, cb=1.0, res=None, out_idx=None, out_rows=E, mlp=mlp)
+
+        launch = launch_fwd
+        freal, fskel = timed(0), timed(4096)
+        launch = launch_rel
+        falg = 44.0 * E   # (as the bench counts the forward: bf16 rows + int32 ids in, e~ out)
+        fwd = {"kernel": "mlp16_fwd_skel_kernel<1, 3, true, false, 4, true>", "skeleton_ms": fskel, "kernel_ms_isolated": freal,
+               "frac": falg / (fskel * 1e-3) / 1e9 / (PEAK_HBM_TBPS * 1e3), "share_of_kernel": fskel / freal}
+    except Exception as e_:   # noqa: BLE001
+        fwd = {"error": f"{type(e_).__name__}: {e_}"}
+    return {"kernel": "mlp16_bwd_skel_kernel<1, 3, 2, true, false, 2, IoRelational<3, false> >", "head": head, "forward": fwd,
             "what": "loads + stores of the relational backward (three upstream terms) without its arithmetic, same "
                     "occupancy and prefetch distance, this run's batch; launched alone (HIP events around launch + "
                     "partial reduction), median of %d" % iters,

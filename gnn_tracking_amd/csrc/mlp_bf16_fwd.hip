@@ -38,8 +38,16 @@ namespace gnntrk {
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);           \
         }                                                                               \
     }
+// the I/O skeleton of the two large forward shapes (three hidden tiles, shared output tile): debug_flags & 4096
+#define GNNTRK_FWD16_SKEL(S_, W_)                                                       \
+    if (!launched && (a->debug_flags & 4096) && P.KI == 1 && P.HT == 3 && three && share && sig == S_ && wide == W_) { \
+        auto kfn = mlp16_fwd_skel_kernel<1, 3, true, S_, 4, W_>;                        \
+        GNNTRK_FWD16_GRID(kfn)                                                          \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), 0, stream, *a);               \
+        launched = true;                                                                \
+    }
 #define GNNTRK_FWD16_CASE(KI_, HT_)                                                     \
-    if (P.KI == KI_ && P.HT == HT_) {                                                   \
+    if (!launched && P.KI == KI_ && P.HT == HT_) {                                      \
         if (three && sig && share) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, true, 4)         \
         else if (three && sig) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, true, 1)             \
         else if (three && share) GNNTRK_FWD16_LAUNCH(KI_, HT_, true, false, 4)          \
@@ -163,6 +171,8 @@ int mlp_forward_bf16_launch(const gnntrk_mlp_fwd_args *a, hipStream_t stream) {
         if (!launched) return fail(GNNTRK_EUNSUPPORTED, "mlp_forward_bf16: no instantiation (bias_init)");
         return check_launch("mlp_forward_bf16");
     }
+    GNNTRK_FWD16_SKEL(false, true)    // relational / object-shaped: bf16 output, 16-byte loads
+    GNNTRK_FWD16_SKEL(true, false)    // the edge-weight head: fp32 sigmoid output, 8-byte loads
     GNNTRK_FWD16_CASE(1, 1)
     GNNTRK_FWD16_CASE(1, 2)
     GNNTRK_FWD16_CASE(1, 3)

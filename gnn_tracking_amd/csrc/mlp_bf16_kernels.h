@@ -369,21 +369,31 @@ __host__ __device__ constexpr int fwd16_waves_per_simd() {
 template <int KI, int HT, bool THREE, bool SIG, int R_, bool WIDE_>
 __global__ __launch_bounds__(kBlock, (fwd16_waves_per_simd<KI, HT, THREE, SIG, R_, WIDE_>())) void mlp16_fwd_kernel(const gnntrk_mlp_fwd_args a) {
     constexpr int R = R_, OT = 1;
-    constexpr bool WIDE = WIDE_, BI = false;
+    constexpr bool WIDE = WIDE_, BI = false, kFwdSkel = false;
+#include "mlp_bf16_fwd_body.inc"
+}
+// The I/O SKELETON of a forward launch (debug_flags & 4096; results are NOT outputs): every load and every store of
+// the kernel above - id streams, gathered and tile rows, the output rows - with the same prefetch distance, workgroup
+// shape and launch bounds, and an XOR where the MLP is.  Its time is the floor this access pattern sets for the real
+// kernel (bench.py: roofline.access_floor.forward), as mlp16_bwd_skel_kernel is for the backward.
+template <int KI, int HT, bool THREE, bool SIG, int R_, bool WIDE_>
+__global__ __launch_bounds__(kBlock, (fwd16_waves_per_simd<KI, HT, THREE, SIG, R_, WIDE_>())) void mlp16_fwd_skel_kernel(const gnntrk_mlp_fwd_args a) {
+    constexpr int R = R_, OT = 1;
+    constexpr bool WIDE = WIDE_, BI = false, kFwdSkel = true;
 #include "mlp_bf16_fwd_body.inc"
 }
 // outputs of 17 .. 48 features (OT output tiles), up to four k-steps of inputs: plain form
 template <int KI, int HT, int OT_, bool THREE>
 __global__ __launch_bounds__(kBlock) void mlp16_fwd_ot_kernel(const gnntrk_mlp_fwd_args a) {
     constexpr int R = 1, OT = OT_;
-    constexpr bool WIDE = false, BI = false, SIG = false;
+    constexpr bool WIDE = false, BI = false, SIG = false, kFwdSkel = false;
 #include "mlp_bf16_fwd_body.inc"
 }
 // hidden width 64 with biases: no constant-one row, biases as accumulator initial values
 template <int KI, int HT, bool THREE, bool SIG>
 __global__ __launch_bounds__(kBlock) void mlp16_fwd_bi_kernel(const gnntrk_mlp_fwd_args a) {
     constexpr int R = 1, OT = 1;
-    constexpr bool WIDE = false, BI = true;
+    constexpr bool WIDE = false, BI = true, kFwdSkel = false;
 #include "mlp_bf16_fwd_body.inc"
 }
 

@@ -201,13 +201,19 @@ class ResidentDataset:
     def __len__(self) -> int:
         return len(self._events)
 
-    def _key_column(self, e: Data):
+    def _policy_column(self):
+        """The column this dataset orders its events by (None: it does not)."""
         from . import locality
 
-        if self.order is False or "node_order_key" in e or (self.order is True and locality.mode() == "off"):
+        if self.order is False or (self.order is True and locality.mode() == "off"):
             return None
-        col = int(self.order) if self.order is not True else (
+        return int(self.order) if self.order is not True else (
             locality.AUTO_COLUMN if locality.mode() == "auto" else int(locality.mode()))
+
+    def _key_column(self, e: Data):
+        col = self._policy_column()
+        if col is None or "node_order_key" in e:
+            return None
         x = e.x
         return col if x.dim() == 2 and x.dtype == torch.float32 and 0 <= col < x.shape[1] and x.shape[0] >= 2 else None
 
@@ -236,7 +242,9 @@ class ResidentDataset:
         for s in range(0, len(idx), int(batch_size)):
             evs = [self.event(i) for i in idx[s:s + int(batch_size)]]
             batch = collate([e for e, _ in evs])
-            ops.place_graph_indices([p for _, p in evs], batch)
+            # (events the loader renumbered when it read them keep their order: nothing to place through)
+            oc = self._policy_column() if any("node_order_key" not in e for e, _ in evs) else None
+            ops.place_graph_indices([p for _, p in evs], batch, order_col=oc)
             yield batch
 
 

@@ -310,7 +310,7 @@ def graph_index(edge_index: Tensor, n_nodes: int, *, cache: bool = True,
     return gi
 
 
-def place_graph_indices(parts: Sequence[GraphIndex], batch) -> GraphIndex:
+def place_graph_indices(parts: Sequence[GraphIndex], batch, order_col: Optional[int] = None) -> GraphIndex:
     """The graph index of a collated ``batch`` (``data.collate`` of the events the ``parts`` were built from, in that
     order) from CACHED per-event indices: every part is copied into the batch arrays at its node / edge offset
     (gnntrk_graph_index_place) - identical to building the index of ``batch.edge_index``, carried labels / edge
@@ -345,12 +345,14 @@ def place_graph_indices(parts: Sequence[GraphIndex], batch) -> GraphIndex:
         if sizes != [p.n_nodes for p in parts]:
             raise ValueError(f"place_graph_indices: the events of the batch hold {sizes} nodes, the parts {[p.n_nodes for p in parts]}")
     # an event the loader left unordered (fewer than two hits, no key column) among ordered ones is its own order
+    # (``order_col``: the loader orders its events by this column - a batch of nothing but such events is still ordered)
+    want_order = any(ordered) or order_col is not None
     ident = {}
-    if any(ordered) and not all(ordered):
+    if want_order and not all(ordered):
         for i, p in enumerate(parts):
             if not ordered[i]:
                 ident[i] = torch.arange(p.n_nodes, dtype=torch.int32, device=dev)
-    if any(ordered):
+    if want_order:
         gi.node_perm, gi.node_rank = mk(N), mk(N)
     lab_b = torch.empty(E, dtype=torch.uint8, device=dev) if has_lab else None
     rows_b = None
@@ -376,8 +378,8 @@ def place_graph_indices(parts: Sequence[GraphIndex], batch) -> GraphIndex:
         gi._label_csr = (id(y), y._version, weakref.ref(y), lab_b)
     if rows_b is not None and isinstance(ea, Tensor):
         gi._rows_csr = (id(ea), ea._version, weakref.ref(ea), rows_b)
-    if any(ordered):
-        col = parts[ordered.index(True)].order_sig[2]
+    if want_order:
+        col = parts[ordered.index(True)].order_sig[2] if any(ordered) else int(order_col)
         bt = getattr(batch, "batch", None)
         gi.order_sig, gi._order_ref = _order_sig((batch.x, col, bt if isinstance(bt, Tensor) else None)), weakref.ref(batch.x)
     gi._built_from = (weakref.ref(ei), ei._version)

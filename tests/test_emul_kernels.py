@@ -30,7 +30,7 @@ def test_graph_index_placed_from_cached_events():
 
 def test_resident_dataset():
     with emulated():
-        P.case_resident_dataset("cpu", sizes=((300, 2500), (97, 800), (513, 4000), (50, 333)))
+        P.case_resident_dataset("cpu", sizes=((300, 2500), (97, 800), (1, 0), (513, 4000), (50, 333)))
 
 
 def test_graph_index_carry_and_fused_bce():

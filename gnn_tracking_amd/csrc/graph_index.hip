@@ -37,6 +37,9 @@ namespace gnntrk {
 
 constexpr int kTpb = 256;
 
+#ifndef GNNTRK_REMAP_NT
+#define GNNTRK_REMAP_NT 3   // (bit 0: non-temporal id loads, bit 1: non-temporal stores of gi_remap_kernel - A/B builds)
+#endif
 #ifndef GNNTRK_NO_LIBRARY_SORT_OFF
 #define GNNTRK_NO_LIBRARY_SORT_OFF 0   // (1: gnntrk_node_order always takes the exact radix form - A/B builds)
 #endif
@@ -265,7 +268,11 @@ __global__ __launch_bounds__(kTpb) void gi_remap_kernel(const int64_t *__restric
             // (the id streams and the outputs pass through once: non-temporal, the lookup table keeps the L2)
             typedef int i4_hw __attribute__((ext_vector_type(4)));
             auto ld2 = [](const int64_t *p, long long &a, long long &b) {   // two ids as one 16-byte non-temporal load
+#if GNNTRK_REMAP_NT & 1
                 const i4_hw v = __builtin_nontemporal_load(reinterpret_cast<const i4_hw *>(p));
+#else
+                const i4_hw v = *reinterpret_cast<const i4_hw *>(p);
+#endif
                 a = (long long)(((unsigned long long)(uint32_t)v[1] << 32) | (uint32_t)v[0]);
                 b = (long long)(((unsigned long long)(uint32_t)v[3] << 32) | (uint32_t)v[2]);
             };
@@ -279,10 +286,20 @@ __global__ __launch_bounds__(kTpb) void gi_remap_kernel(const int64_t *__restric
                 it[q] = chk(it[q]);
                 is[q] = chk(is[q]);
             }
+#if GNNTRK_REMAP_NT & 4   // (timing probe: no table lookups - results are NOT a renumbering)
+            const i4_hw ot = {(int)it[0], (int)it[1], (int)it[2], (int)it[3]};
+            const i4_hw os = {(int)is[0], (int)is[1], (int)is[2], (int)is[3]};
+#else
             const i4_hw ot = {rank[it[0]], rank[it[1]], rank[it[2]], rank[it[3]]};
             const i4_hw os = {rank[is[0]], rank[is[1]], rank[is[2]], rank[is[3]]};
+#endif
+#if GNNTRK_REMAP_NT & 2
             __builtin_nontemporal_store(ot, reinterpret_cast<i4_hw *>(tgt32 + e));
             __builtin_nontemporal_store(os, reinterpret_cast<i4_hw *>(src32 + e));
+#else
+            *reinterpret_cast<i4_hw *>(tgt32 + e) = ot;
+            *reinterpret_cast<i4_hw *>(src32 + e) = os;
+#endif
         } else {
             for (int q = 0; q < 4 && e + q < E; ++q) {
                 tgt32[e + q] = rank[chk(tgt[e + q])];

@@ -282,9 +282,9 @@ typedef struct gnntrk_gseg {
  * The rows of an interaction network's relational model / of the edge-weight head are in CSR order, i.e. sorted by
  * target node (models/interaction_network.py:67,75-89; models/edge_classifier.py:108-116), so the gradient of the
  * target-gathered node rows can leave the kernel already summed per node instead of as one row per edge that a
- * segment sum re-reads (16 B written + 16 B read per edge).  With `seg >= 0`:
- *   - gseg[seg].ptr addresses the FOLDED gradient: [n_nodes] padded bf16 rows of gseg[seg].stride elements,
- *     ZERO-FILLED by the caller (nodes without an edge are not written); gseg[seg].idx must be NULL;
+ * segment sum re-reads (16 B written + 16 B read per edge).  With `ids != NULL`:
+ *   - gseg[seg].ptr addresses the FOLDED gradient: [n_nodes] padded bf16 rows of gseg[seg].stride = 8 elements
+ *     (+ the carry rows, below), ZERO-FILLED by the caller (nodes without an edge are not written); gseg[seg].idx must be NULL;
  *   - ids = the sorted id stream the segment is gathered through (== seg[seg].idx: int32[n_rows], non-decreasing);
  *   - a unit of the kernel is 32 consecutive rows: every run of equal ids that STARTS in a unit is written to its
  *     node's row (its part inside the unit, NOT yet gated by the segment's ReLU); the part of a run that began in

@@ -318,7 +318,9 @@ def place_graph_indices(parts: Sequence[GraphIndex], batch, order_col: Optional[
     device across epochs (the reference's are static: utils/loading.py:97-100): build ``graph_index(ev.edge_index,
     ev.num_nodes, cache=False, carry_label=ev.y, carry_rows=ev.edge_attr, order_by=...)`` once per event, collate
     as usual, call this per batch.  The result is registered in the cache under ``batch.edge_index`` (and the
-    batch's ``y`` / ``edge_attr`` / ``x``), so ``ECForGraphTCN`` and the losses find it."""
+    batch's ``y`` / ``edge_attr`` / ``x``), so ``ECForGraphTCN`` and the losses find it.  Parts without a node order
+    among ordered ones (a single-hit event) take the identity order; ``order_col``: the column the loader orders its
+    events by - a batch of nothing but unordered parts is then still an ordered batch (identity everywhere)."""
     parts = list(parts)
     if not parts:
         raise ValueError("place_graph_indices: no parts")

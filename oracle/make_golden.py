@@ -476,6 +476,21 @@ def g6_mlgc(test_graph):
         arrs[f"k{k}_r{r}/edge_index"] = out.edge_index
         arrs[f"k{k}_r{r}/y"] = out.y
         arrs[f"k{k}_r{r}/edge_attr"] = out.edge_attr
+    # the false-edge subsampling of training mode (graph_construction.py:373-384: the FIRST int(n_true * ratio) false
+    # edges, then every true edge - no random draw)
+    for k, r, rof in ((16, 0.5, 0.5), (4, 1.0, 2.0)):
+        m = MLGraphConstruction(ml=None, embedding_slice=(0, 3), max_radius=r, max_num_neighbors=k, ratio_of_false=rof)
+        m.train()
+        d = Data(**{a: getattr(test_graph, a) for a in test_graph.keys()})
+        out = m(d)
+        ei = O.knn_with_max_radius(test_graph.x[:, :3], k, r)
+        yy, ff, ei2 = O.ml_graph_construction_edges(test_graph.x, test_graph.particle_id, ei, ratio_of_false=rof)
+        assert torch.equal(ei2, out.edge_index) and torch.equal(yy, out.y.long()), "ratio_of_false"
+        close(ff, out.edge_attr, 0.0, "edge features (ratio_of_false)")
+        assert out.edge_index.shape[1] < ei.shape[1], "the ratio should have dropped false edges on this graph"
+        arrs[f"k{k}_r{r}_rof{rof}/edge_index"] = out.edge_index
+        arrs[f"k{k}_r{r}_rof{rof}/y"] = out.y
+        arrs[f"k{k}_r{r}_rof{rof}/edge_attr"] = out.edge_attr
     print("  oracle == reference (bit-exact)")
     npz("g6_mlgc.npz", **arrs)
 

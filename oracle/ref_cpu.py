@@ -259,12 +259,22 @@ def knn_with_max_radius(x: Tensor, k: int, max_radius: float | None = None) -> T
     return ei
 
 
-def ml_graph_construction_edges(x: Tensor, particle_id: Tensor, edge_index: Tensor):
+def ml_graph_construction_edges(x: Tensor, particle_id: Tensor, edge_index: Tensor, ratio_of_false=None):
     """models/graph_construction.py:365-367 and :386-393: edge labels (int64
     compare, noise pid<=0 never true) and edge features ``[x_j - x_i, x_j + x_i]``
-    with j = edge_index[0], i = edge_index[1]."""
+    with j = edge_index[0], i = edge_index[1].  ``ratio_of_false`` (:373-384, training mode only): the FIRST
+    ``int(n_true * ratio)`` false edges are kept, then all true edges - returns the new edge list as a third value."""
     e0, e1 = edge_index[0], edge_index[1]
     y = (particle_id[e0] == particle_id[e1]) & (particle_id[e0] > 0)
+    if ratio_of_false:
+        n_keep = int(y.sum() * ratio_of_false)
+        false_edges = edge_index[:, ~y][:, :n_keep]
+        true_edges = edge_index[:, y]
+        edge_index = torch.cat((false_edges, true_edges), dim=1)
+        y = torch.cat((torch.zeros(false_edges.shape[1]), torch.ones(true_edges.shape[1])))
+        e0, e1 = edge_index[0], edge_index[1]
+        feat = torch.cat([x[e0] - x[e1], x[e0] + x[e1]], dim=1)
+        return y.long(), feat, edge_index
     feat = torch.cat([x[e0] - x[e1], x[e0] + x[e1]], dim=1)
     return y.long(), feat
 

@@ -655,6 +655,22 @@ def case_ml_graph_construction(device):
         assert torch.equal(out.edge_index.cpu(), tt(z[f"k{k}_r{r}/edge_index"]))
         assert torch.equal(out.y.cpu(), tt(z[f"k{k}_r{r}/y"]))
         assert torch.equal(out.edge_attr.cpu(), tt(z[f"k{k}_r{r}/edge_attr"])), "edge features"
+    # training mode with ``ratio_of_false``: the first int(n_true * ratio) false edges, then every true edge (G6, bit for bit);
+    # in eval mode the ratio is ignored
+    for k, r, rof in ((16, 0.5, 0.5), (4, 1.0, 2.0)):
+        d = G.Data(x=tt(g1["x"], device), edge_index=tt(g1["edge_index"], device),
+                   particle_id=tt(g1["particle_id"], device), pt=tt(g1["pt"], device),
+                   eta=tt(g1["eta"], device), reconstructable=tt(g1["reconstructable"], device),
+                   layer=tt(g1["layer"], device), sector=tt(g1["sector"], device))
+        m = MLGraphConstruction(ml=None, embedding_slice=(0, 3), max_radius=r, max_num_neighbors=k, ratio_of_false=rof)
+        m.train()
+        out = m(d)
+        tag = f"k{k}_r{r}_rof{rof}"
+        assert torch.equal(out.edge_index.cpu(), tt(z[f"{tag}/edge_index"])), "ratio_of_false: edge list"
+        assert torch.equal(out.y.cpu(), tt(z[f"{tag}/y"]).long()), "ratio_of_false: labels"
+        assert torch.equal(out.edge_attr.cpu(), tt(z[f"{tag}/edge_attr"])), "ratio_of_false: edge features"
+        m.eval()
+        assert torch.equal(m(d).edge_index.cpu(), tt(z[f"k{k}_r{r}/edge_index"])), "ratio_of_false is a training-mode switch"
     # the edge features are differentiable w.r.t. the node features (graph_construction.py:386-393
     # is plain indexing + cat in the reference): gradient against torch autograd of that expression
     g = np.random.default_rng(4)

@@ -117,6 +117,12 @@ def test_ml_graph_construction_edges():
         assert torch.equal(ei, tt(z[f"k{k}_r{r}/edge_index"]))
         assert torch.equal(y, tt(z[f"k{k}_r{r}/y"]))
         assert torch.equal(f, tt(z[f"k{k}_r{r}/edge_attr"]))
+    for k, r, rof in ((16, 0.5, 0.5), (4, 1.0, 2.0)):   # training mode's false-edge subsampling (graph_construction.py:373-384)
+        ei = O.knn_with_max_radius(x[:, :3], k, r)
+        y, f, ei2 = O.ml_graph_construction_edges(x, pid, ei, ratio_of_false=rof)
+        assert torch.equal(ei2, tt(z[f"k{k}_r{r}_rof{rof}/edge_index"]))
+        assert torch.equal(y, tt(z[f"k{k}_r{r}_rof{rof}/y"]).long())
+        assert torch.equal(f, tt(z[f"k{k}_r{r}_rof{rof}/edge_attr"]))
 
 
 def test_graph_tcn():

@@ -174,13 +174,15 @@ def case_node_order(device, n_hits=10_000, n_edges=100_000, modes=("f32", "bf16"
         inv = torch.empty_like(o)
         inv[o] = torch.arange(N)
         assert torch.equal(rank.cpu().long(), inv), "node_order: rank inverts perm"
-    # the counting-sort form: 5 events of 900 .. 3000 nodes (two empty ones in between), ties, a NaN, infinities apart
-    sizes2 = (900, 0, 3000, 1, 1200, 0)
+    # the counting-sort form: 5 events of 900 .. 7000 nodes (two empty ones in between), ties, a NaN, infinities apart
+    sizes2 = (900, 0, 7000, 1, 1200, 0)
     batch2 = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes2)])
     x2 = torch.from_numpy(g.uniform(-1, 1, (int(batch2.numel()), 3)).astype(np.float32))
     x2[::11, 1] = 0.125
     x2[17, 1] = float("nan")
-    for b, col, n_ev in ((batch2, 1, len(sizes2)), (None, 2, 0), (batch2, 2, 64)):
+    x2[:, 0] = 0.75          # a constant key: every node of an event on ONE level (a bucket far beyond the LDS capacity)
+    x2[900:2500, 0] = -3.0   # ... and two levels, 1 600 + 5 400 nodes (the latter beyond the 5 120 records a bucket holds in LDS), in the second event
+    for b, col, n_ev in ((batch2, 1, len(sizes2)), (None, 2, 0), (batch2, 2, 64), (batch2, 0, len(sizes2)), (None, 0, 1)):
         perm, rank = ops.node_order(x2.to(device), col, None if b is None else b.to(device), n_ev)
         o = torch.argsort(levels(x2[:, col], torch.zeros_like(batch2) if b is None else b), stable=True)
         if b is not None:

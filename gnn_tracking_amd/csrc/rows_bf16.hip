@@ -170,6 +170,12 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_kernel(
 // fills with coalesced 16-byte loads, four per lane in flight - the walk above waits for one dependent round
 // trip to HBM per 4-16 rows of a segment.  A wave owns 16 consecutive segments at a time and stages their rows
 // in chunks of 256.
+#ifndef GNNTRK_PAIR8_NT
+#define GNNTRK_PAIR8_NT 0   // (measured, round 6: 125 -> 166 us per 64 M rows - the pairs shared by neighbouring segments must stay cached)
+#endif
+#ifndef GNNTRK_SEGSUM_NT
+#define GNNTRK_SEGSUM_NT 1   // (non-temporal loads of the once-read gradient rows: 231-235 -> 225 us per 64 M rows, round 6)
+#endif
 #ifndef GNNTRK_SEGSUM_STREAM
 #define GNNTRK_SEGSUM_STREAM 1
 #endif
@@ -196,7 +202,11 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_stream16_kernel(
 #pragma unroll
             for (int u = 0; u < kStreamChunk / 64; ++u) {
                 const int32_t r = c0 + lane + 64 * u;
+#if GNNTRK_SEGSUM_NT   // (A/B: non-temporal loads of the once-read rows - measured, round 6: see DESIGN.md 4.4)
+                v[u] = r < r1 ? __builtin_nontemporal_load(r16 + r) : u32x4{0u, 0u, 0u, 0u};
+#else
                 v[u] = r < r1 ? r16[r] : u32x4{0u, 0u, 0u, 0u};
+#endif
             }
             lds_wave_order();   // (the previous chunk's reads are issued before these writes)
 #pragma unroll
@@ -271,7 +281,11 @@ __global__ __launch_bounds__(kTpb16) void segment_sum_bf16_pair8_kernel(
             auto load_pair = [&](int32_t p) {
                 u32x4 v;
                 if (2 * p + 1 < n_rows) {
+#if GNNTRK_PAIR8_NT
+                    v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + (int64_t)p * 8));
+#else
                     v = *reinterpret_cast<const u32x4 *>(rows + (int64_t)p * 8);
+#endif
                 } else {  // the odd last row of the whole tensor: nothing may be read behind it
                     const u32x2 h = *reinterpret_cast<const u32x2 *>(rows + (int64_t)p * 8);
                     v[0] = h[0], v[1] = h[1], v[2] = 0u, v[3] = 0u;
